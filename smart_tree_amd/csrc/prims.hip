@@ -1,0 +1,241 @@
+// Device-wide exclusive scan and stable LSD radix sort (wave64 / LDS based), used by the
+// voxeliser, the rulebook builder and the graph stage for order-preserving compaction.
+// No inter-workgroup communication inside a launch: scan = reduce / scan-of-sums / apply.
+#include <cstdarg>
+
+#include "st_common.h"
+
+// ------------------------------------------------------------------------------ error text ---
+static thread_local char g_err[512] = "";
+
+void st_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* st_last_error(void) { return g_err; }
+extern "C" int st_version(void) { return 100; }
+
+// ------------------------------------------------------------------------------------ scan ---
+#define SCAN_BLOCK 256
+#define SCAN_ITEMS 8
+#define SCAN_TILE (SCAN_BLOCK * SCAN_ITEMS)
+
+// exclusive scan of one value per thread across the workgroup; *total = workgroup sum.
+// lds needs SCAN_BLOCK/64 + 1 words.  Must be reached by every thread of the workgroup.
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* lds, uint32_t* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nw = (blockDim.x + 63) >> 6;
+    uint32_t x = v;
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t y = __shfl_up(x, d);
+        if (lane >= d) x += y;
+    }
+    __syncthreads();  // lds may still be read from a previous call
+    if (lane == 63) lds[wave] = x;
+    __syncthreads();
+    if (wave == 0) {
+        uint32_t t = lane < nw ? lds[lane] : 0u;
+        uint32_t s = t;
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t y = __shfl_up(s, d);
+            if (lane >= d) s += y;
+        }
+        if (lane < nw) lds[lane] = s - t;
+        if (lane == nw - 1) lds[nw] = s;
+    }
+    __syncthreads();
+    *total = lds[nw];
+    return x - v + lds[wave];
+}
+
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_reduce(const uint32_t* in, uint32_t* block_sums, int64_t n) {
+    __shared__ uint32_t lds[SCAN_BLOCK / 64 + 1];
+    int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    uint32_t s = 0;
+    for (int i = 0; i < SCAN_ITEMS; i++)
+        if (base + i < n) s += in[base + i];
+    uint32_t total;
+    block_exclusive_scan(s, lds, &total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_sums(uint32_t* block_sums, int64_t nb, uint32_t* total_out) {
+    __shared__ uint32_t lds[SCAN_BLOCK / 64 + 1];
+    uint32_t carry = 0;
+    for (int64_t base = 0; base < nb; base += SCAN_BLOCK) {
+        int64_t i = base + threadIdx.x;
+        uint32_t v = i < nb ? block_sums[i] : 0u;
+        uint32_t total;
+        uint32_t ex = block_exclusive_scan(v, lds, &total);
+        if (i < nb) block_sums[i] = ex + carry;
+        carry += total;
+    }
+    if (threadIdx.x == 0 && total_out) *total_out = carry;
+}
+
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_apply(const uint32_t* in, uint32_t* out, const uint32_t* block_sums,
+                                                           int64_t n) {
+    __shared__ uint32_t lds[SCAN_BLOCK / 64 + 1];
+    int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS];
+    uint32_t s = 0;
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        v[i] = base + i < n ? in[base + i] : 0u;
+        s += v[i];
+    }
+    uint32_t total;
+    uint32_t ex = block_exclusive_scan(s, lds, &total) + block_sums[blockIdx.x];
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        if (base + i < n) out[base + i] = ex;
+        ex += v[i];
+    }
+}
+
+int64_t st_scan_ws_bytes(int64_t n) {
+    StArena a(nullptr, 0);
+    a.take<uint32_t>(st_div_up(n > 0 ? n : 1, SCAN_TILE));
+    return a.used;
+}
+
+int st_exclusive_scan_u32(const uint32_t* in, uint32_t* out, int64_t n, uint32_t* total, void* ws, int64_t ws_bytes,
+                          hipStream_t stream) {
+    if (n <= 0) {
+        if (total) (void)hipMemsetAsync(total, 0, sizeof(uint32_t), stream);
+        return ST_OK;
+    }
+    StArena a(ws, ws_bytes);
+    int64_t nb = st_div_up(n, SCAN_TILE);
+    uint32_t* sums = a.take<uint32_t>(nb);
+    if (!sums) {
+        st_set_error("scan: workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)a.used);
+        return ST_ERR_WORKSPACE;
+    }
+    hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, stream, in, sums, n);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_BLOCK), 0, stream, sums, nb, total);
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, stream, in, out, (const uint32_t*)sums, n);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}
+
+// ------------------------------------------------------------------------------ radix sort ---
+#define SORT_BLOCK 256
+#define SORT_ITEMS 4
+#define SORT_TILE (SORT_BLOCK * SORT_ITEMS)
+#define SORT_WAVES (SORT_BLOCK / 64)
+
+__global__ void __launch_bounds__(SORT_BLOCK) k_sort_hist(const uint32_t* keys, int64_t n, int shift, uint32_t* hist,
+                                                          int64_t nb) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    int64_t base = (int64_t)blockIdx.x * SORT_TILE;
+    for (int r = 0; r < SORT_ITEMS; r++) {
+        int64_t e = base + (int64_t)r * SORT_BLOCK + threadIdx.x;
+        if (e < n) atomicAdd(&h[(keys[e] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[(int64_t)threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];
+}
+
+__global__ void __launch_bounds__(SORT_BLOCK) k_sort_scatter(const uint32_t* keys, const uint32_t* vals, uint32_t* okeys,
+                                                             uint32_t* ovals, int64_t n, int shift, const uint32_t* hist,
+                                                             int64_t nb) {
+    __shared__ uint32_t running[256];
+    __shared__ uint32_t wd[SORT_WAVES][256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    running[tid] = hist[(int64_t)tid * nb + blockIdx.x];
+    for (int w = 0; w < SORT_WAVES; w++) wd[w][tid] = 0;
+    __syncthreads();
+    int64_t base = (int64_t)blockIdx.x * SORT_TILE;
+    for (int r = 0; r < SORT_ITEMS; r++) {
+        int64_t e = base + (int64_t)r * SORT_BLOCK + tid;
+        bool valid = e < n;
+        uint32_t key = valid ? keys[e] : 0u;
+        uint32_t val = valid ? vals[e] : 0u;
+        uint32_t digit = (key >> shift) & 255u;
+        // peers = valid lanes of this wave holding the same digit
+        unsigned long long peers = __ballot(valid);
+        for (int b = 0; b < 8; b++) {
+            bool bit = (digit >> b) & 1u;
+            unsigned long long bal = __ballot(valid && bit);
+            peers &= bit ? bal : ~bal;
+        }
+        unsigned long long below = peers & ((1ull << lane) - 1ull);
+        uint32_t rank = (uint32_t)__popcll(below);
+        if (valid && rank == 0) wd[wave][digit] = (uint32_t)__popcll(peers);
+        __syncthreads();
+        if (valid) {
+            uint32_t off = running[digit] + rank;
+            for (int w = 0; w < wave; w++) off += wd[w][digit];
+            okeys[off] = key;
+            ovals[off] = val;
+        }
+        __syncthreads();
+        uint32_t add = 0;
+        for (int w = 0; w < SORT_WAVES; w++) {
+            add += wd[w][tid];
+            wd[w][tid] = 0;
+        }
+        running[tid] += add;
+        __syncthreads();
+    }
+}
+
+int64_t st_sort_ws_bytes(int64_t n) {
+    if (n <= 0) n = 1;
+    StArena a(nullptr, 0);
+    int64_t nb = st_div_up(n, SORT_TILE);
+    a.take<uint32_t>(n);
+    a.take<uint32_t>(n);
+    a.take<uint32_t>(256 * nb);
+    a.take<char>(st_scan_ws_bytes(256 * nb));
+    return a.used;
+}
+
+int st_radix_sort_pairs_u32(uint32_t* keys, uint32_t* vals, int64_t n, int key_bits, void* ws, int64_t ws_bytes,
+                            hipStream_t stream) {
+    if (n <= 1 || key_bits <= 0) return ST_OK;
+    StArena a(ws, ws_bytes);
+    int64_t nb = st_div_up(n, SORT_TILE);
+    uint32_t* tk = a.take<uint32_t>(n);
+    uint32_t* tv = a.take<uint32_t>(n);
+    uint32_t* hist = a.take<uint32_t>(256 * nb);
+    int64_t scan_bytes = st_scan_ws_bytes(256 * nb);
+    char* scan_ws = a.take<char>(scan_bytes);
+    if (!tk || !tv || !hist || !scan_ws) {
+        st_set_error("sort: workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)a.used);
+        return ST_ERR_WORKSPACE;
+    }
+    uint32_t *ik = keys, *iv = vals, *ok = tk, *ov = tv;
+    for (int shift = 0; shift < key_bits; shift += 8) {
+        hipLaunchKernelGGL(k_sort_hist, dim3((unsigned)nb), dim3(SORT_BLOCK), 0, stream, (const uint32_t*)ik, n, shift,
+                           hist, nb);
+        ST_TRY(st_exclusive_scan_u32(hist, hist, 256 * nb, nullptr, scan_ws, scan_bytes, stream));
+        hipLaunchKernelGGL(k_sort_scatter, dim3((unsigned)nb), dim3(SORT_BLOCK), 0, stream, (const uint32_t*)ik,
+                           (const uint32_t*)iv, ok, ov, n, shift, (const uint32_t*)hist, nb);
+        uint32_t* t;
+        t = ik; ik = ok; ok = t;
+        t = iv; iv = ov; ov = t;
+    }
+    if (ik != keys) {
+        (void)hipMemcpyAsync(keys, ik, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream);
+        (void)hipMemcpyAsync(vals, iv, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream);
+    }
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}
+
+// exported for the primitive-level tests
+extern "C" int64_t st_scan_workspace_bytes(int64_t n) { return st_scan_ws_bytes(n); }
+extern "C" int st_scan_u32(const uint32_t* in, uint32_t* out, int64_t n, uint32_t* total, void* ws, int64_t ws_bytes,
+                           void* stream) {
+    return st_exclusive_scan_u32(in, out, n, total, ws, ws_bytes, (hipStream_t)stream);
+}
+extern "C" int64_t st_sort_workspace_bytes(int64_t n) { return st_sort_ws_bytes(n); }
+extern "C" int st_sort_pairs_u32(uint32_t* keys, uint32_t* vals, int64_t n, int key_bits, void* ws, int64_t ws_bytes,
+                                 void* stream) {
+    return st_radix_sort_pairs_u32(keys, vals, n, key_bits, ws, ws_bytes, (hipStream_t)stream);
+}

@@ -1,0 +1,135 @@
+// Shared helpers for the smart-tree HIP kernels (gfx950, wave64).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#define ST_WAVE 64
+
+// ---- status / error text (C ABI: every entry point returns int, 0 = ok) -------------------
+enum StStatus : int {
+    ST_OK = 0,
+    ST_ERR_INVALID = -1,    // bad argument
+    ST_ERR_WORKSPACE = -2,  // caller workspace too small
+    ST_ERR_LAUNCH = -3,     // HIP launch / runtime error
+};
+
+void st_set_error(const char* fmt, ...);
+
+#define ST_REQUIRE(cond, ...)            \
+    do {                                 \
+        if (!(cond)) {                   \
+            st_set_error(__VA_ARGS__);   \
+            return ST_ERR_INVALID;       \
+        }                                \
+    } while (0)
+
+#define ST_CHECK_LAUNCH()                                                  \
+    do {                                                                   \
+        hipError_t e__ = hipGetLastError();                                \
+        if (e__ != hipSuccess) {                                           \
+            st_set_error("%s:%d HIP error: %s", __FILE__, __LINE__, hipGetErrorString(e__)); \
+            return ST_ERR_LAUNCH;                                          \
+        }                                                                  \
+    } while (0)
+
+#define ST_TRY(expr)              \
+    do {                          \
+        int rc__ = (expr);        \
+        if (rc__ != ST_OK) return rc__; \
+    } while (0)
+
+// ---- bump allocator over the caller-provided workspace --------------------------------------
+struct StArena {
+    char* base;
+    int64_t size;
+    int64_t used;
+    bool dry;  // size query: no pointers handed out
+    StArena(void* p, int64_t n) : base((char*)p), size(n), used(0), dry(p == nullptr) {}
+    template <class T>
+    T* take(int64_t count) {
+        int64_t bytes = ((int64_t)sizeof(T) * (count > 0 ? count : 1) + 255) & ~(int64_t)255;
+        int64_t at = used;
+        used += bytes;
+        if (dry || used > size) return nullptr;
+        return (T*)(base + at);
+    }
+    bool ok() const { return dry || used <= size; }
+};
+
+static inline int64_t st_div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int64_t st_next_pow2(int64_t v) {
+    int64_t p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+// ---- device helpers ---------------------------------------------------------------------------
+template <class T>
+__device__ __forceinline__ T st_min(T a, T b) { return a < b ? a : b; }
+template <class T>
+__device__ __forceinline__ T st_max(T a, T b) { return a > b ? a : b; }
+
+// order-preserving float <-> uint map (for atomicMin/Max on floats)
+__device__ __forceinline__ unsigned st_f2ord(float f) {
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float st_ord2f(unsigned u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+// 64-bit voxel key: block (16 bit) | z | y | x (16 bit each); EMPTY = all ones
+#define ST_EMPTY_KEY 0xffffffffffffffffull
+__device__ __forceinline__ unsigned long long st_pack_key(int b, int z, int y, int x) {
+    return ((unsigned long long)(unsigned)b << 48) | ((unsigned long long)(unsigned)z << 32) |
+           ((unsigned long long)(unsigned)y << 16) | (unsigned long long)(unsigned)x;
+}
+__device__ __forceinline__ unsigned long long st_hash64(unsigned long long k) {
+    k ^= k >> 33;
+    k *= 0xff51afd7ed558ccdull;
+    k ^= k >> 33;
+    k *= 0xc4ceb9fe1a85ec53ull;
+    k ^= k >> 33;
+    return k;
+}
+
+// Open-addressing table: keys[cap] (u64), vals[cap] (u32).  cap is a power of two.
+// insert-with-min: the smallest value ever offered for a key wins (deterministic).
+__device__ __forceinline__ bool st_hash_insert_min(unsigned long long* keys, unsigned* vals, unsigned long long cap,
+                                                   unsigned long long key, unsigned val) {
+    unsigned long long slot = st_hash64(key) & (cap - 1);
+    for (unsigned long long probe = 0; probe < cap; probe++) {
+        unsigned long long prev = atomicCAS(&keys[slot], (unsigned long long)ST_EMPTY_KEY, key);
+        if (prev == ST_EMPTY_KEY || prev == key) {
+            atomicMin(&vals[slot], val);
+            return true;
+        }
+        slot = (slot + 1) & (cap - 1);
+    }
+    return false;
+}
+__device__ __forceinline__ int st_hash_find(const unsigned long long* keys, const unsigned* vals, unsigned long long cap,
+                                            unsigned long long key) {
+    unsigned long long slot = st_hash64(key) & (cap - 1);
+    for (unsigned long long probe = 0; probe < cap; probe++) {
+        unsigned long long k = keys[slot];
+        if (k == key) return (int)vals[slot];
+        if (k == ST_EMPTY_KEY) return -1;
+        slot = (slot + 1) & (cap - 1);
+    }
+    return -1;
+}
+
+// ---- internal primitives (prims.hip) --------------------------------------------------------------
+int64_t st_scan_ws_bytes(int64_t n);
+// out[i] = sum_{j<i} in[j]; if total != nullptr, *total = sum of all (device pointer). in may alias out.
+int st_exclusive_scan_u32(const uint32_t* in, uint32_t* out, int64_t n, uint32_t* total, void* ws, int64_t ws_bytes,
+                          hipStream_t stream);
+int64_t st_sort_ws_bytes(int64_t n);
+// Stable LSD radix sort of (key, val) pairs on key bits [0, key_bits).  Result lands in keys/vals.
+int st_radix_sort_pairs_u32(uint32_t* keys, uint32_t* vals, int64_t n, int key_bits, void* ws, int64_t ws_bytes,
+                            hipStream_t stream);

@@ -1,0 +1,129 @@
+"""Point-cloud container with the reference's field names and method surface.
+
+Mirrors `smart_tree/data_types/cloud.py:19-264` (fields :21-28; `filter` :72-95;
+`filter_by_class` :97-103; `to_device` :138-161; `translate` :197-198; `root_idx` :204-206;
+`bbox` :222-227; `medial_pts` :229-231; `from_numpy` :233-252; `radius` :254-256).  The open3d
+visualisation helpers are out of scope.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, fields, replace
+from pathlib import Path
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+_PER_POINT = ("xyz", "rgb", "medial_vector", "branch_direction", "branch_ids", "class_l")
+
+
+@dataclass
+class Cloud:
+    xyz: torch.Tensor
+    rgb: Optional[torch.Tensor] = None
+    medial_vector: Optional[torch.Tensor] = None
+    branch_direction: Optional[torch.Tensor] = None
+    branch_ids: Optional[torch.Tensor] = None
+    class_l: Optional[torch.Tensor] = None
+    filename: Optional[Path] = None
+
+    def __post_init__(self):
+        n = self.xyz.shape[0]
+        if self.xyz.ndim != 2 or self.xyz.shape[1] != 3:
+            raise TypeError(f"xyz must be [N,3], got {tuple(self.xyz.shape)}")
+        for name, width in (("rgb", 3), ("medial_vector", 3), ("branch_direction", 3), ("branch_ids", 1), ("class_l", 1)):
+            t = getattr(self, name)
+            if t is not None and tuple(t.shape) != (n, width):
+                raise TypeError(f"{name} must be [{n},{width}], got {tuple(t.shape)}")
+
+    def __len__(self) -> int:
+        return self.xyz.shape[0]
+
+    def __str__(self) -> str:
+        return (f"Cloud with {len(self)} points, min {self.min_xyz.tolist()}, "
+                f"max {self.max_xyz.tolist()}, device {self.xyz.device}")
+
+    # -- generic per-point map -------------------------------------------------------------
+    def _map(self, fn) -> "Cloud":
+        changed = {name: fn(getattr(self, name)) for name in _PER_POINT if getattr(self, name) is not None}
+        return replace(self, **changed)
+
+    def filter(self, mask) -> "Cloud":
+        """Boolean-mask or index gather of every per-point field (reference cloud.py:72-95)."""
+        mask = mask.to(self.xyz.device)
+        return self._map(lambda t: t[mask])
+
+    def filter_by_class(self, classes) -> "Cloud":
+        wanted = torch.as_tensor(classes, device=self.class_l.device)
+        return self.filter(torch.isin(self.class_l, wanted).view(-1))
+
+    def to_device(self, device) -> "Cloud":
+        return self._map(lambda t: t.to(device))
+
+    def cpu(self) -> "Cloud":
+        return self.to_device(torch.device("cpu"))
+
+    def pin_memory(self) -> "Cloud":
+        return self._map(lambda t: t.pin_memory())
+
+    def cat(self) -> torch.Tensor:
+        return torch.cat((self.xyz, self.rgb), 1)
+
+    # -- geometry (these drop every field but xyz/rgb, as the reference does: cloud.py:194-202)
+    def scale(self, factor) -> "Cloud":
+        return Cloud(self.xyz * factor, self.rgb)
+
+    def translate(self, offset) -> "Cloud":
+        return Cloud(self.xyz + offset.to(self.xyz.device), self.rgb)
+
+    def rotate(self, rot_mat) -> "Cloud":
+        rot_mat = rot_mat.to(device=self.xyz.device, dtype=self.xyz.dtype)
+        return Cloud(self.xyz @ rot_mat, self.rgb)
+
+    @property
+    def max_xyz(self) -> torch.Tensor:
+        return self.xyz.max(0)[0]
+
+    @property
+    def min_xyz(self) -> torch.Tensor:
+        return self.xyz.min(0)[0]
+
+    @property
+    def bbox(self):
+        """(centre, half-extent), reference cloud.py:222-227."""
+        half = (self.max_xyz - self.min_xyz) / 2
+        return self.min_xyz + half, half
+
+    @property
+    def root_idx(self) -> int:
+        """Index of the lowest point (first minimum of y), reference cloud.py:204-206."""
+        return int(torch.argmin(self.xyz[:, 1]).item())
+
+    @property
+    def number_classes(self) -> int:
+        return 1 if self.class_l is None else int(self.class_l.max().item()) + 1
+
+    @property
+    def medial_pts(self) -> torch.Tensor:
+        return self.xyz + self.medial_vector
+
+    @property
+    def radius(self) -> torch.Tensor:
+        return self.medial_vector.pow(2).sum(1).sqrt()
+
+    @property
+    def direction(self) -> torch.Tensor:
+        return F.normalize(self.medial_vector)
+
+    @staticmethod
+    def from_numpy(**arrays) -> "Cloud":
+        """Keys as in the reference's .npz clouds (cloud.py:233-252); legacy key `vector`."""
+        known = {f.name for f in fields(Cloud)} - {"filename"}
+        kw = {}
+        for key, value in arrays.items():
+            if key in known:
+                kw[key] = torch.as_tensor(np.asarray(value)).float()
+            elif key == "vector":
+                kw["medial_vector"] = torch.as_tensor(np.asarray(value))
+        return Cloud(**kw)

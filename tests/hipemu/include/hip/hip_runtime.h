@@ -1,0 +1,327 @@
+// TEST INFRASTRUCTURE ONLY -- a CPU "sanitizer build" shim for the HIP kernel sources.
+//
+// tests/hipemu/build.py compiles smart_tree_amd/csrc/*.hip UNCHANGED with the host clang++ and
+// this directory first on the include path, so `#include <hip/hip_runtime.h>` resolves here.
+// Every workgroup runs as a set of cooperative fibers (ucontext) inside one OS thread:
+// __syncthreads() and the wavefront collectives (__ballot/__shfl*/readfirstlane/MFMA) are
+// rendezvous points.  This lets the `-m "not gpu"` suite execute the real kernel logic against
+// the oracle (and under ASan/UBSan, which the GPU pool does not offer) before GPU minutes are
+// spent.  It is NOT a product path: smart_tree_amd/_lib.py loads only libsmarttree_hip.so and
+// raises if it is missing; nothing under smart_tree_amd/ references this directory.
+//
+// Limits (kernels are written to respect them): 1-D grids/blocks, static __shared__ only, no
+// inter-workgroup communication inside a launch, wave collectives only in wave-convergent code.
+#pragma once
+
+#include <ucontext.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static
+#define __launch_bounds__(...)
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+typedef void* hipStream_t;
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1 };
+inline const char* hipGetErrorString(hipError_t) { return "hipemu"; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+
+struct float2 { float x, y; };
+struct float3 { float x, y, z; };
+struct alignas(16) float4 { float x, y, z, w; };
+struct int2 { int x, y; };
+struct alignas(16) int4 { int x, y, z, w; };
+struct uint2 { unsigned x, y; };
+struct alignas(16) uint4 { unsigned x, y, z, w; };
+inline float2 make_float2(float x, float y) { return {x, y}; }
+inline float3 make_float3(float x, float y, float z) { return {x, y, z}; }
+inline float4 make_float4(float x, float y, float z, float w) { return {x, y, z, w}; }
+inline int2 make_int2(int x, int y) { return {x, y}; }
+inline int4 make_int4(int x, int y, int z, int w) { return {x, y, z, w}; }
+inline uint2 make_uint2(unsigned x, unsigned y) { return {x, y}; }
+inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return {x, y, z, w}; }
+
+namespace hipemu {
+
+enum State { READY = 0, AT_BARRIER = 1, AT_WAVEOP = 2, DONE = 3 };
+
+struct Fiber {
+    ucontext_t ctx;
+    int state;
+    dim3 tid;
+    uint64_t deposit[2];
+};
+
+struct Runtime {
+    ucontext_t sched;
+    std::vector<Fiber> fibers;
+    std::vector<char> stacks;
+    Fiber* cur = nullptr;
+    dim3 bid, bdim, gdim;
+    std::function<void()> body;
+    // snapshot of the last resolved wave op, per wave
+    std::vector<uint64_t> snap;      // [nwaves][64][2]
+    std::vector<uint64_t> snap_mask; // [nwaves]
+    static constexpr size_t kStack = 256 * 1024;
+};
+
+inline Runtime& rt() {
+    static Runtime r;
+    return r;
+}
+
+inline void yield_to_sched(int state) {
+    Runtime& r = rt();
+    Fiber* f = r.cur;
+    f->state = state;
+    swapcontext(&f->ctx, &r.sched);
+}
+
+inline void fiber_entry() {
+    Runtime& r = rt();
+    r.body();
+    r.cur->state = DONE;
+    swapcontext(&r.cur->ctx, &r.sched);
+}
+
+[[noreturn]] inline void die(const char* msg) {
+    fprintf(stderr, "hipemu: %s\n", msg);
+    abort();
+}
+
+inline void run_block(unsigned nthreads) {
+    Runtime& r = rt();
+    if (r.fibers.size() < nthreads) r.fibers.resize(nthreads);
+    if (r.stacks.size() < (size_t)nthreads * Runtime::kStack) r.stacks.resize((size_t)nthreads * Runtime::kStack);
+    unsigned nwaves = (nthreads + 63) / 64;
+    r.snap.assign((size_t)nwaves * 64 * 2, 0);
+    r.snap_mask.assign(nwaves, 0);
+    for (unsigned t = 0; t < nthreads; t++) {
+        Fiber& f = r.fibers[t];
+        getcontext(&f.ctx);
+        f.ctx.uc_stack.ss_sp = r.stacks.data() + (size_t)t * Runtime::kStack;
+        f.ctx.uc_stack.ss_size = Runtime::kStack;
+        f.ctx.uc_link = nullptr;
+        makecontext(&f.ctx, (void (*)())fiber_entry, 0);
+        f.state = READY;
+        f.tid = dim3(t);
+    }
+    for (;;) {
+        for (unsigned t = 0; t < nthreads; t++) {
+            Fiber& f = r.fibers[t];
+            if (f.state != READY) continue;
+            r.cur = &f;
+            swapcontext(&r.sched, &f.ctx);
+        }
+        // everyone is now parked or finished
+        bool released = false;
+        unsigned at_barrier = 0, done = 0;
+        for (unsigned w = 0; w < nwaves; w++) {
+            unsigned lo = w * 64, hi = lo + 64 < nthreads ? lo + 64 : nthreads;
+            unsigned nop = 0, nbar = 0, ndone = 0;
+            for (unsigned t = lo; t < hi; t++) {
+                int s = r.fibers[t].state;
+                nop += s == AT_WAVEOP;
+                nbar += s == AT_BARRIER;
+                ndone += s == DONE;
+            }
+            at_barrier += nbar;
+            done += ndone;
+            if (nop == 0) continue;
+            if (nbar != 0) die("wave collective reached by some lanes while others wait at __syncthreads (divergent wave op)");
+            uint64_t mask = 0;
+            for (unsigned t = lo; t < hi; t++) {
+                Fiber& f = r.fibers[t];
+                if (f.state != AT_WAVEOP) continue;
+                unsigned lane = t - lo;
+                mask |= 1ull << lane;
+                r.snap[((size_t)w * 64 + lane) * 2] = f.deposit[0];
+                r.snap[((size_t)w * 64 + lane) * 2 + 1] = f.deposit[1];
+                f.state = READY;
+            }
+            r.snap_mask[w] = mask;
+            released = true;
+        }
+        if (released) continue;
+        if (done == nthreads) break;
+        if (at_barrier + done == nthreads) {
+            for (unsigned t = 0; t < nthreads; t++)
+                if (r.fibers[t].state == AT_BARRIER) r.fibers[t].state = READY;
+            continue;
+        }
+        die("deadlock: no runnable fiber");
+    }
+    r.cur = nullptr;
+}
+
+template <class F>
+inline void launch(dim3 grid, dim3 block, F&& body) {
+    Runtime& r = rt();
+    if (grid.y != 1 || grid.z != 1 || block.y != 1 || block.z != 1) die("only 1-D launches are emulated");
+    r.gdim = grid;
+    r.bdim = block;
+    r.body = body;
+    for (unsigned b = 0; b < grid.x; b++) {
+        r.bid = dim3(b);
+        run_block(block.x);
+    }
+}
+
+// wave rendezvous: deposit two 64-bit words, get everyone's words back
+struct WaveView {
+    const uint64_t* data;
+    uint64_t mask;
+    unsigned lane;
+    uint64_t lo(unsigned l) const { return data[l * 2]; }
+    uint64_t hi(unsigned l) const { return data[l * 2 + 1]; }
+};
+
+inline WaveView wave_exchange(uint64_t a, uint64_t b = 0) {
+    Runtime& r = rt();
+    Fiber* f = r.cur;
+    f->deposit[0] = a;
+    f->deposit[1] = b;
+    yield_to_sched(AT_WAVEOP);
+    unsigned t = f->tid.x, w = t / 64;
+    return WaveView{r.snap.data() + (size_t)w * 64 * 2, r.snap_mask[w], t % 64};
+}
+
+template <class T>
+inline uint64_t to_bits(T v) {
+    static_assert(sizeof(T) <= 8, "");
+    uint64_t u = 0;
+    memcpy(&u, &v, sizeof(T));
+    return u;
+}
+template <class T>
+inline T from_bits(uint64_t u) {
+    T v;
+    memcpy(&v, &u, sizeof(T));
+    return v;
+}
+
+}  // namespace hipemu
+
+#define threadIdx (hipemu::rt().cur->tid)
+#define blockIdx (hipemu::rt().bid)
+#define blockDim (hipemu::rt().bdim)
+#define gridDim (hipemu::rt().gdim)
+#define warpSize 64
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+    hipemu::launch(dim3(grid), dim3(block), [=]() { kernel(__VA_ARGS__); })
+
+inline void __syncthreads() { hipemu::yield_to_sched(hipemu::AT_BARRIER); }
+inline void __threadfence() {}
+inline void __threadfence_block() {}
+
+// ---- wave collectives ------------------------------------------------------------------
+inline unsigned long long __ballot(int pred) {
+    auto v = hipemu::wave_exchange(pred ? 1 : 0);
+    unsigned long long m = 0;
+    for (unsigned l = 0; l < 64; l++)
+        if ((v.mask >> l) & 1 && v.lo(l)) m |= 1ull << l;
+    return m;
+}
+inline int __any(int pred) { return __ballot(pred) != 0; }
+inline int __all(int pred) {
+    auto v = hipemu::wave_exchange(pred ? 1 : 0);
+    for (unsigned l = 0; l < 64; l++)
+        if ((v.mask >> l) & 1 && !v.lo(l)) return 0;
+    return 1;
+}
+template <class T>
+inline T __shfl(T x, int src, int width = 64) {
+    auto v = hipemu::wave_exchange(hipemu::to_bits(x));
+    unsigned base = v.lane & ~(unsigned)(width - 1);
+    unsigned s = base + ((unsigned)src & (unsigned)(width - 1));
+    return hipemu::from_bits<T>(v.lo(s));
+}
+template <class T>
+inline T __shfl_up(T x, unsigned delta, int width = 64) {
+    auto v = hipemu::wave_exchange(hipemu::to_bits(x));
+    unsigned in = v.lane & (unsigned)(width - 1);
+    return in >= delta ? hipemu::from_bits<T>(v.lo(v.lane - delta)) : x;
+}
+template <class T>
+inline T __shfl_down(T x, unsigned delta, int width = 64) {
+    auto v = hipemu::wave_exchange(hipemu::to_bits(x));
+    unsigned in = v.lane & (unsigned)(width - 1);
+    return in + delta < (unsigned)width ? hipemu::from_bits<T>(v.lo(v.lane + delta)) : x;
+}
+template <class T>
+inline T __shfl_xor(T x, int m, int width = 64) {
+    auto v = hipemu::wave_exchange(hipemu::to_bits(x));
+    unsigned s = v.lane ^ (unsigned)m;
+    (void)width;
+    return hipemu::from_bits<T>(v.lo(s));
+}
+inline int __builtin_amdgcn_readfirstlane(int x) {
+    auto v = hipemu::wave_exchange((uint64_t)(uint32_t)x);
+    return (int)(uint32_t)v.lo(__builtin_ctzll(v.mask));
+}
+inline unsigned __lane_id() { return threadIdx.x % 64; }
+
+typedef float hipemu_v4f __attribute__((ext_vector_type(4)));
+// v_mfma_f32_16x16x4_f32: A[i][k] held by lane k*16+i, B[k][j] by lane k*16+j,
+// D[row][col]: col = lane&15, row = (lane>>4)*4 + reg; k-ordered fmaf chain (guide section 3).
+inline hipemu_v4f __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, hipemu_v4f c, int, int, int) {
+    auto v = hipemu::wave_exchange(hipemu::to_bits(a), hipemu::to_bits(b));
+    unsigned col = v.lane & 15;
+    for (int reg = 0; reg < 4; reg++) {
+        unsigned row = (v.lane >> 4) * 4 + reg;
+        float acc = c[reg];
+        for (unsigned k = 0; k < 4; k++) {
+            float av = hipemu::from_bits<float>(v.lo(k * 16 + row));
+            float bv = hipemu::from_bits<float>(v.hi(k * 16 + col));
+            acc = fmaf(av, bv, acc);
+        }
+        c[reg] = acc;
+    }
+    return c;
+}
+
+// ---- bit / math helpers ----------------------------------------------------------------
+inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+inline int __popc(unsigned x) { return __builtin_popcount(x); }
+inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }
+inline int __ffs(unsigned x) { return __builtin_ffs((int)x); }
+inline int __clz(unsigned x) { return x ? __builtin_clz(x) : 32; }
+inline int __clzll(unsigned long long x) { return x ? __builtin_clzll(x) : 64; }
+inline unsigned __float_as_uint(float f) { return hipemu::from_bits<unsigned>(hipemu::to_bits(f)); }
+inline int __float_as_int(float f) { return hipemu::from_bits<int>(hipemu::to_bits(f)); }
+inline float __uint_as_float(unsigned u) { return hipemu::from_bits<float>((uint64_t)u); }
+inline float __int_as_float(int u) { return hipemu::from_bits<float>((uint64_t)(uint32_t)u); }
+inline float __expf(float x) { return expf(x); }
+inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+template <class T> inline T min(T a, T b) { return a < b ? a : b; }
+template <class T> inline T max(T a, T b) { return a > b ? a : b; }
+
+// ---- atomics (fibers never run concurrently, plain RMW is exact) -------------------------
+template <class T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
+template <class T> inline T atomicSub(T* p, T v) { T o = *p; *p = o - v; return o; }
+template <class T> inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
+template <class T> inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
+template <class T> inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
+template <class T> inline T atomicAnd(T* p, T v) { T o = *p; *p = o & v; return o; }
+template <class T> inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
+template <class T> inline T atomicCAS(T* p, T cmp, T v) { T o = *p; if (o == cmp) *p = v; return o; }
