@@ -1,0 +1,96 @@
+"""ctypes binding of libsmarttree_hip.so (the C-ABI declared in include/smarttree_hip.h).
+
+The product path has exactly one backend: the HIP library built for gfx950.  If it is missing,
+or a tensor that is not on the GPU reaches a kernel wrapper, this module raises -- there is no
+CPU fallback.  (tests/hipemu swaps `_LIB` for a CPU *sanitizer build of the same kernel
+sources* inside the CPU test-suite only; nothing in this package refers to it.)
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import c_double, c_float, c_int, c_int64, c_void_p
+from pathlib import Path
+
+import torch
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "libsmarttree_hip.so"
+
+_LIB = None
+_ALLOW_HOST_POINTERS = False  # flipped only by tests/hipemu (CPU sanitizer build of the kernels)
+
+P = c_void_p
+I64 = c_int64
+
+# name -> (restype, argtypes); mirrors include/smarttree_hip.h
+SIGNATURES = {
+    "st_version": (c_int, []),
+    "st_last_error": (ctypes.c_char_p, []),
+    "st_scan_workspace_bytes": (I64, [I64]),
+    "st_scan_u32": (c_int, [P, P, I64, P, P, I64, P]),
+    "st_sort_workspace_bytes": (I64, [I64]),
+    "st_sort_pairs_u32": (c_int, [P, P, I64, c_int, P, I64, P]),
+    "st_voxelize_workspace_bytes": (I64, [I64, c_int, I64]),
+    "st_voxelize_blocks": (c_int, [P, P, I64, c_double, c_double, c_double, c_int, c_int, I64, P, P, P, P, P,
+                                   ctypes.POINTER(I64), ctypes.POINTER(I64), P, I64, P]),
+    "st_hash_capacity": (I64, [I64]),
+    "st_build_coord_hash": (c_int, [P, I64, P, P, I64, P]),
+    "st_build_subm_rulebook": (c_int, [P, I64, P, P, I64, P, P]),
+    "st_strided_workspace_bytes": (I64, [I64]),
+    "st_build_strided_outputs": (c_int, [P, I64, I64, P, P, P, I64, ctypes.POINTER(I64), ctypes.POINTER(ctypes.c_int32),
+                                         P, I64, P]),
+    "st_build_strided_rulebook": (c_int, [P, I64, P, P, I64, P, I64, P, P, I64, ctypes.POINTER(ctypes.c_int32), P, P, P]),
+    "st_sparse_conv_fwd": (c_int, [P, c_int, P, c_int, P, c_int, I64, P, c_int, P, P, P, c_int, P, P]),
+    "st_head_param_floats": (c_int, []),
+    "st_pointwise_mlp_heads": (c_int, [P, I64, P, P, P, P, P, P, P]),
+}
+
+
+def declare(cdll):
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(cdll, name)
+        fn.restype = res
+        fn.argtypes = args
+    return cdll
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not LIB_PATH.exists():
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built. "
+                "Run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
+                "smart_tree_amd has no CPU fallback.")
+        _LIB = declare(ctypes.CDLL(str(LIB_PATH)))
+    return _LIB
+
+
+class StError(RuntimeError):
+    pass
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise StError(f"smarttree_hip error {rc}: {lib().st_last_error().decode()}")
+
+
+def ptr(t):
+    """Device pointer of a contiguous tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda and not _ALLOW_HOST_POINTERS:
+        raise StError("smart_tree_amd kernels need tensors on the GPU (got a CPU tensor); there is no CPU fallback")
+    if not t.is_contiguous():
+        raise StError("smart_tree_amd kernels need contiguous tensors")
+    return t.data_ptr()
+
+
+def stream(device=None):
+    if torch.cuda.is_available() and not _ALLOW_HOST_POINTERS:
+        return torch.cuda.current_stream(device).cuda_stream
+    return None
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)

@@ -23,34 +23,6 @@ extern "C" int st_version(void) { return 100; }
 #define SCAN_ITEMS 8
 #define SCAN_TILE (SCAN_BLOCK * SCAN_ITEMS)
 
-// exclusive scan of one value per thread across the workgroup; *total = workgroup sum.
-// lds needs SCAN_BLOCK/64 + 1 words.  Must be reached by every thread of the workgroup.
-__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* lds, uint32_t* total) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nw = (blockDim.x + 63) >> 6;
-    uint32_t x = v;
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t y = __shfl_up(x, d);
-        if (lane >= d) x += y;
-    }
-    __syncthreads();  // lds may still be read from a previous call
-    if (lane == 63) lds[wave] = x;
-    __syncthreads();
-    if (wave == 0) {
-        uint32_t t = lane < nw ? lds[lane] : 0u;
-        uint32_t s = t;
-        for (int d = 1; d < 64; d <<= 1) {
-            uint32_t y = __shfl_up(s, d);
-            if (lane >= d) s += y;
-        }
-        if (lane < nw) lds[lane] = s - t;
-        if (lane == nw - 1) lds[nw] = s;
-    }
-    __syncthreads();
-    *total = lds[nw];
-    return x - v + lds[wave];
-}
-
 __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_reduce(const uint32_t* in, uint32_t* block_sums, int64_t n) {
     __shared__ uint32_t lds[SCAN_BLOCK / 64 + 1];
     int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;

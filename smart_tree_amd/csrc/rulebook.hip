@@ -1,0 +1,273 @@
+// Rulebooks (neighbour tables) for the sparse convolutions, built on the GPU.
+//
+// Replaces what spconv builds inside every conv call of the reference network
+// (smart_tree/model/model_blocks.py:135-142 constructs all 14 SubMConv3d with indice_key=None, so
+// spconv rebuilds the same 27-offset rulebook 14 times; the strided pairs are stored under
+// indice_key 1..3 by SparseConv3d, :58-67, and re-used by SparseInverseConv3d, :91-98).
+// Here each level's tables are built once and shared by every conv of that level.
+//
+// All tables are OUTPUT-stationary: nbr[k * n_out + o] = input row feeding output row o through
+// kernel offset k (k = (kz*3+ky)*3+kx), or -1.  Orientation follows the oracle
+// (oracle/unet_oracle.py): subm  in = out + (k-1);  strided (k3,s2,p1)  in = 2*out - 1 + k;
+// inverse: the strided pairs with roles swapped, same k.
+// The strided output set is emitted in canonical first-appearance order (inputs in row order,
+// k ascending) via hash insert with atomicMin(candidate id) + ordered compaction -- no sort, no
+// atomics-order dependence, bit-reproducible.
+#include "st_common.h"
+
+#define RB_BLOCK 256
+
+static inline unsigned rb_grid(int64_t n) {
+    int64_t g = st_div_up(n > 0 ? n : 1, RB_BLOCK);
+    return (unsigned)(g < 8192 ? g : 8192);
+}
+
+__global__ void __launch_bounds__(RB_BLOCK) k_rb_insert(const int32_t* coords, int64_t n, unsigned long long* keys,
+                                                        unsigned* vals, unsigned long long cap, unsigned* fail) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        unsigned long long key = st_pack_key(coords[4 * i], coords[4 * i + 1], coords[4 * i + 2], coords[4 * i + 3]);
+        if (!st_hash_insert_min(keys, vals, cap, key, (unsigned)i) && fail) atomicOr(fail, 1u);
+    }
+}
+
+__global__ void __launch_bounds__(RB_BLOCK) k_rb_subm(const int32_t* coords, int64_t n, const unsigned long long* keys,
+                                                      const unsigned* vals, unsigned long long cap, int32_t* nbr) {
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < n; o += (int64_t)gridDim.x * blockDim.x) {
+        int b = coords[4 * o], z = coords[4 * o + 1], y = coords[4 * o + 2], x = coords[4 * o + 3];
+        int k = 0;
+        for (int dz = -1; dz <= 1; dz++)
+            for (int dy = -1; dy <= 1; dy++)
+                for (int dx = -1; dx <= 1; dx++, k++) {
+                    int zz = z + dz, yy = y + dy, xx = x + dx;
+                    int r = -1;
+                    if (k == 13) r = (int)o;
+                    else if (zz >= 0 && yy >= 0 && xx >= 0 && zz < 65535 && yy < 65535 && xx < 65535)
+                        r = st_hash_find(keys, vals, cap, st_pack_key(b, zz, yy, xx));
+                    nbr[(int64_t)k * n + o] = r;
+                }
+    }
+}
+
+struct RbState {
+    int ext[3];       // max coordinate per axis (z,y,x) over the whole batch
+    uint32_t n_out;
+    uint32_t fail;
+};
+
+__global__ void k_rb_state_init(RbState* st) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { st->ext[0] = st->ext[1] = st->ext[2] = 0; st->n_out = 0; st->fail = 0; }
+}
+
+__global__ void __launch_bounds__(RB_BLOCK) k_rb_extent(const int32_t* coords, int64_t n, RbState* st) {
+    __shared__ int m[3];
+    if (threadIdx.x < 3) m[threadIdx.x] = 0;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        for (int a = 0; a < 3; a++) {
+            int c = coords[4 * i + 1 + a];
+            if (c > m[a]) atomicMax(&m[a], c);
+        }
+    __syncthreads();
+    if (threadIdx.x < 3) atomicMax(&st->ext[threadIdx.x], m[threadIdx.x]);
+}
+
+// candidate outputs of input voxel i: o = (c + 1 - k) / 2 per axis when even and inside out_shape
+// PASS 0: insert(o -> min candidate id i*27+k); PASS 1: count candidates that won; PASS 2: emit rows
+template <int PASS>
+__global__ void __launch_bounds__(RB_BLOCK) k_rb_down_pass(const int32_t* coords, int64_t n, RbState* st,
+                                                           unsigned long long* keys, unsigned* vals, unsigned long long cap,
+                                                           uint32_t* cnt_or_off, int32_t* out_coords, int64_t max_out) {
+    int oshape[3];
+    for (int a = 0; a < 3; a++) oshape[a] = st->ext[a] / 2 + 1;  // ((ext+1) - 1)/2 + 1
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int b = coords[4 * i], c[3] = {coords[4 * i + 1], coords[4 * i + 2], coords[4 * i + 3]};
+        uint32_t mine = 0;
+        uint32_t off = PASS == 2 ? cnt_or_off[i] : 0u;
+        int k = 0;
+        for (int kz = 0; kz < 3; kz++)
+            for (int ky = 0; ky < 3; ky++)
+                for (int kx = 0; kx < 3; kx++, k++) {
+                    int nz = c[0] + 1 - kz, ny = c[1] + 1 - ky, nx = c[2] + 1 - kx;
+                    if ((nz | ny | nx) & 1) continue;
+                    if (nz < 0 || ny < 0 || nx < 0) continue;
+                    int oz = nz >> 1, oy = ny >> 1, ox = nx >> 1;
+                    if (oz >= oshape[0] || oy >= oshape[1] || ox >= oshape[2]) continue;
+                    unsigned long long key = st_pack_key(b, oz, oy, ox);
+                    unsigned cand = (unsigned)(i * 27 + k);
+                    if (PASS == 0) {
+                        if (!st_hash_insert_min(keys, vals, cap, key, cand)) atomicOr(&st->fail, 1u);
+                    } else {
+                        // find the slot: the winner is the candidate whose id is stored there
+                        unsigned long long slot = st_hash64(key) & (cap - 1);
+                        while (keys[slot] != key) slot = (slot + 1) & (cap - 1);
+                        if (PASS == 1) {
+                            if (vals[slot] == cand) mine++;
+                        } else if (vals[slot] == cand) {
+                            uint32_t row = off + mine;
+                            if ((int64_t)row < max_out) {
+                                out_coords[4 * row] = b;
+                                out_coords[4 * row + 1] = oz;
+                                out_coords[4 * row + 2] = oy;
+                                out_coords[4 * row + 3] = ox;
+                            }
+                            mine++;
+                        }
+                    }
+                }
+        if (PASS == 1) cnt_or_off[i] = mine;
+    }
+}
+
+// after compaction: table value := output row (was: winning candidate id)
+__global__ void __launch_bounds__(RB_BLOCK) k_rb_relabel(const int32_t* out_coords, int64_t m, const unsigned long long* keys,
+                                                         unsigned* vals, unsigned long long cap) {
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < m; o += (int64_t)gridDim.x * blockDim.x) {
+        unsigned long long key = st_pack_key(out_coords[4 * o], out_coords[4 * o + 1], out_coords[4 * o + 2], out_coords[4 * o + 3]);
+        unsigned long long slot = st_hash64(key) & (cap - 1);
+        while (keys[slot] != key) slot = (slot + 1) & (cap - 1);
+        vals[slot] = (unsigned)o;
+    }
+}
+
+__global__ void __launch_bounds__(RB_BLOCK) k_rb_down_nbr(const int32_t* out_coords, int64_t m, const unsigned long long* fkeys,
+                                                          const unsigned* fvals, unsigned long long fcap, int32_t* nbr) {
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < m; o += (int64_t)gridDim.x * blockDim.x) {
+        int b = out_coords[4 * o], z = out_coords[4 * o + 1], y = out_coords[4 * o + 2], x = out_coords[4 * o + 3];
+        int k = 0;
+        for (int kz = 0; kz < 3; kz++)
+            for (int ky = 0; ky < 3; ky++)
+                for (int kx = 0; kx < 3; kx++, k++) {
+                    int zz = 2 * z - 1 + kz, yy = 2 * y - 1 + ky, xx = 2 * x - 1 + kx;
+                    int r = -1;
+                    if (zz >= 0 && yy >= 0 && xx >= 0 && zz < 65535 && yy < 65535 && xx < 65535)
+                        r = st_hash_find(fkeys, fvals, fcap, st_pack_key(b, zz, yy, xx));
+                    nbr[(int64_t)k * m + o] = r;
+                }
+    }
+}
+
+struct RbShape { int v[3]; };
+
+__global__ void __launch_bounds__(RB_BLOCK) k_rb_up_nbr(const int32_t* coords, int64_t n, RbShape osh,
+                                                        const unsigned long long* ckeys, const unsigned* cvals,
+                                                        unsigned long long ccap, int32_t* nbr) {
+    int oshape[3] = {osh.v[0], osh.v[1], osh.v[2]};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int b = coords[4 * i], c[3] = {coords[4 * i + 1], coords[4 * i + 2], coords[4 * i + 3]};
+        int k = 0;
+        for (int kz = 0; kz < 3; kz++)
+            for (int ky = 0; ky < 3; ky++)
+                for (int kx = 0; kx < 3; kx++, k++) {
+                    int nz = c[0] + 1 - kz, ny = c[1] + 1 - ky, nx = c[2] + 1 - kx;
+                    int r = -1;
+                    if (!((nz | ny | nx) & 1) && nz >= 0 && ny >= 0 && nx >= 0) {
+                        int oz = nz >> 1, oy = ny >> 1, ox = nx >> 1;
+                        if (oz < oshape[0] && oy < oshape[1] && ox < oshape[2])
+                            r = st_hash_find(ckeys, cvals, ccap, st_pack_key(b, oz, oy, ox));
+                    }
+                    nbr[(int64_t)k * n + i] = r;
+                }
+    }
+}
+
+extern "C" int64_t st_hash_capacity(int64_t n) { return st_next_pow2(2 * (n > 0 ? n : 1)); }
+
+extern "C" int st_build_coord_hash(const int32_t* coords, int64_t n, unsigned long long* keys, unsigned* vals, int64_t cap,
+                                   void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    ST_REQUIRE(cap >= 2 * n && (cap & (cap - 1)) == 0, "coord hash: capacity must be a power of two >= 2n");
+    (void)hipMemsetAsync(keys, 0xff, cap * sizeof(unsigned long long), stream);
+    (void)hipMemsetAsync(vals, 0xff, cap * sizeof(unsigned), stream);
+    if (n > 0) {
+        // capacity >= 2n: an insert can never run out of slots, the flag word is only a guard
+        hipLaunchKernelGGL(k_rb_insert, dim3(rb_grid(n)), dim3(RB_BLOCK), 0, stream, coords, n, keys, vals,
+                           (unsigned long long)cap, (unsigned*)nullptr);
+    }
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}
+
+extern "C" int st_build_subm_rulebook(const int32_t* coords, int64_t n, const unsigned long long* keys, const unsigned* vals,
+                                      int64_t cap, int32_t* nbr, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n <= 0) return ST_OK;
+    hipLaunchKernelGGL(k_rb_subm, dim3(rb_grid(n)), dim3(RB_BLOCK), 0, stream, coords, n, keys, vals, (unsigned long long)cap,
+                       nbr);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}
+
+extern "C" int64_t st_strided_workspace_bytes(int64_t n_fine) {
+    StArena a(nullptr, 0);
+    a.take<RbState>(1);
+    a.take<uint32_t>(n_fine);
+    a.take<char>(st_scan_ws_bytes(n_fine));
+    return a.used;
+}
+
+// Phase 1: discover the coarse active set (canonical order), build its hash.  Returns n_out on the host.
+extern "C" int st_build_strided_outputs(const int32_t* coords, int64_t n, int64_t max_out, int32_t* out_coords,
+                                        unsigned long long* ckeys, unsigned* cvals, int64_t ccap, int64_t* n_out_host,
+                                        int32_t* extent_host /*[3] max (z,y,x) coordinate*/, void* ws, int64_t ws_bytes,
+                                        void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    *n_out_host = 0;
+    extent_host[0] = extent_host[1] = extent_host[2] = 0;
+    ST_REQUIRE(ccap >= 2 * max_out && (ccap & (ccap - 1)) == 0, "strided: coarse hash capacity must be a power of two >= 2*max_out");
+    ST_REQUIRE(n < (1ll << 31) / 27, "strided: too many voxels for 32-bit candidate ids");
+    StArena a(ws, ws_bytes);
+    RbState* st = a.take<RbState>(1);
+    uint32_t* cnt = a.take<uint32_t>(n);
+    int64_t scan_bytes = st_scan_ws_bytes(n);
+    char* scan_ws = a.take<char>(scan_bytes);
+    if (!st || !cnt || !scan_ws) {
+        st_set_error("strided: workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)a.used);
+        return ST_ERR_WORKSPACE;
+    }
+    (void)hipMemsetAsync(ckeys, 0xff, ccap * sizeof(unsigned long long), stream);
+    (void)hipMemsetAsync(cvals, 0xff, ccap * sizeof(unsigned), stream);
+    hipLaunchKernelGGL(k_rb_state_init, dim3(1), dim3(64), 0, stream, st);
+    if (n == 0) return ST_OK;
+    const unsigned g = rb_grid(n);
+    hipLaunchKernelGGL(k_rb_extent, dim3(g), dim3(RB_BLOCK), 0, stream, coords, n, st);
+    hipLaunchKernelGGL((k_rb_down_pass<0>), dim3(g), dim3(RB_BLOCK), 0, stream, coords, n, st, ckeys, cvals,
+                       (unsigned long long)ccap, cnt, out_coords, max_out);
+    RbState h;
+    (void)hipMemcpyAsync(&h, st, sizeof(RbState), hipMemcpyDeviceToHost, stream);
+    (void)hipStreamSynchronize(stream);
+    ST_REQUIRE(!h.fail, "strided: more than max_out=%lld output voxels", (long long)max_out);
+    hipLaunchKernelGGL((k_rb_down_pass<1>), dim3(g), dim3(RB_BLOCK), 0, stream, coords, n, st, ckeys, cvals,
+                       (unsigned long long)ccap, cnt, out_coords, max_out);
+    ST_TRY(st_exclusive_scan_u32(cnt, cnt, n, &st->n_out, scan_ws, scan_bytes, stream));
+    hipLaunchKernelGGL((k_rb_down_pass<2>), dim3(g), dim3(RB_BLOCK), 0, stream, coords, n, st, ckeys, cvals,
+                       (unsigned long long)ccap, cnt, out_coords, max_out);
+    (void)hipMemcpyAsync(&h, st, sizeof(RbState), hipMemcpyDeviceToHost, stream);
+    (void)hipStreamSynchronize(stream);
+    ST_CHECK_LAUNCH();
+    ST_REQUIRE((int64_t)h.n_out <= max_out, "strided: %u output voxels exceed max_out=%lld", h.n_out, (long long)max_out);
+    *n_out_host = h.n_out;
+    for (int a = 0; a < 3; a++) extent_host[a] = h.ext[a];
+    if (h.n_out)
+        hipLaunchKernelGGL(k_rb_relabel, dim3(rb_grid(h.n_out)), dim3(RB_BLOCK), 0, stream, (const int32_t*)out_coords,
+                           (int64_t)h.n_out, (const unsigned long long*)ckeys, cvals, (unsigned long long)ccap);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}
+
+// Phase 2: the two neighbour tables of the pair set: nbr_down [27][n_out] (fine rows), nbr_up [27][n] (coarse rows)
+extern "C" int st_build_strided_rulebook(const int32_t* coords, int64_t n, const unsigned long long* fkeys,
+                                         const unsigned* fvals, int64_t fcap, const int32_t* out_coords, int64_t n_out,
+                                         const unsigned long long* ckeys, const unsigned* cvals, int64_t ccap,
+                                         const int32_t* extent_host, int32_t* nbr_down, int32_t* nbr_up, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n == 0) return ST_OK;
+    RbShape osh;
+    for (int a = 0; a < 3; a++) osh.v[a] = extent_host[a] / 2 + 1;
+    if (n_out)
+        hipLaunchKernelGGL(k_rb_down_nbr, dim3(rb_grid(n_out)), dim3(RB_BLOCK), 0, stream, out_coords, n_out, fkeys, fvals,
+                           (unsigned long long)fcap, nbr_down);
+    hipLaunchKernelGGL(k_rb_up_nbr, dim3(rb_grid(n)), dim3(RB_BLOCK), 0, stream, coords, n, osh, ckeys, cvals,
+                       (unsigned long long)ccap, nbr_up);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}

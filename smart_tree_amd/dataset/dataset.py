@@ -1,0 +1,90 @@
+"""Inference-side blocking + voxelisation, device resident.
+
+Reference: `SingleTreeInference` (smart_tree/dataset/dataset.py:144-229) cuts the cloud into 4 m
+blocks with a 0.4 m halo through a host loop of full-cloud masks and per-block D->H copies, then
+voxelises each block on the CPU with spconv's `PointToVoxel` inside a DataLoader
+(`load_dataloader`, :232-242) and `batch_collate`s <=4 blocks (smart_tree/model/sparse.py:40-61).
+Here the whole of it is one call into `st_voxelize_blocks` (csrc/voxelize.hip); every block of
+the cloud lands in a single batch (eval-mode BatchNorm: batching cannot change a value) in the
+deterministic order "blocks as torch.unique sorts them, voxels by first point" -- the order the
+reference would produce with its accidental `shuffle=True` removed.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from .. import _lib
+from ..data_types.cloud import Cloud
+
+
+@dataclass
+class VoxelBatch:
+    feats: torch.Tensor  # [M,6] float32 representative point (xyz, rgb)
+    coords: torch.Tensor  # [M,4] int32 (block, z, y, x)
+    mask: torch.Tensor  # [M] bool: representative point inside the un-buffered block
+    point_index: torch.Tensor  # [M] int64 index of the representative point in the input cloud
+    block_centres: torch.Tensor  # [B,3] float32
+
+
+def voxelize_blocks(xyz: torch.Tensor, rgb: Optional[torch.Tensor], voxel_size: float, block_size: float = 4,
+                    buffer_size: float = 0.4, min_points: int = 20, max_blocks: int = 4096) -> VoxelBatch:
+    L = _lib.lib()
+    dev = xyz.device
+    xyz = xyz.contiguous().float()
+    rgb = rgb.contiguous().float() if rgb is not None else None
+    n = xyz.shape[0]
+    n_vox, n_blk = ctypes.c_int64(0), ctypes.c_int64(0)
+    for cap in (3 * n + 1024, 8 * n + 1024):  # a point sits in <= 8 halo cubes
+        feats = torch.empty((cap, 6), dtype=torch.float32, device=dev)
+        coords = torch.empty((cap, 4), dtype=torch.int32, device=dev)
+        mask = torch.empty((cap,), dtype=torch.uint8, device=dev)
+        pidx = torch.empty((cap,), dtype=torch.int64, device=dev)
+        centres = torch.empty((max_blocks, 3), dtype=torch.float32, device=dev)
+        ws = _lib.workspace(L.st_voxelize_workspace_bytes(n, max_blocks, cap), dev)
+        rc = L.st_voxelize_blocks(_lib.ptr(xyz), _lib.ptr(rgb), n, float(voxel_size), float(block_size),
+                                  float(buffer_size), int(min_points), int(max_blocks), cap, _lib.ptr(feats),
+                                  _lib.ptr(coords), _lib.ptr(mask), _lib.ptr(pidx), _lib.ptr(centres),
+                                  ctypes.byref(n_vox), ctypes.byref(n_blk), _lib.ptr(ws), ws.numel(), _lib.stream(dev))
+        if rc == 0 or b"exceed max_voxels" not in L.st_last_error():
+            break
+    _lib.check(rc)
+    m, b = n_vox.value, n_blk.value
+    return VoxelBatch(feats[:m], coords[:m], mask[:m].bool(), pidx[:m], centres[:b])
+
+
+class SingleTreeInference:
+    """Same constructor surface as the reference class (dataset.py:145-164)."""
+
+    def __init__(self, cloud: Cloud, voxel_size: float, block_size: float = 4, buffer_size: float = 0.4,
+                 min_points: int = 20, file_name=None, device=None):
+        self.cloud = cloud
+        self.voxel_size = voxel_size
+        self.block_size = block_size
+        self.buffer_size = buffer_size
+        self.min_points = min_points
+        self.file_name = file_name
+        self.batch = voxelize_blocks(cloud.xyz, cloud.rgb, voxel_size, block_size, buffer_size, min_points)
+        self.block_centres = self.batch.block_centres
+
+    def __len__(self) -> int:
+        return self.block_centres.shape[0]
+
+    def __getitem__(self, idx):
+        """(feats, coords, mask, filename) of block idx, coords[:,0] = 0 as dataset.py:218-226."""
+        sel = self.batch.coords[:, 0] == idx
+        coords = self.batch.coords[sel].clone()
+        coords[:, 0] = 0
+        return self.batch.feats[sel], coords, self.batch.mask[sel], self.file_name
+
+
+def load_dataloader(cloud: Cloud, voxel_size: float, block_size: float, buffer_size: float, num_workers: float,
+                    batch_size: float):
+    """Reference signature (dataset.py:232-242).  Yields ONE collated batch holding every block;
+    `num_workers` / `batch_size` are accepted for drop-in compatibility and ignored."""
+    ds = SingleTreeInference(cloud, voxel_size, block_size, buffer_size)
+    b = ds.batch
+    return [(b.feats, b.coords, b.mask, ds.file_name)]

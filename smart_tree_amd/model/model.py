@@ -1,0 +1,132 @@
+"""The Smart_Tree network as the shipped checkpoints define it, executed by HIP kernels.
+
+Reference: `Smart_Tree.forward` (smart_tree/model/model.py:77-87) over `SubMConvBlock`, `UBlock`,
+`ResBlock`, `EncoderBlock`, `DecoderBlock`, `SparseFC` (smart_tree/model/model_blocks.py).  The
+graph is rebuilt from the state_dict's key names and shapes -- the pickled
+module `*_model.pt` is never unpickled.  `forward(sparse_input)` keeps the reference contract:
+input exposes `.features [N,3]` / `.indices [N,4] int32 (b,z,y,x)`, output is the dict
+{"radius" [N,1] (log radius), "direction" [N,3] (unit), "class_l" [N,2] (logits)}.
+"""
+from __future__ import annotations
+
+from typing import Dict, Mapping
+
+import numpy as np
+import torch
+
+from . import sparse_ops as ops
+
+BN_EPS = 1e-4  # attribute stored in the checkpoints (model.py:23 would default to 1e-5)
+
+
+def _conv_weight(t: torch.Tensor) -> torch.Tensor:
+    """[Cout, kz, ky, kx, Cin] -> [K, Cin, Cout] (k = (kz*3+ky)*3+kx)."""
+    cout, cin = t.shape[0], t.shape[-1]
+    return t.reshape(cout, -1, cin).permute(1, 2, 0).contiguous().float()
+
+
+class _Affine:
+    """Eval-mode BatchNorm1d folded to y*scale + shift (computed in float64, stored float32)."""
+
+    def __init__(self, sd: Mapping[str, torch.Tensor], prefix: str, device):
+        g = sd[prefix + ".weight"].double()
+        b = sd[prefix + ".bias"].double()
+        m = sd[prefix + ".running_mean"].double()
+        v = sd[prefix + ".running_var"].double()
+        s = g / torch.sqrt(v + BN_EPS)
+        self.scale = s.float().contiguous().to(device)
+        self.shift = (b - m * s).float().contiguous().to(device)
+
+
+class Smart_Tree:
+    def __init__(self, state_dict: Mapping[str, torch.Tensor], device=torch.device("cuda:0")):
+        sd = {k: torch.as_tensor(np.asarray(v)) if not torch.is_tensor(v) else v.detach().cpu()
+              for k, v in state_dict.items()}
+        self._state = sd
+        self.device = torch.device(device)
+        self.depth = 0
+        while f"UNet.{'U.' * (self.depth + 1)}Head.sequence.0.weight" in sd:
+            self.depth += 1
+        self.planes = [sd[f"UNet.{'U.' * l}Head.sequence.0.weight"].shape[0] for l in range(self.depth + 1)]
+        self.w: Dict[str, torch.Tensor] = {}
+        self.bn: Dict[str, _Affine] = {}
+        for key, t in sd.items():
+            if key.endswith(".weight") and t.ndim == 5 and "_head." not in key:
+                self.w[key[: -len(".weight")]] = _conv_weight(t).to(self.device)
+            elif key.endswith(".running_mean") and "_head." not in key:
+                p = key[: -len(".running_mean")]
+                self.bn[p] = _Affine(sd, p, self.device)
+        self.head_params = self._pack_heads(sd).to(self.device)
+
+    # nn.Module look-alikes so reference call sites keep working
+    def eval(self):
+        return self
+
+    def to(self, device):
+        return self if torch.device(device) == self.device else Smart_Tree(self._state, device)
+
+    @staticmethod
+    def _pack_heads(sd) -> torch.Tensor:
+        """radius / direction / class heads -> the packed block `st_pointwise_mlp_heads` expects."""
+        blocks = []
+        for name, nout in (("radius_head", 1), ("direction_head", 3), ("class_head", 2)):
+            def mat(i):  # [Cout,1,1,1,Cin] -> [Cin, Cout]
+                t = sd[f"{name}.sequence.{i}.weight"]
+                return t.reshape(t.shape[0], t.shape[-1]).T.contiguous().double()
+
+            def affine(i):
+                g, b = sd[f"{name}.sequence.{i}.weight"].double(), sd[f"{name}.sequence.{i}.bias"].double()
+                m, v = sd[f"{name}.sequence.{i}.running_mean"].double(), sd[f"{name}.sequence.{i}.running_var"].double()
+                s = g / torch.sqrt(v + BN_EPS)
+                return s, b - m * s
+
+            s1, t1 = affine(1)
+            s2, t2 = affine(4)
+            w3 = torch.zeros(12, dtype=torch.float64)
+            w3[: 4 * nout] = mat(6).reshape(-1)
+            blocks.append(torch.cat([mat(0).reshape(-1), s1, t1, mat(3).reshape(-1), s2, t2, w3]))
+        return torch.cat(blocks).float().contiguous()
+
+    # -- building blocks ---------------------------------------------------------------------
+    def _conv(self, name, x, nbr, n_out, x1=None, bn=None, residual=None, relu=False):
+        a = self.bn[bn] if bn else None
+        return ops.sparse_conv(x, self.w[name], nbr, n_out, x1=x1, scale=a.scale if a else None,
+                               shift=a.shift if a else None, residual=residual, relu=relu)
+
+    def _res_block(self, prefix, x, nbr, x1=None):
+        """ResBlock.forward (model_blocks.py:149-156); x1 != None is the Tail on cat(skip, decoded)."""
+        n = x.shape[0]
+        h = self._conv(prefix + ".sequence.0", x, nbr, n, x1=x1, bn=prefix + ".sequence.1", relu=True)
+        ident = self._conv(prefix + ".identity.0", x, None, n, x1=x1) if x1 is not None else x
+        return self._conv(prefix + ".sequence.3", h, nbr, n, bn=prefix + ".sequence.4", residual=ident, relu=True)
+
+    def _ublock(self, prefix, x, pyr, level):
+        """UBlock.forward (model_blocks.py:224-243)."""
+        x = self._res_block(prefix + ".Head", x, pyr.subm[level])
+        if level == self.depth:
+            return x
+        n_fine, n_coarse = x.shape[0], pyr.coords[level + 1].shape[0]
+        z = self._conv(prefix + ".Encode.sequence.0", x, pyr.down[level], n_coarse, bn=prefix + ".Encode.sequence.1",
+                       relu=True)
+        z = self._ublock(prefix + ".U", z, pyr, level + 1)
+        d = self._conv(prefix + ".Decode.sequence.0", z, pyr.up[level], n_fine, bn=prefix + ".Decode.sequence.1",
+                       relu=True)
+        return self._res_block(prefix + ".Tail", x, pyr.subm[level], x1=d)
+
+    def features(self, sparse_input):
+        """input conv + UNet -> [N, planes[0]] features of the finest level."""
+        coords = sparse_input.indices.contiguous()
+        feats = sparse_input.features.contiguous().float()
+        pyr = ops.build_pyramid(coords, self.depth)
+        x = self._conv("input_conv.sequence.0", feats, None, feats.shape[0], bn="input_conv.sequence.1", relu=True)
+        return self._ublock("UNet", x, pyr, 0)
+
+    def forward(self, sparse_input) -> Dict[str, torch.Tensor]:
+        radius, direction, class_l, _, _ = ops.mlp_heads(self.features(sparse_input), self.head_params)
+        return {"radius": radius, "direction": direction, "class_l": class_l}
+
+    __call__ = forward
+
+    def forward_fused_tail(self, sparse_input):
+        """forward() plus ModelInference's exp(radius)*direction and argmax in the same kernel."""
+        return ops.mlp_heads(self.features(sparse_input), self.head_params, with_tail=True)

@@ -1,0 +1,54 @@
+"""Sparse tensor container + batch helpers (reference smart_tree/model/sparse.py:9-61).
+
+`SparseConvTensor` stands in for spconv's class with the attributes the reference touches
+(`features`, `indices`, `spatial_shape`, `batch_size`, `replace_feature`; uses at
+model_blocks.py:149-155,227-240 and sparse.py:17-19).
+"""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+
+
+class SparseConvTensor:
+    def __init__(self, features: torch.Tensor, indices: torch.Tensor, spatial_shape, batch_size: int):
+        self.features = features
+        self.indices = indices  # [N,4] int32 (batch, z, y, x)
+        self.spatial_shape = spatial_shape
+        self.batch_size = batch_size
+        self.indice_dict = {}
+
+    def replace_feature(self, new_features: torch.Tensor) -> "SparseConvTensor":
+        out = SparseConvTensor(new_features, self.indices, self.spatial_shape, self.batch_size)
+        out.indice_dict = self.indice_dict
+        return out
+
+
+def sparse_from_batch(features: torch.Tensor, coordinates: torch.Tensor, device) -> SparseConvTensor:
+    """Reference sparse.py:9-19, quirks kept on the attributes: spatial_shape = max coordinate (not
+    +1) and batch_size = number of voxels.  The kernels derive the true extent from the indices."""
+    batch_size = features.shape[0]
+    features = features.to(device)
+    coordinates = coordinates.to(device)
+    if coordinates.shape[0]:
+        values, _ = torch.max(coordinates, 0)
+        shape = values[1:]
+    else:
+        shape = torch.zeros(3, dtype=coordinates.dtype, device=device)
+    return SparseConvTensor(features.contiguous(), coordinates.int().contiguous(), shape, batch_size=batch_size)
+
+
+def batch_collate(batch):
+    """Reference sparse.py:40-61 (inference form): write the sample index into coords[:,0], concatenate."""
+    feats, coords, masks, names = zip(*batch)
+    coords = [c.clone() for c in coords]
+    for i, c in enumerate(coords):
+        c[:, 0] = i
+    return [torch.cat(feats), torch.cat(coords), torch.cat(masks), names]
+
+
+def split_sparse(sparse_tensor: SparseConvTensor) -> List:
+    ids = sparse_tensor.indices[:, 0]
+    n = int(ids.max().item()) + 1 if ids.numel() else 0
+    return [(sparse_tensor.indices[ids == i], sparse_tensor.features[ids == i]) for i in range(n)]

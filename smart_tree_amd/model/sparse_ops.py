@@ -1,0 +1,128 @@
+"""Thin torch-tensor wrappers over the C-ABI rulebook / conv entry points (csrc/rulebook.hip,
+csrc/sparse_conv.hip).  Every function allocates its outputs with torch (plumbing only) and
+enqueues on the current HIP stream."""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import torch
+
+from .. import _lib
+
+
+@dataclass
+class CoordHash:
+    keys: torch.Tensor  # [cap] int64 (bit pattern of the u64 keys)
+    vals: torch.Tensor  # [cap] int32
+    cap: int
+
+
+def build_coord_hash(coords: torch.Tensor) -> CoordHash:
+    L = _lib.lib()
+    n = coords.shape[0]
+    cap = L.st_hash_capacity(n)
+    keys = torch.empty(cap, dtype=torch.int64, device=coords.device)
+    vals = torch.empty(cap, dtype=torch.int32, device=coords.device)
+    _lib.check(L.st_build_coord_hash(_lib.ptr(coords), n, _lib.ptr(keys), _lib.ptr(vals), cap, _lib.stream(coords.device)))
+    return CoordHash(keys, vals, cap)
+
+
+def build_subm_rulebook(coords: torch.Tensor, h: CoordHash) -> torch.Tensor:
+    """nbr [27, N] int32: input row at o + (k-1) or -1."""
+    L = _lib.lib()
+    n = coords.shape[0]
+    nbr = torch.empty((27, n), dtype=torch.int32, device=coords.device)
+    _lib.check(L.st_build_subm_rulebook(_lib.ptr(coords), n, _lib.ptr(h.keys), _lib.ptr(h.vals), h.cap, _lib.ptr(nbr),
+                                        _lib.stream(coords.device)))
+    return nbr
+
+
+@dataclass
+class StridedRulebook:
+    out_coords: torch.Tensor  # [M,4] int32 coarse active set, canonical order
+    out_hash: CoordHash
+    nbr_down: torch.Tensor  # [27, M] fine rows
+    nbr_up: torch.Tensor  # [27, N] coarse rows
+
+
+def build_strided_rulebook(coords: torch.Tensor, h: CoordHash) -> StridedRulebook:
+    L = _lib.lib()
+    dev = coords.device
+    n = coords.shape[0]
+    ws = _lib.workspace(L.st_strided_workspace_bytes(n), dev)
+    n_out = ctypes.c_int64(0)
+    extent = (ctypes.c_int32 * 3)()
+    rc = -1
+    for max_out in (2 * n + 1024, 8 * n + 1024):  # k3 s2 p1: an input reaches <= 8 outputs
+        out_coords = torch.empty((max_out, 4), dtype=torch.int32, device=dev)
+        ccap = L.st_hash_capacity(max_out)
+        ckeys = torch.empty(ccap, dtype=torch.int64, device=dev)
+        cvals = torch.empty(ccap, dtype=torch.int32, device=dev)
+        rc = L.st_build_strided_outputs(_lib.ptr(coords), n, max_out, _lib.ptr(out_coords), _lib.ptr(ckeys),
+                                        _lib.ptr(cvals), ccap, ctypes.byref(n_out), extent, _lib.ptr(ws), ws.numel(),
+                                        _lib.stream(dev))
+        if rc == 0 or b"max_out" not in L.st_last_error():
+            break
+    _lib.check(rc)
+    m = n_out.value
+    out_coords = out_coords[:m].contiguous()
+    nbr_down = torch.empty((27, m), dtype=torch.int32, device=dev)
+    nbr_up = torch.empty((27, n), dtype=torch.int32, device=dev)
+    _lib.check(L.st_build_strided_rulebook(_lib.ptr(coords), n, _lib.ptr(h.keys), _lib.ptr(h.vals), h.cap,
+                                           _lib.ptr(out_coords), m, _lib.ptr(ckeys), _lib.ptr(cvals), ccap, extent,
+                                           _lib.ptr(nbr_down), _lib.ptr(nbr_up), _lib.stream(dev)))
+    return StridedRulebook(out_coords, CoordHash(ckeys, cvals, ccap), nbr_down, nbr_up)
+
+
+@dataclass
+class RulebookPyramid:
+    """Per-level active sets and neighbour tables of one batch; built once, shared by all convs."""
+    coords: List[torch.Tensor] = field(default_factory=list)
+    subm: List[torch.Tensor] = field(default_factory=list)
+    down: List[torch.Tensor] = field(default_factory=list)  # down[l]: level l -> l+1
+    up: List[torch.Tensor] = field(default_factory=list)  # up[l]:   level l+1 -> l
+
+
+def build_pyramid(coords: torch.Tensor, depth: int) -> RulebookPyramid:
+    pyr = RulebookPyramid()
+    h = build_coord_hash(coords)
+    for level in range(depth + 1):
+        pyr.coords.append(coords)
+        pyr.subm.append(build_subm_rulebook(coords, h))
+        if level == depth:
+            break
+        s = build_strided_rulebook(coords, h)
+        pyr.down.append(s.nbr_down)
+        pyr.up.append(s.nbr_up)
+        coords, h = s.out_coords, s.out_hash
+    return pyr
+
+
+def sparse_conv(x0: torch.Tensor, w: torch.Tensor, nbr: Optional[torch.Tensor], n_out: int,
+                x1: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None,
+                shift: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+                relu: bool = False) -> torch.Tensor:
+    """y = act(bn(sum_k W_k . cat(x0, x1)[nbr[k]]) + residual); w is [K, Cin, Cout]."""
+    L = _lib.lib()
+    K, cin, cout = w.shape
+    c0 = x0.shape[1]
+    y = torch.empty((n_out, cout), dtype=torch.float32, device=x0.device)
+    _lib.check(L.st_sparse_conv_fwd(_lib.ptr(x0), c0, _lib.ptr(x1), cin, _lib.ptr(nbr), K, n_out, _lib.ptr(w), cout,
+                                    _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(residual), int(relu), _lib.ptr(y),
+                                    _lib.stream(x0.device)))
+    return y
+
+
+def mlp_heads(x: torch.Tensor, params: torch.Tensor, with_tail: bool = False):
+    L = _lib.lib()
+    n, dev = x.shape[0], x.device
+    radius = torch.empty((n, 1), dtype=torch.float32, device=dev)
+    direction = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    class_l = torch.empty((n, 2), dtype=torch.float32, device=dev)
+    mv = torch.empty((n, 3), dtype=torch.float32, device=dev) if with_tail else None
+    cls = torch.empty((n, 1), dtype=torch.int64, device=dev) if with_tail else None
+    _lib.check(L.st_pointwise_mlp_heads(_lib.ptr(x), n, _lib.ptr(params), _lib.ptr(radius), _lib.ptr(direction),
+                                        _lib.ptr(class_l), _lib.ptr(mv), _lib.ptr(cls), _lib.stream(dev)))
+    return radius, direction, class_l, mv, cls

@@ -1,0 +1,112 @@
+"""Rulebooks (bit-exact) and network outputs (fp32 tolerance) of the HIP path vs oracle/unet_oracle.py."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import unet_oracle as uo
+from oracle import voxel_oracle as vo
+from smart_tree_amd.model import sparse_ops as ops
+from smart_tree_amd.model.model import Smart_Tree
+from smart_tree_amd.model.sparse import sparse_from_batch
+from smart_tree_amd.synthetic import sample_tree_cloud
+
+WEIGHTS = Path(__file__).resolve().parents[1] / "smart_tree_amd" / "model" / "weights"
+
+
+def _small_batch(n=6000, voxel=0.05, seed=5):
+    c = sample_tree_cloud(n, seed=seed, scale=0.6, max_depth=4)
+    xyz = vo.centre_cloud(c["xyz"])
+    return vo.voxelize_cloud(xyz, c["rgb"], voxel, block_size=2.0, buffer_size=0.2)
+
+
+def test_rulebooks_bit_exact(backend):
+    vx = _small_batch()
+    coords = torch.from_numpy(vx["coords"]).to(backend)
+    pyr = ops.build_pyramid(coords, depth=3)
+    level_coords = vx["coords"]
+    for level in range(4):
+        np.testing.assert_array_equal(pyr.coords[level].cpu().numpy(), level_coords)
+        np.testing.assert_array_equal(pyr.subm[level].cpu().numpy(), uo.subm_rulebook(level_coords))
+        if level == 3:
+            break
+        coarse = uo.strided_out_coords(level_coords)
+        np.testing.assert_array_equal(pyr.down[level].cpu().numpy(), uo.down_rulebook(coarse, level_coords))
+        np.testing.assert_array_equal(pyr.up[level].cpu().numpy(), uo.up_rulebook(level_coords, coarse))
+        level_coords = coarse
+
+
+def test_rulebook_empty(backend):
+    coords = torch.zeros((0, 4), dtype=torch.int32, device=backend)
+    pyr = ops.build_pyramid(coords, depth=3)
+    assert all(c.shape[0] == 0 for c in pyr.coords)
+
+
+def _tolerance_check(got, ref64, ref32, name):
+    """fp32 parity bar: within 1e-4 relative of the fp64 oracle, measured against each output
+    tensor's own scale (rms), and never worse than 4x the fp32 oracle's own distance from fp64
+    (the checkpoints' BatchNorm statistics -- |mean| up to 4e3, var down to 1e-21 -- make ANY fp32
+    evaluation order noisy at that level)."""
+    scale = np.sqrt(np.mean(ref64 ** 2)) + 1e-30
+    err = np.abs(got - ref64).max() / scale
+    base = np.abs(ref32 - ref64).max() / scale
+    assert err <= max(1e-4, 4 * base), f"{name}: rel err {err:.3e} (fp32 oracle itself {base:.3e})"
+
+
+@pytest.mark.parametrize("ckpt", ["noble-elevator-58", "peach-forest-65"])
+def test_unet_forward_matches_oracle(backend, ckpt):
+    vx = _small_batch()
+    w = uo.load_weights(WEIGHTS / f"{ckpt}.npz")
+    ref64 = uo.OracleNet(w, dtype=torch.float64).forward(vx["feats"][:, :3], vx["coords"])
+    ref32 = uo.OracleNet(w, dtype=torch.float32).forward(vx["feats"][:, :3], vx["coords"])
+    net = Smart_Tree(w, device=backend)
+    sp = sparse_from_batch(torch.from_numpy(vx["feats"][:, :3]), torch.from_numpy(vx["coords"]), backend)
+    out = net.forward(sp)
+    assert set(out) == {"radius", "direction", "class_l"}
+    for k in out:
+        assert out[k].shape == ref64[k].shape
+        _tolerance_check(out[k].cpu().numpy().astype(np.float64), ref64[k], ref32[k].astype(np.float64), k)
+    # fused inference tail: exp(radius) * direction, argmax
+    r, d, c, mv, cls = net.forward_fused_tail(sp)
+    mv_ref, cls_ref = uo.inference_tail(r.cpu().numpy(), d.cpu().numpy(), c.cpu().numpy())
+    np.testing.assert_allclose(mv.cpu().numpy(), mv_ref, rtol=2e-6, atol=1e-30)
+    np.testing.assert_array_equal(cls.cpu().numpy(), cls_ref)
+
+
+def random_state_dict(template, seed=0):
+    """Same keys/shapes as a checkpoint but well-conditioned random values, so every channel is
+    alive (the shipped checkpoints saturate on small synthetic inputs and exercise little)."""
+    rng = np.random.RandomState(seed)
+    sd = {}
+    for k, v in template.items():
+        if k.endswith("num_batches_tracked"):
+            sd[k] = v
+        elif v.ndim == 5:
+            fan_in = v.shape[1] * v.shape[2] * v.shape[3] * v.shape[4]
+            sd[k] = (rng.randn(*v.shape) * np.sqrt(2.0 / fan_in)).astype(np.float32)
+        elif k.endswith("running_var"):
+            sd[k] = rng.uniform(0.5, 1.5, v.shape).astype(np.float32)
+        elif k.endswith("running_mean"):
+            sd[k] = (rng.randn(*v.shape) * 0.1).astype(np.float32)
+        elif k.endswith(".weight"):
+            sd[k] = rng.uniform(0.5, 1.5, v.shape).astype(np.float32)
+        else:
+            sd[k] = (rng.randn(*v.shape) * 0.1).astype(np.float32)
+    return sd
+
+
+def test_unet_random_weights_every_layer(backend):
+    vx = _small_batch(n=5000, seed=9)
+    w = random_state_dict(uo.load_weights(WEIGHTS / "noble-elevator-58.npz"), seed=1)
+    oracle = uo.OracleNet(w, dtype=torch.float64)
+    ref = oracle.forward(vx["feats"][:, :3], vx["coords"])
+    net = Smart_Tree(w, device=backend)
+    sp = sparse_from_batch(torch.from_numpy(vx["feats"][:, :3]), torch.from_numpy(vx["coords"]), backend)
+    feats = net.features(sp).cpu().numpy()
+    tail0 = oracle.trace["tail0"].numpy()
+    assert (tail0 > 0).mean() > 0.2, "test input does not exercise the network"
+    np.testing.assert_allclose(feats, tail0, rtol=1e-4, atol=1e-4 * np.abs(tail0).max())
+    out = net.forward(sp)
+    for k in out:
+        np.testing.assert_allclose(out[k].cpu().numpy(), ref[k], rtol=1e-4, atol=1e-4 * np.abs(ref[k]).max())
