@@ -1,0 +1,289 @@
+// Graph construction for the skeleton stage: edge list, connected components, component layout.
+//
+//   st_make_edges            smart_tree/skeleton/graph.py:52-60 (make_edges, incl. the `idx > 0` filter)
+//   st_connected_components  smart_tree/data_types/graph.py:32-37 (cugraph.connected_components)
+//   st_component_layout      smart_tree/data_types/graph.py:38-51 (size filter, sort by size desc) +
+//                            smart_tree/skeleton/skeletonize.py:60-71 / graph.py:94-104 (vertex
+//                            renumbering by rank) -- done for ALL components at once, on the device,
+//                            instead of a host loop over every label with cudf/pandas round trips
+//   st_component_csr         undirected adjacency (both directions) in the renumbered vertex space
+//
+// Component labels are canonical (smallest member vertex id), component order is size descending
+// then label ascending, vertices inside a component keep ascending original id: the same choices
+// as oracle/skeleton_oracle.py.
+#include "st_common.h"
+
+#define GR_BLOCK 256
+static inline unsigned gr_grid(int64_t n) {
+    int64_t g = st_div_up(n > 0 ? n : 1, GR_BLOCK);
+    return (unsigned)(g < 8192 ? g : 8192);
+}
+#define GR_LOOP(i, n) for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (int64_t)gridDim.x * blockDim.x)
+
+// --------------------------------------------------------------- medial points and radii ---
+// Cloud.medial_pts / Cloud.radius (smart_tree/data_types/cloud.py:229-231,254-256) evaluated in one
+// pass with a fixed float32 operation order: medial = xyz + mv, radius = sqrtf((x*x + y*y) + z*z)
+// (correctly rounded sqrt) -- the exact values the oracle uses, independent of torch's math library.
+__global__ void __launch_bounds__(GR_BLOCK) k_medial(const float* xyz, const float* mv, int64_t n, float* medial, float* radius) {
+    GR_LOOP(i, n) {
+        const float x = mv[3 * i], y = mv[3 * i + 1], z = mv[3 * i + 2];
+        medial[3 * i] = xyz[3 * i] + x;
+        medial[3 * i + 1] = xyz[3 * i + 1] + y;
+        medial[3 * i + 2] = xyz[3 * i + 2] + z;
+        float s = x * x;
+        float t = y * y;
+        s = s + t;
+        t = z * z;
+        s = s + t;
+        radius[i] = sqrtf(s);
+    }
+}
+
+extern "C" int st_medial_points(const float* xyz, const float* mv, int64_t n, float* medial, float* radius, void* stream_) {
+    if (n <= 0) return ST_OK;
+    hipLaunchKernelGGL(k_medial, dim3(gr_grid(n)), dim3(GR_BLOCK), 0, (hipStream_t)stream_, xyz, mv, n, medial, radius);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}
+
+// ------------------------------------------------------------------------------ make_edges ---
+__global__ void __launch_bounds__(GR_BLOCK) k_edge_count(const int64_t* idx, int64_t n, int K, uint32_t* cnt) {
+    GR_LOOP(i, n) {
+        uint32_t c = 0;
+        for (int k = 0; k < K; k++) c += idx[i * K + k] > 0;
+        cnt[i] = c;
+    }
+}
+__global__ void __launch_bounds__(GR_BLOCK) k_edge_emit(const int64_t* idx, const float* dist, int64_t n, int K,
+                                                        const uint32_t* off, int64_t* edges, float* w) {
+    GR_LOOP(i, n) {
+        uint32_t o = off[i];
+        for (int k = 0; k < K; k++) {
+            int64_t j = idx[i * K + k];
+            if (j > 0) { edges[2 * (int64_t)o] = i; edges[2 * (int64_t)o + 1] = j; w[o] = dist[i * K + k]; o++; }
+        }
+    }
+}
+
+extern "C" int64_t st_make_edges_workspace_bytes(int64_t n) {
+    StArena a(nullptr, 0);
+    a.take<uint32_t>(n + 1);
+    a.take<char>(st_scan_ws_bytes(n));
+    return a.used;
+}
+
+// idx/dist [n,K] from st_knn_radius (after the caller's radius filter); edges [n*K,2] int64, w [n*K].
+extern "C" int st_make_edges(const int64_t* idx, const float* dist, int64_t n, int K, int64_t* edges, float* w,
+                             int64_t* n_edges_host, void* ws, int64_t ws_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    *n_edges_host = 0;
+    if (n <= 0) return ST_OK;
+    StArena a(ws, ws_bytes);
+    uint32_t* cnt = a.take<uint32_t>(n + 1);
+    int64_t sb = st_scan_ws_bytes(n);
+    char* sw = a.take<char>(sb);
+    if (!cnt || !sw) { st_set_error("make_edges: workspace too small"); return ST_ERR_WORKSPACE; }
+    hipLaunchKernelGGL(k_edge_count, dim3(gr_grid(n)), dim3(GR_BLOCK), 0, stream, idx, n, K, cnt);
+    ST_TRY(st_exclusive_scan_u32(cnt, cnt, n, cnt + n, sw, sb, stream));
+    hipLaunchKernelGGL(k_edge_emit, dim3(gr_grid(n)), dim3(GR_BLOCK), 0, stream, idx, dist, n, K, (const uint32_t*)cnt, edges, w);
+    uint32_t total = 0;
+    (void)hipMemcpyAsync(&total, cnt + n, sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+    (void)hipStreamSynchronize(stream);
+    ST_CHECK_LAUNCH();
+    *n_edges_host = total;
+    return ST_OK;
+}
+
+// ------------------------------------------------------------------ connected components ---
+__device__ __forceinline__ int cc_find(const int* label, int x) {
+    int p = __atomic_load_n(&label[x], __ATOMIC_RELAXED);
+    while (p != x) { x = p; p = __atomic_load_n(&label[x], __ATOMIC_RELAXED); }
+    return x;
+}
+__global__ void __launch_bounds__(GR_BLOCK) k_cc_init(int* label, int64_t n) { GR_LOOP(i, n) label[i] = (int)i; }
+__global__ void __launch_bounds__(GR_BLOCK) k_cc_hook(const int64_t* edges, int64_t E, int* label, unsigned* changed) {
+    GR_LOOP(e, E) {
+        int a = cc_find(label, (int)edges[2 * e]), b = cc_find(label, (int)edges[2 * e + 1]);
+        if (a == b) continue;
+        int hi = a > b ? a : b, lo = a > b ? b : a;
+        atomicMin(&label[hi], lo);
+        *changed = 1u;
+    }
+}
+__global__ void __launch_bounds__(GR_BLOCK) k_cc_compress(int* label, int64_t n) {
+    GR_LOOP(i, n) { int r = cc_find(label, (int)i); label[i] = r; }
+}
+
+// labels [n] int32 out: smallest vertex id of each vertex's component.  scratch: one uint32.
+extern "C" int st_connected_components(const int64_t* edges, int64_t E, int64_t n, int32_t* labels, void* ws,
+                                       int64_t ws_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    ST_REQUIRE(n < (1ll << 31), "cc: too many vertices");
+    if (n <= 0) return ST_OK;
+    StArena a(ws, ws_bytes);
+    unsigned* changed = a.take<unsigned>(1);
+    if (!changed) { st_set_error("cc: workspace too small"); return ST_ERR_WORKSPACE; }
+    hipLaunchKernelGGL(k_cc_init, dim3(gr_grid(n)), dim3(GR_BLOCK), 0, stream, labels, n);
+    for (int it = 0; it < 64 && E > 0; it++) {
+        (void)hipMemsetAsync(changed, 0, sizeof(unsigned), stream);
+        hipLaunchKernelGGL(k_cc_hook, dim3(gr_grid(E)), dim3(GR_BLOCK), 0, stream, edges, E, labels, changed);
+        hipLaunchKernelGGL(k_cc_compress, dim3(gr_grid(n)), dim3(GR_BLOCK), 0, stream, labels, n);
+        unsigned h = 0;
+        (void)hipMemcpyAsync(&h, changed, sizeof(unsigned), hipMemcpyDeviceToHost, stream);
+        (void)hipStreamSynchronize(stream);
+        if (!h) break;
+    }
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}
+
+// ---------------------------------------------------------------------- component layout ---
+__global__ void __launch_bounds__(GR_BLOCK) k_cl_sizes(const int* label, int64_t n, uint32_t* size) {
+    GR_LOOP(i, n) atomicAdd(&size[label[i]], 1u);
+}
+__global__ void __launch_bounds__(GR_BLOCK) k_cl_rootflag(const int* label, const uint32_t* size, int64_t n, uint32_t minv,
+                                                          uint32_t* flag) {
+    GR_LOOP(i, n) flag[i] = (label[i] == (int)i && size[i] >= minv) ? 1u : 0u;
+}
+__global__ void __launch_bounds__(GR_BLOCK) k_cl_rootlist(const uint32_t* flag_off, const int* label, const uint32_t* size,
+                                                          int64_t n, uint32_t minv, uint32_t* key, uint32_t* root) {
+    GR_LOOP(i, n) if (label[i] == (int)i && size[i] >= minv) { key[flag_off[i]] = 0xffffffffu - size[i]; root[flag_off[i]] = (uint32_t)i; }
+}
+__global__ void __launch_bounds__(GR_BLOCK) k_cl_rank(const uint32_t* root_sorted, const uint32_t* key_sorted, int64_t C,
+                                                      int* rank_of_root, uint32_t* comp_size) {
+    GR_LOOP(c, C) { rank_of_root[root_sorted[c]] = (int)c; comp_size[c] = 0xffffffffu - key_sorted[c]; }
+}
+__global__ void __launch_bounds__(GR_BLOCK) k_cl_vflag(const int* label, const int* rank_of_root, int64_t n, uint32_t* flag) {
+    GR_LOOP(i, n) flag[i] = rank_of_root[label[i]] >= 0 ? 1u : 0u;
+}
+__global__ void __launch_bounds__(GR_BLOCK) k_cl_vlist(const uint32_t* flag_off, const int* label, const int* rank_of_root,
+                                                       int64_t n, uint32_t* vkey, uint32_t* vid) {
+    GR_LOOP(i, n) {
+        int r = rank_of_root[label[i]];
+        if (r >= 0) { vkey[flag_off[i]] = (uint32_t)r; vid[flag_off[i]] = (uint32_t)i; }
+    }
+}
+__global__ void __launch_bounds__(GR_BLOCK) k_cl_newid(const uint32_t* vid_sorted, int64_t m, int* new_id, int32_t* vert_order) {
+    GR_LOOP(p, m) { new_id[vid_sorted[p]] = (int)p; vert_order[p] = (int32_t)vid_sorted[p]; }
+}
+__global__ void __launch_bounds__(GR_BLOCK) k_fill_i32(int* p, int64_t n, int v) { GR_LOOP(i, n) p[i] = v; }
+
+extern "C" int64_t st_component_layout_workspace_bytes(int64_t n) {
+    StArena a(nullptr, 0);
+    a.take<uint32_t>(n);      // size
+    a.take<uint32_t>(n + 1);  // flag / offsets
+    a.take<uint32_t>(n);      // key
+    a.take<uint32_t>(n);      // val
+    a.take<int>(n);           // rank_of_root
+    a.take<char>(st_sort_ws_bytes(n) > st_scan_ws_bytes(n + 1) ? st_sort_ws_bytes(n) : st_scan_ws_bytes(n + 1));
+    return a.used;
+}
+
+// Outputs (caller-allocated, capacity n each): comp_size [C], comp_off [C+1], vert_order [m] (original
+// vertex ids grouped by component, ascending inside), new_id [n] (-1 for dropped vertices).
+extern "C" int st_component_layout(const int32_t* labels, int64_t n, int min_vertices, int32_t* comp_size, int32_t* comp_off,
+                                   int32_t* vert_order, int32_t* new_id, int64_t* n_comp_host, int64_t* n_kept_host,
+                                   void* ws, int64_t ws_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    *n_comp_host = 0;
+    *n_kept_host = 0;
+    if (n <= 0) return ST_OK;
+    StArena a(ws, ws_bytes);
+    uint32_t* size = a.take<uint32_t>(n);
+    uint32_t* flag = a.take<uint32_t>(n + 1);
+    uint32_t* key = a.take<uint32_t>(n);
+    uint32_t* val = a.take<uint32_t>(n);
+    int* rank_of_root = a.take<int>(n);
+    int64_t sb = st_sort_ws_bytes(n) > st_scan_ws_bytes(n + 1) ? st_sort_ws_bytes(n) : st_scan_ws_bytes(n + 1);
+    char* sw = a.take<char>(sb);
+    if (!a.ok() || !sw) { st_set_error("component_layout: workspace too small"); return ST_ERR_WORKSPACE; }
+    const unsigned g = gr_grid(n);
+    uint32_t minv = min_vertices > 0 ? (uint32_t)min_vertices : 0u;
+    (void)hipMemsetAsync(size, 0, n * sizeof(uint32_t), stream);
+    hipLaunchKernelGGL(k_cl_sizes, dim3(g), dim3(GR_BLOCK), 0, stream, labels, n, size);
+    hipLaunchKernelGGL(k_cl_rootflag, dim3(g), dim3(GR_BLOCK), 0, stream, labels, (const uint32_t*)size, n, minv, flag);
+    ST_TRY(st_exclusive_scan_u32(flag, flag, n, flag + n, sw, sb, stream));
+    uint32_t C = 0;
+    (void)hipMemcpyAsync(&C, flag + n, sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+    (void)hipStreamSynchronize(stream);
+    ST_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_fill_i32, dim3(g), dim3(GR_BLOCK), 0, stream, new_id, n, -1);
+    if (C == 0) { ST_CHECK_LAUNCH(); return ST_OK; }
+    hipLaunchKernelGGL(k_cl_rootlist, dim3(g), dim3(GR_BLOCK), 0, stream, (const uint32_t*)flag, labels, (const uint32_t*)size, n,
+                       minv, key, val);
+    ST_TRY(st_radix_sort_pairs_u32(key, val, C, 32, sw, sb, stream));  // size desc; stable => root id asc on ties
+    hipLaunchKernelGGL(k_fill_i32, dim3(g), dim3(GR_BLOCK), 0, stream, rank_of_root, n, -1);
+    hipLaunchKernelGGL(k_cl_rank, dim3(gr_grid(C)), dim3(GR_BLOCK), 0, stream, (const uint32_t*)val, (const uint32_t*)key,
+                       (int64_t)C, rank_of_root, (uint32_t*)comp_size);
+    // comp_off = exclusive scan of comp_size (+ total at [C])
+    ST_TRY(st_exclusive_scan_u32((const uint32_t*)comp_size, (uint32_t*)comp_off, C, (uint32_t*)comp_off + C, sw, sb, stream));
+    // vertices of kept components, ascending id, then stable sort by component rank
+    hipLaunchKernelGGL(k_cl_vflag, dim3(g), dim3(GR_BLOCK), 0, stream, labels, (const int*)rank_of_root, n, flag);
+    ST_TRY(st_exclusive_scan_u32(flag, flag, n, flag + n, sw, sb, stream));
+    uint32_t m = 0;
+    (void)hipMemcpyAsync(&m, flag + n, sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+    (void)hipStreamSynchronize(stream);
+    hipLaunchKernelGGL(k_cl_vlist, dim3(g), dim3(GR_BLOCK), 0, stream, (const uint32_t*)flag, labels, (const int*)rank_of_root, n,
+                       key, val);
+    int bits = 1;
+    while ((1u << bits) < C && bits < 32) bits++;
+    ST_TRY(st_radix_sort_pairs_u32(key, val, m, bits, sw, sb, stream));
+    hipLaunchKernelGGL(k_cl_newid, dim3(gr_grid(m)), dim3(GR_BLOCK), 0, stream, (const uint32_t*)val, (int64_t)m, new_id,
+                       vert_order);
+    ST_CHECK_LAUNCH();
+    *n_comp_host = C;
+    *n_kept_host = m;
+    return ST_OK;
+}
+
+// ---------------------------------------------------------------------------- component CSR ---
+__global__ void __launch_bounds__(GR_BLOCK) k_csr_count(const int64_t* edges, int64_t E, const int* new_id, uint32_t* deg) {
+    GR_LOOP(e, E) {
+        int64_t u = edges[2 * e], v = edges[2 * e + 1];
+        if (u == v) continue;  // self loops (every vertex but 0 has one) never matter for paths
+        int a = new_id[u], b = new_id[v];
+        if (a < 0 || b < 0) continue;
+        atomicAdd(&deg[a], 1u);
+        atomicAdd(&deg[b], 1u);
+    }
+}
+__global__ void __launch_bounds__(GR_BLOCK) k_csr_fill(const int64_t* edges, const float* w, int64_t E, const int* new_id,
+                                                       uint32_t* cursor, uint32_t* col, float* wgt) {
+    GR_LOOP(e, E) {
+        int64_t u = edges[2 * e], v = edges[2 * e + 1];
+        if (u == v) continue;
+        int a = new_id[u], b = new_id[v];
+        if (a < 0 || b < 0) continue;
+        uint32_t pa = atomicAdd(&cursor[a], 1u);
+        col[pa] = (uint32_t)b; wgt[pa] = w[e];
+        uint32_t pb = atomicAdd(&cursor[b], 1u);
+        col[pb] = (uint32_t)a; wgt[pb] = w[e];
+    }
+}
+
+extern "C" int64_t st_component_csr_workspace_bytes(int64_t m) {
+    StArena a(nullptr, 0);
+    a.take<uint32_t>(m + 1);
+    a.take<char>(st_scan_ws_bytes(m + 1));
+    return a.used;
+}
+
+// row_off [m+1] uint32, col / wgt capacity 2*E.  Adjacency order inside a row is unspecified
+// (atomic cursors); every consumer is order independent.
+extern "C" int st_component_csr(const int64_t* edges, const float* w, int64_t E, const int32_t* new_id, int64_t m,
+                                uint32_t* row_off, uint32_t* col, float* wgt, void* ws, int64_t ws_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (m <= 0) return ST_OK;
+    StArena a(ws, ws_bytes);
+    uint32_t* cursor = a.take<uint32_t>(m + 1);
+    int64_t sb = st_scan_ws_bytes(m + 1);
+    char* sw = a.take<char>(sb);
+    if (!cursor || !sw) { st_set_error("component_csr: workspace too small"); return ST_ERR_WORKSPACE; }
+    (void)hipMemsetAsync(row_off, 0, (m + 1) * sizeof(uint32_t), stream);
+    if (E > 0) hipLaunchKernelGGL(k_csr_count, dim3(gr_grid(E)), dim3(GR_BLOCK), 0, stream, edges, E, new_id, row_off);
+    ST_TRY(st_exclusive_scan_u32(row_off, row_off, m + 1, nullptr, sw, sb, stream));
+    (void)hipMemcpyAsync(cursor, row_off, (m + 1) * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream);
+    if (E > 0) hipLaunchKernelGGL(k_csr_fill, dim3(gr_grid(E)), dim3(GR_BLOCK), 0, stream, edges, w, E, new_id, cursor, col, wgt);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}

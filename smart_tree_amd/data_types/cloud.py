@@ -110,7 +110,11 @@ class Cloud:
 
     @property
     def radius(self) -> torch.Tensor:
-        return self.medial_vector.pow(2).sum(1).sqrt()
+        """|medial_vector| (reference cloud.py:254-256 writes `.pow(2).sum(1).sqrt()`, whose summation
+        order is backend dependent; the explicit (x*x + y*y) + z*z below is the same value up to the
+        last bit and is identical on every device and in the oracle)."""
+        v = self.medial_vector
+        return ((v[:, 0] * v[:, 0] + v[:, 1] * v[:, 1]) + v[:, 2] * v[:, 2]).sqrt()
 
     @property
     def direction(self) -> torch.Tensor:

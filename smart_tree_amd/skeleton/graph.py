@@ -1,0 +1,148 @@
+"""Neighbourhood graph of the medial points (reference smart_tree/skeleton/graph.py).
+
+`knn` / `nn` keep the reference signatures and return conventions (graph.py:12-33): idx [n,K]
+int64 with -1 padding, distances = sqrt of the squared FRNN distances (NaN where padded).  The
+search itself is `st_knn_radius` (csrc/knn.hip); edge list, connected components and the
+per-component renumbering are csrc/graph.hip.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from .. import _lib
+from ..data_types.graph import Graph
+
+BOUND_NONE, BOUND_LE, BOUND_LT = 0, 1, 2
+
+
+def knn(src: torch.Tensor, dest: torch.Tensor, K: int = 50, r: float = 1.0, grid=None, bound: Optional[torch.Tensor] = None,
+        bound_mode: int = BOUND_NONE, cell: float = 0.0):
+    """The <= K nearest `dest` points of every `src` point with d^2 < r^2, ascending (ties: lower index).
+
+    `bound` (per query) additionally keeps only d <= bound[i] (BOUND_LE) or d < bound[i] (BOUND_LT);
+    used by nn_graph / outlier_removal, whose own filters make that exact (csrc/knn.hip header).
+    """
+    L = _lib.lib()
+    dev = src.device
+    src = src.contiguous().float()
+    dest = dest.contiguous().float()
+    n1, n2 = src.shape[0], dest.shape[0]
+    idx = torch.empty((n1, K), dtype=torch.int64, device=dev)
+    dist = torch.empty((n1, K), dtype=torch.float32, device=dev)
+    if n1 == 0:
+        return idx, dist, grid
+    if n2 == 0:
+        return idx.fill_(-1), dist.fill_(float("nan")), grid
+    ws = _lib.workspace(L.st_knn_workspace_bytes(n2), dev)
+    b = bound.contiguous().float() if bound is not None else None
+    _lib.check(L.st_knn_radius(_lib.ptr(src), n1, _lib.ptr(dest), n2, K, float(r), _lib.ptr(b), bound_mode, float(cell),
+                               _lib.ptr(idx), _lib.ptr(dist), _lib.ptr(ws), ws.numel(), _lib.stream(dev)))
+    return idx, dist, grid
+
+
+def medial_points(xyz: torch.Tensor, medial_vector: torch.Tensor):
+    """(xyz + medial_vector, |medial_vector|) with the float32 operation order fixed in csrc/graph.hip
+    (`Cloud.medial_pts` / `Cloud.radius`, reference data_types/cloud.py:229-231,254-256)."""
+    L = _lib.lib()
+    xyz = xyz.contiguous().float()
+    mv = medial_vector.contiguous().float()
+    n = xyz.shape[0]
+    medial = torch.empty_like(xyz)
+    radius = torch.empty((n,), dtype=torch.float32, device=xyz.device)
+    _lib.check(L.st_medial_points(_lib.ptr(xyz), _lib.ptr(mv), n, _lib.ptr(medial), _lib.ptr(radius), _lib.stream(xyz.device)))
+    return medial, radius
+
+
+def nn(src, dest, r=1.0, grid=None):
+    idx, dist, grid = knn(src, dest, K=1, r=r, grid=grid)
+    return idx.squeeze(1), dist.squeeze(1), grid
+
+
+def _search_cell(radii: torch.Tensor, r_max: float) -> float:
+    """Grid cell for per-query bounded searches: fine enough for thin twigs, coarse enough that
+    the thickest branch scans a bounded number of cells."""
+    return max(r_max / 8.0, 1e-4)
+
+
+def make_edges(dists: torch.Tensor, idxs: torch.Tensor):
+    """graph.py:52-60: edges (i -> idx) for idx > 0 (the reference's filter drops every edge INTO
+    vertex 0 and vertex 0's self loop; kept), in (i, k) order."""
+    L = _lib.lib()
+    dev = dists.device
+    n, K = dists.shape
+    edges = torch.empty((max(n * K, 1), 2), dtype=torch.int64, device=dev)
+    w = torch.empty((max(n * K, 1),), dtype=torch.float32, device=dev)
+    ne = ctypes.c_int64(0)
+    ws = _lib.workspace(L.st_make_edges_workspace_bytes(n), dev)
+    _lib.check(L.st_make_edges(_lib.ptr(idxs.contiguous()), _lib.ptr(dists.contiguous()), n, K, _lib.ptr(edges), _lib.ptr(w),
+                               ctypes.byref(ne), _lib.ptr(ws), ws.numel(), _lib.stream(dev)))
+    return edges[: ne.value], w[: ne.value]
+
+
+def nn_graph(points: torch.Tensor, radii: torch.Tensor, K: int = 40) -> Graph:
+    """graph.py:36-40: kNN with r = max radius, neighbours farther than the point's own radius dropped."""
+    if points.shape[0] == 0:
+        return Graph(points, torch.zeros((0, 2), dtype=torch.int64, device=points.device),
+                     torch.zeros((0,), dtype=torch.float32, device=points.device))
+    r_max = radii.max().item()
+    idxs, dists, _ = knn(points, points, K=K, r=r_max, bound=radii, bound_mode=BOUND_LE, cell=_search_cell(radii, r_max))
+    edges, edge_weights = make_edges(dists, idxs)
+    return Graph(points, edges, edge_weights)
+
+
+@dataclass
+class ComponentSet:
+    """Connected components with >= minimum_vertices members, size descending (data_types/graph.py:32-51),
+    laid out for the per-component kernels: vertices renumbered so each component is contiguous."""
+    n_components: int
+    comp_size: torch.Tensor  # [C] int32
+    comp_off: torch.Tensor  # [C+1] int32
+    vert_order: torch.Tensor  # [m] int32 original vertex ids, grouped by component, ascending inside
+    new_id: torch.Tensor  # [n] int32, -1 for vertices of dropped components
+    labels: torch.Tensor  # [n] int32 smallest member id of each vertex's component
+    row_off: torch.Tensor  # CSR over the renumbered vertices (undirected, self loops removed)
+    col: torch.Tensor
+    wgt: torch.Tensor
+
+    def __len__(self):
+        return self.n_components
+
+    def vertices(self, c: int) -> torch.Tensor:
+        a, b = int(self.comp_off[c]), int(self.comp_off[c + 1])
+        return self.vert_order[a:b].long()
+
+
+def connected_components(graph: Graph, minimum_vertices: int = 0) -> ComponentSet:
+    L = _lib.lib()
+    dev = graph.vertices.device
+    n = graph.vertices.shape[0]
+    edges = graph.edges.contiguous()
+    w = graph.edge_weights.contiguous()
+    E = edges.shape[0]
+    i32 = lambda k: torch.empty((max(k, 1),), dtype=torch.int32, device=dev)
+    labels = i32(n)
+    ws = _lib.workspace(256, dev)
+    _lib.check(L.st_connected_components(_lib.ptr(edges), E, n, _lib.ptr(labels), _lib.ptr(ws), ws.numel(), _lib.stream(dev)))
+    comp_size, comp_off, vert_order, new_id = i32(n), i32(n + 1), i32(n), i32(n)
+    nc, nk = ctypes.c_int64(0), ctypes.c_int64(0)
+    ws = _lib.workspace(L.st_component_layout_workspace_bytes(n), dev)
+    _lib.check(L.st_component_layout(_lib.ptr(labels), n, int(minimum_vertices), _lib.ptr(comp_size), _lib.ptr(comp_off),
+                                     _lib.ptr(vert_order), _lib.ptr(new_id), ctypes.byref(nc), ctypes.byref(nk),
+                                     _lib.ptr(ws), ws.numel(), _lib.stream(dev)))
+    C, m = nc.value, nk.value
+    row_off, col, wgt = i32(m + 1), i32(2 * E), torch.empty((max(2 * E, 1),), dtype=torch.float32, device=dev)
+    if m > 0:
+        ws = _lib.workspace(L.st_component_csr_workspace_bytes(m), dev)
+        _lib.check(L.st_component_csr(_lib.ptr(edges), _lib.ptr(w), E, _lib.ptr(new_id), m, _lib.ptr(row_off), _lib.ptr(col),
+                                      _lib.ptr(wgt), _lib.ptr(ws), ws.numel(), _lib.stream(dev)))
+    return ComponentSet(C, comp_size[:C], comp_off[: C + 1], vert_order[:m], new_id[:n], labels[:n], row_off[: m + 1], col, wgt)
+
+
+def remap_edges(edges: torch.Tensor) -> torch.Tensor:
+    """graph.py:94-104: renumber vertex ids by rank (kept for API parity; the kernels use ComponentSet.new_id)."""
+    _, inverse = torch.unique(edges, return_inverse=True)
+    return inverse.reshape(edges.shape)

@@ -1,0 +1,139 @@
+"""Skeleton stage of the HIP path vs oracle/skeleton_oracle.{c,py}: everything bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import skeleton_oracle as so
+from oracle import voxel_oracle as vo
+from smart_tree_amd.data_types.cloud import Cloud
+from smart_tree_amd.data_types.graph import Graph
+from smart_tree_amd.skeleton import graph as G
+from smart_tree_amd.skeleton.filter import outlier_removal
+from smart_tree_amd.skeleton.skeletonize import (STAGE_SAMPLE, STAGE_SSSP, STAGE_TREE_DISTANCE, Skeletonizer,
+                                                 run_components)
+from smart_tree_amd.synthetic import sample_tree_cloud
+
+
+def _tree(n=2500, seed=4, voxel=0.04, exact_medial=False):
+    c = sample_tree_cloud(n, seed=seed, scale=0.6, max_depth=4)
+    xyz = vo.centre_cloud(c["xyz"])
+    vx = vo.voxelize_cloud(xyz, c["rgb"], voxel, block_size=2.0, buffer_size=0.2)
+    keep = vx["mask"]
+    pts = vx["feats"][keep, :3]
+    mv = c["medial_vector"][vx["point"][keep]]
+    if exact_medial:  # rings collapse onto (nearly) the same axis point: duplicates, plateaus, ties
+        mv = np.round(mv * 50) / 50
+        pts = np.round(pts * 50) / 50
+    return pts.astype(np.float32), mv.astype(np.float32)
+
+
+@pytest.mark.parametrize("K", [1, 8, 16])
+def test_knn_matches_oracle(backend, K):
+    rng = np.random.RandomState(K)
+    dst = rng.uniform(0, 1, (1500, 3)).astype(np.float32)
+    dst[100:140] = dst[50]  # exact duplicates: index tie-break
+    src = np.concatenate([dst[:300], rng.uniform(-0.2, 1.2, (150, 3)).astype(np.float32)])
+    r = 0.12
+    ref_idx, ref_d = so.knn(src, dst, K, r)
+    idx, d, _ = G.knn(torch.from_numpy(src).to(backend), torch.from_numpy(dst).to(backend), K=K, r=r)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ref_idx)
+    np.testing.assert_array_equal(d.cpu().numpy(), ref_d)  # NaN == NaN under assert_array_equal
+
+
+def test_outlier_and_graph_match_oracle(backend):
+    pts, mv = _tree()
+    medial = pts + mv
+    radius = np.sqrt(((mv * mv)[:, 0] + (mv * mv)[:, 1]) + (mv * mv)[:, 2]).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).to(backend)
+    keep = outlier_removal(t(medial), t(radius).unsqueeze(1), nb_points=8)
+    ref_keep = so.outlier_removal(medial, radius, 8)
+    np.testing.assert_array_equal(keep.cpu().numpy(), ref_keep)
+    medial, radius = medial[ref_keep], np.maximum(radius[ref_keep], np.float32(0.02))
+    g = G.nn_graph(t(medial), t(radius), K=16)
+    ref_e, ref_w = so.nn_graph(medial, radius, 16)
+    np.testing.assert_array_equal(g.edges.cpu().numpy(), ref_e)
+    np.testing.assert_array_equal(g.edge_weights.cpu().numpy(), ref_w)
+    assert not (ref_e[:, 1] == 0).any() and (ref_e[:, 0] == ref_e[:, 1]).sum() == len(medial) - 1  # idx > 0 quirk
+    comps = G.connected_components(g, minimum_vertices=32)
+    labels = so.cc_labels(len(medial), ref_e)
+    np.testing.assert_array_equal(comps.labels.cpu().numpy(), labels)
+    roots, counts = np.unique(labels, return_counts=True)
+    order = np.lexsort((roots, -counts))
+    order = [i for i in order if counts[i] >= 32]
+    assert comps.n_components == len(order)
+    np.testing.assert_array_equal(comps.comp_size.cpu().numpy(), counts[order])
+    ref_verts = np.concatenate([np.nonzero(labels == roots[i])[0] for i in order]) if order else np.zeros(0, int)
+    np.testing.assert_array_equal(comps.vert_order.cpu().numpy(), ref_verts)
+
+
+def _compare_components(backend, pts, mv, block_threads):
+    ref = so.skeletonize(pts, mv, K=16, min_connection_length=0.02, minimum_graph_vertices=32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(backend)
+    cloud = Cloud(xyz=t(pts), medial_vector=t(mv))
+    medial, radius = G.medial_points(cloud.xyz, cloud.medial_vector)
+    keep = outlier_removal(medial, radius.unsqueeze(1), nb_points=8)
+    np.testing.assert_array_equal(keep.cpu().numpy(), ref.keep_mask)
+    cloud = cloud.filter(keep)
+    medial, radius = medial[keep], radius[keep]
+    g = G.nn_graph(medial, radius.clamp(min=0.02), K=16)
+    comps = g.connected_cugraph_components(minimum_vertices=32)
+    assert comps.n_components == len(ref.components) and comps.n_components > 0
+    res = run_components(comps, medial, radius, cloud.xyz[:, 1].contiguous(),
+                         stages=STAGE_SSSP | STAGE_TREE_DISTANCE | STAGE_SAMPLE, block_threads=block_threads)
+    off = comps.comp_off.cpu().numpy()
+    n_branches = 0
+    for c, rc in enumerate(ref.components):
+        a, b = off[c], off[c + 1]
+        np.testing.assert_array_equal(comps.vert_order[a:b].cpu().numpy(), rc.vertex_ids)
+        assert int(res.root_local[c]) == rc.root
+        np.testing.assert_array_equal(res.dist[a:b].cpu().numpy(), rc.dist)
+        np.testing.assert_array_equal(res.pred[a:b].cpu().numpy(), rc.preds)
+        np.testing.assert_array_equal(res.tree_dist[a:b].cpu().numpy(), rc.tree_dist)
+        np.testing.assert_array_equal(rc.tree_dist, rc.dist)  # the second SSSP is the identity
+        assert int(res.n_branches[c]) == len(rc.branches)
+        for br in rc.branches:
+            i = a + br.branch_id
+            assert int(res.branch_parent[i]) == br.parent_id
+            s = a + int(res.branch_off[i])
+            np.testing.assert_array_equal(res.path_verts[s: s + int(res.branch_len[i])].cpu().numpy(), br.verts)
+        np.testing.assert_array_equal(res.branch_of[a:b].cpu().numpy(), rc.branch_of_point)
+        n_branches += len(rc.branches)
+    return n_branches
+
+
+def test_components_match_oracle(backend):
+    pts, mv = _tree()
+    assert _compare_components(backend, pts, mv, block_threads=128) >= 2
+
+
+def test_components_with_duplicates_and_plateaus(backend):
+    pts, mv = _tree(n=2000, seed=8, exact_medial=True)
+    _compare_components(backend, pts, mv, block_threads=64)
+
+
+def test_skeletonizer_forward_objects(backend):
+    pts, mv = _tree(n=2000, seed=6)
+    ref = so.skeletonize(pts, mv)
+    t = lambda a: torch.from_numpy(a).to(backend)
+    sk = Skeletonizer(K=16, min_connection_length=0.02, minimum_graph_vertices=32, device=backend)
+    sk.block_threads = 128
+    out = sk.forward(Cloud(xyz=t(pts), medial_vector=t(mv)))
+    assert len(out.skeletons) == len(ref.components)
+    kept = np.nonzero(ref.keep_mask)[0]
+    medial = (pts + mv)[kept]
+    radius = np.sqrt(((mv * mv)[:, 0] + (mv * mv)[:, 1]) + (mv * mv)[:, 2]).astype(np.float32)[kept]
+    for tree, rc in zip(out.skeletons, ref.components):
+        assert list(tree.branches.keys()) == [b.branch_id for b in rc.branches]
+        for br in rc.branches:
+            got = tree.branches[br.branch_id]
+            assert got.parent_id == br.parent_id and got.radii.shape == (len(br.verts), 1)
+            np.testing.assert_array_equal(got.xyz.numpy(), medial[rc.vertex_ids[br.verts]])
+            np.testing.assert_array_equal(got.radii.numpy()[:, 0], radius[rc.vertex_ids[br.verts]])
+
+
+def test_skeletonizer_empty_cloud(backend):
+    sk = Skeletonizer(K=16, min_connection_length=0.02, minimum_graph_vertices=32, device=backend)
+    empty = Cloud(xyz=torch.zeros((0, 3), device=backend), medial_vector=torch.zeros((0, 3), device=backend))
+    assert sk.forward(empty).skeletons == []
+    few = Cloud(xyz=torch.rand((10, 3), device=backend), medial_vector=torch.rand((10, 3), device=backend) * 0.01)
+    assert sk.forward(few).skeletons == []
