@@ -1,0 +1,39 @@
+"""Preprocessing used by the inference pipeline (reference smart_tree/dataset/augmentations.py).
+
+Only `CentreCloud` (:38-41) and `AugmentationPipeline` (:108-116) are on the inference path; the
+training-time augmentations are out of scope."""
+from __future__ import annotations
+
+from abc import ABC, abstractmethod
+from typing import Sequence
+
+import torch
+
+from ..data_types.cloud import Cloud
+
+
+class Augmentation(ABC):
+    @abstractmethod
+    def __call__(self, cloud: Cloud) -> Cloud:
+        ...
+
+
+class CentreCloud(Augmentation):
+    """x and z centred on the bounding box, lowest point moved to y = 0; drops every field but xyz/rgb
+    (Cloud.translate), as the reference does."""
+
+    def __call__(self, cloud: Cloud) -> Cloud:
+        centre, half = cloud.bbox
+        lift = torch.zeros(3, device=centre.device, dtype=centre.dtype)
+        lift[1] = half[1]
+        return cloud.translate(-centre + lift)
+
+
+class AugmentationPipeline(Augmentation):
+    def __init__(self, augmentations: Sequence[Augmentation]):
+        self.augmentations = list(augmentations)
+
+    def __call__(self, cloud: Cloud) -> Cloud:
+        for aug in self.augmentations:
+            cloud = aug(cloud)
+        return cloud

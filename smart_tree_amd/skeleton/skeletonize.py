@@ -13,7 +13,7 @@ from typing import List
 
 import torch
 
-from .. import _lib
+from .. import _lib, profiling
 from ..data_types.branch import BranchSkeleton
 from ..data_types.cloud import Cloud
 from ..data_types.tree import DisjointTreeSkeleton, TreeSkeleton
@@ -59,7 +59,9 @@ def run_components(comps: ComponentSet, medial_pts: torch.Tensor, radius: torch.
         return res
     r_max = rad.max().item()
     ws = _lib.workspace(L.st_skeleton_workspace_bytes(m), dev)
-    _lib.check(L.st_skeleton_components(
+    n_adj = int(comps.row_off[-1].item()) if profiling.enabled() else 0
+    with profiling.kernel("k_skeleton_components", n_adj * 8 + m * (8 + 24)):
+      _lib.check(L.st_skeleton_components(
         C, _lib.ptr(comps.comp_off.contiguous()), m, _lib.ptr(pts), _lib.ptr(rad), _lib.ptr(ys), _lib.ptr(comps.row_off),
         _lib.ptr(comps.col), _lib.ptr(comps.wgt), float(max(r_max / 4.0, 1e-4)), int(stages), int(block_threads),
         _lib.ptr(res.dist), _lib.ptr(res.pred), _lib.ptr(res.root_local), _lib.ptr(res.tree_dist),
@@ -78,14 +80,20 @@ class Skeletonizer:
         self.block_threads = 0  # 0 = library default (512 lanes per component workgroup)
 
     def forward(self, cloud: Cloud) -> DisjointTreeSkeleton:
-        medial, radius = medial_points(cloud.xyz, cloud.medial_vector)
-        mask = outlier_removal(medial, radius.unsqueeze(1), nb_points=8)
-        cloud = cloud.filter(mask)
-        medial, radius = medial[mask], radius[mask]
-        graph = nn_graph(medial, radius.clamp(min=self.min_connection_length), K=self.K)
-        comps = graph.connected_cugraph_components(minimum_vertices=self.minimum_graph_vertices)
-        res = run_components(comps, medial, radius, cloud.xyz[:, 1].contiguous(), block_threads=self.block_threads)
-        return DisjointTreeSkeleton(self._assemble(comps, res, medial, radius))
+        with profiling.stage("outlier_removal"):
+            medial, radius = medial_points(cloud.xyz, cloud.medial_vector)
+            mask = outlier_removal(medial, radius.unsqueeze(1), nb_points=8)
+            cloud = cloud.filter(mask)
+            medial, radius = medial[mask], radius[mask]
+        with profiling.stage("nn_graph"):
+            graph = nn_graph(medial, radius.clamp(min=self.min_connection_length), K=self.K)
+        with profiling.stage("components"):
+            comps = graph.connected_cugraph_components(minimum_vertices=self.minimum_graph_vertices)
+        with profiling.stage("sssp_sample_tree"):
+            res = run_components(comps, medial, radius, cloud.xyz[:, 1].contiguous(), block_threads=self.block_threads)
+        with profiling.stage("assemble"):
+            trees = self._assemble(comps, res, medial, radius)
+        return DisjointTreeSkeleton(trees)
 
     def process_subgraph(self, cloud: Cloud, subgraph, skeleton_id: int = 0) -> TreeSkeleton:
         """Reference entry point (skeletonize.py:57-95) for ONE component of a ComponentSet."""

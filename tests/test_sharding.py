@@ -1,0 +1,81 @@
+"""Cloud sharding + skeleton gather with a world_size-2 gloo process group on CPU."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from smart_tree_amd.data_types.branch import BranchSkeleton
+from smart_tree_amd.data_types.tree import DisjointTreeSkeleton, TreeSkeleton
+from smart_tree_amd.sharding import gather_skeletons, pack_skeleton, shard_indices, unpack_skeletons
+
+
+def _fake_skeleton(seed: int) -> DisjointTreeSkeleton:
+    g = torch.Generator().manual_seed(seed)
+    trees = []
+    for t in range(1 + seed % 2):
+        branches = {}
+        for b in range(2 + seed % 3):
+            m = 2 + int(torch.randint(0, 5, (1,), generator=g))
+            branches[b] = BranchSkeleton(b, b - 1, torch.rand((m, 3), generator=g), torch.rand((m, 1), generator=g))
+        trees.append(TreeSkeleton(t, branches))
+    return DisjointTreeSkeleton(trees)
+
+
+def _same(a: DisjointTreeSkeleton, b: DisjointTreeSkeleton):
+    assert len(a.skeletons) == len(b.skeletons)
+    for ta, tb in zip(a.skeletons, b.skeletons):
+        assert list(ta.branches) == list(tb.branches)
+        for k in ta.branches:
+            x, y = ta.branches[k], tb.branches[k]
+            assert x.parent_id == y.parent_id and torch.equal(x.xyz, y.xyz) and torch.equal(x.radii, y.radii)
+
+
+def test_shard_indices_partition():
+    owned = [shard_indices(11, r, 4) for r in range(4)]
+    assert sorted(i for o in owned for i in o) == list(range(11))
+    assert owned[1] == [1, 5, 9]
+
+
+def test_pack_roundtrip_single_process():
+    sk = _fake_skeleton(3)
+    tables, geoms = gather_skeletons([pack_skeleton(sk, cloud_id=7)])
+    _same(unpack_skeletons(tables[0], geoms[0])[7], sk)
+    empty = DisjointTreeSkeleton([])
+    t, g = pack_skeleton(empty)
+    assert t.shape == (0, 6) and g.shape == (0, 4) and unpack_skeletons(t, g) == {}
+
+
+def _worker(rank: int, world: int, port: int, n_clouds: int, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = shard_indices(n_clouds, rank, world)
+    tables, geoms = gather_skeletons([pack_skeleton(_fake_skeleton(i), cloud_id=i) for i in mine])
+    if rank == 0:
+        merged = {}
+        for t, g in zip(tables, geoms):
+            merged.update(unpack_skeletons(t, g))
+        q.put({k: pack_skeleton(v, k) for k, v in merged.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_world_size_2_gloo():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    n_clouds = 5
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_clouds, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert sorted(got) == list(range(n_clouds))
+    for i in range(n_clouds):
+        t, g = got[i]
+        _same(unpack_skeletons(t, g)[i], _fake_skeleton(i))
