@@ -44,13 +44,25 @@ def build_pipeline(device):
                     device=device)
 
 
+def usable_cores() -> int:
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
 def cpu_baseline(n_points: int):
     """The oracle pipeline on the host cores, one full cloud (bounded: ~30 s)."""
     from oracle import pipeline_oracle as po
     from oracle import unet_oracle as uo
     from smart_tree_amd.synthetic import sample_tree_cloud
 
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     c = sample_tree_cloud(n_points, seed=0)
     w = uo.load_weights(WEIGHTS)

@@ -56,20 +56,21 @@ def prune(tree: OTree, min_radius: float, min_length: float) -> None:
 
 
 def nearest_tube_offset(pt: np.ndarray, parent: OBranch) -> np.ndarray:
-    """queries.py:89-133 for one point against the parent's tube chain (float32 torch ops)."""
+    """queries.py:89-133 for one point against the parent's tube chain (float32).  The reference
+    evaluates the dot products with torch.einsum; written here as explicit elementwise products and
+    sums over the 3 coordinates (same values up to float32 summation order)."""
     p = torch.from_numpy(pt.reshape(1, 3).astype(F32))
     a = torch.from_numpy(parent.xyz[:-1])
     b = torch.from_numpy(parent.xyz[1:])
-    r1 = torch.from_numpy(parent.radii.reshape(-1)[:-1]).reshape(1, -1)
-    r2 = torch.from_numpy(parent.radii.reshape(-1)[1:]).reshape(1, -1)
+    r1 = torch.from_numpy(parent.radii.reshape(-1)[:-1])
+    r2 = torch.from_numpy(parent.radii.reshape(-1)[1:])
     ab = b - a
-    ap = p[:, None, :] - a[None]
-    t = (torch.einsum("nmd,md->nm", ap, ab) / torch.einsum("md,md->m", ab, ab)).clip(0.0, 1.0)
-    proj = a[None] + torch.einsum("nm,md->nmd", t, ab)
+    ap = p - a
+    t = ((ap * ab).sum(1) / (ab * ab).sum(1)).clip(0.0, 1.0)
+    proj = a + t.unsqueeze(1) * ab
     r = (1 - t) * r1 + t * r2
-    dist = (proj - p[:, None, :]).square().sum(2).sqrt()
-    idx = torch.argmin(torch.abs(dist - r), 1)
-    return (proj[0, idx[0]] - p[0]).numpy()
+    dist = (proj - p).square().sum(1).sqrt()
+    return (proj[torch.argmin(torch.abs(dist - r))] - p[0]).numpy()
 
 
 def repair(tree: OTree) -> None:
@@ -82,7 +83,7 @@ def repair(tree: OTree) -> None:
         if len(parent.xyz) < 2:
             continue
         v = nearest_tube_offset(b.xyz[0], parent)
-        b.xyz = np.concatenate([(b.xyz[0] + v).reshape(1, 3), b.xyz]).astype(F32)
+        b.xyz = np.concatenate([(b.xyz[0] + v).reshape(1, 3), b.xyz]).astype(F32)  # tree.py:89-91
         b.radii = np.concatenate([b.radii[[0]], b.radii])
 
 

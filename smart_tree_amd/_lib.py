@@ -55,7 +55,7 @@ SIGNATURES = {
     "st_component_csr": (c_int, [P, P, I64, P, I64, P, P, P, P, I64, P]),
     "st_skeleton_workspace_bytes": (I64, [I64]),
     "st_skeleton_components": (c_int, [c_int, P, I64, P, P, P, P, P, P, c_float, c_int, c_int, P, P, P, P, P, P, P, P,
-                                       P, P, P, I64, P]),
+                                       P, P, P, P, I64, P]),
 }
 
 

@@ -138,8 +138,23 @@ extern "C" int st_connected_components(const int64_t* edges, int64_t E, int64_t 
 }
 
 // ---------------------------------------------------------------------- component layout ---
+// component sizes; lanes of a wave that share a label are counted by one atomic (a big tree is one
+// component: per-lane atomics on its root word would serialise the whole launch)
 __global__ void __launch_bounds__(GR_BLOCK) k_cl_sizes(const int* label, int64_t n, uint32_t* size) {
-    GR_LOOP(i, n) atomicAdd(&size[label[i]], 1u);
+    const int lane = threadIdx.x & 63;
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < n; base += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = base + threadIdx.x;
+        const bool valid = i < n;
+        const int lab = valid ? label[i] : -1;
+        unsigned long long todo = __ballot(valid);
+        while (todo) {  // wave-uniform
+            const int leader = __ffsll(todo) - 1;
+            const int l = __shfl(lab, leader);
+            const unsigned long long same = __ballot(valid && lab == l);
+            if (lane == leader) atomicAdd(&size[l], (uint32_t)__popcll(same));
+            todo &= ~same;
+        }
+    }
 }
 __global__ void __launch_bounds__(GR_BLOCK) k_cl_rootflag(const int* label, const uint32_t* size, int64_t n, uint32_t minv,
                                                           uint32_t* flag) {

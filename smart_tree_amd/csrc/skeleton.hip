@@ -18,6 +18,7 @@
 #include "st_grid.h"
 
 #define SK_MAX_WAVES 16
+#define SK_LIFT 24  // 2^24 hops bound the deepest predecessor chain
 #define SK_EMPTY64 0xffffffffffffffffull
 
 struct SkArgs {
@@ -51,14 +52,18 @@ struct SkArgs {
     unsigned* term;      // termination set
     unsigned long long* best;  // claim race: (d2 bits << 32) | path position
     unsigned* touched;
+    int* anc;            // [SK_LIFT][m] binary-lifting table over the predecessor tree (component-local ids)
+    int64_t m;
+    long long* ticks;    // optional [C][8] phase timestamps (wall_clock64), NULL = off
 };
 
+// agent scope: served by the L2 (never a stale per-CU L1 line, never a trip to HBM for a hot word)
 template <class T>
-__device__ __forceinline__ T ld(const T* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
+__device__ __forceinline__ T ld(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <class T>
-__device__ __forceinline__ void st(T* p, T v) { __atomic_store_n(p, v, __ATOMIC_RELAXED); }
-__device__ __forceinline__ float ld(const float* p) { return __uint_as_float(__atomic_load_n((const unsigned*)p, __ATOMIC_RELAXED)); }
-__device__ __forceinline__ void st(float* p, float v) { __atomic_store_n((unsigned*)p, __float_as_uint(v), __ATOMIC_RELAXED); }
+__device__ __forceinline__ void st(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld(const float* p) { return __uint_as_float(ld((const unsigned*)p)); }
+__device__ __forceinline__ void st(float* p, float v) { st((unsigned*)p, __float_as_uint(v)); }
 
 // workgroup-wide max of a 64-bit key; every thread must call; lds needs SK_MAX_WAVES words
 __device__ __forceinline__ unsigned long long block_max_u64(unsigned long long v, unsigned long long* lds) {
@@ -96,16 +101,34 @@ __device__ void sk_sssp(const SkArgs& A, int base, int n, int root) {
     if (tid == 0) { q[0] = (unsigned)root; s_next = 0; }
     __syncthreads();
     unsigned count = 1, round = 1;
+    unsigned long long visits = 0;
     while (count > 0) {
-        for (unsigned f = wave; f < count; f += nw) {
-            const unsigned u = q[f];
-            const float du = st_ord2f(ld(&A.dist_ord[base + u]));
-            const uint32_t s = A.row_off[base + u], e = A.row_off[base + u + 1];
-            for (uint32_t t = s + lane; t < e; t += 64) {
-                const unsigned v = A.col[t] - (unsigned)base;
-                const unsigned o = st_f2ord(du + A.wgt[t]);
-                const unsigned old = atomicMin(&A.dist_ord[base + v], o);
-                if (o < old && atomicExch(&A.stamp[base + v], round) != round) qn[atomicAdd(&s_next, 1u)] = v;
+        visits += count;
+        if (count >= 2u * (unsigned)nw) {
+            // wide frontier: one lane per frontier vertex, its edges relaxed back to back
+            for (unsigned f = tid; f < count; f += blockDim.x) {
+                const unsigned u = q[f];
+                const float du = st_ord2f(ld(&A.dist_ord[base + u]));
+                const uint32_t s = A.row_off[base + u], e = A.row_off[base + u + 1];
+                for (uint32_t t = s; t < e; t++) {
+                    const unsigned v = A.col[t] - (unsigned)base;
+                    const unsigned o = st_f2ord(du + A.wgt[t]);
+                    const unsigned old = atomicMin(&A.dist_ord[base + v], o);
+                    if (o < old && atomicExch(&A.stamp[base + v], round) != round) qn[atomicAdd(&s_next, 1u)] = v;
+                }
+            }
+        } else {
+            // narrow frontier: one wave per frontier vertex, lanes over its edges
+            for (unsigned f = wave; f < count; f += nw) {
+                const unsigned u = q[f];
+                const float du = st_ord2f(ld(&A.dist_ord[base + u]));
+                const uint32_t s = A.row_off[base + u], e = A.row_off[base + u + 1];
+                for (uint32_t t = s + lane; t < e; t += 64) {
+                    const unsigned v = A.col[t] - (unsigned)base;
+                    const unsigned o = st_f2ord(du + A.wgt[t]);
+                    const unsigned old = atomicMin(&A.dist_ord[base + v], o);
+                    if (o < old && atomicExch(&A.stamp[base + v], round) != round) qn[atomicAdd(&s_next, 1u)] = v;
+                }
             }
         }
         __syncthreads();
@@ -117,6 +140,7 @@ __device__ void sk_sssp(const SkArgs& A, int base, int n, int root) {
         __syncthreads();
     }
     for (int v = tid; v < n; v += blockDim.x) A.dist[base + v] = st_ord2f(ld(&A.dist_ord[base + v]));
+    if (A.ticks && tid == 0) { A.ticks[(int64_t)blockIdx.x * 8 + 6] = (long long)round; A.ticks[(int64_t)blockIdx.x * 8 + 7] = (long long)visits; }
     __syncthreads();
 }
 
@@ -206,13 +230,50 @@ __device__ void sk_tree_distance(const SkArgs& A, int base, int n, int root, flo
     }
 }
 
+// anc[k][v] = 2^k-th ancestor of v in the predecessor tree (-1 past the root); returns levels built
+__device__ int sk_build_lifting(const SkArgs& A, int base, int n) {
+    __shared__ unsigned s_any;
+    const int tid = threadIdx.x;
+    for (int v = tid; v < n; v += blockDim.x) A.anc[base + v] = A.pred[base + v];
+    int levels = 1;
+    for (int k = 1; k < SK_LIFT; k++) {
+        __syncthreads();
+        if (tid == 0) s_any = 0;
+        __syncthreads();
+        const int* prev = A.anc + (int64_t)(k - 1) * A.m + base;
+        int* cur = A.anc + (int64_t)k * A.m + base;
+        unsigned any = 0;
+        for (int v = tid; v < n; v += blockDim.x) {
+            const int h = prev[v];
+            const int a = h >= 0 ? prev[h] : -1;
+            cur[v] = a;
+            any |= a >= 0;
+        }
+        if (any) s_any = 1;
+        __syncthreads();
+        levels = k + 1;
+        if (!s_any) break;
+    }
+    __syncthreads();
+    return levels;
+}
+
+// j-th ancestor of v (j = 0: v itself); -1 once the chain passes the root
+__device__ __forceinline__ int sk_ancestor(const SkArgs& A, int base, int v, unsigned j, int levels) {
+    for (int k = 0; j != 0 && v >= 0; k++, j >>= 1) {
+        if (k >= levels) return -1;
+        if (j & 1u) v = A.anc[(int64_t)k * A.m + base + v];
+    }
+    return v;
+}
+
 // ----------------------------------------------------------------------------- sample_tree ---
 // `distances` = per-vertex tree distance (path.py:53); results in branch_* / path_verts / branch_of.
 __device__ void sk_sample_tree(const SkArgs& A, int base, int n, const float* distances, int comp) {
     __shared__ unsigned long long s_red[SK_MAX_WAVES];
     __shared__ int s_len, s_term, s_parent, s_nb, s_total;
     __shared__ unsigned s_ntouched;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = (blockDim.x + 63) >> 6;
+    const int tid = threadIdx.x;
     const StGrid* g = A.grid;
     for (int v = tid; v < n; v += blockDim.x) {
         st(&A.alloc[base + v], A.pred[base + v] > 0 ? distances[base + v] : -1.0f);  // path.py:71-72
@@ -224,24 +285,44 @@ __device__ void sk_sample_tree(const SkArgs& A, int base, int n, const float* di
     __syncthreads();
     unsigned* tmp = A.q0 + base;
     int* path_out = A.path_verts + base;
+    const int levels = sk_build_lifting(A, base, n);
     for (;;) {
-        // 1. farthest unallocated vertex, first maximum (path.py:92)
+        // 1. farthest unallocated vertex, first maximum (path.py:92).  `alloc` is only written with
+        //    write-through stores (st) before a barrier; one L1 invalidate makes plain, pipelined
+        //    loads of each lane's contiguous slice safe.
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         unsigned long long key = 0;
-        for (int v = tid; v < n; v += blockDim.x) {
-            const unsigned long long k = ((unsigned long long)st_f2ord(ld(&A.alloc[base + v])) << 32) | (0xffffffffu - (unsigned)v);
-            key = k > key ? k : key;
+        {
+            const int per = (n + (int)blockDim.x - 1) / (int)blockDim.x;
+            const int v0 = tid * per, v1 = st_min(v0 + per, n);
+            const float* al = A.alloc + base;
+            for (int v = v0; v < v1; v++) {
+                const unsigned long long k = ((unsigned long long)st_f2ord(al[v]) << 32) | (0xffffffffu - (unsigned)v);
+                key = k > key ? k : key;
+            }
         }
         key = block_max_u64(key, s_red);
         const int far = (int)(0xffffffffu - (unsigned)(key & 0xffffffffu));
         const float dfar = st_ord2f((unsigned)(key >> 32));
         if (!(dfar > 0.0f)) break;  // path.py:94-95 (uniform: every thread holds the same key)
-        // 2. trace_route (path.py:9-16): one lane chases predecessors until an allocated vertex / the root
-        if (tid == 0) {
-            int len = 0, idx = far;
-            while (idx >= 0 && ld(&A.term[base + idx]) == 0u) { tmp[len++] = (unsigned)idx; idx = A.pred[base + idx]; }
-            s_len = len;
-            s_term = idx;
-            s_ntouched = 0;
+        // 2. trace_route (path.py:9-16): walk the predecessors until an allocated vertex / past the root.
+        //    Lane j looks at the j-th ancestor (binary lifting) so a whole chunk of the chain is
+        //    inspected per round instead of one dependent load per hop.
+        {
+            int found = -1;
+            for (unsigned chunk = 0; found < 0; chunk += blockDim.x) {
+                const unsigned j = chunk + tid;
+                const int node = sk_ancestor(A, base, far, j, levels);
+                const bool end = node < 0 || ld(&A.term[base + node]) != 0u;
+                if (!end) tmp[j] = (unsigned)node;
+                // smallest j that ends the walk: max over (~j) of the lanes that see an end
+                unsigned long long k = end ? ((unsigned long long)(0xffffffffu - j) << 32) | (unsigned)(node + 1) : 0ull;
+                k = block_max_u64(k, s_red);
+                if (k != 0ull) {
+                    found = (int)(0xffffffffu - (unsigned)(k >> 32));
+                    if (tid == 0) { s_len = found; s_term = (int)(unsigned)(k & 0xffffffffu) - 1; s_ntouched = 0; }
+                }
+            }
         }
         __syncthreads();
         const int len = s_len, total = s_total, nb = s_nb;
@@ -260,30 +341,32 @@ __device__ void sk_sample_tree(const SkArgs& A, int base, int n, const float* di
         // 4. claim race: every path vertex offers (d2, position) to the points within r of it
         int reach = rp > 0.0f ? (int)ceilf(rp / g->cell) : 0;
         if (reach < 1) reach = 1;
-        for (int qi = wave; qi < len; qi += nw) {
-            const float* pv = A.pts + 3 * (int64_t)(base + path_out[total + qi]);
-            const int cx = (int)floorf((pv[0] - g->lo[0]) / g->cell), cy = (int)floorf((pv[1] - g->lo[1]) / g->cell),
-                      cz = (int)floorf((pv[2] - g->lo[2]) / g->cell);
-            const int x0 = st_max(cx - reach, 0), x1 = st_min(cx + reach, g->dim[0] - 1);
-            const int y0 = st_max(cy - reach, 0), y1 = st_min(cy + reach, g->dim[1] - 1);
-            const int z0 = st_max(cz - reach, 0), z1 = st_min(cz + reach, g->dim[2] - 1);
-            if (z0 > z1) continue;
-            for (int x = x0; x <= x1; x++)
-                for (int y = y0; y <= y1; y++) {
-                    const int64_t row = ((int64_t)x * g->dim[1] + y) * g->dim[2];
-                    const uint32_t s = A.cell_start[row + z0], e = A.cell_start[row + z1 + 1];
-                    for (uint32_t t = s + lane; t < e; t += 64) {
-                        const float4 r4 = A.recs[t];
-                        const int p = (int)__float_as_uint(r4.w) - base;
-                        if (p < 0 || p >= n) continue;  // other component
-                        const float pp[3] = {r4.x, r4.y, r4.z};
-                        const float d2 = sk_dist(pp, pv);
-                        if (!(d2 < rp2)) continue;
-                        const unsigned long long pk = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)qi;
-                        const unsigned long long old = atomicMin(&A.best[base + p], pk);
-                        if (old == SK_EMPTY64) A.touched[base + atomicAdd(&s_ntouched, 1u)] = (unsigned)p;
-                    }
+        {
+            const int side = 2 * reach + 1, nrow = side * side;
+            const int64_t items = (int64_t)len * nrow;
+            for (int64_t it = tid; it < items; it += blockDim.x) {  // one lane per (path vertex, x/y grid row)
+                const int qi = (int)(it / nrow), rr = (int)(it % nrow);
+                const float* pv = A.pts + 3 * (int64_t)(base + path_out[total + qi]);
+                const int x = (int)floorf((pv[0] - g->lo[0]) / g->cell) - reach + rr / side;
+                const int y = (int)floorf((pv[1] - g->lo[1]) / g->cell) - reach + rr % side;
+                if (x < 0 || x >= g->dim[0] || y < 0 || y >= g->dim[1]) continue;
+                const int cz = (int)floorf((pv[2] - g->lo[2]) / g->cell);
+                const int z0 = st_max(cz - reach, 0), z1 = st_min(cz + reach, g->dim[2] - 1);
+                if (z0 > z1) continue;
+                const int64_t row = ((int64_t)x * g->dim[1] + y) * g->dim[2];
+                const uint32_t s = A.cell_start[row + z0], e = A.cell_start[row + z1 + 1];
+                for (uint32_t t = s; t < e; t++) {
+                    const float4 r4 = A.recs[t];
+                    const int p = (int)__float_as_uint(r4.w) - base;
+                    if (p < 0 || p >= n) continue;  // other component
+                    const float pp[3] = {r4.x, r4.y, r4.z};
+                    const float d2 = sk_dist(pp, pv);
+                    if (!(d2 < rp2)) continue;
+                    const unsigned long long pk = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)qi;
+                    const unsigned long long old = atomicMin(&A.best[base + p], pk);
+                    if (old == SK_EMPTY64) A.touched[base + atomicAdd(&s_ntouched, 1u)] = (unsigned)p;
                 }
+            }
         }
         __syncthreads();
         // 5. parent id is read BEFORE this branch stamps anything (path.py:128-136);
@@ -330,6 +413,8 @@ __global__ void __launch_bounds__(1024) k_skeleton_components(SkArgs A, int stag
     const int c = blockIdx.x;
     const int base = A.comp_off[c], n = A.comp_off[c + 1] - base;
     if (n <= 0) { if (threadIdx.x == 0 && (stages & 4)) A.n_branches[c] = 0; return; }
+#define SK_TICK(i) if (A.ticks && threadIdx.x == 0) A.ticks[(int64_t)c * 8 + (i)] = wall_clock64()
+    SK_TICK(0);
     int root;
     if (stages & 1) {
         // root = first minimum of the surface y (cloud.py:204-206)
@@ -341,13 +426,18 @@ __global__ void __launch_bounds__(1024) k_skeleton_components(SkArgs A, int stag
         key = block_max_u64(key, s_red);
         root = (int)(0xffffffffu - (unsigned)(key & 0xffffffffu));
         if (threadIdx.x == 0) A.root_local[c] = root;
+        SK_TICK(1);
         sk_sssp(A, base, n, root);
+        SK_TICK(2);
         sk_preds(A, base, n, root);
+        SK_TICK(3);
     } else {
         root = A.root_local[c];
     }
     if (stages & 2) sk_tree_distance(A, base, n, root, tree_dist);
+    SK_TICK(4);
     if (stages & 4) sk_sample_tree(A, base, n, (stages & 2) ? tree_dist : A.dist, c);
+    SK_TICK(5);
 }
 
 // ------------------------------------------------------------------------------- host side ---
@@ -355,6 +445,7 @@ struct SkScratch {
     unsigned *dist_ord, *stamp, *q0, *q1, *term, *touched;
     float* alloc;
     unsigned long long* best;
+    int* anc;
 };
 static void sk_scratch(StArena& a, int64_t m, SkScratch* s) {
     s->dist_ord = a.take<unsigned>(m);
@@ -365,6 +456,7 @@ static void sk_scratch(StArena& a, int64_t m, SkScratch* s) {
     s->touched = a.take<unsigned>(m);
     s->alloc = a.take<float>(m);
     s->best = a.take<unsigned long long>(m);
+    s->anc = a.take<int>((int64_t)SK_LIFT * m);
 }
 
 #define SK_GRID_CELLS (1ll << 24)
@@ -389,7 +481,8 @@ extern "C" int st_skeleton_components(int n_comp, const int32_t* comp_off, int64
                                       float grid_cell, int stages, int block_threads, float* dist, int32_t* pred,
                                       int32_t* root_local, float* tree_dist, int32_t* branch_parent, int32_t* branch_off,
                                       int32_t* branch_len, int32_t* n_branches, int32_t* path_verts, int32_t* branch_of,
-                                      void* ws, int64_t ws_bytes, void* stream_) {
+                                      long long* phase_ticks /* optional [n_comp][8] device buffer, NULL = off */, void* ws,
+                                      int64_t ws_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n_comp <= 0 || m <= 0) return ST_OK;
     ST_REQUIRE(!(stages & 2) || tree_dist != nullptr, "skeleton: stage 2 needs a tree_dist buffer");
@@ -415,7 +508,7 @@ extern "C" int st_skeleton_components(int n_comp, const int32_t* comp_off, int64
     A.branch_parent = branch_parent; A.branch_off = branch_off; A.branch_len = branch_len; A.n_branches = n_branches;
     A.path_verts = path_verts; A.branch_of = branch_of;
     A.dist_ord = s.dist_ord; A.stamp = s.stamp; A.q0 = s.q0; A.q1 = s.q1; A.alloc = s.alloc; A.term = s.term;
-    A.best = s.best; A.touched = s.touched;
+    A.best = s.best; A.touched = s.touched; A.anc = s.anc; A.m = m; A.ticks = phase_ticks;
     hipLaunchKernelGGL(k_skeleton_components, dim3((unsigned)n_comp), dim3((unsigned)block_threads), 0, stream, A, stages,
                        tree_dist);
     ST_CHECK_LAUNCH();

@@ -62,14 +62,25 @@ __device__ __forceinline__ bool vx_dims(const VxState* st, int* d) {
     return total <= VX_TABLE_CAP;
 }
 
+#define VX_LDS_CELLS 2048
 __global__ void __launch_bounds__(VX_BLOCK) k_vx_hist(const float* xyz, int64_t n, float bs, VxState* st, int* table) {
+    __shared__ int h[VX_LDS_CELLS];
     int d[3];
     if (!vx_dims(st, d)) { if (threadIdx.x == 0 && blockIdx.x == 0) atomicOr(&st->overflow, 1u); return; }
+    // a tree spans a few dozen blocks: count in LDS, flush once per workgroup (global atomics on a
+    // handful of words would serialise a million points)
+    const int ncell = d[0] * d[1] * d[2];
+    const bool use_lds = ncell <= VX_LDS_CELLS;
+    if (use_lds) for (int c = threadIdx.x; c < ncell; c += blockDim.x) h[c] = 0;
+    __syncthreads();
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         int cx = vx_block_id(xyz[3 * i], bs) - st->lo[0], cy = vx_block_id(xyz[3 * i + 1], bs) - st->lo[1],
             cz = vx_block_id(xyz[3 * i + 2], bs) - st->lo[2];
-        atomicAdd(&table[(cx * d[1] + cy) * d[2] + cz], 1);
+        const int c = (cx * d[1] + cy) * d[2] + cz;
+        if (use_lds) atomicAdd(&h[c], 1); else atomicAdd(&table[c], 1);
     }
+    __syncthreads();
+    if (use_lds) for (int c = threadIdx.x; c < ncell; c += blockDim.x) if (h[c]) atomicAdd(&table[c], h[c]);
 }
 
 // single workgroup: counts -> block rank (or -1), centres, bbox init

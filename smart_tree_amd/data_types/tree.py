@@ -22,6 +22,20 @@ from .branch import BranchSkeleton
 from .tube import Tube
 
 
+def offset_to_nearest_tube(pt: torch.Tensor, chain_xyz: torch.Tensor, chain_radii: torch.Tensor) -> torch.Tensor:
+    """Vector from `pt` to its projection on the tube (of the chain a_i -> a_{i+1} with radii r_i -> r_{i+1}) that
+    minimises |distance - interpolated radius| (reference util/queries.py:89-133 for N = 1)."""
+    a, b = chain_xyz[:-1], chain_xyz[1:]
+    r1, r2 = chain_radii[:-1], chain_radii[1:]
+    ab = b - a
+    ap = pt.reshape(1, 3).float() - a
+    t = ((ap * ab).sum(1) / (ab * ab).sum(1)).clip(0.0, 1.0)
+    proj = a + t.unsqueeze(1) * ab
+    r = (1 - t) * r1 + t * r2
+    dist = (proj - pt.reshape(1, 3)).square().sum(1).sqrt()
+    return proj[torch.argmin(torch.abs(dist - r))] - pt.reshape(3)
+
+
 @dataclass
 class TreeSkeleton:
     _id: int
@@ -37,16 +51,17 @@ class TreeSkeleton:
         return [t for b in self.branches.values() for t in b.to_tubes()]
 
     def repair(self) -> None:
-        from ..util.queries import pts_to_nearest_tube  # late: util.queries imports data_types.tube
-
+        """Vectorised over the parent's tube chain (no per-tube objects): same arithmetic as
+        `pts_to_nearest_tube` for one query point."""
         known = set(b._id for b in self.branches.values())
         for branch in self.branches.values():
             if branch.parent_id not in known:
                 continue
-            tubes = self.branches[branch.parent_id].to_tubes()
-            tip = branch.xyz[0].reshape(-1, 3)
-            offset, _, _ = pts_to_nearest_tube(tip, tubes)
-            branch.xyz = torch.cat((tip.cpu() + offset[0].cpu(), branch.xyz))
+            parent = self.branches[branch.parent_id]
+            if len(parent) < 2:
+                continue
+            v = offset_to_nearest_tube(branch.xyz[0], parent.xyz, parent.radii.reshape(-1))
+            branch.xyz = torch.cat(((branch.xyz[0] + v).reshape(1, 3), branch.xyz))  # tree.py:89-91
             branch.radii = torch.cat((branch.radii[[0]], branch.radii))
 
     def prune(self, min_radius: float, min_length: float, root_id=None) -> "TreeSkeleton":

@@ -39,7 +39,7 @@ class ComponentResult:
 
 
 def run_components(comps: ComponentSet, medial_pts: torch.Tensor, radius: torch.Tensor, surface_y: torch.Tensor,
-                   stages: int = STAGE_SSSP | STAGE_SAMPLE, block_threads: int = 0) -> ComponentResult:
+                   stages: int = STAGE_SSSP | STAGE_SAMPLE, block_threads: int = 0, phase_ticks=None) -> ComponentResult:
     """SSSP from the lowest surface point, canonical predecessor tree, greedy branch extraction for
     every component.  The reference's second SSSP over the predecessor tree (skeletonize.py:80-85)
     re-adds the same float32 edge lengths in the same order and therefore reproduces the first
@@ -66,7 +66,7 @@ def run_components(comps: ComponentSet, medial_pts: torch.Tensor, radius: torch.
         _lib.ptr(comps.col), _lib.ptr(comps.wgt), float(max(r_max / 4.0, 1e-4)), int(stages), int(block_threads),
         _lib.ptr(res.dist), _lib.ptr(res.pred), _lib.ptr(res.root_local), _lib.ptr(res.tree_dist),
         _lib.ptr(res.branch_parent), _lib.ptr(res.branch_off), _lib.ptr(res.branch_len), _lib.ptr(res.n_branches),
-        _lib.ptr(res.path_verts), _lib.ptr(res.branch_of), _lib.ptr(ws), ws.numel(), _lib.stream(dev)))
+        _lib.ptr(res.path_verts), _lib.ptr(res.branch_of), _lib.ptr(phase_ticks), _lib.ptr(ws), ws.numel(), _lib.stream(dev)))
     return res
 
 
@@ -109,19 +109,27 @@ class Skeletonizer:
         C = comps.n_components
         if C == 0:
             return []
-        order = comps.vert_order.long()
-        pts = medial[order].cpu()
-        rad = radius[order].cpu()
+        nb = res.n_branches[:C].cpu().tolist()
         off = comps.comp_off.cpu().tolist()
-        nb = res.n_branches.cpu().tolist()
-        parent, boff, blen, verts = (t.cpu() for t in (res.branch_parent, res.branch_off, res.branch_len, res.path_verts))
-        skeletons = []
-        for c in range(C):
-            base = off[c]
-            branches = {}
-            for b in range(nb[c]):
-                s = base + int(boff[base + b])
-                ids = verts[s: s + int(blen[base + b])].long() + base
-                branches[b] = BranchSkeleton(b, int(parent[base + b]), xyz=pts[ids], radii=rad[ids].unsqueeze(1))
-            skeletons.append(TreeSkeleton(c, branches))
-        return skeletons
+        # flat branch table on the device: (component, branch) -> global path slice, then ONE gather + ONE copy
+        rows = [(c, b) for c in range(C) for b in range(nb[c])]
+        if not rows:
+            return [TreeSkeleton(c, {}) for c in range(C)]
+        dev = medial.device
+        comp_of = torch.tensor([r[0] for r in rows], device=dev)
+        slot = torch.tensor([off[c] + b for c, b in rows], device=dev)
+        base = torch.tensor([off[c] for c, _ in rows], device=dev)
+        lens = res.branch_len[slot].long()
+        starts = base + res.branch_off[slot].long()
+        total = int(lens.sum().item())
+        seg = torch.repeat_interleave(torch.arange(len(rows), device=dev), lens, output_size=total)
+        first = torch.cumsum(lens, 0) - lens
+        pos = torch.arange(total, device=dev) - first[seg] + starts[seg]
+        ids = comps.vert_order.long()[res.path_verts[pos].long() + base[seg]]
+        geom = torch.cat((medial[ids], radius[ids].unsqueeze(1)), dim=1).cpu()
+        parents = res.branch_parent[slot].cpu().tolist()
+        pieces = torch.split(geom, lens.cpu().tolist())
+        trees = [TreeSkeleton(c, {}) for c in range(C)]
+        for (c, b), parent, g in zip(rows, parents, pieces):
+            trees[c].branches[b] = BranchSkeleton(b, parent, xyz=g[:, :3].contiguous(), radii=g[:, 3:4].contiguous())
+        return trees

@@ -316,6 +316,13 @@ inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 template <class T> inline T min(T a, T b) { return a < b ? a : b; }
 template <class T> inline T max(T a, T b) { return a > b ? a : b; }
 
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __HIP_MEMORY_SCOPE_WORKGROUP 3
+#define __hip_atomic_load(p, order, scope) __atomic_load_n((p), (order))
+#define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), (order))
+inline long long wall_clock64() { return 0; }
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
+
 // ---- atomics (fibers never run concurrently, plain RMW is exact) -------------------------
 template <class T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 template <class T> inline T atomicSub(T* p, T v) { T o = *p; *p = o - v; return o; }
