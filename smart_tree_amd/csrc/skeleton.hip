@@ -1,32 +1,47 @@
-// Per-component skeleton extraction: SSSP, predecessor tree, tree distance, greedy sample_tree.
+// Skeleton extraction for ALL components of a cloud at once: SSSP, predecessor tree, (literal
+// second SSSP), greedy sample_tree.
 //
 // Reference (smart_tree/skeleton): process_subgraph skeletonize.py:57-95, shortest_paths
 // shortest_path.py:12-21 (cugraph.sssp), pred_graph :46-55 + second sssp skeletonize.py:80-85,
 // sample_tree / trace_route / select_path_points path.py:9-140.  There every component costs
 // several cugraph builds, a cudf->pandas->torch round trip, and per branch a host-synchronising
 // argmax, a Python pointer chase with an O(|T|) tensor membership test per step and an ALL-points
-// FRNN query.  Here ONE persistent workgroup owns a component from root search to the last branch:
-// no host round trip, the termination set is a flag array, and the K=1 "nearest path vertex" query
-// is inverted (path vertices scan the uniform grid around themselves and race with a packed
-// atomicMin(d2 | path position)), which visits only points near the path and yields the same
-// assignment.  Components run concurrently, one workgroup each (largest first).
-// Semantics and tie-breaks: oracle/skeleton_oracle.c (so_sssp, so_tree_distance, so_sample_tree).
+// FRNN query, one component after the other.
 //
-// Everything a workgroup shares through global memory is touched with relaxed atomic
-// loads/stores or atomic RMWs (L2 coherent); workgroups never talk to each other.
+// Here every phase is a chip-wide, level-synchronous kernel over the renumbered vertex space of
+// st_component_layout (components contiguous), and all components advance in lockstep:
+//   * SSSP: frontier rounds (one wavefront per frontier vertex, lanes over its edges, atomicMin on
+//     order-preserving float bits, wave-aggregated queue push); every component's root is a source.
+//     The distances are the least fixed point of d[v] = min fl32(d[u]+w) -- schedule independent.
+//   * predecessors: canonical choice (smallest tight in-neighbour, plateau rounds), one lane/vertex.
+//   * sample_tree, one iteration = the next branch of EVERY unfinished component:
+//       select   (one workgroup per component) argmax of the remaining distances, path trace by
+//                binary lifting over the predecessor tree (lane j inspects the j-th ancestor),
+//                path radius, parent lookup, branch record
+//       claim    (workgroups proportional to component size) the K=1 "nearest path vertex" query
+//                inverted: every (path vertex, grid row) pair scans the uniform grid and races
+//                with a packed atomicMin(d2 bits | path position) per point
+//       finalize on-path test, allocation / termination / branch-id stamps
+//   Launches are enqueued in batches; the host reads one small counter block per batch.
+// Semantics and tie-breaks: oracle/skeleton_oracle.c (so_sssp, so_tree_distance, so_sample_tree).
 #include "st_common.h"
 #include "st_grid.h"
 
 #define SK_MAX_WAVES 16
-#define SK_LIFT 24  // 2^24 hops bound the deepest predecessor chain
 #define SK_EMPTY64 0xffffffffffffffffull
+#define SK_LIFT 24         // 2^24 hops bound the deepest predecessor chain
+#define SK_WIDE_BLOCK 256  // block size of the vertex / frontier kernels
+#define SK_SSSP_BLOCKS 512
+#define SK_MARK 0xfffffffeu
 
 struct SkArgs {
     int C;
-    const int* comp_off;    // [C+1] offsets into the renumbered vertex space
-    const float* pts;       // [m,3] medial points
-    const float* rad;       // [m] raw radius (cloud.radius)
-    const float* ysurf;     // [m] y of the surface point (root = lowest surface point)
+    int64_t m;
+    const int* comp_off;  // [C+1] offsets into the renumbered vertex space
+    int* comp_of;         // [m] component of each vertex
+    const float* pts;     // [m,3] medial points
+    const float* rad;     // [m] raw radius (cloud.radius)
+    const float* ysurf;   // [m] y of the surface point (root = lowest surface point)
     const uint32_t* row_off;  // [m+1]
     const uint32_t* col;      // renumbered neighbour ids
     const float* wgt;
@@ -34,9 +49,10 @@ struct SkArgs {
     const uint32_t* cell_start;
     const float4* recs;
     // outputs
-    float* dist;       // [m]
-    int* pred;         // [m] component-local predecessor, -1 at the root
-    int* root_local;   // [C]
+    float* dist;         // [m]
+    int* pred;           // [m] component-local predecessor, -1 at the root
+    int* root_local;     // [C]
+    float* tree_dist;    // [m] optional
     int* branch_parent;  // [m] (component slice)
     int* branch_off;     // [m] offset into the component's path_verts slice
     int* branch_len;     // [m]
@@ -45,25 +61,30 @@ struct SkArgs {
     int* branch_of;      // [m] final branch id per point (-1: none)
     // scratch [m]
     unsigned* dist_ord;
-    unsigned* stamp;     // SSSP: queued-in-round marker; preds: resolution round
+    unsigned* stamp;  // SSSP: queued-in-round marker; preds: resolution round; tree distance: visited
     unsigned* q0;
     unsigned* q1;
-    float* alloc;        // sample_tree's `distances` (-1 once allocated)
-    unsigned* term;      // termination set
+    float* alloc;     // sample_tree's `distances` (-1 once allocated)
+    unsigned* term;   // termination set
     unsigned long long* best;  // claim race: (d2 bits << 32) | path position
     unsigned* touched;
-    int* anc;            // [SK_LIFT][m] binary-lifting table over the predecessor tree (component-local ids)
-    int64_t m;
-    long long* ticks;    // optional [C][8] phase timestamps (wall_clock64), NULL = off
+    int* anc;         // [levels][m] binary-lifting table (component-local ids)
+    // global counters: [0..2] rotating frontier counts, [3] unresolved, [4] plateau progress, [5] components done
+    unsigned* cnt;
+    // per-component sample_tree state [C]
+    int* s_done;
+    int* s_len;
+    int* s_cur_id;   // branch id being stamped (-1: path shorter than 2, nothing stamped)
+    int* s_cur_off;  // where this iteration's path sits in the component's path_verts slice
+    int* s_nb;
+    int* s_total;
+    float* s_rp;
+    unsigned* s_ntouched;
+    // claim / finalize grid: workgroup b works for component blk_comp[b], as slice (b - blk_first[c]) of blk_count[c]
+    const int* blk_comp;
+    const int* blk_first;
+    const int* blk_count;
 };
-
-// agent scope: served by the L2 (never a stale per-CU L1 line, never a trip to HBM for a hot word)
-template <class T>
-__device__ __forceinline__ T ld(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-template <class T>
-__device__ __forceinline__ void st(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float ld(const float* p) { return __uint_as_float(ld((const unsigned*)p)); }
-__device__ __forceinline__ void st(float* p, float v) { st((unsigned*)p, __float_as_uint(v)); }
 
 // workgroup-wide max of a 64-bit key; every thread must call; lds needs SK_MAX_WAVES words
 __device__ __forceinline__ unsigned long long block_max_u64(unsigned long long v, unsigned long long* lds) {
@@ -90,175 +111,182 @@ __device__ __forceinline__ float sk_dist(const float* a, const float* b) {
     return s;
 }
 
-// ------------------------------------------------------------------------------------ SSSP ---
-__device__ void sk_sssp(const SkArgs& A, int base, int n, int root) {
-    __shared__ unsigned s_next;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = (blockDim.x + 63) >> 6;
+#define SK_VERTEX_LOOP(v) \
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < A.m; v += (int64_t)gridDim.x * blockDim.x)
+
+// ------------------------------------------------------------------------------- set-up ---
+__global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_init(SkArgs A) {
     const unsigned inf = st_f2ord(__uint_as_float(0x7f800000u));
-    for (int v = tid; v < n; v += blockDim.x) { st(&A.dist_ord[base + v], v == root ? st_f2ord(0.0f) : inf); st(&A.stamp[base + v], 0u); }
-    unsigned* q = A.q0 + base;
-    unsigned* qn = A.q1 + base;
-    if (tid == 0) { q[0] = (unsigned)root; s_next = 0; }
-    __syncthreads();
-    unsigned count = 1, round = 1;
-    unsigned long long visits = 0;
-    while (count > 0) {
-        visits += count;
-        if (count >= 2u * (unsigned)nw) {
-            // wide frontier: one lane per frontier vertex, its edges relaxed back to back
-            for (unsigned f = tid; f < count; f += blockDim.x) {
-                const unsigned u = q[f];
-                const float du = st_ord2f(ld(&A.dist_ord[base + u]));
-                const uint32_t s = A.row_off[base + u], e = A.row_off[base + u + 1];
-                for (uint32_t t = s; t < e; t++) {
-                    const unsigned v = A.col[t] - (unsigned)base;
-                    const unsigned o = st_f2ord(du + A.wgt[t]);
-                    const unsigned old = atomicMin(&A.dist_ord[base + v], o);
-                    if (o < old && atomicExch(&A.stamp[base + v], round) != round) qn[atomicAdd(&s_next, 1u)] = v;
-                }
-            }
-        } else {
-            // narrow frontier: one wave per frontier vertex, lanes over its edges
-            for (unsigned f = wave; f < count; f += nw) {
-                const unsigned u = q[f];
-                const float du = st_ord2f(ld(&A.dist_ord[base + u]));
-                const uint32_t s = A.row_off[base + u], e = A.row_off[base + u + 1];
-                for (uint32_t t = s + lane; t < e; t += 64) {
-                    const unsigned v = A.col[t] - (unsigned)base;
-                    const unsigned o = st_f2ord(du + A.wgt[t]);
-                    const unsigned old = atomicMin(&A.dist_ord[base + v], o);
-                    if (o < old && atomicExch(&A.stamp[base + v], round) != round) qn[atomicAdd(&s_next, 1u)] = v;
-                }
-            }
-        }
-        __syncthreads();
-        count = s_next;
-        __syncthreads();
-        if (tid == 0) s_next = 0;
-        unsigned* tq = q; q = qn; qn = tq;
-        round++;
-        __syncthreads();
-    }
-    for (int v = tid; v < n; v += blockDim.x) A.dist[base + v] = st_ord2f(ld(&A.dist_ord[base + v]));
-    if (A.ticks && tid == 0) { A.ticks[(int64_t)blockIdx.x * 8 + 6] = (long long)round; A.ticks[(int64_t)blockIdx.x * 8 + 7] = (long long)visits; }
-    __syncthreads();
+    SK_VERTEX_LOOP(v) { A.dist_ord[v] = inf; A.stamp[v] = 0u; }
+    if (blockIdx.x == 0 && threadIdx.x < 8) A.cnt[threadIdx.x] = threadIdx.x == 0 ? (unsigned)A.C : 0u;
 }
 
-// canonical predecessors (see oracle so_sssp): smallest tight in-neighbour with smaller distance;
-// plateau members are resolved in synchronous rounds from already resolved plateau neighbours
-__device__ void sk_preds(const SkArgs& A, int base, int n, int root) {
-    __shared__ unsigned s_unres, s_prog;
-    const int tid = threadIdx.x;
-    if (tid == 0) s_unres = 0;
-    __syncthreads();
-    for (int v = tid; v < n; v += blockDim.x) {
-        const float dv = A.dist[base + v];
-        int best = 0x7fffffff;
-        if (v != root) {
-            for (uint32_t t = A.row_off[base + v]; t < A.row_off[base + v + 1]; t++) {
-                const int u = (int)(A.col[t] - (unsigned)base);
-                if (u == v) continue;
-                const float du = A.dist[base + u];
+// one workgroup per component: comp_of[], root = first minimum of the surface y (cloud.py:204-206)
+__global__ void __launch_bounds__(1024) k_sk_roots(SkArgs A) {
+    __shared__ unsigned long long s_red[SK_MAX_WAVES];
+    const int c = blockIdx.x, base = A.comp_off[c], n = A.comp_off[c + 1] - base;
+    unsigned long long key = 0;
+    for (int v = threadIdx.x; v < n; v += blockDim.x) {
+        A.comp_of[base + v] = c;
+        const unsigned long long k = ((unsigned long long)(0xffffffffu - st_f2ord(A.ysurf[base + v])) << 32) | (0xffffffffu - (unsigned)v);
+        key = k > key ? k : key;
+    }
+    key = block_max_u64(key, s_red);
+    if (threadIdx.x == 0) {
+        const int root = n > 0 ? (int)(0xffffffffu - (unsigned)(key & 0xffffffffu)) : 0;
+        A.root_local[c] = root;
+        A.q0[c] = (unsigned)(base + root);  // round 0 frontier = every component's root
+        if (n > 0) A.dist_ord[base + root] = st_f2ord(0.0f);
+    }
+}
+
+// ------------------------------------------------------------------------------------ SSSP ---
+// round r: frontier r%2 -> (r+1)%2; counts rotate through cnt[0..2]
+__global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_sssp_round(SkArgs A, int r) {
+    const unsigned count = A.cnt[r % 3];
+    if (blockIdx.x == 0 && threadIdx.x == 0) A.cnt[(r + 2) % 3] = 0u;
+    if (count == 0) return;
+    const unsigned* q = (r & 1) ? A.q1 : A.q0;
+    unsigned* qn = (r & 1) ? A.q0 : A.q1;
+    unsigned* cnt_out = &A.cnt[(r + 1) % 3];
+    const unsigned round = (unsigned)r + 1u;
+    const int lane = threadIdx.x & 63;
+    const unsigned gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, tw = (gridDim.x * blockDim.x) >> 6;
+    for (unsigned f = gw; f < count; f += tw) {  // wave-uniform
+        const unsigned u = q[f];
+        const float du = st_ord2f(A.dist_ord[u]);
+        const uint32_t s = A.row_off[u], e = A.row_off[u + 1];
+        for (uint32_t t0 = s; t0 < e; t0 += 64) {
+            const uint32_t t = t0 + lane;
+            bool push = false;
+            unsigned v = 0;
+            if (t < e) {
+                v = A.col[t];
+                const unsigned o = st_f2ord(du + A.wgt[t]);
+                const unsigned old = atomicMin(&A.dist_ord[v], o);
+                push = o < old && atomicExch(&A.stamp[v], round) != round;
+            }
+            const unsigned long long mask = __ballot(push);  // wave-aggregated queue push
+            if (mask) {
+                const int leader = __ffsll(mask) - 1;
+                unsigned slot = 0;
+                if (lane == leader) slot = atomicAdd(cnt_out, (unsigned)__popcll(mask));
+                slot = __shfl(slot, leader);
+                if (push) qn[slot + (unsigned)__popcll(mask & ((1ull << lane) - 1ull))] = v;
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_dist_out(SkArgs A) {
+    SK_VERTEX_LOOP(v) A.dist[v] = st_ord2f(A.dist_ord[v]);
+}
+
+// canonical predecessors (oracle so_sssp): smallest tight in-neighbour with smaller distance
+__global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_preds(SkArgs A) {
+    SK_VERTEX_LOOP(v) {
+        const int c = A.comp_of[v], base = A.comp_off[c];
+        const bool is_root = (int)(v - base) == A.root_local[c];
+        const float dv = A.dist[v];
+        unsigned best = 0xffffffffu;
+        if (!is_root)
+            for (uint32_t t = A.row_off[v]; t < A.row_off[v + 1]; t++) {
+                const unsigned u = A.col[t];
+                if (u == (unsigned)v) continue;
+                const float du = A.dist[u];
                 if (du < dv && du + A.wgt[t] == dv && u < best) best = u;
             }
-        }
-        const bool ok = v == root || best != 0x7fffffff;
-        A.pred[base + v] = v == root ? -1 : (ok ? best : -1);
-        st(&A.stamp[base + v], ok ? 1u : 0u);
-        if (!ok) atomicAdd(&s_unres, 1u);
-    }
-    __syncthreads();
-    unsigned unres = s_unres, round = 2;
-    while (unres > 0) {
-        __syncthreads();
-        if (tid == 0) s_prog = 0;
-        __syncthreads();
-        for (int v = tid; v < n; v += blockDim.x) {
-            if (ld(&A.stamp[base + v]) != 0u) continue;
-            const float dv = A.dist[base + v];
-            int best = 0x7fffffff;
-            for (uint32_t t = A.row_off[base + v]; t < A.row_off[base + v + 1]; t++) {
-                const int u = (int)(A.col[t] - (unsigned)base);
-                if (u == v) continue;
-                const unsigned su = ld(&A.stamp[base + u]);
-                if (su == 0u || su >= round) continue;  // only vertices resolved in EARLIER rounds
-                const float du = A.dist[base + u];
-                if (du == dv && du + A.wgt[t] == dv && u < best) best = u;
-            }
-            if (best != 0x7fffffff) { A.pred[base + v] = best; st(&A.stamp[base + v], round); atomicAdd(&s_prog, 1u); }
-        }
-        __syncthreads();
-        const unsigned prog = s_prog;
-        if (prog == 0) break;  // unreachable leftovers (cannot happen inside one component)
-        unres -= prog;
-        round++;
-    }
-    __syncthreads();
-}
-
-// second SSSP of the reference on the predecessor tree (recomputed Euclidean edge lengths):
-// breadth-first down the tree, td[child] = td[parent] + |p_child - p_parent|
-__device__ void sk_tree_distance(const SkArgs& A, int base, int n, int root, float* td) {
-    __shared__ unsigned s_next;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = (blockDim.x + 63) >> 6;
-    unsigned* q = A.q0 + base;
-    unsigned* qn = A.q1 + base;
-    for (int v = tid; v < n; v += blockDim.x) td[base + v] = __uint_as_float(0x7f800000u);
-    __syncthreads();
-    if (tid == 0) { q[0] = (unsigned)root; s_next = 0; td[base + root] = 0.0f; }
-    __syncthreads();
-    unsigned count = 1;
-    while (count > 0) {
-        for (unsigned f = wave; f < count; f += nw) {
-            const unsigned u = q[f];
-            const float du = ld(&td[base + u]);
-            for (uint32_t t = A.row_off[base + u] + lane; t < A.row_off[base + u + 1]; t += 64) {
-                const unsigned v = A.col[t] - (unsigned)base;
-                if (A.pred[base + v] != (int)u) continue;
-                // duplicate (u,v) edges may exist: only the first writer enqueues
-                if (atomicExch(&A.stamp[base + v], 0xfffffffeu) == 0xfffffffeu) continue;
-                st(&td[base + v], du + sqrtf(sk_dist(A.pts + 3 * (int64_t)(base + v), A.pts + 3 * (int64_t)(base + u))));
-                qn[atomicAdd(&s_next, 1u)] = v;
-            }
-        }
-        __syncthreads();
-        count = s_next;
-        __syncthreads();
-        if (tid == 0) s_next = 0;
-        unsigned* tq = q; q = qn; qn = tq;
-        __syncthreads();
+        const bool ok = is_root || best != 0xffffffffu;
+        A.pred[v] = (is_root || !ok) ? -1 : (int)best - base;
+        A.stamp[v] = ok ? 1u : 0u;
+        if (!ok) atomicAdd(&A.cnt[3], 1u);
     }
 }
 
-// anc[k][v] = 2^k-th ancestor of v in the predecessor tree (-1 past the root); returns levels built
-__device__ int sk_build_lifting(const SkArgs& A, int base, int n) {
-    __shared__ unsigned s_any;
-    const int tid = threadIdx.x;
-    for (int v = tid; v < n; v += blockDim.x) A.anc[base + v] = A.pred[base + v];
-    int levels = 1;
-    for (int k = 1; k < SK_LIFT; k++) {
-        __syncthreads();
-        if (tid == 0) s_any = 0;
-        __syncthreads();
-        const int* prev = A.anc + (int64_t)(k - 1) * A.m + base;
-        int* cur = A.anc + (int64_t)k * A.m + base;
-        unsigned any = 0;
-        for (int v = tid; v < n; v += blockDim.x) {
-            const int h = prev[v];
-            const int a = h >= 0 ? prev[h] : -1;
-            cur[v] = a;
-            any |= a >= 0;
+// plateau members: resolved in synchronous rounds from plateau neighbours resolved in EARLIER rounds
+__global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_preds_plateau(SkArgs A, unsigned round) {
+    SK_VERTEX_LOOP(v) {
+        if (A.stamp[v] != 0u) continue;
+        const int base = A.comp_off[A.comp_of[v]];
+        const float dv = A.dist[v];
+        unsigned best = 0xffffffffu;
+        for (uint32_t t = A.row_off[v]; t < A.row_off[v + 1]; t++) {
+            const unsigned u = A.col[t];
+            if (u == (unsigned)v) continue;
+            const unsigned su = __hip_atomic_load(&A.stamp[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (su == 0u || su >= round) continue;
+            const float du = A.dist[u];
+            if (du == dv && du + A.wgt[t] == dv && u < best) best = u;
         }
-        if (any) s_any = 1;
-        __syncthreads();
-        levels = k + 1;
-        if (!s_any) break;
+        if (best != 0xffffffffu) {
+            A.pred[v] = (int)best - base;
+            __hip_atomic_store(&A.stamp[v], round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            atomicAdd(&A.cnt[4], 1u);
+        }
     }
-    __syncthreads();
-    return levels;
 }
 
-// j-th ancestor of v (j = 0: v itself); -1 once the chain passes the root
+// ------------------------------------------------- literal second SSSP on the predecessor tree ---
+__global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_td_init(SkArgs A) {
+    SK_VERTEX_LOOP(v) { A.tree_dist[v] = __uint_as_float(0x7f800000u); A.stamp[v] = 0u; }
+    if (blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < A.C; c += blockDim.x) A.q0[c] = (unsigned)(A.comp_off[c] + A.root_local[c]);
+        if (threadIdx.x < 3) A.cnt[threadIdx.x] = threadIdx.x == 0 ? (unsigned)A.C : 0u;
+    }
+}
+__global__ void k_sk_td_roots(SkArgs A) {
+    for (int c = threadIdx.x; c < A.C; c += blockDim.x) A.tree_dist[A.comp_off[c] + A.root_local[c]] = 0.0f;
+}
+
+// breadth first down the tree: td[child] = td[parent] + |p_child - p_parent| (skeletonize.py:80-85)
+__global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_td_round(SkArgs A, int r) {
+    const unsigned count = A.cnt[r % 3];
+    if (blockIdx.x == 0 && threadIdx.x == 0) A.cnt[(r + 2) % 3] = 0u;
+    if (count == 0) return;
+    const unsigned* q = (r & 1) ? A.q1 : A.q0;
+    unsigned* qn = (r & 1) ? A.q0 : A.q1;
+    unsigned* cnt_out = &A.cnt[(r + 1) % 3];
+    const int lane = threadIdx.x & 63;
+    const unsigned gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, tw = (gridDim.x * blockDim.x) >> 6;
+    for (unsigned f = gw; f < count; f += tw) {
+        const unsigned u = q[f];
+        const int base = A.comp_off[A.comp_of[u]];
+        const float du = A.tree_dist[u];
+        for (uint32_t t = A.row_off[u] + lane; t < A.row_off[u + 1]; t += 64) {
+            const unsigned v = A.col[t];
+            if (A.pred[v] != (int)u - base) continue;
+            if (atomicExch(&A.stamp[v], SK_MARK) == SK_MARK) continue;  // duplicate (u,v) edges: first one enqueues
+            A.tree_dist[v] = du + sqrtf(sk_dist(A.pts + 3 * (int64_t)v, A.pts + 3 * (int64_t)u));
+            qn[atomicAdd(cnt_out, 1u)] = v;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------- sample_tree ---
+__global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_lift_init(SkArgs A, const float* distances) {
+    SK_VERTEX_LOOP(v) {
+        const int p = A.pred[v];
+        A.anc[v] = p;
+        A.alloc[v] = p > 0 ? distances[v] : -1.0f;  // path.py:71-72
+        A.term[v] = 0u;
+        A.branch_of[v] = -1;
+        A.best[v] = SK_EMPTY64;
+    }
+    if (blockIdx.x == 0)
+        for (int c = threadIdx.x; c < A.C; c += blockDim.x) { A.s_done[c] = 0; A.s_nb[c] = 0; A.s_total[c] = 0; A.s_len[c] = 0; }
+}
+
+// anc[k][v] = 2^k-th ancestor (component-local id), -1 past the root
+__global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_lift_level(SkArgs A, int k) {
+    const int* prev = A.anc + (int64_t)(k - 1) * A.m;
+    int* cur = A.anc + (int64_t)k * A.m;
+    SK_VERTEX_LOOP(v) {
+        const int base = A.comp_off[A.comp_of[v]];
+        const int h = prev[v];
+        cur[v] = h >= 0 ? prev[base + h] : -1;
+    }
+}
+
 __device__ __forceinline__ int sk_ancestor(const SkArgs& A, int base, int v, unsigned j, int levels) {
     for (int k = 0; j != 0 && v >= 0; k++, j >>= 1) {
         if (k >= levels) return -1;
@@ -267,250 +295,334 @@ __device__ __forceinline__ int sk_ancestor(const SkArgs& A, int base, int v, uns
     return v;
 }
 
-// ----------------------------------------------------------------------------- sample_tree ---
-// `distances` = per-vertex tree distance (path.py:53); results in branch_* / path_verts / branch_of.
-__device__ void sk_sample_tree(const SkArgs& A, int base, int n, const float* distances, int comp) {
+// select: one workgroup per component -- farthest unallocated vertex, trace, radius, parent, record
+__global__ void __launch_bounds__(1024) k_sk_select(SkArgs A, int levels) {
     __shared__ unsigned long long s_red[SK_MAX_WAVES];
-    __shared__ int s_len, s_term, s_parent, s_nb, s_total;
-    __shared__ unsigned s_ntouched;
-    const int tid = threadIdx.x;
-    const StGrid* g = A.grid;
-    for (int v = tid; v < n; v += blockDim.x) {
-        st(&A.alloc[base + v], A.pred[base + v] > 0 ? distances[base + v] : -1.0f);  // path.py:71-72
-        st(&A.term[base + v], 0u);
-        st(&A.branch_of[base + v], -1);
-        st(&A.best[base + v], (unsigned long long)SK_EMPTY64);
-    }
-    if (tid == 0) { s_nb = 0; s_total = 0; }
-    __syncthreads();
-    unsigned* tmp = A.q0 + base;
-    int* path_out = A.path_verts + base;
-    const int levels = sk_build_lifting(A, base, n);
-    for (;;) {
-        // 1. farthest unallocated vertex, first maximum (path.py:92).  `alloc` is only written with
-        //    write-through stores (st) before a barrier; one L1 invalidate makes plain, pipelined
-        //    loads of each lane's contiguous slice safe.
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        unsigned long long key = 0;
-        {
-            const int per = (n + (int)blockDim.x - 1) / (int)blockDim.x;
-            const int v0 = tid * per, v1 = st_min(v0 + per, n);
-            const float* al = A.alloc + base;
-            for (int v = v0; v < v1; v++) {
-                const unsigned long long k = ((unsigned long long)st_f2ord(al[v]) << 32) | (0xffffffffu - (unsigned)v);
-                key = k > key ? k : key;
-            }
-        }
-        key = block_max_u64(key, s_red);
-        const int far = (int)(0xffffffffu - (unsigned)(key & 0xffffffffu));
-        const float dfar = st_ord2f((unsigned)(key >> 32));
-        if (!(dfar > 0.0f)) break;  // path.py:94-95 (uniform: every thread holds the same key)
-        // 2. trace_route (path.py:9-16): walk the predecessors until an allocated vertex / past the root.
-        //    Lane j looks at the j-th ancestor (binary lifting) so a whole chunk of the chain is
-        //    inspected per round instead of one dependent load per hop.
-        {
-            int found = -1;
-            for (unsigned chunk = 0; found < 0; chunk += blockDim.x) {
-                const unsigned j = chunk + tid;
-                const int node = sk_ancestor(A, base, far, j, levels);
-                const bool end = node < 0 || ld(&A.term[base + node]) != 0u;
-                if (!end) tmp[j] = (unsigned)node;
-                // smallest j that ends the walk: max over (~j) of the lanes that see an end
-                unsigned long long k = end ? ((unsigned long long)(0xffffffffu - j) << 32) | (unsigned)(node + 1) : 0ull;
-                k = block_max_u64(k, s_red);
-                if (k != 0ull) {
-                    found = (int)(0xffffffffu - (unsigned)(k >> 32));
-                    if (tid == 0) { s_len = found; s_term = (int)(unsigned)(k & 0xffffffffu) - 1; s_ntouched = 0; }
-                }
-            }
-        }
-        __syncthreads();
-        const int len = s_len, total = s_total, nb = s_nb;
-        const bool keep = len >= 2;  // path.py:125-126
-        // 3. path stored root side first; r = max radius on the path (path.py:31)
-        unsigned long long rk = 0;
-        for (int qi = tid; qi < len; qi += blockDim.x) {
-            const int v = (int)tmp[len - 1 - qi];
-            path_out[total + qi] = v;
-            const unsigned long long k = (unsigned long long)st_f2ord(A.rad[base + v]) << 32;
-            rk = k > rk ? k : rk;
-        }
-        rk = block_max_u64(rk, s_red);  // (barriers inside also publish path_out)
-        const float rp = st_ord2f((unsigned)(rk >> 32));
-        const float rp2 = rp * rp;
-        // 4. claim race: every path vertex offers (d2, position) to the points within r of it
-        int reach = rp > 0.0f ? (int)ceilf(rp / g->cell) : 0;
-        if (reach < 1) reach = 1;
-        {
-            const int side = 2 * reach + 1, nrow = side * side;
-            const int64_t items = (int64_t)len * nrow;
-            for (int64_t it = tid; it < items; it += blockDim.x) {  // one lane per (path vertex, x/y grid row)
-                const int qi = (int)(it / nrow), rr = (int)(it % nrow);
-                const float* pv = A.pts + 3 * (int64_t)(base + path_out[total + qi]);
-                const int x = (int)floorf((pv[0] - g->lo[0]) / g->cell) - reach + rr / side;
-                const int y = (int)floorf((pv[1] - g->lo[1]) / g->cell) - reach + rr % side;
-                if (x < 0 || x >= g->dim[0] || y < 0 || y >= g->dim[1]) continue;
-                const int cz = (int)floorf((pv[2] - g->lo[2]) / g->cell);
-                const int z0 = st_max(cz - reach, 0), z1 = st_min(cz + reach, g->dim[2] - 1);
-                if (z0 > z1) continue;
-                const int64_t row = ((int64_t)x * g->dim[1] + y) * g->dim[2];
-                const uint32_t s = A.cell_start[row + z0], e = A.cell_start[row + z1 + 1];
-                for (uint32_t t = s; t < e; t++) {
-                    const float4 r4 = A.recs[t];
-                    const int p = (int)__float_as_uint(r4.w) - base;
-                    if (p < 0 || p >= n) continue;  // other component
-                    const float pp[3] = {r4.x, r4.y, r4.z};
-                    const float d2 = sk_dist(pp, pv);
-                    if (!(d2 < rp2)) continue;
-                    const unsigned long long pk = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)qi;
-                    const unsigned long long old = atomicMin(&A.best[base + p], pk);
-                    if (old == SK_EMPTY64) A.touched[base + atomicAdd(&s_ntouched, 1u)] = (unsigned)p;
-                }
-            }
-        }
-        __syncthreads();
-        // 5. parent id is read BEFORE this branch stamps anything (path.py:128-136);
-        //    termination -1 reads branch_ids[-1] = the last vertex (quirk kept)
-        if (tid == 0) s_parent = ld(&A.branch_of[base + (s_term < 0 ? n - 1 : s_term)]);
-        __syncthreads();
-        // 6. on-path test (path.py:35-40) and bookkeeping (:112-122,135-136)
-        const unsigned nt = s_ntouched;
-        for (unsigned t = tid; t < nt; t += blockDim.x) {
-            const int p = (int)A.touched[base + t];
-            const unsigned long long pk = ld(&A.best[base + p]);
-            st(&A.best[base + p], (unsigned long long)SK_EMPTY64);
-            const float d2 = __uint_as_float((unsigned)(pk >> 32));
-            const int qi = (int)(pk & 0xffffffffu);
-            if (sqrtf(d2) < A.rad[base + path_out[total + qi]]) {
-                st(&A.alloc[base + p], -1.0f);
-                st(&A.term[base + p], 1u);
-                if (keep) st(&A.branch_of[base + p], nb);
-            }
-        }
-        for (int qi = tid; qi < len; qi += blockDim.x) {
-            const int v = path_out[total + qi];
-            st(&A.alloc[base + v], -1.0f);
-            st(&A.term[base + v], 1u);
-            if (keep) st(&A.branch_of[base + v], nb);
-        }
-        __syncthreads();
-        if (tid == 0 && keep) {
-            A.branch_parent[base + nb] = s_parent;
-            A.branch_off[base + nb] = total;
-            A.branch_len[base + nb] = len;
-            s_nb = nb + 1;
-            s_total = total + len;
-        }
-        __syncthreads();
-    }
-    if (tid == 0) A.n_branches[comp] = s_nb;
-    __syncthreads();
-}
-
-// stages: bit0 root+sssp+preds, bit1 literal tree distance (into `alloc`-independent td buffer), bit2 sample_tree
-__global__ void __launch_bounds__(1024) k_skeleton_components(SkArgs A, int stages, float* tree_dist) {
-    __shared__ unsigned long long s_red[SK_MAX_WAVES];
-    const int c = blockIdx.x;
+    __shared__ int s_term;
+    const int c = blockIdx.x, tid = threadIdx.x;
+    if (A.s_done[c]) return;
     const int base = A.comp_off[c], n = A.comp_off[c + 1] - base;
-    if (n <= 0) { if (threadIdx.x == 0 && (stages & 4)) A.n_branches[c] = 0; return; }
-#define SK_TICK(i) if (A.ticks && threadIdx.x == 0) A.ticks[(int64_t)c * 8 + (i)] = wall_clock64()
-    SK_TICK(0);
-    int root;
-    if (stages & 1) {
-        // root = first minimum of the surface y (cloud.py:204-206)
-        unsigned long long key = 0;
-        for (int v = threadIdx.x; v < n; v += blockDim.x) {
-            const unsigned long long k = ((unsigned long long)(0xffffffffu - st_f2ord(A.ysurf[base + v])) << 32) | (0xffffffffu - (unsigned)v);
+    // 1. argmax of the remaining distances, first maximum (path.py:92): contiguous slice per lane
+    unsigned long long key = 0;
+    {
+        const int per = (n + (int)blockDim.x - 1) / (int)blockDim.x;
+        const int v0 = tid * per, v1 = st_min(v0 + per, n);
+        const float* al = A.alloc + base;
+        for (int v = v0; v < v1; v++) {
+            const unsigned long long k = ((unsigned long long)st_f2ord(al[v]) << 32) | (0xffffffffu - (unsigned)v);
             key = k > key ? k : key;
         }
-        key = block_max_u64(key, s_red);
-        root = (int)(0xffffffffu - (unsigned)(key & 0xffffffffu));
-        if (threadIdx.x == 0) A.root_local[c] = root;
-        SK_TICK(1);
-        sk_sssp(A, base, n, root);
-        SK_TICK(2);
-        sk_preds(A, base, n, root);
-        SK_TICK(3);
-    } else {
-        root = A.root_local[c];
     }
-    if (stages & 2) sk_tree_distance(A, base, n, root, tree_dist);
-    SK_TICK(4);
-    if (stages & 4) sk_sample_tree(A, base, n, (stages & 2) ? tree_dist : A.dist, c);
-    SK_TICK(5);
+    key = block_max_u64(key, s_red);
+    const int far = (int)(0xffffffffu - (unsigned)(key & 0xffffffffu));
+    const float dfar = n > 0 ? st_ord2f((unsigned)(key >> 32)) : -1.0f;
+    if (!(dfar > 0.0f)) {  // path.py:94-95 (uniform)
+        if (tid == 0) { A.s_done[c] = 1; A.s_len[c] = 0; A.n_branches[c] = A.s_nb[c]; atomicAdd(&A.cnt[5], 1u); }
+        return;
+    }
+    // 2. trace_route (path.py:9-16): lane j inspects the j-th ancestor; the first allocated one (or
+    //    the step past the root) ends the walk
+    unsigned* tmp = A.q0 + base;
+    int len = -1;
+    for (unsigned chunk = 0; len < 0; chunk += blockDim.x) {
+        const unsigned j = chunk + tid;
+        const int node = sk_ancestor(A, base, far, j, levels);
+        const bool end = node < 0 || A.term[base + node] != 0u;
+        if (!end) tmp[j] = (unsigned)node;
+        unsigned long long k = end ? ((unsigned long long)(0xffffffffu - j) << 32) | (unsigned)(node + 1) : 0ull;
+        k = block_max_u64(k, s_red);
+        if (k != 0ull) {
+            len = (int)(0xffffffffu - (unsigned)(k >> 32));
+            if (tid == 0) s_term = (int)(unsigned)(k & 0xffffffffu) - 1;
+        }
+    }
+    __syncthreads();
+    // 3. path root side first; r = max radius on the path (path.py:31)
+    const int total = A.s_total[c];
+    int* path_out = A.path_verts + base + total;
+    unsigned long long rk = 0;
+    for (int qi = tid; qi < len; qi += blockDim.x) {
+        const int v = (int)tmp[len - 1 - qi];
+        path_out[qi] = v;
+        const unsigned long long k = (unsigned long long)st_f2ord(A.rad[base + v]) << 32;
+        rk = k > rk ? k : rk;
+    }
+    rk = block_max_u64(rk, s_red);
+    if (tid == 0) {
+        const bool keep = len >= 2;  // path.py:125-126: shorter paths still consume their points
+        const int nb = A.s_nb[c];
+        A.s_len[c] = len;
+        A.s_rp[c] = st_ord2f((unsigned)(rk >> 32));
+        A.s_ntouched[c] = 0u;
+        A.s_cur_off[c] = total;
+        A.s_cur_id[c] = keep ? nb : -1;
+        if (keep) {
+            // parent id is read BEFORE this branch stamps anything (path.py:128-136);
+            // termination -1 reads branch_ids[-1] = the last vertex (quirk kept)
+            A.branch_parent[base + nb] = A.branch_of[base + (s_term < 0 ? n - 1 : s_term)];
+            A.branch_off[base + nb] = total;
+            A.branch_len[base + nb] = len;
+            A.s_nb[c] = nb + 1;
+            A.s_total[c] = total + len;
+        }
+    }
+}
+
+// claim: every (path vertex, x/y grid row) pair offers (d2, position) to the points within r of it
+__global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_claim(SkArgs A) {
+    const int c = A.blk_comp[blockIdx.x];
+    if (A.s_done[c]) return;
+    const int len = A.s_len[c];
+    const int base = A.comp_off[c], n = A.comp_off[c + 1] - base;
+    const int slice = blockIdx.x - A.blk_first[c], nslice = A.blk_count[c];
+    const StGrid* g = A.grid;
+    const float rp = A.s_rp[c], rp2 = rp * rp;
+    int reach = rp > 0.0f ? (int)ceilf(rp / g->cell) : 0;
+    if (reach < 1) reach = 1;
+    const int side = 2 * reach + 1, nrow = side * side;
+    const int64_t items = (int64_t)len * nrow;
+    const int* path = A.path_verts + base + A.s_cur_off[c];
+    for (int64_t it = (int64_t)slice * blockDim.x + threadIdx.x; it < items; it += (int64_t)nslice * blockDim.x) {
+        const int qi = (int)(it / nrow), rr = (int)(it % nrow);
+        const float* pv = A.pts + 3 * (int64_t)(base + path[qi]);
+        const int x = (int)floorf((pv[0] - g->lo[0]) / g->cell) - reach + rr / side;
+        const int y = (int)floorf((pv[1] - g->lo[1]) / g->cell) - reach + rr % side;
+        if (x < 0 || x >= g->dim[0] || y < 0 || y >= g->dim[1]) continue;
+        const int cz = (int)floorf((pv[2] - g->lo[2]) / g->cell);
+        const int z0 = st_max(cz - reach, 0), z1 = st_min(cz + reach, g->dim[2] - 1);
+        if (z0 > z1) continue;
+        const int64_t row = ((int64_t)x * g->dim[1] + y) * g->dim[2];
+        const uint32_t s = A.cell_start[row + z0], e = A.cell_start[row + z1 + 1];
+        for (uint32_t t = s; t < e; t++) {
+            const float4 r4 = A.recs[t];
+            const int p = (int)__float_as_uint(r4.w) - base;
+            if (p < 0 || p >= n) continue;  // other component
+            const float pp[3] = {r4.x, r4.y, r4.z};
+            const float d2 = sk_dist(pp, pv);
+            if (!(d2 < rp2)) continue;
+            const unsigned long long pk = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)qi;
+            const unsigned long long old = atomicMin(&A.best[base + p], pk);
+            if (old == SK_EMPTY64) A.touched[base + atomicAdd(&A.s_ntouched[c], 1u)] = (unsigned)p;
+        }
+    }
+}
+
+// finalize: on-path test (path.py:35-40) and bookkeeping (:112-122,135-136)
+__global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_finalize(SkArgs A) {
+    const int c = A.blk_comp[blockIdx.x];
+    if (A.s_done[c]) return;
+    const int len = A.s_len[c], id = A.s_cur_id[c];
+    const int base = A.comp_off[c];
+    const int slice = blockIdx.x - A.blk_first[c], nslice = A.blk_count[c];
+    const int* path = A.path_verts + base + A.s_cur_off[c];
+    const unsigned nt = A.s_ntouched[c];
+    for (unsigned t = slice * blockDim.x + threadIdx.x; t < nt; t += nslice * blockDim.x) {
+        const int p = (int)A.touched[base + t];
+        const unsigned long long pk = A.best[base + p];
+        A.best[base + p] = SK_EMPTY64;
+        const float d2 = __uint_as_float((unsigned)(pk >> 32));
+        const int qi = (int)(pk & 0xffffffffu);
+        if (sqrtf(d2) < A.rad[base + path[qi]]) {
+            A.alloc[base + p] = -1.0f;
+            A.term[base + p] = 1u;
+            if (id >= 0) A.branch_of[base + p] = id;
+        }
+    }
+    for (int qi = slice * blockDim.x + threadIdx.x; qi < len; qi += nslice * blockDim.x) {
+        const int v = path[qi];
+        A.alloc[base + v] = -1.0f;
+        A.term[base + v] = 1u;
+        if (id >= 0) A.branch_of[base + v] = id;
+    }
 }
 
 // ------------------------------------------------------------------------------- host side ---
-struct SkScratch {
-    unsigned *dist_ord, *stamp, *q0, *q1, *term, *touched;
-    float* alloc;
+#define SK_GRID_CELLS (1ll << 24)
+#define SK_MAX_CLAIM_BLOCKS 256
+
+struct SkLayout {
+    unsigned *dist_ord, *stamp, *q0, *q1, *term, *touched, *cnt, *s_ntouched;
+    float *alloc, *s_rp;
     unsigned long long* best;
-    int* anc;
+    int *anc, *comp_of, *s_done, *s_len, *s_cur_id, *s_cur_off, *s_nb, *s_total, *blk_comp, *blk_first, *blk_count;
+    StGrid* g;
+    uint32_t* cell_start;
+    float4* recs;
+    char* gws;
+    int64_t gws_bytes;
 };
-static void sk_scratch(StArena& a, int64_t m, SkScratch* s) {
+
+static void sk_layout(StArena& a, int64_t m, int64_t C, SkLayout* s) {
     s->dist_ord = a.take<unsigned>(m);
     s->stamp = a.take<unsigned>(m);
-    s->q0 = a.take<unsigned>(m);
-    s->q1 = a.take<unsigned>(m);
+    s->q0 = a.take<unsigned>(m + C);
+    s->q1 = a.take<unsigned>(m + C);
     s->term = a.take<unsigned>(m);
     s->touched = a.take<unsigned>(m);
     s->alloc = a.take<float>(m);
     s->best = a.take<unsigned long long>(m);
     s->anc = a.take<int>((int64_t)SK_LIFT * m);
+    s->comp_of = a.take<int>(m);
+    s->cnt = a.take<unsigned>(8);
+    s->s_done = a.take<int>(C);
+    s->s_len = a.take<int>(C);
+    s->s_cur_id = a.take<int>(C);
+    s->s_cur_off = a.take<int>(C);
+    s->s_nb = a.take<int>(C);
+    s->s_total = a.take<int>(C);
+    s->s_rp = a.take<float>(C);
+    s->s_ntouched = a.take<unsigned>(C);
+    s->blk_first = a.take<int>(C);
+    s->blk_count = a.take<int>(C);
+    s->blk_comp = a.take<int>(C + st_div_up(m, 1024));
+    s->g = a.take<StGrid>(1);
+    s->cell_start = a.take<uint32_t>(SK_GRID_CELLS + 1);
+    s->recs = a.take<float4>(m);
+    s->gws_bytes = st_grid_ws_bytes(m, SK_GRID_CELLS);
+    s->gws = a.take<char>(s->gws_bytes);
 }
 
-#define SK_GRID_CELLS (1ll << 24)
-
-extern "C" int64_t st_skeleton_workspace_bytes(int64_t m) {
+extern "C" int64_t st_skeleton_workspace_bytes(int64_t m, int64_t n_comp) {
     StArena a(nullptr, 0);
-    SkScratch s;
-    sk_scratch(a, m, &s);
-    a.take<StGrid>(1);
-    a.take<uint32_t>(SK_GRID_CELLS + 1);
-    a.take<float4>(m);
-    a.take<char>(st_grid_ws_bytes(m, SK_GRID_CELLS));
-    a.take<int>(4);
+    SkLayout s;
+    sk_layout(a, m > 0 ? m : 1, n_comp > 0 ? n_comp : 1, &s);
     return a.used;
 }
 
-// All components of one cloud: root search, SSSP, predecessors, (optional literal tree distance),
-// sample_tree.  Vertex arrays are in the renumbered space of st_component_layout.
-// stages: 1 = sssp+preds, 2 = literal second SSSP (tree_dist must be given), 4 = sample_tree.
-extern "C" int st_skeleton_components(int n_comp, const int32_t* comp_off, int64_t m, const float* pts, const float* rad,
-                                      const float* ysurf, const uint32_t* row_off, const uint32_t* col, const float* wgt,
-                                      float grid_cell, int stages, int block_threads, float* dist, int32_t* pred,
-                                      int32_t* root_local, float* tree_dist, int32_t* branch_parent, int32_t* branch_off,
-                                      int32_t* branch_len, int32_t* n_branches, int32_t* path_verts, int32_t* branch_of,
-                                      long long* phase_ticks /* optional [n_comp][8] device buffer, NULL = off */, void* ws,
+static inline unsigned sk_vgrid(int64_t m) {
+    int64_t g = st_div_up(m > 0 ? m : 1, SK_WIDE_BLOCK);
+    return (unsigned)(g < 2048 ? g : 2048);
+}
+
+static int sk_read(void* dst, const void* src, size_t bytes, hipStream_t stream) {
+    (void)hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream);
+    (void)hipStreamSynchronize(stream);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}
+
+static inline int sk_claim_blocks(int64_t comp_size) {
+    int64_t k = st_div_up(comp_size, 1024);
+    return (int)(k < 1 ? 1 : (k > SK_MAX_CLAIM_BLOCKS ? SK_MAX_CLAIM_BLOCKS : k));
+}
+
+// All components of one cloud.  Vertex arrays are in the renumbered space of st_component_layout;
+// comp_size_host [n_comp] = component sizes (host copy, sizes the claim grid).
+// stages: 1 = roots + SSSP + predecessors, 2 = literal second SSSP into tree_dist, 4 = sample_tree
+// (on tree_dist if stage 2 ran, else on dist -- the two are bit-identical).
+// block_threads: lanes of the per-component select workgroup (0 = 1024).
+// stats_host (optional, 4 x int64): SSSP rounds, plateau rounds, sample_tree iterations, lifting levels.
+extern "C" int st_skeleton_components(int n_comp, const int32_t* comp_off, const int32_t* comp_size_host, int64_t m,
+                                      const float* pts, const float* rad, const float* ysurf, const uint32_t* row_off,
+                                      const uint32_t* col, const float* wgt, float grid_cell, int stages, int block_threads,
+                                      float* dist, int32_t* pred, int32_t* root_local, float* tree_dist,
+                                      int32_t* branch_parent, int32_t* branch_off, int32_t* branch_len, int32_t* n_branches,
+                                      int32_t* path_verts, int32_t* branch_of, int64_t* stats_host, void* ws,
                                       int64_t ws_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    if (stats_host) stats_host[0] = stats_host[1] = stats_host[2] = stats_host[3] = 0;
     if (n_comp <= 0 || m <= 0) return ST_OK;
     ST_REQUIRE(!(stages & 2) || tree_dist != nullptr, "skeleton: stage 2 needs a tree_dist buffer");
-    if (block_threads <= 0) block_threads = 512;
+    if (block_threads <= 0) block_threads = 1024;
     ST_REQUIRE(block_threads % 64 == 0 && block_threads <= 1024, "skeleton: block_threads must be a multiple of 64, <= 1024");
     StArena a(ws, ws_bytes);
-    SkScratch s;
-    sk_scratch(a, m, &s);
-    StGrid* g = a.take<StGrid>(1);
-    uint32_t* cell_start = a.take<uint32_t>(SK_GRID_CELLS + 1);
-    float4* recs = a.take<float4>(m);
-    int64_t gb = st_grid_ws_bytes(m, SK_GRID_CELLS);
-    char* gws = a.take<char>(gb);
-    if (!a.ok() || !gws) {
+    SkLayout s;
+    sk_layout(a, m, n_comp, &s);
+    if (!a.ok() || !s.gws) {
         st_set_error("skeleton: workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)a.used);
         return ST_ERR_WORKSPACE;
     }
-    if (stages & 4) ST_TRY(st_grid_build(pts, m, grid_cell, SK_GRID_CELLS, g, cell_start, recs, gws, gb, stream));
     SkArgs A;
-    A.C = n_comp; A.comp_off = comp_off; A.pts = pts; A.rad = rad; A.ysurf = ysurf;
-    A.row_off = row_off; A.col = col; A.wgt = wgt; A.grid = g; A.cell_start = cell_start; A.recs = recs;
-    A.dist = dist; A.pred = pred; A.root_local = root_local;
+    memset(&A, 0, sizeof(A));
+    A.C = n_comp; A.m = m; A.comp_off = comp_off; A.comp_of = s.comp_of; A.pts = pts; A.rad = rad; A.ysurf = ysurf;
+    A.row_off = row_off; A.col = col; A.wgt = wgt; A.grid = s.g; A.cell_start = s.cell_start; A.recs = s.recs;
+    A.dist = dist; A.pred = pred; A.root_local = root_local; A.tree_dist = tree_dist;
     A.branch_parent = branch_parent; A.branch_off = branch_off; A.branch_len = branch_len; A.n_branches = n_branches;
     A.path_verts = path_verts; A.branch_of = branch_of;
     A.dist_ord = s.dist_ord; A.stamp = s.stamp; A.q0 = s.q0; A.q1 = s.q1; A.alloc = s.alloc; A.term = s.term;
-    A.best = s.best; A.touched = s.touched; A.anc = s.anc; A.m = m; A.ticks = phase_ticks;
-    hipLaunchKernelGGL(k_skeleton_components, dim3((unsigned)n_comp), dim3((unsigned)block_threads), 0, stream, A, stages,
-                       tree_dist);
+    A.best = s.best; A.touched = s.touched; A.anc = s.anc; A.cnt = s.cnt;
+    A.s_done = s.s_done; A.s_len = s.s_len; A.s_cur_id = s.s_cur_id; A.s_cur_off = s.s_cur_off; A.s_nb = s.s_nb;
+    A.s_total = s.s_total; A.s_rp = s.s_rp; A.s_ntouched = s.s_ntouched;
+    A.blk_comp = s.blk_comp; A.blk_first = s.blk_first; A.blk_count = s.blk_count;
+
+    const unsigned vg = sk_vgrid(m);
+    unsigned h[8];
+    int64_t sssp_rounds = 0;
+    if (stages & 1) {
+        hipLaunchKernelGGL(k_sk_init, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A);
+        hipLaunchKernelGGL(k_sk_roots, dim3((unsigned)n_comp), dim3((unsigned)block_threads), 0, stream, A);
+        for (int r = 0;;) {  // frontier rounds in batches of 32 launches, one counter read-back per batch
+            for (int b = 0; b < 32; b++, r++)
+                hipLaunchKernelGGL(k_sk_sssp_round, dim3(SK_SSSP_BLOCKS), dim3(SK_WIDE_BLOCK), 0, stream, A, r);
+            ST_TRY(sk_read(h, s.cnt, sizeof(unsigned) * 8, stream));
+            sssp_rounds = r;
+            if (h[r % 3] == 0) break;
+            ST_REQUIRE(r < (1 << 24), "skeleton: SSSP did not converge");
+        }
+        hipLaunchKernelGGL(k_sk_dist_out, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A);
+        hipLaunchKernelGGL(k_sk_preds, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A);
+        ST_TRY(sk_read(h, s.cnt, sizeof(unsigned) * 8, stream));
+        unsigned unresolved = h[3], round = 2;
+        while (unresolved > 0) {
+            (void)hipMemsetAsync(&s.cnt[4], 0, sizeof(unsigned), stream);
+            hipLaunchKernelGGL(k_sk_preds_plateau, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A, round);
+            ST_TRY(sk_read(h, s.cnt, sizeof(unsigned) * 8, stream));
+            if (h[4] == 0) break;  // unreachable leftovers (cannot happen inside a component)
+            unresolved -= h[4];
+            round++;
+        }
+        if (stats_host) { stats_host[0] = sssp_rounds; stats_host[1] = round - 2; }
+    }
+    if (stages & 2) {
+        hipLaunchKernelGGL(k_sk_td_init, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A);
+        hipLaunchKernelGGL(k_sk_td_roots, dim3(1), dim3(SK_WIDE_BLOCK), 0, stream, A);
+        for (int r = 0;;) {
+            for (int b = 0; b < 32; b++, r++)
+                hipLaunchKernelGGL(k_sk_td_round, dim3(SK_SSSP_BLOCKS), dim3(SK_WIDE_BLOCK), 0, stream, A, r);
+            ST_TRY(sk_read(h, s.cnt, sizeof(unsigned) * 8, stream));
+            if (h[r % 3] == 0) break;
+            ST_REQUIRE(r < (1 << 24), "skeleton: tree distance did not converge");
+        }
+    }
+    if (stages & 4) {
+        // claim / finalize grid: workgroups per component proportional to its size
+        int nblk = 0;
+        for (int c = 0; c < n_comp; c++) nblk += sk_claim_blocks(comp_size_host[c]);
+        int* hb = (int*)malloc(sizeof(int) * ((size_t)nblk + 2 * (size_t)n_comp));
+        int *bc = hb, *bf = hb + nblk, *bn = bf + n_comp;
+        for (int c = 0, at = 0; c < n_comp; c++) {
+            const int k = sk_claim_blocks(comp_size_host[c]);
+            bf[c] = at;
+            bn[c] = k;
+            for (int j = 0; j < k; j++) bc[at++] = c;
+        }
+        (void)hipMemcpyAsync(s.blk_comp, bc, sizeof(int) * (size_t)nblk, hipMemcpyHostToDevice, stream);
+        (void)hipMemcpyAsync(s.blk_first, bf, sizeof(int) * (size_t)n_comp, hipMemcpyHostToDevice, stream);
+        (void)hipMemcpyAsync(s.blk_count, bn, sizeof(int) * (size_t)n_comp, hipMemcpyHostToDevice, stream);
+        int rc = st_grid_build(pts, m, grid_cell, SK_GRID_CELLS, s.g, s.cell_start, s.recs, s.gws, s.gws_bytes, stream);  // syncs
+        free(hb);
+        ST_TRY(rc);
+        // binary lifting over the predecessor tree; its depth is bounded by the SSSP round count
+        int levels = 1;
+        const int64_t depth_bound = (stages & 1) ? sssp_rounds : m;
+        while ((1ll << levels) <= depth_bound && levels < SK_LIFT) levels++;
+        (void)hipMemsetAsync(&s.cnt[5], 0, sizeof(unsigned), stream);
+        hipLaunchKernelGGL(k_sk_lift_init, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A,
+                           (const float*)((stages & 2) ? tree_dist : dist));
+        for (int k = 1; k < levels; k++) hipLaunchKernelGGL(k_sk_lift_level, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A, k);
+        int64_t iters = 0;
+        for (;;) {  // branch iterations in batches of 16 (48 launches), one counter read-back per batch
+            for (int b = 0; b < 16; b++, iters++) {
+                hipLaunchKernelGGL(k_sk_select, dim3((unsigned)n_comp), dim3((unsigned)block_threads), 0, stream, A, levels);
+                hipLaunchKernelGGL(k_sk_claim, dim3((unsigned)nblk), dim3(SK_WIDE_BLOCK), 0, stream, A);
+                hipLaunchKernelGGL(k_sk_finalize, dim3((unsigned)nblk), dim3(SK_WIDE_BLOCK), 0, stream, A);
+            }
+            ST_TRY(sk_read(h, s.cnt, sizeof(unsigned) * 8, stream));
+            if (h[5] >= (unsigned)n_comp) break;
+            ST_REQUIRE(iters <= m + 16, "skeleton: sample_tree did not terminate");
+        }
+        if (stats_host) { stats_host[2] = iters; stats_host[3] = levels; }
+    }
     ST_CHECK_LAUNCH();
     return ST_OK;
 }

@@ -8,6 +8,7 @@ branches come back in a single device-to-host copy.
 """
 from __future__ import annotations
 
+import ctypes
 from dataclasses import dataclass
 from typing import List
 
@@ -36,10 +37,11 @@ class ComponentResult:
     n_branches: torch.Tensor
     path_verts: torch.Tensor
     branch_of: torch.Tensor
+    stats: dict = None
 
 
 def run_components(comps: ComponentSet, medial_pts: torch.Tensor, radius: torch.Tensor, surface_y: torch.Tensor,
-                   stages: int = STAGE_SSSP | STAGE_SAMPLE, block_threads: int = 0, phase_ticks=None) -> ComponentResult:
+                   stages: int = STAGE_SSSP | STAGE_SAMPLE, block_threads: int = 0) -> ComponentResult:
     """SSSP from the lowest surface point, canonical predecessor tree, greedy branch extraction for
     every component.  The reference's second SSSP over the predecessor tree (skeletonize.py:80-85)
     re-adds the same float32 edge lengths in the same order and therefore reproduces the first
@@ -58,15 +60,18 @@ def run_components(comps: ComponentSet, medial_pts: torch.Tensor, radius: torch.
     if C == 0:
         return res
     r_max = rad.max().item()
-    ws = _lib.workspace(L.st_skeleton_workspace_bytes(m), dev)
+    sizes = comps.comp_size.cpu().numpy().astype("int32")  # host copy: sizes the claim grid
+    stats = (ctypes.c_int64 * 4)()
+    ws = _lib.workspace(L.st_skeleton_workspace_bytes(m, C), dev)
     n_adj = int(comps.row_off[-1].item()) if profiling.enabled() else 0
-    with profiling.kernel("k_skeleton_components", n_adj * 8 + m * (8 + 24)):
-      _lib.check(L.st_skeleton_components(
-        C, _lib.ptr(comps.comp_off.contiguous()), m, _lib.ptr(pts), _lib.ptr(rad), _lib.ptr(ys), _lib.ptr(comps.row_off),
-        _lib.ptr(comps.col), _lib.ptr(comps.wgt), float(max(r_max / 4.0, 1e-4)), int(stages), int(block_threads),
-        _lib.ptr(res.dist), _lib.ptr(res.pred), _lib.ptr(res.root_local), _lib.ptr(res.tree_dist),
-        _lib.ptr(res.branch_parent), _lib.ptr(res.branch_off), _lib.ptr(res.branch_len), _lib.ptr(res.n_branches),
-        _lib.ptr(res.path_verts), _lib.ptr(res.branch_of), _lib.ptr(phase_ticks), _lib.ptr(ws), ws.numel(), _lib.stream(dev)))
+    with profiling.kernel("skeleton_stage", n_adj * 8 + m * (8 + 24)):
+        _lib.check(L.st_skeleton_components(
+            C, _lib.ptr(comps.comp_off.contiguous()), sizes.ctypes.data, m, _lib.ptr(pts), _lib.ptr(rad), _lib.ptr(ys),
+            _lib.ptr(comps.row_off), _lib.ptr(comps.col), _lib.ptr(comps.wgt), float(max(r_max / 4.0, 1e-4)), int(stages),
+            int(block_threads), _lib.ptr(res.dist), _lib.ptr(res.pred), _lib.ptr(res.root_local), _lib.ptr(res.tree_dist),
+            _lib.ptr(res.branch_parent), _lib.ptr(res.branch_off), _lib.ptr(res.branch_len), _lib.ptr(res.n_branches),
+            _lib.ptr(res.path_verts), _lib.ptr(res.branch_of), stats, _lib.ptr(ws), ws.numel(), _lib.stream(dev)))
+    res.stats = {"sssp_rounds": stats[0], "plateau_rounds": stats[1], "branch_iterations": stats[2], "lift_levels": stats[3]}
     return res
 
 
@@ -77,7 +82,7 @@ class Skeletonizer:
         self.min_connection_length = min_connection_length
         self.minimum_graph_vertices = minimum_graph_vertices
         self.device = device
-        self.block_threads = 0  # 0 = library default (512 lanes per component workgroup)
+        self.block_threads = 0  # 0 = library default (1024 lanes in the per-component select workgroup)
 
     def forward(self, cloud: Cloud) -> DisjointTreeSkeleton:
         with profiling.stage("outlier_removal"):

@@ -24,11 +24,15 @@ print("after outlier", len(bc), "radius q", torch.quantile(radius, torch.tensor(
 g = G.nn_graph(medial, radius.clamp(min=0.02), K=16)
 comps = g.connected_cugraph_components(32)
 print("edges", g.edges.shape[0], "comps", comps.n_components, comps.comp_size[:8].tolist())
-for bt in (256, 512, 1024):
-    ticks = torch.zeros((max(comps.n_components,1), 8), dtype=torch.int64, device=dev)
+for bt in (256, 1024):
+    for rep in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        res = run_components(comps, medial, radius, bc.xyz[:,1].contiguous(), block_threads=bt)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print(f"select block {bt}: total {dt*1e3:.2f} ms; stats {res.stats}; branches {int(res.n_branches[0])}")
+from smart_tree_amd.skeleton.skeletonize import STAGE_SSSP
+for rep in range(2):
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    res = run_components(comps, medial, radius, bc.xyz[:,1].contiguous(), block_threads=bt, phase_ticks=ticks)
+    res = run_components(comps, medial, radius, bc.xyz[:,1].contiguous(), stages=STAGE_SSSP)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    t = ticks.cpu().numpy()[0]
-    d = np.diff(t[:6]) / 100.0; print("sssp rounds", t[6], "visits", t[7])  # wall_clock64 = 100 MHz -> us
-    print(f"block {bt}: total {dt*1e3:.2f} ms; comp0 phases us: root {d[0]:.0f} sssp {d[1]:.0f} preds {d[2]:.0f} (td) {d[3]:.0f} sample_tree {d[4]:.0f}; branches {int(res.n_branches[0])}")
+print(f"sssp+preds only: {dt*1e3:.2f} ms {res.stats}")
