@@ -21,7 +21,8 @@
 //       claim    (workgroups proportional to component size) the K=1 "nearest path vertex" query
 //                inverted: every (path vertex, grid row) pair scans the uniform grid and races
 //                with a packed atomicMin(d2 bits | path position) per point
-//       finalize on-path test, allocation / termination / branch-id stamps
+//       (the on-path test and the allocation / termination / branch-id stamps of iteration i run at
+//        the head of select i+1, inside the component's own workgroup: two launches per iteration)
 //   Launches are enqueued in batches; the host reads one small counter block per batch.
 // Semantics and tie-breaks: oracle/skeleton_oracle.c (so_sssp, so_tree_distance, so_sample_tree).
 #include "st_common.h"
@@ -80,7 +81,7 @@ struct SkArgs {
     int* s_total;
     float* s_rp;
     unsigned* s_ntouched;
-    // claim / finalize grid: workgroup b works for component blk_comp[b], as slice (b - blk_first[c]) of blk_count[c]
+    // claim grid: workgroup b works for component blk_comp[b], as slice (b - blk_first[c]) of blk_count[c]
     const int* blk_comp;
     const int* blk_first;
     const int* blk_count;
@@ -302,6 +303,32 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A, int levels) {
     const int c = blockIdx.x, tid = threadIdx.x;
     if (A.s_done[c]) return;
     const int base = A.comp_off[c], n = A.comp_off[c + 1] - base;
+    // 0. finish the PREVIOUS iteration of this component: on-path test of the claimed points
+    //    (path.py:35-40) and the allocation / termination / branch-id stamps (:112-122,135-136)
+    {
+        const int plen = A.s_len[c], id = A.s_cur_id[c];
+        const int* ppath = A.path_verts + base + A.s_cur_off[c];
+        const unsigned nt = plen > 0 ? A.s_ntouched[c] : 0u;
+        for (unsigned t = tid; t < nt; t += blockDim.x) {
+            const int p = (int)A.touched[base + t];
+            const unsigned long long pk = A.best[base + p];
+            A.best[base + p] = SK_EMPTY64;
+            const float d2 = __uint_as_float((unsigned)(pk >> 32));
+            const int qi = (int)(pk & 0xffffffffu);
+            if (sqrtf(d2) < A.rad[base + ppath[qi]]) {
+                A.alloc[base + p] = -1.0f;
+                A.term[base + p] = 1u;
+                if (id >= 0) A.branch_of[base + p] = id;
+            }
+        }
+        for (int qi = tid; qi < plen; qi += blockDim.x) {
+            const int v = ppath[qi];
+            A.alloc[base + v] = -1.0f;
+            A.term[base + v] = 1u;
+            if (id >= 0) A.branch_of[base + v] = id;
+        }
+        __syncthreads();  // workgroup-scope release/acquire: the scans below see these stores
+    }
     // 1. argmax of the remaining distances, first maximum (path.py:92): contiguous slice per lane
     unsigned long long key = 0;
     {
@@ -382,7 +409,11 @@ __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_claim(SkArgs A) {
     const int side = 2 * reach + 1, nrow = side * side;
     const int64_t items = (int64_t)len * nrow;
     const int* path = A.path_verts + base + A.s_cur_off[c];
-    for (int64_t it = (int64_t)slice * blockDim.x + threadIdx.x; it < items; it += (int64_t)nslice * blockDim.x) {
+    // a 16-lane group per item: the records of its cells are raced in parallel (a lone lane would
+    // chain one returning atomic per record)
+    const int sub = threadIdx.x & 15;
+    const int64_t group = ((int64_t)slice * blockDim.x + threadIdx.x) >> 4, ngroup = ((int64_t)nslice * blockDim.x) >> 4;
+    for (int64_t it = group; it < items; it += ngroup) {
         const int qi = (int)(it / nrow), rr = (int)(it % nrow);
         const float* pv = A.pts + 3 * (int64_t)(base + path[qi]);
         const int x = (int)floorf((pv[0] - g->lo[0]) / g->cell) - reach + rr / side;
@@ -393,7 +424,7 @@ __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_claim(SkArgs A) {
         if (z0 > z1) continue;
         const int64_t row = ((int64_t)x * g->dim[1] + y) * g->dim[2];
         const uint32_t s = A.cell_start[row + z0], e = A.cell_start[row + z1 + 1];
-        for (uint32_t t = s; t < e; t++) {
+        for (uint32_t t = s + sub; t < e; t += 16) {
             const float4 r4 = A.recs[t];
             const int p = (int)__float_as_uint(r4.w) - base;
             if (p < 0 || p >= n) continue;  // other component
@@ -404,35 +435,6 @@ __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_claim(SkArgs A) {
             const unsigned long long old = atomicMin(&A.best[base + p], pk);
             if (old == SK_EMPTY64) A.touched[base + atomicAdd(&A.s_ntouched[c], 1u)] = (unsigned)p;
         }
-    }
-}
-
-// finalize: on-path test (path.py:35-40) and bookkeeping (:112-122,135-136)
-__global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_finalize(SkArgs A) {
-    const int c = A.blk_comp[blockIdx.x];
-    if (A.s_done[c]) return;
-    const int len = A.s_len[c], id = A.s_cur_id[c];
-    const int base = A.comp_off[c];
-    const int slice = blockIdx.x - A.blk_first[c], nslice = A.blk_count[c];
-    const int* path = A.path_verts + base + A.s_cur_off[c];
-    const unsigned nt = A.s_ntouched[c];
-    for (unsigned t = slice * blockDim.x + threadIdx.x; t < nt; t += nslice * blockDim.x) {
-        const int p = (int)A.touched[base + t];
-        const unsigned long long pk = A.best[base + p];
-        A.best[base + p] = SK_EMPTY64;
-        const float d2 = __uint_as_float((unsigned)(pk >> 32));
-        const int qi = (int)(pk & 0xffffffffu);
-        if (sqrtf(d2) < A.rad[base + path[qi]]) {
-            A.alloc[base + p] = -1.0f;
-            A.term[base + p] = 1u;
-            if (id >= 0) A.branch_of[base + p] = id;
-        }
-    }
-    for (int qi = slice * blockDim.x + threadIdx.x; qi < len; qi += nslice * blockDim.x) {
-        const int v = path[qi];
-        A.alloc[base + v] = -1.0f;
-        A.term[base + v] = 1u;
-        if (id >= 0) A.branch_of[base + v] = id;
     }
 }
 
@@ -611,15 +613,14 @@ extern "C" int st_skeleton_components(int n_comp, const int32_t* comp_off, const
                            (const float*)((stages & 2) ? tree_dist : dist));
         for (int k = 1; k < levels; k++) hipLaunchKernelGGL(k_sk_lift_level, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A, k);
         int64_t iters = 0;
-        for (;;) {  // branch iterations in batches of 16 (48 launches), one counter read-back per batch
-            for (int b = 0; b < 16; b++, iters++) {
+        for (;;) {  // branch iterations in batches of 32 (64 launches), one counter read-back per batch
+            for (int b = 0; b < 32; b++, iters++) {
                 hipLaunchKernelGGL(k_sk_select, dim3((unsigned)n_comp), dim3((unsigned)block_threads), 0, stream, A, levels);
                 hipLaunchKernelGGL(k_sk_claim, dim3((unsigned)nblk), dim3(SK_WIDE_BLOCK), 0, stream, A);
-                hipLaunchKernelGGL(k_sk_finalize, dim3((unsigned)nblk), dim3(SK_WIDE_BLOCK), 0, stream, A);
             }
             ST_TRY(sk_read(h, s.cnt, sizeof(unsigned) * 8, stream));
             if (h[5] >= (unsigned)n_comp) break;
-            ST_REQUIRE(iters <= m + 16, "skeleton: sample_tree did not terminate");
+            ST_REQUIRE(iters <= m + 64, "skeleton: sample_tree did not terminate");
         }
         if (stats_host) { stats_host[2] = iters; stats_host[3] = levels; }
     }
