@@ -37,40 +37,50 @@ class OTree:
 
 
 # ------------------------------------------------------------------------- post-processing ---
+# Float32 operation order (shared with csrc/postprocess.hip; the reference leaves it to torch's
+# einsum / norm / sum / conv1d kernels, which differ from this only in the last bit):
+#   dot(a,b) = (ax*bx + ay*by) + az*bz;  length = sequential sum of segment norms;
+#   box filter = sequential sum over the window of r*w with w = fl32(1/k).
+def _dot(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    return (a[..., 0] * b[..., 0] + a[..., 1] * b[..., 1]) + a[..., 2] * b[..., 2]
+
+
 def branch_length(b: OBranch) -> F32:
-    """branch.py:61-63 (torch: norm over dim 1 then sum, float32)."""
-    d = torch.from_numpy(b.xyz[1:] - b.xyz[:-1])
-    return d.norm(dim=1).sum().numpy()
+    """branch.py:61-63."""
+    d = (b.xyz[1:] - b.xyz[:-1]).astype(F32)
+    seg = np.sqrt(_dot(d, d)).astype(F32)
+    return np.cumsum(seg, dtype=F32)[-1] if len(seg) else F32(0)
 
 
 def prune(tree: OTree, min_radius: float, min_length: float) -> None:
-    """tree.py:94-121."""
+    """tree.py:94-121 (thresholds compared in float32, as torch compares a float32 tensor with a Python float)."""
     root_id = min(tree.branches.keys())
     keep = {root_id: tree.branches[root_id]}
     for key, b in tree.branches.items():
         orphan = b.parent_id not in keep and b._id != root_id
         initial_radius = max(b.radii.reshape(-1)[0], b.radii.reshape(-1)[-1])  # branch.py:65-67
-        if not (orphan or branch_length(b) < min_length or initial_radius < min_radius):
+        if not (orphan or branch_length(b) < F32(min_length) or initial_radius < F32(min_radius)):
             keep[key] = b
     tree.branches = keep
 
 
 def nearest_tube_offset(pt: np.ndarray, parent: OBranch) -> np.ndarray:
-    """queries.py:89-133 for one point against the parent's tube chain (float32).  The reference
-    evaluates the dot products with torch.einsum; written here as explicit elementwise products and
-    sums over the 3 coordinates (same values up to float32 summation order)."""
-    p = torch.from_numpy(pt.reshape(1, 3).astype(F32))
-    a = torch.from_numpy(parent.xyz[:-1])
-    b = torch.from_numpy(parent.xyz[1:])
-    r1 = torch.from_numpy(parent.radii.reshape(-1)[:-1])
-    r2 = torch.from_numpy(parent.radii.reshape(-1)[1:])
+    """queries.py:89-133 for one point against the parent's tube chain: vector to the projection on the
+    tube that minimises |distance - interpolated radius| (first minimum; NaN counts as minimal)."""
+    p = pt.reshape(1, 3).astype(F32)
+    a, b = parent.xyz[:-1].astype(F32), parent.xyz[1:].astype(F32)
+    r1, r2 = parent.radii.reshape(-1)[:-1].astype(F32), parent.radii.reshape(-1)[1:].astype(F32)
     ab = b - a
     ap = p - a
-    t = ((ap * ab).sum(1) / (ab * ab).sum(1)).clip(0.0, 1.0)
-    proj = a + t.unsqueeze(1) * ab
-    r = (1 - t) * r1 + t * r2
-    dist = (proj - p).square().sum(1).sqrt()
-    return (proj[torch.argmin(torch.abs(dist - r))] - p[0]).numpy()
+    with np.errstate(invalid="ignore", divide="ignore"):
+        t = _dot(ap, ab) / _dot(ab, ab)
+    t = np.where(t < 0, F32(0), np.where(t > 1, F32(1), t)).astype(F32)
+    proj = a + t[:, None] * ab
+    r = (F32(1) - t) * r1 + t * r2
+    d = proj - p
+    score = np.abs(np.sqrt(_dot(d, d)) - r)
+    i = int(np.argmax(np.isnan(score))) if np.isnan(score).any() else int(np.argmin(score))
+    return proj[i] - p[0]
 
 
 def repair(tree: OTree) -> None:
@@ -80,20 +90,24 @@ def repair(tree: OTree) -> None:
         if b.parent_id not in ids:
             continue
         parent = tree.branches[b.parent_id]
-        if len(parent.xyz) < 2:
-            continue
         v = nearest_tube_offset(b.xyz[0], parent)
         b.xyz = np.concatenate([(b.xyz[0] + v).reshape(1, 3), b.xyz]).astype(F32)  # tree.py:89-91
         b.radii = np.concatenate([b.radii[[0]], b.radii])
 
 
 def smooth(tree: OTree, kernel_size: int) -> None:
-    """tree.py:123-134: zero-padded box filter, only when len > kernel; radii become 1-D."""
-    box = torch.ones(1, 1, kernel_size) / kernel_size
+    """tree.py:123-134: zero-padded box filter (F.conv1d padding="same"), only when len > kernel; radii become 1-D."""
+    w = F32(1) / F32(kernel_size)
+    half = kernel_size // 2
     for b in tree.branches.values():
-        if b.radii.shape[0] > kernel_size:
-            r = torch.from_numpy(np.ascontiguousarray(b.radii.reshape(1, 1, -1)))
-            b.radii = torch.nn.functional.conv1d(r, box, padding="same").reshape(-1).numpy()
+        n = b.radii.shape[0]
+        if n > kernel_size:
+            padded = np.zeros(n + kernel_size, F32)
+            padded[half: half + n] = b.radii.reshape(-1)
+            acc = np.zeros(n, F32)
+            for j in range(kernel_size):
+                acc = acc + padded[j: j + n] * w
+            b.radii = acc
 
 
 def post_process(trees: List[OTree], prune_skeletons=True, min_radius=0.01, min_length=0.02, repair_skeletons=True,

@@ -95,9 +95,16 @@ extern "C" int st_make_edges(const int64_t* idx, const float* dist, int64_t n, i
 }
 
 // ------------------------------------------------------------------ connected components ---
-__device__ __forceinline__ int cc_find(const int* label, int x) {
+__device__ __forceinline__ int cc_find(int* label, int x) {
+    // chase to the root; path halving (label only ever decreases towards the root, so writing a
+    // grandparent is always a valid shortcut, whatever other lanes do concurrently)
     int p = __atomic_load_n(&label[x], __ATOMIC_RELAXED);
-    while (p != x) { x = p; p = __atomic_load_n(&label[x], __ATOMIC_RELAXED); }
+    while (p != x) {
+        const int gp = __atomic_load_n(&label[p], __ATOMIC_RELAXED);
+        if (gp != p) atomicMin(&label[x], gp);
+        x = p;
+        p = gp;
+    }
     return x;
 }
 __global__ void __launch_bounds__(GR_BLOCK) k_cc_init(int* label, int64_t n) { GR_LOOP(i, n) label[i] = (int)i; }

@@ -1,0 +1,170 @@
+// st_post_process: prune / repair / smooth of the extracted skeletons on the device, before the one
+// device-to-host copy that materialises the BranchSkeleton objects.
+//
+// Reference (host loops over small tensors, one GPU einsum per branch):
+//   Pipeline.post_process            smart_tree/pipeline.py:95-106
+//   DisjointTreeSkeleton.prune/...   smart_tree/data_types/tree.py:164-176 (only skeleton 0 is pruned)
+//   TreeSkeleton.prune               tree.py:94-121  (+ BranchSkeleton.length / initial_radius, branch.py:61-67)
+//   TreeSkeleton.repair              tree.py:73-92   (+ pts_to_nearest_tube_gpu, util/queries.py:89-133)
+//   TreeSkeleton.smooth              tree.py:123-134 (zero-padded box filter, only when len > kernel)
+// One workgroup per tree.  Branches are visited in id order (a parent always has a smaller id than its
+// children, so a child sees its parent already repaired, exactly like the reference's dict walk).
+// Float32 operation order is fixed and mirrored by oracle/pipeline_oracle.py:
+//   dot(a,b) = (ax*bx + ay*by) + az*bz, no contraction; length = sequential sum of segment norms;
+//   box filter = sequential sum of r*w with w = fl32(1/k).
+//
+// Geometry layout: branch b owns slots [start[b], start[b] + len[b] + 1); slot start[b] is reserved for
+// the connection point `repair` prepends (its radius slot must already hold a copy of the first
+// radius, tree.py:92), the extracted path sits in start[b]+1 ...
+#include "st_common.h"
+
+#define PP_BLOCK 256
+#define PP_WAVES (PP_BLOCK / 64)
+
+struct PpArgs {
+    int n_trees;
+    const int* tree_off;  // [T+1] branch ranges
+    const int* parent;    // [B] parent branch id inside the tree (-1 / any id outside [0,nb): none)
+    const int* start;     // [B]
+    const int* len;       // [B] extracted path length (>= 2)
+    float* xyz;           // [P,3]
+    const float* rad_in;  // [P]
+    float* rad_out;       // [P]
+    uint8_t* keep;        // [B]
+    uint8_t* repaired;    // [B]
+    uint8_t* smoothed;    // [B]
+    int do_prune, do_repair, do_smooth, kernel;
+    float min_radius, min_length;
+};
+
+__device__ __forceinline__ float pp_dot(const float* a, const float* b) {
+    float s = a[0] * b[0];
+    float t = a[1] * b[1];
+    s = s + t;
+    t = a[2] * b[2];
+    return s + t;
+}
+
+__global__ void __launch_bounds__(PP_BLOCK) k_post_process(PpArgs A) {
+    __shared__ unsigned long long s_red[PP_WAVES];
+    const int tree = blockIdx.x, tid = threadIdx.x;
+    const int b0 = A.tree_off[tree], nb = A.tree_off[tree + 1] - b0;
+    // ---- prune (tree 0 only): length / initial radius per branch in parallel, then the keep chain
+    for (int b = tid; b < nb; b += PP_BLOCK) A.keep[b0 + b] = 1;
+    __syncthreads();
+    if (A.do_prune && tree == 0 && nb > 0) {
+        for (int b = tid; b < nb; b += PP_BLOCK) {
+            const int s = A.start[b0 + b] + 1, n = A.len[b0 + b];
+            float length = 0.0f;
+            for (int i = 0; i + 1 < n; i++) {
+                const float d[3] = {A.xyz[3 * (s + i + 1)] - A.xyz[3 * (s + i)], A.xyz[3 * (s + i + 1) + 1] - A.xyz[3 * (s + i) + 1],
+                                    A.xyz[3 * (s + i + 1) + 2] - A.xyz[3 * (s + i) + 2]};
+                length = length + sqrtf(pp_dot(d, d));
+            }
+            const float r0 = A.rad_in[s], r1 = A.rad_in[s + n - 1];
+            const float initial = r0 > r1 ? r0 : r1;
+            A.keep[b0 + b] = !(length < A.min_length) && !(initial < A.min_radius);  // own tests (tree.py:113-116)
+        }
+        __syncthreads();
+        if (tid == 0) {
+            A.keep[b0] = 1;  // the root (smallest id) always stays (tree.py:101-103,120)
+            for (int b = 1; b < nb; b++) {
+                const int p = A.parent[b0 + b];
+                const bool parent_kept = p >= 0 && p < nb && A.keep[b0 + p];
+                if (!parent_kept) A.keep[b0 + b] = 0;  // tree.py:111-112
+            }
+        }
+        __syncthreads();
+    }
+    // ---- repair: nearest point on the (already repaired) parent's tube chain
+    for (int b = tid; b < nb; b += PP_BLOCK) A.repaired[b0 + b] = 0;
+    __syncthreads();
+    if (A.do_repair) {
+        for (int b = 0; b < nb; b++) {
+            const int p = A.parent[b0 + b];
+            const bool go = A.keep[b0 + b] && p >= 0 && p < nb && A.keep[b0 + p];  // tree.py:80-82
+            if (!go) continue;                                                    // uniform
+            const int ps = A.start[b0 + p] + (A.repaired[b0 + p] ? 0 : 1);
+            const int pn = A.len[b0 + p] + (A.repaired[b0 + p] ? 1 : 0);
+            const int s = A.start[b0 + b];
+            const float pt[3] = {A.xyz[3 * (s + 1)], A.xyz[3 * (s + 1) + 1], A.xyz[3 * (s + 1) + 2]};
+            // argmin over the parent's tubes of |dist - radius| (first minimum; NaN counts as minimal)
+            unsigned long long key = 0;
+            for (int i = tid; i + 1 < pn; i += PP_BLOCK) {
+                const float* a = A.xyz + 3 * (ps + i);
+                const float* bb = A.xyz + 3 * (ps + i + 1);
+                const float ab[3] = {bb[0] - a[0], bb[1] - a[1], bb[2] - a[2]};
+                const float ap[3] = {pt[0] - a[0], pt[1] - a[1], pt[2] - a[2]};
+                float t = pp_dot(ap, ab) / pp_dot(ab, ab);
+                t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
+                const float proj[3] = {a[0] + t * ab[0], a[1] + t * ab[1], a[2] + t * ab[2]};
+                const float r = (1.0f - t) * A.rad_in[ps + i] + t * A.rad_in[ps + i + 1];
+                const float d[3] = {proj[0] - pt[0], proj[1] - pt[1], proj[2] - pt[2]};
+                const float score = fabsf(sqrtf(pp_dot(d, d)) - r);
+                const unsigned bits = score != score ? 0u : __float_as_uint(score) + 1u;  // >= 0: bits are ordered
+                const unsigned long long k = ((unsigned long long)(0xffffffffu - bits) << 32) | (0xffffffffu - (unsigned)i);
+                key = k > key ? k : key;
+            }
+            // workgroup max of the inverted key = minimum score, smallest index
+            for (int d = 32; d > 0; d >>= 1) {
+                const unsigned long long o = __shfl_xor(key, d);
+                key = o > key ? o : key;
+            }
+            __syncthreads();
+            if ((tid & 63) == 0) s_red[tid >> 6] = key;
+            __syncthreads();
+            if (tid == 0) {
+                for (int w = 1; w < PP_WAVES; w++) key = s_red[w] > key ? s_red[w] : key;
+                const int i = (int)(0xffffffffu - (unsigned)(key & 0xffffffffu));
+                const float* a = A.xyz + 3 * (ps + i);
+                const float* bb = A.xyz + 3 * (ps + i + 1);
+                const float ab[3] = {bb[0] - a[0], bb[1] - a[1], bb[2] - a[2]};
+                const float ap[3] = {pt[0] - a[0], pt[1] - a[1], pt[2] - a[2]};
+                float t = pp_dot(ap, ab) / pp_dot(ab, ab);
+                t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
+                for (int k = 0; k < 3; k++) {
+                    const float proj = a[k] + t * ab[k];
+                    A.xyz[3 * s + k] = pt[k] + (proj - pt[k]);  // tree.py:89: tip + vector to the projection
+                }
+                A.repaired[b0 + b] = 1;
+            }
+            __syncthreads();
+        }
+    }
+    // ---- radii: box filter over the (possibly prepended) radius array
+    const float w = A.kernel > 0 ? 1.0f / (float)A.kernel : 0.0f;
+    const int half = A.kernel / 2;
+    for (int b = 0; b < nb; b++) {
+        const int rep = A.repaired[b0 + b];
+        const int s = A.start[b0 + b] + (rep ? 0 : 1), n = A.len[b0 + b] + rep;
+        const bool sm = A.do_smooth && A.keep[b0 + b] && n > A.kernel;  // tree.py:129
+        if (tid == 0) A.smoothed[b0 + b] = sm;
+        for (int i = tid; i < n; i += PP_BLOCK) {
+            if (!sm) { A.rad_out[s + i] = A.rad_in[s + i]; continue; }
+            float acc = 0.0f;
+            for (int j = 0; j < A.kernel; j++) {
+                const int q = i - half + j;
+                const float v = (q >= 0 && q < n) ? A.rad_in[s + q] : 0.0f;
+                acc = acc + v * w;
+            }
+            A.rad_out[s + i] = acc;
+        }
+    }
+}
+
+// tree_off [T+1], parent/start/len [B], xyz [P,3] (in/out), rad_in/rad_out [P], keep/repaired/smoothed [B]
+extern "C" int st_post_process(int n_trees, const int32_t* tree_off, const int32_t* parent, const int32_t* start,
+                               const int32_t* len, float* xyz, const float* rad_in, float* rad_out, uint8_t* keep,
+                               uint8_t* repaired, uint8_t* smoothed, int do_prune, float min_radius, float min_length,
+                               int do_repair, int do_smooth, int kernel_size, void* stream_) {
+    if (n_trees <= 0) return ST_OK;
+    ST_REQUIRE(!do_smooth || kernel_size > 0, "post_process: smoothing needs kernel_size > 0");
+    PpArgs A;
+    A.n_trees = n_trees; A.tree_off = tree_off; A.parent = parent; A.start = start; A.len = len; A.xyz = xyz;
+    A.rad_in = rad_in; A.rad_out = rad_out; A.keep = keep; A.repaired = repaired; A.smoothed = smoothed;
+    A.do_prune = do_prune; A.do_repair = do_repair; A.do_smooth = do_smooth; A.kernel = kernel_size;
+    A.min_radius = min_radius; A.min_length = min_length;
+    hipLaunchKernelGGL(k_post_process, dim3((unsigned)n_trees), dim3(PP_BLOCK), 0, (hipStream_t)stream_, A);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}

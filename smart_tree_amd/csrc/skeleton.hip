@@ -32,7 +32,7 @@
 #define SK_EMPTY64 0xffffffffffffffffull
 #define SK_LIFT 24         // 2^24 hops bound the deepest predecessor chain
 #define SK_WIDE_BLOCK 256  // block size of the vertex / frontier kernels
-#define SK_SSSP_BLOCKS 512
+#define SK_SSSP_BLOCKS 256  // upper bound; small graphs launch fewer (one wave per frontier vertex)
 #define SK_MARK 0xfffffffeu
 
 struct SkArgs {
@@ -143,10 +143,15 @@ __global__ void __launch_bounds__(1024) k_sk_roots(SkArgs A) {
 
 // ------------------------------------------------------------------------------------ SSSP ---
 // round r: frontier r%2 -> (r+1)%2; counts rotate through cnt[0..2]
+#define SK_LQ 2048  // workgroup-local queue entries staged in LDS before one global reservation
 __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_sssp_round(SkArgs A, int r) {
+    __shared__ unsigned lq[SK_LQ];
+    __shared__ unsigned lq_n, lq_base;
     const unsigned count = A.cnt[r % 3];
     if (blockIdx.x == 0 && threadIdx.x == 0) A.cnt[(r + 2) % 3] = 0u;
     if (count == 0) return;
+    if (threadIdx.x == 0) lq_n = 0;
+    __syncthreads();
     const unsigned* q = (r & 1) ? A.q1 : A.q0;
     unsigned* qn = (r & 1) ? A.q0 : A.q1;
     unsigned* cnt_out = &A.cnt[(r + 1) % 3];
@@ -157,26 +162,23 @@ __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_sssp_round(SkArgs A, int r
         const unsigned u = q[f];
         const float du = st_ord2f(A.dist_ord[u]);
         const uint32_t s = A.row_off[u], e = A.row_off[u + 1];
-        for (uint32_t t0 = s; t0 < e; t0 += 64) {
-            const uint32_t t = t0 + lane;
-            bool push = false;
-            unsigned v = 0;
-            if (t < e) {
-                v = A.col[t];
-                const unsigned o = st_f2ord(du + A.wgt[t]);
-                const unsigned old = atomicMin(&A.dist_ord[v], o);
-                push = o < old && atomicExch(&A.stamp[v], round) != round;
-            }
-            const unsigned long long mask = __ballot(push);  // wave-aggregated queue push
-            if (mask) {
-                const int leader = __ffsll(mask) - 1;
-                unsigned slot = 0;
-                if (lane == leader) slot = atomicAdd(cnt_out, (unsigned)__popcll(mask));
-                slot = __shfl(slot, leader);
-                if (push) qn[slot + (unsigned)__popcll(mask & ((1ull << lane) - 1ull))] = v;
+        for (uint32_t t = s + lane; t < e; t += 64) {
+            const unsigned v = A.col[t];
+            const unsigned o = st_f2ord(du + A.wgt[t]);
+            const unsigned old = atomicMin(&A.dist_ord[v], o);
+            if (o < old && atomicExch(&A.stamp[v], round) != round) {
+                // stage in LDS (a frontier of thousands pushing on ONE global counter serialises the
+                // round); overflow goes straight to the global queue
+                const unsigned slot = atomicAdd(&lq_n, 1u);
+                if (slot < SK_LQ) lq[slot] = v; else qn[atomicAdd(cnt_out, 1u)] = v;
             }
         }
     }
+    __syncthreads();
+    const unsigned nloc = lq_n < SK_LQ ? lq_n : SK_LQ;
+    if (threadIdx.x == 0 && nloc) lq_base = atomicAdd(cnt_out, nloc);
+    __syncthreads();
+    for (unsigned i = threadIdx.x; i < nloc; i += blockDim.x) qn[lq_base + i] = lq[i];
 }
 
 __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_dist_out(SkArgs A) {
@@ -332,10 +334,8 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A, int levels) {
     // 1. argmax of the remaining distances, first maximum (path.py:92): contiguous slice per lane
     unsigned long long key = 0;
     {
-        const int per = (n + (int)blockDim.x - 1) / (int)blockDim.x;
-        const int v0 = tid * per, v1 = st_min(v0 + per, n);
         const float* al = A.alloc + base;
-        for (int v = v0; v < v1; v++) {
+        for (int v = tid; v < n; v += blockDim.x) {  // coalesced; the index in the key keeps "first maximum"
             const unsigned long long k = ((unsigned long long)st_f2ord(al[v]) << 32) | (0xffffffffu - (unsigned)v);
             key = k > key ? k : key;
         }
@@ -397,6 +397,8 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A, int levels) {
 
 // claim: every (path vertex, x/y grid row) pair offers (d2, position) to the points within r of it
 __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_claim(SkArgs A) {
+    __shared__ unsigned lq[SK_LQ];
+    __shared__ unsigned lq_n, lq_base;
     const int c = A.blk_comp[blockIdx.x];
     if (A.s_done[c]) return;
     const int len = A.s_len[c];
@@ -409,6 +411,8 @@ __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_claim(SkArgs A) {
     const int side = 2 * reach + 1, nrow = side * side;
     const int64_t items = (int64_t)len * nrow;
     const int* path = A.path_verts + base + A.s_cur_off[c];
+    if (threadIdx.x == 0) lq_n = 0;
+    __syncthreads();
     // a 16-lane group per item: the records of its cells are raced in parallel (a lone lane would
     // chain one returning atomic per record)
     const int sub = threadIdx.x & 15;
@@ -433,9 +437,17 @@ __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_claim(SkArgs A) {
             if (!(d2 < rp2)) continue;
             const unsigned long long pk = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)qi;
             const unsigned long long old = atomicMin(&A.best[base + p], pk);
-            if (old == SK_EMPTY64) A.touched[base + atomicAdd(&A.s_ntouched[c], 1u)] = (unsigned)p;
+            if (old == SK_EMPTY64) {  // first touch: remember the point (staged in LDS, see k_sk_sssp_round)
+                const unsigned slot = atomicAdd(&lq_n, 1u);
+                if (slot < SK_LQ) lq[slot] = (unsigned)p; else A.touched[base + atomicAdd(&A.s_ntouched[c], 1u)] = (unsigned)p;
+            }
         }
     }
+    __syncthreads();
+    const unsigned nloc = lq_n < SK_LQ ? lq_n : SK_LQ;
+    if (threadIdx.x == 0 && nloc) lq_base = atomicAdd(&A.s_ntouched[c], nloc);
+    __syncthreads();
+    for (unsigned i = threadIdx.x; i < nloc; i += blockDim.x) A.touched[base + lq_base + i] = lq[i];
 }
 
 // ------------------------------------------------------------------------------- host side ---
@@ -548,6 +560,7 @@ extern "C" int st_skeleton_components(int n_comp, const int32_t* comp_off, const
     A.blk_comp = s.blk_comp; A.blk_first = s.blk_first; A.blk_count = s.blk_count;
 
     const unsigned vg = sk_vgrid(m);
+    const unsigned fg = (unsigned)st_min64(st_div_up(m, SK_WIDE_BLOCK), SK_SSSP_BLOCKS);
     unsigned h[8];
     int64_t sssp_rounds = 0;
     if (stages & 1) {
@@ -555,7 +568,7 @@ extern "C" int st_skeleton_components(int n_comp, const int32_t* comp_off, const
         hipLaunchKernelGGL(k_sk_roots, dim3((unsigned)n_comp), dim3((unsigned)block_threads), 0, stream, A);
         for (int r = 0;;) {  // frontier rounds in batches of 32 launches, one counter read-back per batch
             for (int b = 0; b < 32; b++, r++)
-                hipLaunchKernelGGL(k_sk_sssp_round, dim3(SK_SSSP_BLOCKS), dim3(SK_WIDE_BLOCK), 0, stream, A, r);
+                hipLaunchKernelGGL(k_sk_sssp_round, dim3(fg), dim3(SK_WIDE_BLOCK), 0, stream, A, r);
             ST_TRY(sk_read(h, s.cnt, sizeof(unsigned) * 8, stream));
             sssp_rounds = r;
             if (h[r % 3] == 0) break;
@@ -580,7 +593,7 @@ extern "C" int st_skeleton_components(int n_comp, const int32_t* comp_off, const
         hipLaunchKernelGGL(k_sk_td_roots, dim3(1), dim3(SK_WIDE_BLOCK), 0, stream, A);
         for (int r = 0;;) {
             for (int b = 0; b < 32; b++, r++)
-                hipLaunchKernelGGL(k_sk_td_round, dim3(SK_SSSP_BLOCKS), dim3(SK_WIDE_BLOCK), 0, stream, A, r);
+                hipLaunchKernelGGL(k_sk_td_round, dim3(fg), dim3(SK_WIDE_BLOCK), 0, stream, A, r);
             ST_TRY(sk_read(h, s.cnt, sizeof(unsigned) * 8, stream));
             if (h[r % 3] == 0) break;
             ST_REQUIRE(r < (1 << 24), "skeleton: tree distance did not converge");

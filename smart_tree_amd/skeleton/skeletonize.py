@@ -97,44 +97,124 @@ class Skeletonizer:
         with profiling.stage("sssp_sample_tree"):
             res = run_components(comps, medial, radius, cloud.xyz[:, 1].contiguous(), block_threads=self.block_threads)
         with profiling.stage("assemble"):
-            trees = self._assemble(comps, res, medial, radius)
-        return DisjointTreeSkeleton(trees)
+            return DeviceSkeleton.from_components(comps, res, medial, radius)
 
     def process_subgraph(self, cloud: Cloud, subgraph, skeleton_id: int = 0) -> TreeSkeleton:
         """Reference entry point (skeletonize.py:57-95) for ONE component of a ComponentSet."""
         comps, c = subgraph
         medial, radius = medial_points(cloud.xyz, cloud.medial_vector)
         res = run_components(comps, medial, radius, cloud.xyz[:, 1].contiguous(), block_threads=self.block_threads)
-        return self._assemble(comps, res, medial, radius)[c]
+        return DeviceSkeleton.from_components(comps, res, medial, radius).skeletons[c]
 
+
+
+class DeviceSkeleton(DisjointTreeSkeleton):
+    """A DisjointTreeSkeleton whose branches still live on the GPU as flat arrays.
+
+    `prune` / `repair` / `smooth` -- called in that order by `Pipeline.post_process` (reference
+    pipeline.py:95-106) -- are recorded and executed by ONE launch of `st_post_process`
+    (csrc/postprocess.hip) when `.skeletons` is first read; only then are the geometry and the branch
+    table copied to the host (one copy each) and the BranchSkeleton objects built.  Any other call
+    order materialises first and falls back to the host implementations of the base class."""
+
+    def __init__(self, tree_off, parent, start, length, xyz, rad):
+        self._dev = (tree_off, parent, start, length, xyz, rad)  # device tensors (flat branch layout)
+        self._ops = {}
+        self._trees = None
+
+    # -- construction ---------------------------------------------------------------------------
     @staticmethod
-    def _assemble(comps: ComponentSet, res: ComponentResult, medial: torch.Tensor, radius: torch.Tensor) -> List[TreeSkeleton]:
-        """One D->H copy of the branch tables, then BranchSkeleton objects as path.py:128-133 builds them
-        (xyz = medial_pts[path], radii = medial_radii[path] as [m,1], both on the host)."""
-        C = comps.n_components
-        if C == 0:
-            return []
-        nb = res.n_branches[:C].cpu().tolist()
-        off = comps.comp_off.cpu().tolist()
-        # flat branch table on the device: (component, branch) -> global path slice, then ONE gather + ONE copy
-        rows = [(c, b) for c in range(C) for b in range(nb[c])]
-        if not rows:
-            return [TreeSkeleton(c, {}) for c in range(C)]
+    def from_components(comps: ComponentSet, res: ComponentResult, medial: torch.Tensor, radius: torch.Tensor):
+        """Flat layout: branch k of the cloud owns geometry slots [start[k], start[k] + len[k] + 1); slot
+        start[k] is reserved for the connection point `repair` prepends (radius pre-filled, tree.py:92)."""
         dev = medial.device
-        comp_of = torch.tensor([r[0] for r in rows], device=dev)
-        slot = torch.tensor([off[c] + b for c, b in rows], device=dev)
-        base = torch.tensor([off[c] for c, _ in rows], device=dev)
+        C = comps.n_components
+        i32 = dict(dtype=torch.int32, device=dev)
+        if C == 0:
+            z = torch.zeros(0, **i32)
+            return DeviceSkeleton(torch.zeros(1, **i32), z, z, z, torch.zeros((0, 3), device=dev), torch.zeros(0, device=dev))
+        nb = res.n_branches[:C].long()
+        tree_off = torch.zeros(C + 1, dtype=torch.int64, device=dev)
+        tree_off[1:] = torch.cumsum(nb, 0)
+        B = int(tree_off[-1].item())
+        comp_of_branch = torch.repeat_interleave(torch.arange(C, device=dev), nb, output_size=B)
+        base = comps.comp_off[:C].long()[comp_of_branch]
+        slot = base + torch.arange(B, device=dev) - tree_off[:-1][comp_of_branch]
         lens = res.branch_len[slot].long()
-        starts = base + res.branch_off[slot].long()
-        total = int(lens.sum().item())
-        seg = torch.repeat_interleave(torch.arange(len(rows), device=dev), lens, output_size=total)
-        first = torch.cumsum(lens, 0) - lens
-        pos = torch.arange(total, device=dev) - first[seg] + starts[seg]
-        ids = comps.vert_order.long()[res.path_verts[pos].long() + base[seg]]
-        geom = torch.cat((medial[ids], radius[ids].unsqueeze(1)), dim=1).cpu()
-        parents = res.branch_parent[slot].cpu().tolist()
-        pieces = torch.split(geom, lens.cpu().tolist())
-        trees = [TreeSkeleton(c, {}) for c in range(C)]
-        for (c, b), parent, g in zip(rows, parents, pieces):
-            trees[c].branches[b] = BranchSkeleton(b, parent, xyz=g[:, :3].contiguous(), radii=g[:, 3:4].contiguous())
+        src0 = base + res.branch_off[slot].long()
+        start = torch.cumsum(lens + 1, 0) - (lens + 1)
+        P = int((lens + 1).sum().item()) if B else 0
+        seg = torch.repeat_interleave(torch.arange(B, device=dev), lens + 1, output_size=P)
+        k = torch.arange(P, device=dev) - start[seg]  # 0 = reserved slot
+        src = src0[seg] + (k - 1).clamp(min=0)
+        ids = comps.vert_order.long()[res.path_verts[src].long() + base[seg]]
+        return DeviceSkeleton(tree_off.int(), res.branch_parent[slot].contiguous(), start.int(), lens.int(),
+                              medial[ids].contiguous(), radius[ids].contiguous())
+
+    # -- deferred post-processing ---------------------------------------------------------------
+    def _can_defer(self, op: str) -> bool:
+        order = ("prune", "repair", "smooth")
+        return self._trees is None and op not in self._ops and all(o not in self._ops for o in order[order.index(op) + 1:])
+
+    def prune(self, min_radius, min_length) -> None:
+        if self._can_defer("prune"):
+            self._ops["prune"] = (float(min_radius), float(min_length))
+        else:
+            super().prune(min_radius, min_length)
+
+    def repair(self) -> None:
+        if self._can_defer("repair"):
+            self._ops["repair"] = True
+        else:
+            super().repair()
+
+    def smooth(self, kernel_size: int = 7) -> None:
+        if self._can_defer("smooth") and kernel_size > 0:
+            self._ops["smooth"] = int(kernel_size)
+        else:
+            super().smooth(kernel_size)
+
+    # -- materialisation ------------------------------------------------------------------------
+    @property
+    def skeletons(self) -> List[TreeSkeleton]:
+        if self._trees is None:
+            self._trees = self._materialise()
+        return self._trees
+
+    @skeletons.setter
+    def skeletons(self, value):
+        self._trees = value
+
+    def _materialise(self) -> List[TreeSkeleton]:
+        tree_off, parent, start, length, xyz, rad = self._dev
+        T, B = tree_off.shape[0] - 1, parent.shape[0]
+        if B == 0:
+            return [TreeSkeleton(t, {}) for t in range(T)]
+        dev = xyz.device
+        u8 = lambda: torch.empty(B, dtype=torch.uint8, device=dev)
+        keep, repaired, smoothed = u8(), u8(), u8()
+        rad_out = torch.empty_like(rad)
+        xyz = xyz.clone()
+        pr = self._ops.get("prune")
+        L = _lib.lib()
+        _lib.check(L.st_post_process(T, _lib.ptr(tree_off), _lib.ptr(parent), _lib.ptr(start), _lib.ptr(length), _lib.ptr(xyz),
+                                     _lib.ptr(rad), _lib.ptr(rad_out), _lib.ptr(keep), _lib.ptr(repaired), _lib.ptr(smoothed),
+                                     int(pr is not None), pr[0] if pr else 0.0, pr[1] if pr else 0.0,
+                                     int("repair" in self._ops), int("smooth" in self._ops), self._ops.get("smooth", 0),
+                                     _lib.stream(dev)))
+        geom = torch.cat((xyz, rad_out.unsqueeze(1)), dim=1).cpu()
+        table = torch.stack((parent, start, length, keep.int(), repaired.int(), smoothed.int()), dim=1).cpu().tolist()
+        offs = tree_off.cpu().tolist()
+        trees = []
+        for t in range(T):
+            branches = {}
+            for b in range(offs[t + 1] - offs[t]):
+                par, st, ln, kp, rep, sm = table[offs[t] + b]
+                if not kp:
+                    continue
+                g = geom[st + 1 - rep: st + 1 + ln]
+                radii = g[:, 3].contiguous() if sm else g[:, 3:4].contiguous()  # smooth flattens radii (tree.py:130-134)
+                branches[b] = BranchSkeleton.__new__(BranchSkeleton)
+                branches[b].__dict__.update(_id=b, parent_id=par, xyz=g[:, :3].contiguous(), radii=radii, child_id=None)
+            trees.append(TreeSkeleton(t, branches))
         return trees

@@ -1,0 +1,103 @@
+"""Golden vectors produced by the REFERENCE's own glue code (tools/make_goldens.py, build container
+only): they pin the oracle, and the HIP path is checked against them directly as well."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pipeline_oracle as po
+from oracle import skeleton_oracle as so
+from oracle import voxel_oracle as vo
+from smart_tree_amd.data_types.cloud import Cloud
+from smart_tree_amd.dataset.dataset import voxelize_blocks
+from smart_tree_amd.skeleton.skeletonize import Skeletonizer
+from smart_tree_amd.synthetic import sample_tree_cloud
+
+GOLD = Path(__file__).resolve().parent / "golden"
+CASES = ["skeleton_y_tree", "skeleton_small_tree"]
+
+
+def _radius(mv):
+    return np.sqrt(((mv * mv)[:, 0] + (mv * mv)[:, 1]) + (mv * mv)[:, 2]).astype(np.float32)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_oracle_matches_reference_glue(case):
+    g = np.load(GOLD / f"{case}.npz")
+    xyz, mv = g["raw_xyz"], g["raw_medial_vector"]
+    keep = so.outlier_removal(xyz + mv, _radius(mv), 8)
+    np.testing.assert_array_equal(keep, g["keep_mask"])  # reference outlier_removal
+    xyz, mv = xyz[keep], mv[keep]
+    medial, radius = xyz + mv, _radius(mv)
+    edges, w = so.nn_graph(medial, np.maximum(radius, np.float32(0.02)), 16)
+    np.testing.assert_array_equal(edges, g["edges"])  # reference make_edges incl. the idx > 0 quirk
+    np.testing.assert_array_equal(w, g["weights"])
+    ids = g["component"]
+    branches, _, _ = so.sample_tree(medial[ids], radius[ids], g["preds"], g["dist"])  # reference sample_tree's inputs
+    assert [b.branch_id for b in branches] == g["branch_ids"].tolist()
+    assert [b.parent_id for b in branches] == g["branch_parent"].tolist()
+    for b in branches:
+        np.testing.assert_array_equal(medial[ids][b.verts], g[f"branch_{b.branch_id}_xyz"])
+        np.testing.assert_array_equal(radius[ids][b.verts].reshape(-1, 1), g[f"branch_{b.branch_id}_radii"])
+    # post-processing: same branches survive; floats agree to float32 round-off (the reference's
+    # einsum / conv1d summation order is torch's, the oracle's is explicit)
+    tree = po.OTree(0, {b.branch_id: po.OBranch(b.branch_id, b.parent_id, medial[ids][b.verts],
+                                               radius[ids][b.verts].reshape(-1, 1)) for b in branches})
+    po.post_process([tree], True, 0.01, 0.02, True, True, 11)
+    assert list(tree.branches) == g["post_ids"].tolist()
+    for k, b in tree.branches.items():
+        np.testing.assert_allclose(b.xyz, g[f"post_{k}_xyz"], rtol=1e-5, atol=1e-6)
+        assert b.radii.shape == g[f"post_{k}_radii"].shape
+        np.testing.assert_allclose(b.radii, g[f"post_{k}_radii"], rtol=1e-5, atol=1e-7)
+
+
+def test_oracle_blocking_matches_reference_glue():
+    g = np.load(GOLD / "blocking_50k.npz")
+    c = sample_tree_cloud(50_000, seed=0)
+    xyz = vo.centre_cloud(c["xyz"])
+    np.testing.assert_array_equal(xyz, g["centred_xyz"])  # CentreCloud
+    _, centres = vo.compute_blocks(xyz, 4.0, 20)
+    np.testing.assert_array_equal(centres, g["block_centres"])  # compute_blocks: unique + count > 20
+    for i, ctr in enumerate(centres):
+        member = vo.cube_mask(xyz, ctr, 4.0 + 0.4 * 2)
+        assert member.sum() == g["block_sizes"][i]
+        np.testing.assert_array_equal(xyz[member][:64], g[f"block_{i}_first_xyz"])
+        assert vo.cube_mask(xyz[member], ctr, 4.0).sum() == g[f"block_{i}_inner_count"]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_hip_skeletonizer_matches_reference_glue(backend, case):
+    """HIP path -> the branches the reference's own sample_tree / prune / repair / smooth produced."""
+    if backend.type == "cpu" and case != "skeleton_y_tree":
+        pytest.skip("the CPU sanitizer build is too slow for this case; it runs on the GPU")
+    g = np.load(GOLD / f"{case}.npz")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(backend)
+    sk = Skeletonizer(K=16, min_connection_length=0.02, minimum_graph_vertices=32, device=backend)
+    sk.block_threads = 128 if backend.type == "cpu" else 0
+    out = sk.forward(Cloud(xyz=t(g["raw_xyz"]), medial_vector=t(g["raw_medial_vector"])))
+    out.prune(min_radius=0.01, min_length=0.02)
+    out.repair()
+    out.smooth(11)
+    tree = out.skeletons[0]  # largest component = the one the golden holds
+    assert list(tree.branches) == g["post_ids"].tolist()
+    for k, b in tree.branches.items():
+        np.testing.assert_allclose(b.xyz.numpy(), g[f"post_{k}_xyz"], rtol=1e-5, atol=1e-6)
+        assert tuple(b.radii.shape) == g[f"post_{k}_radii"].shape
+        np.testing.assert_allclose(b.radii.numpy(), g[f"post_{k}_radii"], rtol=1e-5, atol=1e-7)
+    # and un-post-processed: exact
+    raw = sk.forward(Cloud(xyz=t(g["raw_xyz"]), medial_vector=t(g["raw_medial_vector"]))).skeletons[0]
+    assert list(raw.branches) == g["branch_ids"].tolist()
+    for k, b in raw.branches.items():
+        assert b.parent_id == int(g["branch_parent"][list(raw.branches).index(k)])
+        np.testing.assert_array_equal(b.xyz.numpy(), g[f"branch_{k}_xyz"])
+        np.testing.assert_array_equal(b.radii.numpy(), g[f"branch_{k}_radii"])
+
+
+def test_hip_blocking_matches_reference_glue(backend):
+    g = np.load(GOLD / "blocking_50k.npz")
+    xyz = torch.from_numpy(g["centred_xyz"]).to(backend)
+    out = voxelize_blocks(xyz, None, 0.02)
+    np.testing.assert_array_equal(out.block_centres.cpu().numpy(), g["block_centres"])
+    inner = np.bincount(out.coords[:, 0].cpu().numpy()[out.mask.cpu().numpy()], minlength=len(g["block_centres"]))
+    assert (inner <= np.array([g[f"block_{i}_inner_count"] for i in range(len(inner))])).all()

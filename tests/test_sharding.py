@@ -56,7 +56,8 @@ def _worker(rank: int, world: int, port: int, n_clouds: int, q):
         merged = {}
         for t, g in zip(tables, geoms):
             merged.update(unpack_skeletons(t, g))
-        q.put({k: pack_skeleton(v, k) for k, v in merged.items()})
+        # numpy payloads are pickled by value (torch tensors would travel as shared-memory handles that die with the worker)
+        q.put({k: tuple(a.numpy() for a in pack_skeleton(v, k)) for k, v in merged.items()})
     dist.barrier()
     dist.destroy_process_group()
 
@@ -77,5 +78,5 @@ def test_gather_world_size_2_gloo():
         assert p.exitcode == 0
     assert sorted(got) == list(range(n_clouds))
     for i in range(n_clouds):
-        t, g = got[i]
+        t, g = (torch.from_numpy(a) for a in got[i])
         _same(unpack_skeletons(t, g)[i], _fake_skeleton(i))
