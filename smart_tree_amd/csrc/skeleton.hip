@@ -81,11 +81,20 @@ struct SkArgs {
     int* s_total;
     float* s_rp;
     unsigned* s_ntouched;
+    int* s_cursor;   // position in `order` where the search for the next farthest vertex resumes
+    int* s_wide;     // this launch's path is long: the chip-wide claim kernel handles it
+    const unsigned* order;  // [m] vertices of each component by distance descending (ties: index ascending)
+    const float* order_init;  // [m] initial distance of order[j] (<= 0 marks the tail of never-selectable vertices)
     // claim grid: workgroup b works for component blk_comp[b], as slice (b - blk_first[c]) of blk_count[c]
     const int* blk_comp;
     const int* blk_first;
     const int* blk_count;
 };
+
+// agent-scope (L2) accesses for data that the SAME launch wrote earlier (never a stale L1 line)
+template <class T>
+__device__ __forceinline__ T ld(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld(const float* p) { return __uint_as_float(ld((const unsigned*)p)); }
 
 // workgroup-wide max of a 64-bit key; every thread must call; lds needs SK_MAX_WAVES words
 __device__ __forceinline__ unsigned long long block_max_u64(unsigned long long v, unsigned long long* lds) {
@@ -276,7 +285,19 @@ __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_lift_init(SkArgs A, const 
         A.best[v] = SK_EMPTY64;
     }
     if (blockIdx.x == 0)
-        for (int c = threadIdx.x; c < A.C; c += blockDim.x) { A.s_done[c] = 0; A.s_nb[c] = 0; A.s_total[c] = 0; A.s_len[c] = 0; }
+        for (int c = threadIdx.x; c < A.C; c += blockDim.x) { A.s_done[c] = 0; A.s_nb[c] = 0; A.s_total[c] = 0; A.s_len[c] = 0; A.s_cursor[c] = 0; A.s_wide[c] = 0; }
+}
+
+// sort keys: distance descending (masked vertices, alloc = -1, go last); second pass groups by component
+__global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_sort_keys(SkArgs A, uint32_t* keys, uint32_t* vals, int pass) {
+    SK_VERTEX_LOOP(v) {
+        if (pass == 0) { keys[v] = ~st_f2ord(A.alloc[v]); vals[v] = (uint32_t)v; }
+        else keys[v] = (uint32_t)A.comp_of[vals[v]];
+    }
+}
+
+__global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_order_init(SkArgs A, float* order_init) {
+    SK_VERTEX_LOOP(j) order_init[j] = A.alloc[A.order[j]];
 }
 
 // anc[k][v] = 2^k-th ancestor (component-local id), -1 past the root
@@ -298,128 +319,25 @@ __device__ __forceinline__ int sk_ancestor(const SkArgs& A, int base, int v, uns
     return v;
 }
 
-// select: one workgroup per component -- farthest unallocated vertex, trace, radius, parent, record
-__global__ void __launch_bounds__(1024) k_sk_select(SkArgs A, int levels) {
-    __shared__ unsigned long long s_red[SK_MAX_WAVES];
-    __shared__ int s_term;
-    const int c = blockIdx.x, tid = threadIdx.x;
-    if (A.s_done[c]) return;
-    const int base = A.comp_off[c], n = A.comp_off[c + 1] - base;
-    // 0. finish the PREVIOUS iteration of this component: on-path test of the claimed points
-    //    (path.py:35-40) and the allocation / termination / branch-id stamps (:112-122,135-136)
-    {
-        const int plen = A.s_len[c], id = A.s_cur_id[c];
-        const int* ppath = A.path_verts + base + A.s_cur_off[c];
-        const unsigned nt = plen > 0 ? A.s_ntouched[c] : 0u;
-        for (unsigned t = tid; t < nt; t += blockDim.x) {
-            const int p = (int)A.touched[base + t];
-            const unsigned long long pk = A.best[base + p];
-            A.best[base + p] = SK_EMPTY64;
-            const float d2 = __uint_as_float((unsigned)(pk >> 32));
-            const int qi = (int)(pk & 0xffffffffu);
-            if (sqrtf(d2) < A.rad[base + ppath[qi]]) {
-                A.alloc[base + p] = -1.0f;
-                A.term[base + p] = 1u;
-                if (id >= 0) A.branch_of[base + p] = id;
-            }
-        }
-        for (int qi = tid; qi < plen; qi += blockDim.x) {
-            const int v = ppath[qi];
-            A.alloc[base + v] = -1.0f;
-            A.term[base + v] = 1u;
-            if (id >= 0) A.branch_of[base + v] = id;
-        }
-        __syncthreads();  // workgroup-scope release/acquire: the scans below see these stores
-    }
-    // 1. argmax of the remaining distances, first maximum (path.py:92): contiguous slice per lane
-    unsigned long long key = 0;
-    {
-        const float* al = A.alloc + base;
-        for (int v = tid; v < n; v += blockDim.x) {  // coalesced; the index in the key keeps "first maximum"
-            const unsigned long long k = ((unsigned long long)st_f2ord(al[v]) << 32) | (0xffffffffu - (unsigned)v);
-            key = k > key ? k : key;
-        }
-    }
-    key = block_max_u64(key, s_red);
-    const int far = (int)(0xffffffffu - (unsigned)(key & 0xffffffffu));
-    const float dfar = n > 0 ? st_ord2f((unsigned)(key >> 32)) : -1.0f;
-    if (!(dfar > 0.0f)) {  // path.py:94-95 (uniform)
-        if (tid == 0) { A.s_done[c] = 1; A.s_len[c] = 0; A.n_branches[c] = A.s_nb[c]; atomicAdd(&A.cnt[5], 1u); }
-        return;
-    }
-    // 2. trace_route (path.py:9-16): lane j inspects the j-th ancestor; the first allocated one (or
-    //    the step past the root) ends the walk
-    unsigned* tmp = A.q0 + base;
-    int len = -1;
-    for (unsigned chunk = 0; len < 0; chunk += blockDim.x) {
-        const unsigned j = chunk + tid;
-        const int node = sk_ancestor(A, base, far, j, levels);
-        const bool end = node < 0 || A.term[base + node] != 0u;
-        if (!end) tmp[j] = (unsigned)node;
-        unsigned long long k = end ? ((unsigned long long)(0xffffffffu - j) << 32) | (unsigned)(node + 1) : 0ull;
-        k = block_max_u64(k, s_red);
-        if (k != 0ull) {
-            len = (int)(0xffffffffu - (unsigned)(k >> 32));
-            if (tid == 0) s_term = (int)(unsigned)(k & 0xffffffffu) - 1;
-        }
-    }
-    __syncthreads();
-    // 3. path root side first; r = max radius on the path (path.py:31)
-    const int total = A.s_total[c];
-    int* path_out = A.path_verts + base + total;
-    unsigned long long rk = 0;
-    for (int qi = tid; qi < len; qi += blockDim.x) {
-        const int v = (int)tmp[len - 1 - qi];
-        path_out[qi] = v;
-        const unsigned long long k = (unsigned long long)st_f2ord(A.rad[base + v]) << 32;
-        rk = k > rk ? k : rk;
-    }
-    rk = block_max_u64(rk, s_red);
-    if (tid == 0) {
-        const bool keep = len >= 2;  // path.py:125-126: shorter paths still consume their points
-        const int nb = A.s_nb[c];
-        A.s_len[c] = len;
-        A.s_rp[c] = st_ord2f((unsigned)(rk >> 32));
-        A.s_ntouched[c] = 0u;
-        A.s_cur_off[c] = total;
-        A.s_cur_id[c] = keep ? nb : -1;
-        if (keep) {
-            // parent id is read BEFORE this branch stamps anything (path.py:128-136);
-            // termination -1 reads branch_ids[-1] = the last vertex (quirk kept)
-            A.branch_parent[base + nb] = A.branch_of[base + (s_term < 0 ? n - 1 : s_term)];
-            A.branch_off[base + nb] = total;
-            A.branch_len[base + nb] = len;
-            A.s_nb[c] = nb + 1;
-            A.s_total[c] = total + len;
-        }
-    }
-}
-
-// claim: every (path vertex, x/y grid row) pair offers (d2, position) to the points within r of it
-__global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_claim(SkArgs A) {
-    __shared__ unsigned lq[SK_LQ];
-    __shared__ unsigned lq_n, lq_base;
-    const int c = A.blk_comp[blockIdx.x];
-    if (A.s_done[c]) return;
-    const int len = A.s_len[c];
-    const int base = A.comp_off[c], n = A.comp_off[c + 1] - base;
-    const int slice = blockIdx.x - A.blk_first[c], nslice = A.blk_count[c];
+// claim: every (path vertex, x/y grid row) pair offers (d2, position) to the points within r of it.
+// A 16-lane group per pair: the records of its cells are raced in parallel (a lone lane would chain
+// one returning atomic per record).  First touches are staged in LDS and flushed with one reservation.
+#define SK_LQ_CLAIM 2048
+__device__ __forceinline__ void sk_claim_items(const SkArgs& A, int c, int base, int n, int len, float rp, const int* path,
+                                               int slice, int nslice, unsigned* lq, unsigned* lq_n, unsigned* lq_base) {
     const StGrid* g = A.grid;
-    const float rp = A.s_rp[c], rp2 = rp * rp;
+    const float rp2 = rp * rp;
     int reach = rp > 0.0f ? (int)ceilf(rp / g->cell) : 0;
     if (reach < 1) reach = 1;
     const int side = 2 * reach + 1, nrow = side * side;
     const int64_t items = (int64_t)len * nrow;
-    const int* path = A.path_verts + base + A.s_cur_off[c];
-    if (threadIdx.x == 0) lq_n = 0;
+    if (threadIdx.x == 0) *lq_n = 0;
     __syncthreads();
-    // a 16-lane group per item: the records of its cells are raced in parallel (a lone lane would
-    // chain one returning atomic per record)
     const int sub = threadIdx.x & 15;
     const int64_t group = ((int64_t)slice * blockDim.x + threadIdx.x) >> 4, ngroup = ((int64_t)nslice * blockDim.x) >> 4;
     for (int64_t it = group; it < items; it += ngroup) {
         const int qi = (int)(it / nrow), rr = (int)(it % nrow);
-        const float* pv = A.pts + 3 * (int64_t)(base + path[qi]);
+        const float* pv = A.pts + 3 * (int64_t)(base + ld(&path[qi]));
         const int x = (int)floorf((pv[0] - g->lo[0]) / g->cell) - reach + rr / side;
         const int y = (int)floorf((pv[1] - g->lo[1]) / g->cell) - reach + rr % side;
         if (x < 0 || x >= g->dim[0] || y < 0 || y >= g->dim[1]) continue;
@@ -437,17 +355,155 @@ __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_claim(SkArgs A) {
             if (!(d2 < rp2)) continue;
             const unsigned long long pk = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)qi;
             const unsigned long long old = atomicMin(&A.best[base + p], pk);
-            if (old == SK_EMPTY64) {  // first touch: remember the point (staged in LDS, see k_sk_sssp_round)
-                const unsigned slot = atomicAdd(&lq_n, 1u);
-                if (slot < SK_LQ) lq[slot] = (unsigned)p; else A.touched[base + atomicAdd(&A.s_ntouched[c], 1u)] = (unsigned)p;
+            if (old == SK_EMPTY64) {
+                const unsigned slot = atomicAdd(lq_n, 1u);
+                if (slot < SK_LQ_CLAIM) lq[slot] = (unsigned)p; else A.touched[base + atomicAdd(&A.s_ntouched[c], 1u)] = (unsigned)p;
             }
         }
     }
     __syncthreads();
-    const unsigned nloc = lq_n < SK_LQ ? lq_n : SK_LQ;
-    if (threadIdx.x == 0 && nloc) lq_base = atomicAdd(&A.s_ntouched[c], nloc);
+    const unsigned nloc = *lq_n < SK_LQ_CLAIM ? *lq_n : SK_LQ_CLAIM;
+    if (threadIdx.x == 0 && nloc) *lq_base = atomicAdd(&A.s_ntouched[c], nloc);
     __syncthreads();
-    for (unsigned i = threadIdx.x; i < nloc; i += blockDim.x) A.touched[base + lq_base + i] = lq[i];
+    for (unsigned i = threadIdx.x; i < nloc; i += blockDim.x) A.touched[base + *lq_base + i] = lq[i];
+    __syncthreads();
+}
+
+// select: one workgroup per component.  Per iteration: finish the previous branch (on-path test and
+// stamps), advance the cursor over the distance-sorted vertices to the farthest unallocated one
+// (path.py:92 -- nothing is ever re-scanned), trace its route by binary lifting, record the branch;
+// short paths are claimed right here and the loop continues, a long path is left to k_sk_claim.
+#define SK_SMALL_ITEMS 768
+#define SK_ITERS_PER_LAUNCH 16
+__global__ void __launch_bounds__(1024) k_sk_select(SkArgs A, int levels) {
+    __shared__ unsigned long long s_red[SK_MAX_WAVES];
+    __shared__ unsigned lq[SK_LQ_CLAIM];
+    __shared__ unsigned lq_n, lq_base;
+    __shared__ int s_term;
+    const int c = blockIdx.x, tid = threadIdx.x;
+    if (A.s_done[c]) return;
+    const int base = A.comp_off[c], n = A.comp_off[c + 1] - base;
+    const unsigned* order = A.order + base;
+    unsigned* tmp = A.q0 + base;
+    for (int iter = 0; iter < SK_ITERS_PER_LAUNCH; iter++) {
+        // 0. finish the previous iteration: on-path test of the claimed points (path.py:35-40) and
+        //    the allocation / termination / branch-id stamps (:112-122,135-136)
+        {
+            const int plen = ld(&A.s_len[c]), id = ld(&A.s_cur_id[c]);
+            const int* ppath = A.path_verts + base + ld(&A.s_cur_off[c]);
+            const unsigned nt = plen > 0 ? ld(&A.s_ntouched[c]) : 0u;
+            for (unsigned t = tid; t < nt; t += blockDim.x) {
+                const int p = (int)ld(&A.touched[base + t]);
+                const unsigned long long pk = ld(&A.best[base + p]);
+                A.best[base + p] = SK_EMPTY64;
+                const float d2 = __uint_as_float((unsigned)(pk >> 32));
+                const int qi = (int)(pk & 0xffffffffu);
+                if (sqrtf(d2) < A.rad[base + ld(&ppath[qi])]) {
+                    A.alloc[base + p] = -1.0f;
+                    A.term[base + p] = 1u;
+                    if (id >= 0) A.branch_of[base + p] = id;
+                }
+            }
+            for (int qi = tid; qi < plen; qi += blockDim.x) {
+                const int v = ld(&ppath[qi]);
+                A.alloc[base + v] = -1.0f;
+                A.term[base + v] = 1u;
+                if (id >= 0) A.branch_of[base + v] = id;
+            }
+            __syncthreads();
+        }
+        // 1. farthest unallocated vertex: first live entry of the sorted order at or after the cursor
+        int far = -1;
+        bool exhausted = false;
+        for (int cur = ld(&A.s_cursor[c]); far < 0 && !exhausted; cur += blockDim.x) {
+            const int j = cur + tid;
+            unsigned long long k = 0;
+            if (j < n) {
+                const int v = (int)order[j] - base;
+                const float a = ld(&A.alloc[base + v]);
+                // entries are sorted by their INITIAL distance: the first non-positive one ends the list
+                const bool live = a > 0.0f, tail = !(A.order_init[base + j] > 0.0f);
+                if (live || tail) k = ((unsigned long long)(0xffffffffu - (unsigned)j) << 32) | (tail ? 0u : (unsigned)v + 1u);
+            } else if (j == n) {
+                k = ((unsigned long long)(0xffffffffu - (unsigned)j) << 32);  // end of the component
+            }
+            k = block_max_u64(k, s_red);
+            if (k != 0ull) {
+                const unsigned lowv = (unsigned)(k & 0xffffffffu);
+                if (lowv == 0u) exhausted = true;
+                else { far = (int)lowv - 1; if (tid == 0) A.s_cursor[c] = (int)(0xffffffffu - (unsigned)(k >> 32)) + 1; }
+            }
+        }
+        if (far < 0) {  // path.py:94-95 (uniform)
+            if (tid == 0) { A.s_done[c] = 1; A.s_len[c] = 0; A.s_wide[c] = 0; A.n_branches[c] = ld(&A.s_nb[c]); atomicAdd(&A.cnt[5], 1u); }
+            return;
+        }
+        // 2. trace_route (path.py:9-16): lane j inspects the j-th ancestor; the first allocated one
+        //    (or the step past the root) ends the walk
+        int len = -1;
+        for (unsigned chunk = 0; len < 0; chunk += blockDim.x) {
+            const unsigned j = chunk + tid;
+            const int node = sk_ancestor(A, base, far, j, levels);
+            const bool end = node < 0 || ld(&A.term[base + node]) != 0u;
+            if (!end) tmp[j] = (unsigned)node;
+            unsigned long long k = end ? ((unsigned long long)(0xffffffffu - j) << 32) | (unsigned)(node + 1) : 0ull;
+            k = block_max_u64(k, s_red);
+            if (k != 0ull) {
+                len = (int)(0xffffffffu - (unsigned)(k >> 32));
+                if (tid == 0) s_term = (int)(unsigned)(k & 0xffffffffu) - 1;
+            }
+        }
+        __syncthreads();
+        // 3. path root side first; r = max radius on the path (path.py:31)
+        const int total = ld(&A.s_total[c]);
+        int* path_out = A.path_verts + base + total;
+        unsigned long long rk = 0;
+        for (int qi = tid; qi < len; qi += blockDim.x) {
+            const int v = (int)ld(&tmp[len - 1 - qi]);
+            path_out[qi] = v;
+            const unsigned long long k = (unsigned long long)st_f2ord(A.rad[base + v]) << 32;
+            rk = k > rk ? k : rk;
+        }
+        rk = block_max_u64(rk, s_red);
+        const float rp = st_ord2f((unsigned)(rk >> 32));
+        int reach = rp > 0.0f ? (int)ceilf(rp / A.grid->cell) : 0;
+        if (reach < 1) reach = 1;
+        const bool small = (int64_t)len * (2 * reach + 1) * (2 * reach + 1) <= SK_SMALL_ITEMS;
+        __syncthreads();
+        if (tid == 0) {
+            const bool keep = len >= 2;  // path.py:125-126: shorter paths still consume their points
+            const int nb = ld(&A.s_nb[c]);
+            A.s_len[c] = len;
+            A.s_rp[c] = rp;
+            A.s_ntouched[c] = 0u;
+            A.s_cur_off[c] = total;
+            A.s_cur_id[c] = keep ? nb : -1;
+            A.s_wide[c] = small ? 0 : 1;
+            if (keep) {
+                // parent id is read BEFORE this branch stamps anything (path.py:128-136);
+                // termination -1 reads branch_ids[-1] = the last vertex (quirk kept)
+                A.branch_parent[base + nb] = ld(&A.branch_of[base + (s_term < 0 ? n - 1 : s_term)]);
+                A.branch_off[base + nb] = total;
+                A.branch_len[base + nb] = len;
+                A.s_nb[c] = nb + 1;
+                A.s_total[c] = total + len;
+            }
+        }
+        __syncthreads();
+        if (!small) return;  // k_sk_claim takes this path; its points are finished at the next launch
+        // path entries are re-read through L2: they were written a few lines up by other lanes
+        sk_claim_items(A, c, base, n, len, rp, path_out, 0, 1, lq, &lq_n, &lq_base);
+    }
+}
+
+__global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_claim(SkArgs A) {
+    __shared__ unsigned lq[SK_LQ_CLAIM];
+    __shared__ unsigned lq_n, lq_base;
+    const int c = A.blk_comp[blockIdx.x];
+    if (A.s_done[c] || !A.s_wide[c]) return;
+    const int base = A.comp_off[c], n = A.comp_off[c + 1] - base;
+    sk_claim_items(A, c, base, n, A.s_len[c], A.s_rp[c], A.path_verts + base + A.s_cur_off[c], blockIdx.x - A.blk_first[c],
+                   A.blk_count[c], lq, &lq_n, &lq_base);
 }
 
 // ------------------------------------------------------------------------------- host side ---
@@ -455,8 +511,11 @@ __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_claim(SkArgs A) {
 #define SK_MAX_CLAIM_BLOCKS 256
 
 struct SkLayout {
-    unsigned *dist_ord, *stamp, *q0, *q1, *term, *touched, *cnt, *s_ntouched;
-    float *alloc, *s_rp;
+    unsigned *dist_ord, *stamp, *q0, *q1, *term, *touched, *cnt, *s_ntouched, *sort_keys, *order;
+    float *alloc, *s_rp, *order_init;
+    int *s_cursor, *s_wide;
+    char* sort_ws;
+    int64_t sort_bytes;
     unsigned long long* best;
     int *anc, *comp_of, *s_done, *s_len, *s_cur_id, *s_cur_off, *s_nb, *s_total, *blk_comp, *blk_first, *blk_count;
     StGrid* g;
@@ -486,6 +545,13 @@ static void sk_layout(StArena& a, int64_t m, int64_t C, SkLayout* s) {
     s->s_total = a.take<int>(C);
     s->s_rp = a.take<float>(C);
     s->s_ntouched = a.take<unsigned>(C);
+    s->s_cursor = a.take<int>(C);
+    s->s_wide = a.take<int>(C);
+    s->sort_keys = a.take<unsigned>(m);
+    s->order = a.take<unsigned>(m);
+    s->order_init = a.take<float>(m);
+    s->sort_bytes = st_sort_ws_bytes(m);
+    s->sort_ws = a.take<char>(s->sort_bytes);
     s->blk_first = a.take<int>(C);
     s->blk_count = a.take<int>(C);
     s->blk_comp = a.take<int>(C + st_div_up(m, 1024));
@@ -558,6 +624,7 @@ extern "C" int st_skeleton_components(int n_comp, const int32_t* comp_off, const
     A.s_done = s.s_done; A.s_len = s.s_len; A.s_cur_id = s.s_cur_id; A.s_cur_off = s.s_cur_off; A.s_nb = s.s_nb;
     A.s_total = s.s_total; A.s_rp = s.s_rp; A.s_ntouched = s.s_ntouched;
     A.blk_comp = s.blk_comp; A.blk_first = s.blk_first; A.blk_count = s.blk_count;
+    A.s_cursor = s.s_cursor; A.s_wide = s.s_wide; A.order = s.order; A.order_init = s.order_init;
 
     const unsigned vg = sk_vgrid(m);
     const unsigned fg = (unsigned)st_min64(st_div_up(m, SK_WIDE_BLOCK), SK_SSSP_BLOCKS);
@@ -625,15 +692,25 @@ extern "C" int st_skeleton_components(int n_comp, const int32_t* comp_off, const
         hipLaunchKernelGGL(k_sk_lift_init, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A,
                            (const float*)((stages & 2) ? tree_dist : dist));
         for (int k = 1; k < levels; k++) hipLaunchKernelGGL(k_sk_lift_level, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A, k);
+        // order the vertices of every component by distance, once: the per-branch argmax becomes a cursor
+        hipLaunchKernelGGL(k_sk_sort_keys, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A, s.sort_keys, s.order, 0);
+        ST_TRY(st_radix_sort_pairs_u32(s.sort_keys, s.order, m, 32, s.sort_ws, s.sort_bytes, stream));
+        if (n_comp > 1) {
+            int bits = 1;
+            while ((1ll << bits) < n_comp) bits++;
+            hipLaunchKernelGGL(k_sk_sort_keys, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A, s.sort_keys, s.order, 1);
+            ST_TRY(st_radix_sort_pairs_u32(s.sort_keys, s.order, m, bits, s.sort_ws, s.sort_bytes, stream));
+        }
+        hipLaunchKernelGGL(k_sk_order_init, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A, s.order_init);
         int64_t iters = 0;
-        for (;;) {  // branch iterations in batches of 32 (64 launches), one counter read-back per batch
-            for (int b = 0; b < 32; b++, iters++) {
+        for (;;) {  // batches of 16 launch pairs (each select runs up to 16 short-path iterations itself)
+            for (int b = 0; b < 16; b++, iters++) {
                 hipLaunchKernelGGL(k_sk_select, dim3((unsigned)n_comp), dim3((unsigned)block_threads), 0, stream, A, levels);
                 hipLaunchKernelGGL(k_sk_claim, dim3((unsigned)nblk), dim3(SK_WIDE_BLOCK), 0, stream, A);
             }
             ST_TRY(sk_read(h, s.cnt, sizeof(unsigned) * 8, stream));
             if (h[5] >= (unsigned)n_comp) break;
-            ST_REQUIRE(iters <= m + 64, "skeleton: sample_tree did not terminate");
+            ST_REQUIRE(iters <= m + 64 && iters < (1 << 26), "skeleton: sample_tree did not terminate");
         }
         if (stats_host) { stats_host[2] = iters; stats_host[3] = levels; }
     }

@@ -53,6 +53,7 @@ class Pipeline:
         skeleton = self.skeletonizer.forward(branch_cloud)
         with profiling.stage("post_process"):
             self.post_process(skeleton)
+            skeleton.skeletons  # materialise: device post-processing kernel, one D->H copy, BranchSkeleton objects
         if self.view_model_output or self.view_skeletons:
             raise NotImplementedError("viewing needs open3d, which is out of scope of smart_tree_amd")
         if self.save_outputs:
