@@ -1,0 +1,130 @@
+/* smarttree_hip.h -- C ABI of libsmarttree_hip.so (MI355X / gfx950).
+ *
+ * The drop-in boundary of the smart-tree inference hot path.  The reference (uc-vision/smart-tree) has no
+ * FFI layer of its own: its heavy arithmetic lives in three CUDA-only third-party packages (spconv, FRNN,
+ * cugraph/cudf) that it calls from Python.  Each entry point below replaces one of those call sites; the
+ * `replaces:` line cites it (paths relative to the reference's smart_tree/ package).  INTEGRATION.md shows
+ * the ctypes binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer into caller-owned memory (torch tensors) unless its name ends in
+ *     `_host`; sizes are explicit; the library never frees or keeps caller memory;
+ *   - scratch comes from a caller-provided workspace (`ws`, `ws_bytes`) sized by the matching
+ *     `*_workspace_bytes` function (or `st_query_workspace`); no hipMalloc inside the library;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream).  Functions that
+ *     return a count to the host (`*_host` out-parameters) synchronise that stream once before returning;
+ *   - return value: 0 = ok, < 0 = error (-1 invalid argument, -2 workspace too small, -3 HIP error);
+ *     `st_last_error()` gives the text (thread local).  Nothing throws.
+ *   - neighbour tables are OUTPUT-stationary: nbr[k * n_out + o] = input row or -1, k = (kz*3+ky)*3+kx.
+ */
+#ifndef SMARTTREE_HIP_H
+#define SMARTTREE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int st_version(void);
+const char* st_last_error(void);
+/* op: 0 scan(n) 1 sort(n) 2 voxelize(n,max_blocks,max_voxels) 3 strided(n) 4 knn(n_dst) 5 make_edges(n)
+ *     6 component_layout(n) 7 component_csr(m) 8 skeleton(m,n_comp) */
+int64_t st_query_workspace(int op, int64_t a, int64_t b, int64_t c);
+
+/* ---- primitives (exported for tests) ------------------------------------------------------------ */
+int64_t st_scan_workspace_bytes(int64_t n);
+int st_scan_u32(const uint32_t* in, uint32_t* out, int64_t n, uint32_t* total, void* ws, int64_t ws_bytes, void* stream);
+int64_t st_sort_workspace_bytes(int64_t n);
+int st_sort_pairs_u32(uint32_t* keys, uint32_t* vals, int64_t n, int key_bits, void* ws, int64_t ws_bytes, void* stream);
+
+/* ---- blocks + voxelisation ------------------------------------------------------------------------
+ * replaces: dataset/dataset.py:166-226 (SingleTreeInference.compute_blocks / __getitem__, i.e.
+ *           spconv.pytorch.utils.PointToVoxel.generate_voxel_with_id on the CPU) and model/sparse.py:40-61
+ *           (batch_collate).  feats [max_voxels,6], coords [max_voxels,4] (block,z,y,x), mask [max_voxels],
+ *           point_index [max_voxels], block_centres [max_blocks,3]. */
+int64_t st_voxelize_workspace_bytes(int64_t n_points, int max_blocks, int64_t max_voxels);
+int st_voxelize_blocks(const float* xyz, const float* rgb, int64_t n, double voxel_size, double block_size,
+                       double buffer_size, int min_points, int max_blocks, int64_t max_voxels, float* feats,
+                       int32_t* coords, uint8_t* mask, int64_t* point_index, float* block_centres,
+                       int64_t* n_voxels_host, int64_t* n_blocks_host, void* ws, int64_t ws_bytes, void* stream);
+
+/* ---- rulebooks ------------------------------------------------------------------------------------
+ * replaces: the indice-pair generation spconv runs inside every SubMConv3d / SparseConv3d /
+ *           SparseInverseConv3d forward (model/model_blocks.py:23-35,57-70,90-101,134-143). */
+int64_t st_hash_capacity(int64_t n);
+int st_build_coord_hash(const int32_t* coords, int64_t n, unsigned long long* keys, unsigned* vals, int64_t cap, void* stream);
+int st_build_subm_rulebook(const int32_t* coords, int64_t n, const unsigned long long* keys, const unsigned* vals,
+                           int64_t cap, int32_t* nbr /*[27,n]*/, void* stream);
+int64_t st_strided_workspace_bytes(int64_t n_fine);
+int st_build_strided_outputs(const int32_t* coords, int64_t n, int64_t max_out, int32_t* out_coords,
+                             unsigned long long* ckeys, unsigned* cvals, int64_t ccap, int64_t* n_out_host,
+                             int32_t* extent_host /*[3]*/, void* ws, int64_t ws_bytes, void* stream);
+int st_build_strided_rulebook(const int32_t* coords, int64_t n, const unsigned long long* fkeys, const unsigned* fvals,
+                              int64_t fcap, const int32_t* out_coords, int64_t n_out, const unsigned long long* ckeys,
+                              const unsigned* cvals, int64_t ccap, const int32_t* extent_host,
+                              int32_t* nbr_down /*[27,n_out]*/, int32_t* nbr_up /*[27,n]*/, void* stream);
+
+/* ---- network --------------------------------------------------------------------------------------
+ * replaces: spconv's gather-GEMM-scatter conv kernels + torch BatchNorm1d/ReLU/add/cat around them
+ *           (model/model_blocks.py:8-243) and, for the heads, SparseFC + F.normalize + exp/argmax
+ *           (model_blocks.py:246-285, model/model.py:83-85, model/model_inference.py:87-88).
+ * st_sparse_conv_fwd: y = act(bn(sum_k W_k . cat(x0,x1)[nbr[k]]) + residual); w is [K][cin][cout]. */
+int st_sparse_conv_fwd(const float* x0, int c0, const float* x1, int cin, const int32_t* nbr, int K, int64_t n_out,
+                       const float* w, int cout, const float* scale, const float* shift, const float* residual,
+                       int relu, float* y, void* stream);
+int st_head_param_floats(void);
+int st_pointwise_mlp_heads(const float* x, int64_t n, const float* params, float* radius, float* direction,
+                           float* class_l, float* medial_vector /*nullable*/, int64_t* class_idx /*nullable*/, void* stream);
+
+/* ---- skeleton stage -------------------------------------------------------------------------------
+ * st_medial_points  replaces: Cloud.medial_pts / Cloud.radius, data_types/cloud.py:229-231,254-256
+ * st_knn_radius     replaces: frnn.frnn_grid_points via skeleton/graph.py:12-33 (filter.py:7, graph.py:37, path.py:30)
+ * st_make_edges     replaces: skeleton/graph.py:52-60
+ * st_connected_components / st_component_layout / st_component_csr
+ *                   replace: cugraph.connected_components + subgraph + the cudf->pandas->torch renumbering,
+ *                            data_types/graph.py:32-66, skeleton/skeletonize.py:60-71, skeleton/graph.py:80-104
+ * st_skeleton_components (stages 1|2|4) and its single-stage forms st_sssp / st_tree_distance / st_sample_tree
+ *                   replace: cugraph.sssp (skeleton/shortest_path.py:12-21), pred_graph + second sssp
+ *                            (shortest_path.py:46-55, skeletonize.py:80-85), sample_tree (skeleton/path.py:9-140)
+ * st_post_process   replaces: pipeline.py:95-106 over data_types/tree.py:73-134,164-176 (+ util/queries.py:89-133) */
+int st_medial_points(const float* xyz, const float* mv, int64_t n, float* medial, float* radius, void* stream);
+int64_t st_knn_workspace_bytes(int64_t n_dst);
+int st_knn_radius(const float* src, int64_t n1, const float* dst, int64_t n2, int K, float r, const float* bound,
+                  int bound_mode, float cell_hint, int64_t* idx, float* dist, void* ws, int64_t ws_bytes, void* stream);
+int64_t st_make_edges_workspace_bytes(int64_t n);
+int st_make_edges(const int64_t* idx, const float* dist, int64_t n, int K, int64_t* edges, float* w,
+                  int64_t* n_edges_host, void* ws, int64_t ws_bytes, void* stream);
+int st_connected_components(const int64_t* edges, int64_t E, int64_t n, int32_t* labels, void* ws, int64_t ws_bytes, void* stream);
+int64_t st_component_layout_workspace_bytes(int64_t n);
+int st_component_layout(const int32_t* labels, int64_t n, int min_vertices, int32_t* comp_size, int32_t* comp_off,
+                        int32_t* vert_order, int32_t* new_id, int64_t* n_comp_host, int64_t* n_kept_host, void* ws,
+                        int64_t ws_bytes, void* stream);
+int64_t st_component_csr_workspace_bytes(int64_t m);
+int st_component_csr(const int64_t* edges, const float* w, int64_t E, const int32_t* new_id, int64_t m, uint32_t* row_off,
+                     uint32_t* col, float* wgt, void* ws, int64_t ws_bytes, void* stream);
+int64_t st_skeleton_workspace_bytes(int64_t m, int64_t n_comp);
+int st_skeleton_components(int n_comp, const int32_t* comp_off, const int32_t* comp_size_host, int64_t m, const float* pts,
+                           const float* rad, const float* ysurf, const uint32_t* row_off, const uint32_t* col,
+                           const float* wgt, float grid_cell, int stages, int block_threads, float* dist, int32_t* pred,
+                           int32_t* root_local, float* tree_dist, int32_t* branch_parent, int32_t* branch_off,
+                           int32_t* branch_len, int32_t* n_branches, int32_t* path_verts, int32_t* branch_of,
+                           int64_t* stats_host, void* ws, int64_t ws_bytes, void* stream);
+#define ST_SKELETON_STAGE_ARGS                                                                                          \
+    int n_comp, const int32_t *comp_off, const int32_t *comp_size_host, int64_t m, const float *pts, const float *rad, \
+        const float *ysurf, const uint32_t *row_off, const uint32_t *col, const float *wgt, float grid_cell,           \
+        int block_threads, float *dist, int32_t *pred, int32_t *root_local, float *tree_dist, int32_t *branch_parent,  \
+        int32_t *branch_off, int32_t *branch_len, int32_t *n_branches, int32_t *path_verts, int32_t *branch_of,        \
+        int64_t *stats_host, void *ws, int64_t ws_bytes, void *stream
+int st_sssp(ST_SKELETON_STAGE_ARGS);
+int st_tree_distance(ST_SKELETON_STAGE_ARGS);
+int st_sample_tree(ST_SKELETON_STAGE_ARGS);
+int st_post_process(int n_trees, const int32_t* tree_off, const int32_t* parent, const int32_t* start, const int32_t* len,
+                    float* xyz, const float* rad_in, float* rad_out, uint8_t* keep, uint8_t* repaired, uint8_t* smoothed,
+                    int do_prune, float min_radius, float min_length, int do_repair, int do_smooth, int kernel_size,
+                    void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMARTTREE_HIP_H */

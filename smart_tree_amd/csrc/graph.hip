@@ -113,7 +113,8 @@ __global__ void __launch_bounds__(GR_BLOCK) k_cc_hook(const int64_t* edges, int6
         int a = cc_find(label, (int)edges[2 * e]), b = cc_find(label, (int)edges[2 * e + 1]);
         if (a == b) continue;
         int hi = a > b ? a : b, lo = a > b ? b : a;
-        atomicMin(&label[hi], lo);
+        // thousands of edges join the same two trees: only the first needs the atomic
+        if (__atomic_load_n(&label[hi], __ATOMIC_RELAXED) > lo) atomicMin(&label[hi], lo);
         *changed = 1u;
     }
 }

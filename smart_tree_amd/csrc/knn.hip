@@ -147,11 +147,21 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn(const float* __restrict__ src
     const int x0 = st_max(c0[0] - reach, 0), x1 = st_min(c0[0] + reach, g->dim[0] - 1);
     const int y0 = st_max(c0[1] - reach, 0), y1 = st_min(c0[1] + reach, g->dim[1] - 1);
     const int z0 = st_max(c0[2] - reach, 0), z1 = st_min(c0[2] + reach, g->dim[2] - 1);
-    for (int x = x0; x <= x1; x++)
+    // rows (x, y) farther than the search radius in the xy-plane are skipped and the z-range of the others
+    // is clipped to the sphere (a slightly inflated radius keeps the pruning conservative)
+    const float rs = reach_r * 1.0001f + 1e-7f, rs2 = rs * rs;
+    for (int x = x0; x <= x1; x++) {
+        const float cx0 = g->lo[0] + (float)x * cell, ex = px < cx0 ? cx0 - px : (px > cx0 + cell ? px - (cx0 + cell) : 0.0f);
         for (int y = y0; y <= y1; y++) {
+            const float cy0 = g->lo[1] + (float)y * cell, ey = py < cy0 ? cy0 - py : (py > cy0 + cell ? py - (cy0 + cell) : 0.0f);
+            const float dxy2 = ex * ex + ey * ey;
+            if (dxy2 > rs2) continue;
+            const float rz = sqrtf(rs2 - dxy2);
+            const int za = st_max((int)floorf((pz - rz - g->lo[2]) / cell) - 1, z0), zb = st_min((int)floorf((pz + rz - g->lo[2]) / cell) + 1, z1);
+            if (za > zb) continue;
             // cells along z are contiguous: one [start, end) range per (x, y) row
             const int64_t row = ((int64_t)x * g->dim[1] + y) * g->dim[2];
-            const uint32_t s = cell_start[row + z0], e = cell_start[row + z1 + 1];
+            const uint32_t s = cell_start[row + za], e = cell_start[row + zb + 1];
             for (uint32_t t = s; t < e; t++) {
                 const float4 q = recs[t];
                 const float dx = px - q.x, dy = py - q.y, dz = pz - q.z;
@@ -177,6 +187,7 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn(const float* __restrict__ src
                 if (knn_less(d2, j, bd[0], bi[0])) { bd[0] = d2; bi[0] = j; }
             }
         }
+    }
 #pragma unroll
     for (int q = 0; q < K; q++) {
         const bool ok = bi[q] != 0x7fffffff;

@@ -211,3 +211,26 @@ extern "C" int st_sort_pairs_u32(uint32_t* keys, uint32_t* vals, int64_t n, int 
                                  void* stream) {
     return st_radix_sort_pairs_u32(keys, vals, n, key_bits, ws, ws_bytes, (hipStream_t)stream);
 }
+
+// One query for every workspace size (SURVEY.md section 8b `st_query_workspace`).
+extern "C" int64_t st_voxelize_workspace_bytes(int64_t, int, int64_t);
+extern "C" int64_t st_strided_workspace_bytes(int64_t);
+extern "C" int64_t st_knn_workspace_bytes(int64_t);
+extern "C" int64_t st_make_edges_workspace_bytes(int64_t);
+extern "C" int64_t st_component_layout_workspace_bytes(int64_t);
+extern "C" int64_t st_component_csr_workspace_bytes(int64_t);
+extern "C" int64_t st_skeleton_workspace_bytes(int64_t, int64_t);
+extern "C" int64_t st_query_workspace(int op, int64_t a, int64_t b, int64_t c) {
+    switch (op) {
+        case 0: return st_scan_ws_bytes(a);
+        case 1: return st_sort_ws_bytes(a);
+        case 2: return st_voxelize_workspace_bytes(a, (int)b, c);
+        case 3: return st_strided_workspace_bytes(a);
+        case 4: return st_knn_workspace_bytes(a);
+        case 5: return st_make_edges_workspace_bytes(a);
+        case 6: return st_component_layout_workspace_bytes(a);
+        case 7: return st_component_csr_workspace_bytes(a);
+        case 8: return st_skeleton_workspace_bytes(a, b);
+        default: st_set_error("st_query_workspace: unknown op %d", op); return -1;
+    }
+}

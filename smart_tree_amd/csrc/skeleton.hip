@@ -717,3 +717,21 @@ extern "C" int st_skeleton_components(int n_comp, const int32_t* comp_off, const
     ST_CHECK_LAUNCH();
     return ST_OK;
 }
+
+// Named single-stage entry points: the same call with one stage selected.
+// st_tree_distance / st_sample_tree expect dist / pred / root_local from an earlier st_sssp call.
+#define SK_STAGE_ENTRY(name, stage_bits)                                                                                  \
+    extern "C" int name(int n_comp, const int32_t* comp_off, const int32_t* comp_size_host, int64_t m, const float* pts,   \
+                        const float* rad, const float* ysurf, const uint32_t* row_off, const uint32_t* col, const float* wgt, \
+                        float grid_cell, int block_threads, float* dist, int32_t* pred, int32_t* root_local, float* tree_dist, \
+                        int32_t* branch_parent, int32_t* branch_off, int32_t* branch_len, int32_t* n_branches,             \
+                        int32_t* path_verts, int32_t* branch_of, int64_t* stats_host, void* ws, int64_t ws_bytes,          \
+                        void* stream) {                                                                                    \
+        return st_skeleton_components(n_comp, comp_off, comp_size_host, m, pts, rad, ysurf, row_off, col, wgt, grid_cell,   \
+                                      stage_bits, block_threads, dist, pred, root_local, tree_dist, branch_parent,         \
+                                      branch_off, branch_len, n_branches, path_verts, branch_of, stats_host, ws, ws_bytes, \
+                                      stream);                                                                             \
+    }
+SK_STAGE_ENTRY(st_sssp, 1)
+SK_STAGE_ENTRY(st_tree_distance, 2)
+SK_STAGE_ENTRY(st_sample_tree, 4)

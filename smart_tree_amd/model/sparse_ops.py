@@ -109,11 +109,11 @@ def sparse_conv(x0: torch.Tensor, w: torch.Tensor, nbr: Optional[torch.Tensor], 
     K, cin, cout = w.shape
     c0 = x0.shape[1]
     y = torch.empty((n_out, cout), dtype=torch.float32, device=x0.device)
-    nbytes = 0
-    if profiling.enabled():  # P*(Cin*4 + 4) + N*Cout*4 (pointwise: N*(Cin+Cout)*4)
-        pairs = _pair_count(nbr) if nbr is not None else n_out
-        nbytes = pairs * (cin * 4 + (4 if nbr is not None else 0)) + n_out * cout * 4
-    with profiling.kernel("k_sparse_conv", nbytes):
+    # algorithmic bytes: P*(Cin*4 + 4) + N*Cout*4 (pointwise: N*(Cin+Cout)*4); the pair count
+    # is evaluated lazily, after the timed region
+    nbytes = (lambda: (_pair_count(nbr) if nbr is not None else n_out) * (cin * 4 + (4 if nbr is not None else 0))
+              + n_out * cout * 4) if profiling.enabled() else 0
+    with profiling.kernel(f"k_sparse_conv<{cin},{cout}>" + ("" if nbr is not None else " k1"), nbytes):
       _lib.check(L.st_sparse_conv_fwd(_lib.ptr(x0), c0, _lib.ptr(x1), cin, _lib.ptr(nbr), K, n_out, _lib.ptr(w), cout,
                                     _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(residual), int(relu), _lib.ptr(y),
                                     _lib.stream(x0.device)))
@@ -125,9 +125,9 @@ _pairs_cache = {}
 
 def _pair_count(nbr: torch.Tensor) -> int:
     """Active (input, output) pairs of a neighbour table (profiling only; cached per table)."""
-    key = (nbr.data_ptr(), tuple(nbr.shape))
+    key = id(nbr)  # the thunk keeps the tensor alive, so the id is stable
     if key not in _pairs_cache:
-        if len(_pairs_cache) > 64:
+        if len(_pairs_cache) > 4096:
             _pairs_cache.clear()
         _pairs_cache[key] = int((nbr >= 0).sum().item())
     return _pairs_cache[key]

@@ -53,7 +53,7 @@ def kernel(name: str, algorithmic_bytes: float):
         yield
     finally:
         b.record()
-        _kernels[name].append((a, b, float(algorithmic_bytes)))
+        _kernels[name].append((a, b, algorithmic_bytes))  # a number, or a thunk evaluated after the timed region
 
 
 def stage_ms(steps: int):
@@ -66,8 +66,9 @@ def kernel_table():
     rows = {}
     for name, recs in _kernels.items():
         ms = [a.elapsed_time(b) for a, b, _ in recs]
+        nbytes = [float(r[2]() if callable(r[2]) else r[2]) for r in recs]
         rows[name] = {"launches": len(recs), "total_ms": sum(ms), "avg_us": 1e3 * sum(ms) / len(ms),
-                      "bytes_per_launch": sum(r[2] for r in recs) / len(recs)}
+                      "bytes_per_launch": sum(nbytes) / len(recs)}
     return rows
 
 
