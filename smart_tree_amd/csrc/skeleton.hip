@@ -591,7 +591,9 @@ static inline int sk_claim_blocks(int64_t comp_size) {
 // stages: 1 = roots + SSSP + predecessors, 2 = literal second SSSP into tree_dist, 4 = sample_tree
 // (on tree_dist if stage 2 ran, else on dist -- the two are bit-identical).
 // block_threads: lanes of the per-component select workgroup (0 = 1024).
-// stats_host (optional, 4 x int64): SSSP rounds, plateau rounds, sample_tree iterations, lifting levels.
+// stats_host (optional, 8 x int64): [0] SSSP rounds, [1] plateau rounds, [2] select/claim launch pairs, [3] lifting
+// levels; if stats_host[7] != 0 on entry, every k_sk_select launch is bracketed by HIP events on `stream` and
+// [4] = their summed duration in ns, [5] = number of launches (profiling aid for bench.py's roofline block).
 extern "C" int st_skeleton_components(int n_comp, const int32_t* comp_off, const int32_t* comp_size_host, int64_t m,
                                       const float* pts, const float* rad, const float* ysurf, const uint32_t* row_off,
                                       const uint32_t* col, const float* wgt, float grid_cell, int stages, int block_threads,
@@ -600,7 +602,8 @@ extern "C" int st_skeleton_components(int n_comp, const int32_t* comp_off, const
                                       int32_t* path_verts, int32_t* branch_of, int64_t* stats_host, void* ws,
                                       int64_t ws_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (stats_host) stats_host[0] = stats_host[1] = stats_host[2] = stats_host[3] = 0;
+    const bool time_select = stats_host && stats_host[7] != 0;
+    if (stats_host) for (int i = 0; i < 7; i++) stats_host[i] = 0;
     if (n_comp <= 0 || m <= 0) return ST_OK;
     ST_REQUIRE(!(stages & 2) || tree_dist != nullptr, "skeleton: stage 2 needs a tree_dist buffer");
     if (block_threads <= 0) block_threads = 1024;
@@ -703,14 +706,30 @@ extern "C" int st_skeleton_components(int n_comp, const int32_t* comp_off, const
         }
         hipLaunchKernelGGL(k_sk_order_init, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A, s.order_init);
         int64_t iters = 0;
+        hipEvent_t ev[32];
+        if (time_select) for (int i = 0; i < 32; i++) (void)hipEventCreate(&ev[i]);
+        double select_ms = 0.0;
         for (;;) {  // batches of 16 launch pairs (each select runs up to 16 short-path iterations itself)
             for (int b = 0; b < 16; b++, iters++) {
+                if (time_select) (void)hipEventRecord(ev[2 * b], stream);
                 hipLaunchKernelGGL(k_sk_select, dim3((unsigned)n_comp), dim3((unsigned)block_threads), 0, stream, A, levels);
+                if (time_select) (void)hipEventRecord(ev[2 * b + 1], stream);
                 hipLaunchKernelGGL(k_sk_claim, dim3((unsigned)nblk), dim3(SK_WIDE_BLOCK), 0, stream, A);
             }
             ST_TRY(sk_read(h, s.cnt, sizeof(unsigned) * 8, stream));
+            if (time_select)
+                for (int b = 0; b < 16; b++) {
+                    float ms = 0.0f;
+                    (void)hipEventElapsedTime(&ms, ev[2 * b], ev[2 * b + 1]);
+                    select_ms += ms;
+                }
             if (h[5] >= (unsigned)n_comp) break;
             ST_REQUIRE(iters <= m + 64 && iters < (1 << 26), "skeleton: sample_tree did not terminate");
+        }
+        if (time_select) {
+            for (int i = 0; i < 32; i++) (void)hipEventDestroy(ev[i]);
+            stats_host[4] = (int64_t)(select_ms * 1e6);
+            stats_host[5] = iters;
         }
         if (stats_host) { stats_host[2] = iters; stats_host[3] = levels; }
     }

@@ -22,6 +22,7 @@ def enable(flag: bool) -> None:
     if flag:
         _stages.clear()
         _kernels.clear()
+        _external.clear()
 
 
 def enabled() -> bool:
@@ -56,6 +57,15 @@ def kernel(name: str, algorithmic_bytes: float):
         _kernels[name].append((a, b, algorithmic_bytes))  # a number, or a thunk evaluated after the timed region
 
 
+_external = defaultdict(list)  # name -> [(total_ms, launches, bytes_thunk)] measured by the library itself
+
+
+def add_kernel_time(name: str, total_ms: float, launches: int, total_bytes) -> None:
+    """Kernel time the C library measured with its own HIP events (launch loops that live in C)."""
+    if _enabled:
+        _external[name].append((float(total_ms), int(launches), total_bytes))
+
+
 def stage_ms(steps: int):
     torch.cuda.synchronize()
     return {k: round(sum(a.elapsed_time(b) for a, b in v) / max(steps, 1), 3) for k, v in _stages.items()}
@@ -69,6 +79,12 @@ def kernel_table():
         nbytes = [float(r[2]() if callable(r[2]) else r[2]) for r in recs]
         rows[name] = {"launches": len(recs), "total_ms": sum(ms), "avg_us": 1e3 * sum(ms) / len(ms),
                       "bytes_per_launch": sum(nbytes) / len(recs)}
+    for name, recs in _external.items():
+        launches = sum(r[1] for r in recs)
+        total = sum(r[0] for r in recs)
+        nbytes = sum(float(r[2]() if callable(r[2]) else r[2]) for r in recs)
+        rows[name] = {"launches": launches, "total_ms": total, "avg_us": 1e3 * total / max(launches, 1),
+                      "bytes_per_launch": nbytes / max(launches, 1)}
     return rows
 
 

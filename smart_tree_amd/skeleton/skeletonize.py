@@ -61,18 +61,33 @@ def run_components(comps: ComponentSet, medial_pts: torch.Tensor, radius: torch.
         return res
     r_max = rad.max().item()
     sizes = comps.comp_size.cpu().numpy().astype("int32")  # host copy: sizes the claim grid
-    stats = (ctypes.c_int64 * 4)()
+    stats = (ctypes.c_int64 * 8)()
+    stats[7] = 1 if profiling.enabled() else 0  # bracket every k_sk_select launch with HIP events
     ws = _lib.workspace(L.st_skeleton_workspace_bytes(m, C), dev)
-    n_adj = int(comps.row_off[-1].item()) if profiling.enabled() else 0
-    with profiling.kernel("skeleton_stage", n_adj * 8 + m * (8 + 24)):
+    with profiling.stage("skeleton_kernels"):
         _lib.check(L.st_skeleton_components(
             C, _lib.ptr(comps.comp_off.contiguous()), sizes.ctypes.data, m, _lib.ptr(pts), _lib.ptr(rad), _lib.ptr(ys),
             _lib.ptr(comps.row_off), _lib.ptr(comps.col), _lib.ptr(comps.wgt), float(max(r_max / 4.0, 1e-4)), int(stages),
             int(block_threads), _lib.ptr(res.dist), _lib.ptr(res.pred), _lib.ptr(res.root_local), _lib.ptr(res.tree_dist),
             _lib.ptr(res.branch_parent), _lib.ptr(res.branch_off), _lib.ptr(res.branch_len), _lib.ptr(res.n_branches),
             _lib.ptr(res.path_verts), _lib.ptr(res.branch_of), stats, _lib.ptr(ws), ws.numel(), _lib.stream(dev)))
-    res.stats = {"sssp_rounds": stats[0], "plateau_rounds": stats[1], "branch_iterations": stats[2], "lift_levels": stats[3]}
+    res.stats = {"sssp_rounds": stats[0], "plateau_rounds": stats[1], "select_launches": stats[2], "lift_levels": stats[3]}
+    if stats[7] and stats[5]:
+        # algorithmic bytes of the branch selection (SURVEY.md 8d "sample_tree"): each path vertex is written once
+        # (24 B: id + xyz lookups), each claimed point raced and stamped once (16 B), plus the sorted-order cursor (8 B/vertex)
+        res_ref = res
+        profiling.add_kernel_time("k_sk_select", stats[4] * 1e-6, stats[5],
+                                  lambda: _select_bytes(res_ref, comps, m))
     return res
+
+
+def _select_bytes(res: ComponentResult, comps: ComponentSet, m: int) -> float:
+    off = comps.comp_off.cpu().tolist()
+    nb = res.n_branches[: comps.n_components].cpu().tolist()
+    lens = res.branch_len.cpu()
+    path_vertices = sum(int(lens[off[c]: off[c] + nb[c]].sum()) for c in range(comps.n_components))
+    claimed = int((res.branch_of[:m] >= 0).sum().item())
+    return path_vertices * 24.0 + claimed * 16.0 + m * 8.0
 
 
 class Skeletonizer:
