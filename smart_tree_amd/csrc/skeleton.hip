@@ -30,10 +30,10 @@
 
 #define SK_MAX_WAVES 16
 #define SK_EMPTY64 0xffffffffffffffffull
-#define SK_LIFT 24         // 2^24 hops bound the deepest predecessor chain
 #define SK_WIDE_BLOCK 256  // block size of the vertex / frontier kernels
 #define SK_SSSP_BLOCKS 256  // upper bound; small graphs launch fewer (one wave per frontier vertex)
 #define SK_MARK 0xfffffffeu
+#define SK_ANC 64  // direct ancestors kept per vertex
 
 struct SkArgs {
     int C;
@@ -69,7 +69,7 @@ struct SkArgs {
     unsigned* term;   // termination set
     unsigned long long* best;  // claim race: (d2 bits << 32) | path position
     unsigned* touched;
-    int* anc;         // [levels][m] binary-lifting table (component-local ids)
+    int* anc;         // [m][64] direct ancestor table (component-local ids)
     // global counters: [0..2] rotating frontier counts, [3] unresolved, [4] plateau progress, [5] components done
     unsigned* cnt;
     // per-component sample_tree state [C]
@@ -278,7 +278,7 @@ __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_td_round(SkArgs A, int r) 
 __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_lift_init(SkArgs A, const float* distances) {
     SK_VERTEX_LOOP(v) {
         const int p = A.pred[v];
-        A.anc[v] = p;
+        A.anc[v * SK_ANC] = p;
         A.alloc[v] = p > 0 ? distances[v] : -1.0f;  // path.py:71-72
         A.term[v] = 0u;
         A.branch_of[v] = -1;
@@ -300,31 +300,39 @@ __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_order_init(SkArgs A, float
     SK_VERTEX_LOOP(j) order_init[j] = A.alloc[A.order[j]];
 }
 
-// anc[k][v] = 2^k-th ancestor (component-local id), -1 past the root
-__global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_lift_level(SkArgs A, int k) {
-    const int* prev = A.anc + (int64_t)(k - 1) * A.m;
-    int* cur = A.anc + (int64_t)k * A.m;
-    SK_VERTEX_LOOP(v) {
+// Ancestor table: anc[v*64 + k] = (k+1)-th ancestor of v (component-local id, -1 past the root).
+// k = 0 is written by k_sk_lift_init; pass `span` (1, 2, 4, .. 32) fills entries [span, 2*span) from
+// the table of the span-th ancestor.  A lane then reads "my j-th ancestor" with ONE load for j <= 64
+// and hops 64 levels at a time beyond (the trace of trace_route, path.py:9-16, without a pointer chase).
+__global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_anc_pass(SkArgs A, int span) {
+    const int64_t total = A.m * span;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t v = i / span;
+        const int k = (int)(i % span);
         const int base = A.comp_off[A.comp_of[v]];
-        const int h = prev[v];
-        cur[v] = h >= 0 ? prev[base + h] : -1;
+        const int h = A.anc[v * SK_ANC + span - 1];  // span-th ancestor
+        A.anc[v * SK_ANC + span + k] = h >= 0 ? A.anc[(int64_t)(base + h) * SK_ANC + k] : -1;
     }
 }
 
-__device__ __forceinline__ int sk_ancestor(const SkArgs& A, int base, int v, unsigned j, int levels) {
-    for (int k = 0; j != 0 && v >= 0; k++, j >>= 1) {
-        if (k >= levels) return -1;
-        if (j & 1u) v = A.anc[(int64_t)k * A.m + base + v];
-    }
-    return v;
+// j-th ancestor of `far` (j = 0: itself); lanes of one 64-chunk share the hop chain (broadcast loads)
+__device__ __forceinline__ int sk_ancestor(const SkArgs& A, int base, int far, unsigned j) {
+    int cur = far;
+    for (unsigned h = j >> 6; h > 0 && cur >= 0; h--) cur = A.anc[(int64_t)(base + cur) * SK_ANC + (SK_ANC - 1)];
+    const unsigned rem = j & 63u;
+    if (rem == 0u || cur < 0) return cur;
+    return A.anc[(int64_t)(base + cur) * SK_ANC + rem - 1];
 }
 
 // claim: every (path vertex, x/y grid row) pair offers (d2, position) to the points within r of it.
 // A 16-lane group per pair: the records of its cells are raced in parallel (a lone lane would chain
 // one returning atomic per record).  First touches are staged in LDS and flushed with one reservation.
 #define SK_LQ_CLAIM 2048
-__device__ __forceinline__ void sk_claim_items(const SkArgs& A, int c, int base, int n, int len, float rp, const int* path,
-                                               int slice, int nslice, unsigned* lq, unsigned* lq_n, unsigned* lq_base) {
+// keep_local: the caller is the component's own workgroup and will finish the branch itself -- if the
+// staged list did not overflow it stays in LDS (returns true) instead of being flushed to `touched`.
+__device__ __forceinline__ bool sk_claim_items(const SkArgs& A, int c, int base, int n, int len, float rp, const int* path,
+                                               bool path_in_lds, int slice, int nslice, unsigned* lq, unsigned* lq_n,
+                                               unsigned* lq_base, bool keep_local) {
     const StGrid* g = A.grid;
     const float rp2 = rp * rp;
     int reach = rp > 0.0f ? (int)ceilf(rp / g->cell) : 0;
@@ -337,7 +345,7 @@ __device__ __forceinline__ void sk_claim_items(const SkArgs& A, int c, int base,
     const int64_t group = ((int64_t)slice * blockDim.x + threadIdx.x) >> 4, ngroup = ((int64_t)nslice * blockDim.x) >> 4;
     for (int64_t it = group; it < items; it += ngroup) {
         const int qi = (int)(it / nrow), rr = (int)(it % nrow);
-        const float* pv = A.pts + 3 * (int64_t)(base + ld(&path[qi]));
+        const float* pv = A.pts + 3 * (int64_t)(base + (path_in_lds ? path[qi] : ld(&path[qi])));
         const int x = (int)floorf((pv[0] - g->lo[0]) / g->cell) - reach + rr / side;
         const int y = (int)floorf((pv[1] - g->lo[1]) / g->cell) - reach + rr % side;
         if (x < 0 || x >= g->dim[0] || y < 0 || y >= g->dim[1]) continue;
@@ -362,22 +370,53 @@ __device__ __forceinline__ void sk_claim_items(const SkArgs& A, int c, int base,
         }
     }
     __syncthreads();
-    const unsigned nloc = *lq_n < SK_LQ_CLAIM ? *lq_n : SK_LQ_CLAIM;
+    const unsigned staged = *lq_n;
+    if (keep_local && staged <= SK_LQ_CLAIM) return true;  // uniform
+    const unsigned nloc = staged < SK_LQ_CLAIM ? staged : SK_LQ_CLAIM;
     if (threadIdx.x == 0 && nloc) *lq_base = atomicAdd(&A.s_ntouched[c], nloc);
     __syncthreads();
     for (unsigned i = threadIdx.x; i < nloc; i += blockDim.x) A.touched[base + *lq_base + i] = lq[i];
     __syncthreads();
+    return false;
 }
 
-// select: one workgroup per component.  Per iteration: finish the previous branch (on-path test and
-// stamps), advance the cursor over the distance-sorted vertices to the farthest unallocated one
-// (path.py:92 -- nothing is ever re-scanned), trace its route by binary lifting, record the branch;
-// short paths are claimed right here and the loop continues, a long path is left to k_sk_claim.
+// select: one workgroup per component, up to SK_ITERS_PER_LAUNCH branches per launch.  Per branch:
+// advance the cursor over the distance-sorted vertices to the farthest unallocated one (path.py:92 --
+// nothing is ever re-scanned), trace its route through the ancestor table, record the branch; a
+// short path is claimed and finished right here (state, path and touched list stay in LDS), a long
+// one is left to the chip-wide k_sk_claim and finished at the head of the next launch.
 #define SK_SMALL_ITEMS 768
-#define SK_ITERS_PER_LAUNCH 16
-__global__ void __launch_bounds__(1024) k_sk_select(SkArgs A, int levels) {
+#define SK_ITERS_PER_LAUNCH 32
+#define SK_LPATH 1024
+
+// on-path test of the claimed points (path.py:35-40) + allocation / termination / branch-id stamps (:112-122,135-136)
+__device__ __forceinline__ void sk_finish_branch(const SkArgs& A, int base, int len, int id, const int* path, bool path_in_lds,
+                                                 const unsigned* touched, bool touched_in_lds, unsigned nt) {
+    for (unsigned t = threadIdx.x; t < nt; t += blockDim.x) {
+        const int p = (int)(touched_in_lds ? touched[t] : ld(&touched[t]));
+        const unsigned long long pk = ld(&A.best[base + p]);
+        A.best[base + p] = SK_EMPTY64;
+        const float d2 = __uint_as_float((unsigned)(pk >> 32));
+        const int qi = (int)(pk & 0xffffffffu);
+        if (sqrtf(d2) < A.rad[base + (path_in_lds ? path[qi] : ld(&path[qi]))]) {
+            A.alloc[base + p] = -1.0f;
+            A.term[base + p] = 1u;
+            if (id >= 0) A.branch_of[base + p] = id;
+        }
+    }
+    for (int qi = threadIdx.x; qi < len; qi += blockDim.x) {
+        const int v = path_in_lds ? path[qi] : ld(&path[qi]);
+        A.alloc[base + v] = -1.0f;
+        A.term[base + v] = 1u;
+        if (id >= 0) A.branch_of[base + v] = id;
+    }
+    __syncthreads();  // stores drained (vmcnt) before anyone re-reads through L2
+}
+
+__global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
     __shared__ unsigned long long s_red[SK_MAX_WAVES];
     __shared__ unsigned lq[SK_LQ_CLAIM];
+    __shared__ int lpath[SK_LPATH];
     __shared__ unsigned lq_n, lq_base;
     __shared__ int s_term;
     const int c = blockIdx.x, tid = threadIdx.x;
@@ -385,44 +424,25 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A, int levels) {
     const int base = A.comp_off[c], n = A.comp_off[c + 1] - base;
     const unsigned* order = A.order + base;
     unsigned* tmp = A.q0 + base;
+    // a long path left over from the previous launch: k_sk_claim filled `touched`
+    {
+        const int plen = A.s_len[c];
+        if (plen > 0)
+            sk_finish_branch(A, base, plen, A.s_cur_id[c], A.path_verts + base + A.s_cur_off[c], false, A.touched + base, false,
+                             A.s_ntouched[c]);
+    }
+    int cursor = A.s_cursor[c], total = A.s_total[c], nb = A.s_nb[c];  // per-component state lives in registers
     for (int iter = 0; iter < SK_ITERS_PER_LAUNCH; iter++) {
-        // 0. finish the previous iteration: on-path test of the claimed points (path.py:35-40) and
-        //    the allocation / termination / branch-id stamps (:112-122,135-136)
-        {
-            const int plen = ld(&A.s_len[c]), id = ld(&A.s_cur_id[c]);
-            const int* ppath = A.path_verts + base + ld(&A.s_cur_off[c]);
-            const unsigned nt = plen > 0 ? ld(&A.s_ntouched[c]) : 0u;
-            for (unsigned t = tid; t < nt; t += blockDim.x) {
-                const int p = (int)ld(&A.touched[base + t]);
-                const unsigned long long pk = ld(&A.best[base + p]);
-                A.best[base + p] = SK_EMPTY64;
-                const float d2 = __uint_as_float((unsigned)(pk >> 32));
-                const int qi = (int)(pk & 0xffffffffu);
-                if (sqrtf(d2) < A.rad[base + ld(&ppath[qi])]) {
-                    A.alloc[base + p] = -1.0f;
-                    A.term[base + p] = 1u;
-                    if (id >= 0) A.branch_of[base + p] = id;
-                }
-            }
-            for (int qi = tid; qi < plen; qi += blockDim.x) {
-                const int v = ld(&ppath[qi]);
-                A.alloc[base + v] = -1.0f;
-                A.term[base + v] = 1u;
-                if (id >= 0) A.branch_of[base + v] = id;
-            }
-            __syncthreads();
-        }
         // 1. farthest unallocated vertex: first live entry of the sorted order at or after the cursor
         int far = -1;
         bool exhausted = false;
-        for (int cur = ld(&A.s_cursor[c]); far < 0 && !exhausted; cur += blockDim.x) {
-            const int j = cur + tid;
+        for (; far < 0 && !exhausted; cursor += blockDim.x) {
+            const int j = cursor + tid;
             unsigned long long k = 0;
             if (j < n) {
                 const int v = (int)order[j] - base;
-                const float a = ld(&A.alloc[base + v]);
-                // entries are sorted by their INITIAL distance: the first non-positive one ends the list
-                const bool live = a > 0.0f, tail = !(A.order_init[base + j] > 0.0f);
+                const bool live = ld(&A.alloc[base + v]) > 0.0f;
+                const bool tail = !(A.order_init[base + j] > 0.0f);  // sorted by INITIAL distance: first non-positive ends the list
                 if (live || tail) k = ((unsigned long long)(0xffffffffu - (unsigned)j) << 32) | (tail ? 0u : (unsigned)v + 1u);
             } else if (j == n) {
                 k = ((unsigned long long)(0xffffffffu - (unsigned)j) << 32);  // end of the component
@@ -431,11 +451,14 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A, int levels) {
             if (k != 0ull) {
                 const unsigned lowv = (unsigned)(k & 0xffffffffu);
                 if (lowv == 0u) exhausted = true;
-                else { far = (int)lowv - 1; if (tid == 0) A.s_cursor[c] = (int)(0xffffffffu - (unsigned)(k >> 32)) + 1; }
+                else { far = (int)lowv - 1; cursor = (int)(0xffffffffu - (unsigned)(k >> 32)) + 1 - (int)blockDim.x; }
             }
         }
         if (far < 0) {  // path.py:94-95 (uniform)
-            if (tid == 0) { A.s_done[c] = 1; A.s_len[c] = 0; A.s_wide[c] = 0; A.n_branches[c] = ld(&A.s_nb[c]); atomicAdd(&A.cnt[5], 1u); }
+            if (tid == 0) {
+                A.s_done[c] = 1; A.s_len[c] = 0; A.s_wide[c] = 0; A.n_branches[c] = nb; A.s_nb[c] = nb; A.s_total[c] = total;
+                atomicAdd(&A.cnt[5], 1u);
+            }
             return;
         }
         // 2. trace_route (path.py:9-16): lane j inspects the j-th ancestor; the first allocated one
@@ -443,9 +466,9 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A, int levels) {
         int len = -1;
         for (unsigned chunk = 0; len < 0; chunk += blockDim.x) {
             const unsigned j = chunk + tid;
-            const int node = sk_ancestor(A, base, far, j, levels);
+            const int node = sk_ancestor(A, base, far, j);
             const bool end = node < 0 || ld(&A.term[base + node]) != 0u;
-            if (!end) tmp[j] = (unsigned)node;
+            if (!end) { if (j < SK_LPATH) lpath[j] = node; else tmp[j] = (unsigned)node; }
             unsigned long long k = end ? ((unsigned long long)(0xffffffffu - j) << 32) | (unsigned)(node + 1) : 0ull;
             k = block_max_u64(k, s_red);
             if (k != 0ull) {
@@ -454,12 +477,12 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A, int levels) {
             }
         }
         __syncthreads();
-        // 3. path root side first; r = max radius on the path (path.py:31)
-        const int total = ld(&A.s_total[c]);
+        // 3. path root side first (global: it is an output); r = max radius on the path (path.py:31)
         int* path_out = A.path_verts + base + total;
         unsigned long long rk = 0;
         for (int qi = tid; qi < len; qi += blockDim.x) {
-            const int v = (int)ld(&tmp[len - 1 - qi]);
+            const int w = len - 1 - qi;  // walk order -> root side first
+            const int v = w < SK_LPATH ? lpath[w] : (int)ld(&tmp[w]);
             path_out[qi] = v;
             const unsigned long long k = (unsigned long long)st_f2ord(A.rad[base + v]) << 32;
             rk = k > rk ? k : rk;
@@ -468,32 +491,39 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A, int levels) {
         const float rp = st_ord2f((unsigned)(rk >> 32));
         int reach = rp > 0.0f ? (int)ceilf(rp / A.grid->cell) : 0;
         if (reach < 1) reach = 1;
-        const bool small = (int64_t)len * (2 * reach + 1) * (2 * reach + 1) <= SK_SMALL_ITEMS;
-        __syncthreads();
-        if (tid == 0) {
-            const bool keep = len >= 2;  // path.py:125-126: shorter paths still consume their points
-            const int nb = ld(&A.s_nb[c]);
-            A.s_len[c] = len;
-            A.s_rp[c] = rp;
-            A.s_ntouched[c] = 0u;
-            A.s_cur_off[c] = total;
-            A.s_cur_id[c] = keep ? nb : -1;
-            A.s_wide[c] = small ? 0 : 1;
-            if (keep) {
-                // parent id is read BEFORE this branch stamps anything (path.py:128-136);
-                // termination -1 reads branch_ids[-1] = the last vertex (quirk kept)
-                A.branch_parent[base + nb] = ld(&A.branch_of[base + (s_term < 0 ? n - 1 : s_term)]);
-                A.branch_off[base + nb] = total;
-                A.branch_len[base + nb] = len;
-                A.s_nb[c] = nb + 1;
-                A.s_total[c] = total + len;
-            }
+        const bool small = len <= SK_LPATH && (int64_t)len * (2 * reach + 1) * (2 * reach + 1) <= SK_SMALL_ITEMS;
+        const bool keep = len >= 2;  // path.py:125-126: shorter paths still consume their points
+        const int id = keep ? nb : -1;
+        if (tid == 0 && keep) {
+            // parent id is read BEFORE this branch stamps anything (path.py:128-136);
+            // termination -1 reads branch_ids[-1] = the last vertex (quirk kept)
+            A.branch_parent[base + nb] = ld(&A.branch_of[base + (s_term < 0 ? n - 1 : s_term)]);
+            A.branch_off[base + nb] = total;
+            A.branch_len[base + nb] = len;
         }
+        const int cur_off = total;
+        if (keep) { nb++; total += len; }
+        if (!small) {  // hand the path to k_sk_claim; its points are finished at the next launch (uniform)
+            if (tid == 0) {
+                A.s_len[c] = len; A.s_rp[c] = rp; A.s_ntouched[c] = 0u; A.s_cur_off[c] = cur_off; A.s_cur_id[c] = id;
+                A.s_wide[c] = 1; A.s_cursor[c] = cursor; A.s_total[c] = total; A.s_nb[c] = nb;
+            }
+            return;
+        }
+        // 4. short path: reverse it in LDS (root side first), claim and finish here
         __syncthreads();
-        if (!small) return;  // k_sk_claim takes this path; its points are finished at the next launch
-        // path entries are re-read through L2: they were written a few lines up by other lanes
-        sk_claim_items(A, c, base, n, len, rp, path_out, 0, 1, lq, &lq_n, &lq_base);
+        for (int qi = tid; qi < len / 2; qi += blockDim.x) {  // each pair is swapped by exactly one lane
+            const int a = lpath[qi];
+            lpath[qi] = lpath[len - 1 - qi];
+            lpath[len - 1 - qi] = a;
+        }
+        if (tid == 0) A.s_ntouched[c] = 0u;
+        __syncthreads();
+        const bool local = sk_claim_items(A, c, base, n, len, rp, lpath, true, 0, 1, lq, &lq_n, &lq_base, true);
+        if (local) sk_finish_branch(A, base, len, id, lpath, true, lq, true, lq_n);
+        else sk_finish_branch(A, base, len, id, lpath, true, A.touched + base, false, ld(&A.s_ntouched[c]));
     }
+    if (tid == 0) { A.s_len[c] = 0; A.s_wide[c] = 0; A.s_cursor[c] = cursor; A.s_total[c] = total; A.s_nb[c] = nb; }
 }
 
 __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_claim(SkArgs A) {
@@ -502,8 +532,8 @@ __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_claim(SkArgs A) {
     const int c = A.blk_comp[blockIdx.x];
     if (A.s_done[c] || !A.s_wide[c]) return;
     const int base = A.comp_off[c], n = A.comp_off[c + 1] - base;
-    sk_claim_items(A, c, base, n, A.s_len[c], A.s_rp[c], A.path_verts + base + A.s_cur_off[c], blockIdx.x - A.blk_first[c],
-                   A.blk_count[c], lq, &lq_n, &lq_base);
+    sk_claim_items(A, c, base, n, A.s_len[c], A.s_rp[c], A.path_verts + base + A.s_cur_off[c], false,
+                   blockIdx.x - A.blk_first[c], A.blk_count[c], lq, &lq_n, &lq_base, false);
 }
 
 // ------------------------------------------------------------------------------- host side ---
@@ -534,7 +564,7 @@ static void sk_layout(StArena& a, int64_t m, int64_t C, SkLayout* s) {
     s->touched = a.take<unsigned>(m);
     s->alloc = a.take<float>(m);
     s->best = a.take<unsigned long long>(m);
-    s->anc = a.take<int>((int64_t)SK_LIFT * m);
+    s->anc = a.take<int>((int64_t)64 * m);
     s->comp_of = a.take<int>(m);
     s->cnt = a.take<unsigned>(8);
     s->s_done = a.take<int>(C);
@@ -687,14 +717,11 @@ extern "C" int st_skeleton_components(int n_comp, const int32_t* comp_off, const
         int rc = st_grid_build(pts, m, grid_cell, SK_GRID_CELLS, s.g, s.cell_start, s.recs, s.gws, s.gws_bytes, stream);  // syncs
         free(hb);
         ST_TRY(rc);
-        // binary lifting over the predecessor tree; its depth is bounded by the SSSP round count
-        int levels = 1;
-        const int64_t depth_bound = (stages & 1) ? sssp_rounds : m;
-        while ((1ll << levels) <= depth_bound && levels < SK_LIFT) levels++;
         (void)hipMemsetAsync(&s.cnt[5], 0, sizeof(unsigned), stream);
         hipLaunchKernelGGL(k_sk_lift_init, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A,
                            (const float*)((stages & 2) ? tree_dist : dist));
-        for (int k = 1; k < levels; k++) hipLaunchKernelGGL(k_sk_lift_level, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A, k);
+        for (int span = 1; span < SK_ANC; span *= 2)  // direct ancestor table by doubling (6 passes)
+            hipLaunchKernelGGL(k_sk_anc_pass, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A, span);
         // order the vertices of every component by distance, once: the per-branch argmax becomes a cursor
         hipLaunchKernelGGL(k_sk_sort_keys, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A, s.sort_keys, s.order, 0);
         ST_TRY(st_radix_sort_pairs_u32(s.sort_keys, s.order, m, 32, s.sort_ws, s.sort_bytes, stream));
@@ -709,10 +736,10 @@ extern "C" int st_skeleton_components(int n_comp, const int32_t* comp_off, const
         hipEvent_t ev[32];
         if (time_select) for (int i = 0; i < 32; i++) (void)hipEventCreate(&ev[i]);
         double select_ms = 0.0;
-        for (;;) {  // batches of 16 launch pairs (each select runs up to 16 short-path iterations itself)
+        for (;;) {  // batches of 16 launch pairs (each select runs up to 32 short-path branches itself)
             for (int b = 0; b < 16; b++, iters++) {
                 if (time_select) (void)hipEventRecord(ev[2 * b], stream);
-                hipLaunchKernelGGL(k_sk_select, dim3((unsigned)n_comp), dim3((unsigned)block_threads), 0, stream, A, levels);
+                hipLaunchKernelGGL(k_sk_select, dim3((unsigned)n_comp), dim3((unsigned)block_threads), 0, stream, A);
                 if (time_select) (void)hipEventRecord(ev[2 * b + 1], stream);
                 hipLaunchKernelGGL(k_sk_claim, dim3((unsigned)nblk), dim3(SK_WIDE_BLOCK), 0, stream, A);
             }
@@ -731,7 +758,7 @@ extern "C" int st_skeleton_components(int n_comp, const int32_t* comp_off, const
             stats_host[4] = (int64_t)(select_ms * 1e6);
             stats_host[5] = iters;
         }
-        if (stats_host) { stats_host[2] = iters; stats_host[3] = levels; }
+        if (stats_host) { stats_host[2] = iters; stats_host[3] = SK_ANC; }
     }
     ST_CHECK_LAUNCH();
     return ST_OK;
