@@ -88,6 +88,8 @@ int st_pointwise_mlp_heads(const float* x, int64_t n, const float* params, float
  *                   replace: cugraph.sssp (skeleton/shortest_path.py:12-21), pred_graph + second sssp
  *                            (shortest_path.py:46-55, skeletonize.py:80-85), sample_tree (skeleton/path.py:9-140)
  * st_post_process   replaces: pipeline.py:95-106 over data_types/tree.py:73-134,164-176 (+ util/queries.py:89-133) */
+/* st_centre_cloud replaces: dataset/augmentations.py:38-41 (CentreCloud over Cloud.bbox, data_types/cloud.py:222-227) */
+int st_centre_cloud(const float* xyz, int64_t n, float* out, void* ws, int64_t ws_bytes, void* stream);
 int st_medial_points(const float* xyz, const float* mv, int64_t n, float* medial, float* radius, void* stream);
 int64_t st_knn_workspace_bytes(int64_t n_dst);
 int st_knn_radius(const float* src, int64_t n1, const float* dst, int64_t n2, int K, float r, const float* bound,
@@ -121,7 +123,7 @@ int st_tree_distance(ST_SKELETON_STAGE_ARGS);
 int st_sample_tree(ST_SKELETON_STAGE_ARGS);
 int st_post_process(int n_trees, const int32_t* tree_off, const int32_t* parent, const int32_t* start, const int32_t* len,
                     float* xyz, const float* rad_in, float* rad_out, uint8_t* keep, uint8_t* repaired, uint8_t* smoothed,
-                    int do_prune, float min_radius, float min_length, int do_repair, int do_smooth, int kernel_size,
+                    int32_t* depth_scratch, int do_prune, float min_radius, float min_length, int do_repair, int do_smooth, int kernel_size,
                     void* stream);
 
 #ifdef __cplusplus

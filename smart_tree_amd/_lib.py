@@ -46,6 +46,7 @@ SIGNATURES = {
     "st_knn_workspace_bytes": (I64, [I64]),
     "st_knn_radius": (c_int, [P, I64, P, I64, c_int, c_float, P, c_int, c_float, P, P, P, I64, P]),
     "st_medial_points": (c_int, [P, P, I64, P, P, P]),
+    "st_centre_cloud": (c_int, [P, I64, P, P, I64, P]),
     "st_make_edges_workspace_bytes": (I64, [I64]),
     "st_make_edges": (c_int, [P, P, I64, c_int, P, P, ctypes.POINTER(I64), P, I64, P]),
     "st_connected_components": (c_int, [P, I64, I64, P, P, I64, P]),
@@ -53,7 +54,7 @@ SIGNATURES = {
     "st_component_layout": (c_int, [P, I64, c_int, P, P, P, P, ctypes.POINTER(I64), ctypes.POINTER(I64), P, I64, P]),
     "st_component_csr_workspace_bytes": (I64, [I64]),
     "st_component_csr": (c_int, [P, P, I64, P, I64, P, P, P, P, I64, P]),
-    "st_post_process": (c_int, [c_int, P, P, P, P, P, P, P, P, P, P, c_int, c_float, c_float, c_int, c_int, c_int, P]),
+    "st_post_process": (c_int, [c_int, P, P, P, P, P, P, P, P, P, P, P, c_int, c_float, c_float, c_int, c_int, c_int, P]),
     "st_skeleton_workspace_bytes": (I64, [I64, I64]),
     "st_skeleton_components": (c_int, [c_int, P, P, I64, P, P, P, P, P, P, c_float, c_int, c_int, P, P, P, P, P, P, P, P,
                                        P, P, ctypes.POINTER(I64), P, I64, P]),

@@ -46,6 +46,53 @@ extern "C" int st_medial_points(const float* xyz, const float* mv, int64_t n, fl
     return ST_OK;
 }
 
+// ------------------------------------------------------------------------------ CentreCloud ---
+// CentreCloud (smart_tree/dataset/augmentations.py:38-41 over Cloud.bbox, data_types/cloud.py:222-227):
+// half = (max - min) / 2, centre = min + half, xyz += -centre + (0, half_y, 0) -- same float32 operation
+// order as torch evaluates it, but one bounding-box pass (LDS reduction) + one translate pass instead of
+// four strided torch reductions.
+__global__ void __launch_bounds__(GR_BLOCK) k_bbox(const float* xyz, int64_t n, unsigned* box /*[6] ord lo, ord hi*/) {
+    __shared__ unsigned lo[3], hi[3];
+    if (threadIdx.x < 3) { lo[threadIdx.x] = 0xffffffffu; hi[threadIdx.x] = 0u; }
+    __syncthreads();
+    unsigned l[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, h[3] = {0u, 0u, 0u};
+    GR_LOOP(i, n)
+        for (int a = 0; a < 3; a++) {
+            const unsigned o = st_f2ord(xyz[3 * i + a]);
+            l[a] = o < l[a] ? o : l[a];
+            h[a] = o > h[a] ? o : h[a];
+        }
+    for (int a = 0; a < 3; a++) { atomicMin(&lo[a], l[a]); atomicMax(&hi[a], h[a]); }
+    __syncthreads();
+    if (threadIdx.x < 3) { atomicMin(&box[threadIdx.x], lo[threadIdx.x]); atomicMax(&box[3 + threadIdx.x], hi[threadIdx.x]); }
+}
+__global__ void __launch_bounds__(GR_BLOCK) k_centre(const float* xyz, int64_t n, const unsigned* box, float* out) {
+    float shift[3];
+    for (int a = 0; a < 3; a++) {
+        const float mn = st_ord2f(box[a]), mx = st_ord2f(box[3 + a]);
+        const float half = (mx - mn) / 2.0f;
+        const float centre = mn + half;
+        shift[a] = -centre + (a == 1 ? half : 0.0f);
+    }
+    GR_LOOP(i, n)
+        for (int a = 0; a < 3; a++) out[3 * i + a] = xyz[3 * i + a] + shift[a];
+}
+
+// out [n,3]; scratch: 6 x uint32
+extern "C" int st_centre_cloud(const float* xyz, int64_t n, float* out, void* ws, int64_t ws_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n <= 0) return ST_OK;
+    StArena a(ws, ws_bytes);
+    unsigned* box = a.take<unsigned>(6);
+    if (!box) { st_set_error("centre_cloud: workspace too small"); return ST_ERR_WORKSPACE; }
+    (void)hipMemsetAsync(box, 0xff, 3 * sizeof(unsigned), stream);
+    (void)hipMemsetAsync(box + 3, 0, 3 * sizeof(unsigned), stream);
+    hipLaunchKernelGGL(k_bbox, dim3(gr_grid(n) < 1024 ? gr_grid(n) : 1024), dim3(GR_BLOCK), 0, stream, xyz, n, box);
+    hipLaunchKernelGGL(k_centre, dim3(gr_grid(n)), dim3(GR_BLOCK), 0, stream, xyz, n, (const unsigned*)box, out);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}
+
 // ------------------------------------------------------------------------------ make_edges ---
 __global__ void __launch_bounds__(GR_BLOCK) k_edge_count(const int64_t* idx, int64_t n, int K, uint32_t* cnt) {
     GR_LOOP(i, n) {

@@ -33,9 +33,15 @@ struct PpArgs {
     uint8_t* keep;        // [B]
     uint8_t* repaired;    // [B]
     uint8_t* smoothed;    // [B]
+    int* depth;           // [B] scratch: level of each branch in the repair order
     int do_prune, do_repair, do_smooth, kernel;
     float min_radius, min_length;
 };
+
+// L2 (agent scope) load of a float another wavefront of this workgroup wrote earlier in the launch
+__device__ __forceinline__ float pp_ldf(const float* p) {
+    return __uint_as_float(__hip_atomic_load((const unsigned*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
 
 __device__ __forceinline__ float pp_dot(const float* a, const float* b) {
     float s = a[0] * b[0];
@@ -46,7 +52,6 @@ __device__ __forceinline__ float pp_dot(const float* a, const float* b) {
 }
 
 __global__ void __launch_bounds__(PP_BLOCK) k_post_process(PpArgs A) {
-    __shared__ unsigned long long s_red[PP_WAVES];
     const int tree = blockIdx.x, tid = threadIdx.x;
     const int b0 = A.tree_off[tree], nb = A.tree_off[tree + 1] - b0;
     // ---- prune (tree 0 only): length / initial radius per branch in parallel, then the keep chain
@@ -76,23 +81,41 @@ __global__ void __launch_bounds__(PP_BLOCK) k_post_process(PpArgs A) {
         }
         __syncthreads();
     }
-    // ---- repair: nearest point on the (already repaired) parent's tube chain
+    // ---- repair: nearest point on the (already repaired) parent's tube chain.  A branch only needs its
+    //      parent finished, so branches are processed level by level of the branch hierarchy (one wavefront
+    //      per branch, lanes over the parent's tubes) instead of one after the other.
+    __shared__ int s_maxdepth;
+    int* depth = A.depth + b0;
     for (int b = tid; b < nb; b += PP_BLOCK) A.repaired[b0 + b] = 0;
-    __syncthreads();
-    if (A.do_repair) {
-        for (int b = 0; b < nb; b++) {
+    if (tid == 0) {
+        int md = 0;
+        for (int b = 0; b < nb; b++) {  // parents have smaller ids: one forward pass
             const int p = A.parent[b0 + b];
-            const bool go = A.keep[b0 + b] && p >= 0 && p < nb && A.keep[b0 + p];  // tree.py:80-82
-            if (!go) continue;                                                    // uniform
-            const int ps = A.start[b0 + p] + (A.repaired[b0 + p] ? 0 : 1);
-            const int pn = A.len[b0 + p] + (A.repaired[b0 + p] ? 1 : 0);
+            const bool go = A.do_repair && A.keep[b0 + b] && p >= 0 && p < nb && A.keep[b0 + p];  // tree.py:80-82
+            depth[b] = go ? (depth[p] < 0 ? 1 : depth[p] + 1) : -1;  // -1: not repaired; a parent without repair is ready at once
+            if (depth[b] > md) md = depth[b];
+        }
+        s_maxdepth = md;
+    }
+    __syncthreads();
+    const int maxdepth = s_maxdepth, lane = tid & 63, wave = tid >> 6;
+    for (int level = 1; level <= maxdepth; level++) {
+        for (int b = wave; b < nb; b += PP_WAVES) {  // wave-uniform
+            if (depth[b] != level) continue;
+            const int p = A.parent[b0 + b];
+            const int prep = __hip_atomic_load(&A.repaired[b0 + p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int ps = A.start[b0 + p] + (prep ? 0 : 1);
+            const int pn = A.len[b0 + p] + (prep ? 1 : 0);
             const int s = A.start[b0 + b];
             const float pt[3] = {A.xyz[3 * (s + 1)], A.xyz[3 * (s + 1) + 1], A.xyz[3 * (s + 1) + 2]};
             // argmin over the parent's tubes of |dist - radius| (first minimum; NaN counts as minimal)
             unsigned long long key = 0;
-            for (int i = tid; i + 1 < pn; i += PP_BLOCK) {
-                const float* a = A.xyz + 3 * (ps + i);
-                const float* bb = A.xyz + 3 * (ps + i + 1);
+            for (int i = lane; i + 1 < pn; i += 64) {
+                float a[3], bb[3];
+                for (int k = 0; k < 3; k++) {
+                    a[k] = pp_ldf(&A.xyz[3 * (ps + i) + k]);
+                    bb[k] = pp_ldf(&A.xyz[3 * (ps + i + 1) + k]);
+                }
                 const float ab[3] = {bb[0] - a[0], bb[1] - a[1], bb[2] - a[2]};
                 const float ap[3] = {pt[0] - a[0], pt[1] - a[1], pt[2] - a[2]};
                 float t = pp_dot(ap, ab) / pp_dot(ab, ab);
@@ -105,19 +128,17 @@ __global__ void __launch_bounds__(PP_BLOCK) k_post_process(PpArgs A) {
                 const unsigned long long k = ((unsigned long long)(0xffffffffu - bits) << 32) | (0xffffffffu - (unsigned)i);
                 key = k > key ? k : key;
             }
-            // workgroup max of the inverted key = minimum score, smallest index
-            for (int d = 32; d > 0; d >>= 1) {
+            for (int d = 32; d > 0; d >>= 1) {  // wave max of the inverted key = minimum score, smallest index
                 const unsigned long long o = __shfl_xor(key, d);
                 key = o > key ? o : key;
             }
-            __syncthreads();
-            if ((tid & 63) == 0) s_red[tid >> 6] = key;
-            __syncthreads();
-            if (tid == 0) {
-                for (int w = 1; w < PP_WAVES; w++) key = s_red[w] > key ? s_red[w] : key;
+            if (lane == 0) {
                 const int i = (int)(0xffffffffu - (unsigned)(key & 0xffffffffu));
-                const float* a = A.xyz + 3 * (ps + i);
-                const float* bb = A.xyz + 3 * (ps + i + 1);
+                float a[3], bb[3];
+                for (int k = 0; k < 3; k++) {
+                    a[k] = pp_ldf(&A.xyz[3 * (ps + i) + k]);
+                    bb[k] = pp_ldf(&A.xyz[3 * (ps + i + 1) + k]);
+                }
                 const float ab[3] = {bb[0] - a[0], bb[1] - a[1], bb[2] - a[2]};
                 const float ap[3] = {pt[0] - a[0], pt[1] - a[1], pt[2] - a[2]};
                 float t = pp_dot(ap, ab) / pp_dot(ab, ab);
@@ -128,18 +149,18 @@ __global__ void __launch_bounds__(PP_BLOCK) k_post_process(PpArgs A) {
                 }
                 A.repaired[b0 + b] = 1;
             }
-            __syncthreads();
         }
+        __syncthreads();  // the next level reads this level's connection points (through L2)
     }
     // ---- radii: box filter over the (possibly prepended) radius array
     const float w = A.kernel > 0 ? 1.0f / (float)A.kernel : 0.0f;
     const int half = A.kernel / 2;
-    for (int b = 0; b < nb; b++) {
-        const int rep = A.repaired[b0 + b];
+    for (int b = wave; b < nb; b += PP_WAVES) {  // one wavefront per branch
+        const int rep = __hip_atomic_load(&A.repaired[b0 + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int s = A.start[b0 + b] + (rep ? 0 : 1), n = A.len[b0 + b] + rep;
         const bool sm = A.do_smooth && A.keep[b0 + b] && n > A.kernel;  // tree.py:129
-        if (tid == 0) A.smoothed[b0 + b] = sm;
-        for (int i = tid; i < n; i += PP_BLOCK) {
+        if (lane == 0) A.smoothed[b0 + b] = sm;
+        for (int i = lane; i < n; i += 64) {
             if (!sm) { A.rad_out[s + i] = A.rad_in[s + i]; continue; }
             float acc = 0.0f;
             for (int j = 0; j < A.kernel; j++) {
@@ -152,16 +173,17 @@ __global__ void __launch_bounds__(PP_BLOCK) k_post_process(PpArgs A) {
     }
 }
 
-// tree_off [T+1], parent/start/len [B], xyz [P,3] (in/out), rad_in/rad_out [P], keep/repaired/smoothed [B]
+// tree_off [T+1], parent/start/len [B], xyz [P,3] (in/out), rad_in/rad_out [P], keep/repaired/smoothed [B],
+// depth_scratch [B] int32
 extern "C" int st_post_process(int n_trees, const int32_t* tree_off, const int32_t* parent, const int32_t* start,
                                const int32_t* len, float* xyz, const float* rad_in, float* rad_out, uint8_t* keep,
-                               uint8_t* repaired, uint8_t* smoothed, int do_prune, float min_radius, float min_length,
-                               int do_repair, int do_smooth, int kernel_size, void* stream_) {
+                               uint8_t* repaired, uint8_t* smoothed, int32_t* depth_scratch, int do_prune, float min_radius,
+                               float min_length, int do_repair, int do_smooth, int kernel_size, void* stream_) {
     if (n_trees <= 0) return ST_OK;
     ST_REQUIRE(!do_smooth || kernel_size > 0, "post_process: smoothing needs kernel_size > 0");
     PpArgs A;
     A.n_trees = n_trees; A.tree_off = tree_off; A.parent = parent; A.start = start; A.len = len; A.xyz = xyz;
-    A.rad_in = rad_in; A.rad_out = rad_out; A.keep = keep; A.repaired = repaired; A.smoothed = smoothed;
+    A.rad_in = rad_in; A.rad_out = rad_out; A.keep = keep; A.repaired = repaired; A.smoothed = smoothed; A.depth = depth_scratch;
     A.do_prune = do_prune; A.do_repair = do_repair; A.do_smooth = do_smooth; A.kernel = kernel_size;
     A.min_radius = min_radius; A.min_length = min_length;
     hipLaunchKernelGGL(k_post_process, dim3((unsigned)n_trees), dim3(PP_BLOCK), 0, (hipStream_t)stream_, A);

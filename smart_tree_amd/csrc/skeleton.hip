@@ -89,6 +89,7 @@ struct SkArgs {
     const int* blk_comp;
     const int* blk_first;
     const int* blk_count;
+    long long* ticks;  // optional developer aid: per-phase wall_clock64 sums of k_sk_select (st_debug_set_ticks)
 };
 
 // agent-scope (L2) accesses for data that the SAME launch wrote earlier (never a stale L1 line)
@@ -413,7 +414,9 @@ __device__ __forceinline__ void sk_finish_branch(const SkArgs& A, int base, int 
     __syncthreads();  // stores drained (vmcnt) before anyone re-reads through L2
 }
 
+#define SK_TICK(i) do { if (A.ticks && tid == 0) { const long long now_ = wall_clock64(); A.ticks[i] += now_ - t_last; t_last = now_; } } while (0)
 __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
+    long long t_last = A.ticks ? wall_clock64() : 0;
     __shared__ unsigned long long s_red[SK_MAX_WAVES];
     __shared__ unsigned lq[SK_LQ_CLAIM];
     __shared__ int lpath[SK_LPATH];
@@ -431,6 +434,7 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
             sk_finish_branch(A, base, plen, A.s_cur_id[c], A.path_verts + base + A.s_cur_off[c], false, A.touched + base, false,
                              A.s_ntouched[c]);
     }
+    SK_TICK(0);
     int cursor = A.s_cursor[c], total = A.s_total[c], nb = A.s_nb[c];  // per-component state lives in registers
     for (int iter = 0; iter < SK_ITERS_PER_LAUNCH; iter++) {
         // 1. farthest unallocated vertex: first live entry of the sorted order at or after the cursor
@@ -454,6 +458,7 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
                 else { far = (int)lowv - 1; cursor = (int)(0xffffffffu - (unsigned)(k >> 32)) + 1 - (int)blockDim.x; }
             }
         }
+        SK_TICK(1);
         if (far < 0) {  // path.py:94-95 (uniform)
             if (tid == 0) {
                 A.s_done[c] = 1; A.s_len[c] = 0; A.s_wide[c] = 0; A.n_branches[c] = nb; A.s_nb[c] = nb; A.s_total[c] = total;
@@ -477,6 +482,7 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
             }
         }
         __syncthreads();
+        SK_TICK(2);
         // 3. path root side first (global: it is an output); r = max radius on the path (path.py:31)
         int* path_out = A.path_verts + base + total;
         unsigned long long rk = 0;
@@ -501,8 +507,10 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
             A.branch_off[base + nb] = total;
             A.branch_len[base + nb] = len;
         }
+        SK_TICK(3);
         const int cur_off = total;
         if (keep) { nb++; total += len; }
+        if (A.ticks && tid == 0) { A.ticks[8] += 1; A.ticks[9] += small ? 1 : 0; A.ticks[10] += len; }
         if (!small) {  // hand the path to k_sk_claim; its points are finished at the next launch (uniform)
             if (tid == 0) {
                 A.s_len[c] = len; A.s_rp[c] = rp; A.s_ntouched[c] = 0u; A.s_cur_off[c] = cur_off; A.s_cur_id[c] = id;
@@ -520,8 +528,10 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
         if (tid == 0) A.s_ntouched[c] = 0u;
         __syncthreads();
         const bool local = sk_claim_items(A, c, base, n, len, rp, lpath, true, 0, 1, lq, &lq_n, &lq_base, true);
+        SK_TICK(4);
         if (local) sk_finish_branch(A, base, len, id, lpath, true, lq, true, lq_n);
         else sk_finish_branch(A, base, len, id, lpath, true, A.touched + base, false, ld(&A.s_ntouched[c]));
+        SK_TICK(5);
     }
     if (tid == 0) { A.s_len[c] = 0; A.s_wide[c] = 0; A.s_cursor[c] = cursor; A.s_total[c] = total; A.s_nb[c] = nb; }
 }
@@ -592,6 +602,9 @@ static void sk_layout(StArena& a, int64_t m, int64_t C, SkLayout* s) {
     s->gws = a.take<char>(s->gws_bytes);
 }
 
+static long long* g_debug_ticks = nullptr;
+extern "C" void st_debug_set_ticks(long long* device_ptr) { g_debug_ticks = device_ptr; }
+
 extern "C" int64_t st_skeleton_workspace_bytes(int64_t m, int64_t n_comp) {
     StArena a(nullptr, 0);
     SkLayout s;
@@ -658,6 +671,7 @@ extern "C" int st_skeleton_components(int n_comp, const int32_t* comp_off, const
     A.s_total = s.s_total; A.s_rp = s.s_rp; A.s_ntouched = s.s_ntouched;
     A.blk_comp = s.blk_comp; A.blk_first = s.blk_first; A.blk_count = s.blk_count;
     A.s_cursor = s.s_cursor; A.s_wide = s.s_wide; A.order = s.order; A.order_init = s.order_init;
+    A.ticks = g_debug_ticks;
 
     const unsigned vg = sk_vgrid(m);
     const unsigned fg = (unsigned)st_min64(st_div_up(m, SK_WIDE_BLOCK), SK_SSSP_BLOCKS);

@@ -9,6 +9,7 @@ from typing import Sequence
 
 import torch
 
+from .. import _lib
 from ..data_types.cloud import Cloud
 
 
@@ -23,7 +24,16 @@ class CentreCloud(Augmentation):
     (Cloud.translate), as the reference does."""
 
     def __call__(self, cloud: Cloud) -> Cloud:
-        centre, half = cloud.bbox
+        if cloud.xyz.is_cuda or _lib._ALLOW_HOST_POINTERS:
+            # one bounding-box pass + one translate pass (csrc/graph.hip st_centre_cloud), same float32 arithmetic
+            L = _lib.lib()
+            xyz = cloud.xyz.contiguous().float()
+            out = torch.empty_like(xyz)
+            ws = _lib.workspace(256, xyz.device)
+            _lib.check(L.st_centre_cloud(_lib.ptr(xyz), xyz.shape[0], _lib.ptr(out), _lib.ptr(ws), ws.numel(),
+                                         _lib.stream(xyz.device)))
+            return Cloud(out, cloud.rgb)
+        centre, half = cloud.bbox  # host tensors (e.g. before upload): plain torch, as the reference writes it
         lift = torch.zeros(3, device=centre.device, dtype=centre.dtype)
         lift[1] = half[1]
         return cloud.translate(-centre + lift)

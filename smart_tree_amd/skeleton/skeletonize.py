@@ -209,27 +209,43 @@ class DeviceSkeleton(DisjointTreeSkeleton):
         u8 = lambda: torch.empty(B, dtype=torch.uint8, device=dev)
         keep, repaired, smoothed = u8(), u8(), u8()
         rad_out = torch.empty_like(rad)
+        depth = torch.empty(B, dtype=torch.int32, device=dev)
         xyz = xyz.clone()
         pr = self._ops.get("prune")
         L = _lib.lib()
         _lib.check(L.st_post_process(T, _lib.ptr(tree_off), _lib.ptr(parent), _lib.ptr(start), _lib.ptr(length), _lib.ptr(xyz),
                                      _lib.ptr(rad), _lib.ptr(rad_out), _lib.ptr(keep), _lib.ptr(repaired), _lib.ptr(smoothed),
-                                     int(pr is not None), pr[0] if pr else 0.0, pr[1] if pr else 0.0,
+                                     _lib.ptr(depth), int(pr is not None), pr[0] if pr else 0.0, pr[1] if pr else 0.0,
                                      int("repair" in self._ops), int("smooth" in self._ops), self._ops.get("smooth", 0),
                                      _lib.stream(dev)))
+        # two copies (geometry, branch table), then views: torch.split builds every slice in one C++ call
         geom = torch.cat((xyz, rad_out.unsqueeze(1)), dim=1).cpu()
-        table = torch.stack((parent, start, length, keep.int(), repaired.int(), smoothed.int()), dim=1).cpu().tolist()
+        table = torch.stack((parent, start, length, keep.int(), repaired.int(), smoothed.int()), dim=1).cpu()
         offs = tree_off.cpu().tolist()
+        rep = table[:, 4]
+        first = (table[:, 1] + 1 - rep).tolist()
+        count = (table[:, 2] + rep).tolist()
+        # slots are laid out back to back: [start_b + 1 - rep_b, start_b + 1 + len_b) with one unused slot when not repaired
+        sizes = []
+        for b in range(B):
+            if not table[b, 4]:
+                sizes.append(1)  # the reserved, unused slot
+            sizes.append(count[b])
+        pieces = iter(torch.split(geom, sizes))
+        rows = table.tolist()
         trees = []
         for t in range(T):
             branches = {}
-            for b in range(offs[t + 1] - offs[t]):
-                par, st, ln, kp, rep, sm = table[offs[t] + b]
+            for b in range(offs[t], offs[t + 1]):
+                par, st, ln, kp, rp, sm = rows[b]
+                if not rp:
+                    next(pieces)
+                g = next(pieces)
                 if not kp:
                     continue
-                g = geom[st + 1 - rep: st + 1 + ln]
-                radii = g[:, 3].contiguous() if sm else g[:, 3:4].contiguous()  # smooth flattens radii (tree.py:130-134)
-                branches[b] = BranchSkeleton.__new__(BranchSkeleton)
-                branches[b].__dict__.update(_id=b, parent_id=par, xyz=g[:, :3].contiguous(), radii=radii, child_id=None)
+                obj = BranchSkeleton.__new__(BranchSkeleton)
+                # smooth flattens radii to 1-D (tree.py:130-134)
+                obj.__dict__.update(_id=b - offs[t], parent_id=par, xyz=g[:, :3], radii=g[:, 3] if sm else g[:, 3:4], child_id=None)
+                branches[b - offs[t]] = obj
             trees.append(TreeSkeleton(t, branches))
         return trees

@@ -30,6 +30,14 @@ for bt in (256, 1024):
         res = run_components(comps, medial, radius, bc.xyz[:,1].contiguous(), block_threads=bt)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print(f"select block {bt}: total {dt*1e3:.2f} ms; stats {res.stats}; branches {int(res.n_branches[0])}")
+import ctypes
+from smart_tree_amd import _lib
+ticks = torch.zeros(16, dtype=torch.int64, device=dev)
+L = _lib.lib(); L.st_debug_set_ticks.argtypes=[ctypes.c_void_p]; L.st_debug_set_ticks(ticks.data_ptr())
+res = run_components(comps, medial, radius, bc.xyz[:,1].contiguous())
+torch.cuda.synchronize(); L.st_debug_set_ticks(None)
+t = ticks.cpu().numpy()
+print('select phases (us, 100MHz ticks): head', t[0]/100, 'cursor', t[1]/100, 'trace', t[2]/100, 'path+record', t[3]/100, 'claim', t[4]/100, 'finish', t[5]/100, '| iterations', t[8], 'small', t[9], 'path verts', t[10])
 from smart_tree_amd.skeleton.skeletonize import STAGE_SSSP
 for rep in range(2):
     torch.cuda.synchronize(); t0 = time.perf_counter()
