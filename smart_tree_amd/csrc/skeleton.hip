@@ -386,7 +386,7 @@ __device__ __forceinline__ bool sk_claim_items(const SkArgs& A, int c, int base,
 // nothing is ever re-scanned), trace its route through the ancestor table, record the branch; a
 // short path is claimed and finished right here (state, path and touched list stay in LDS), a long
 // one is left to the chip-wide k_sk_claim and finished at the head of the next launch.
-#define SK_SMALL_ITEMS 768
+#define SK_SMALL_WORK (4 << 20)  // candidate points x path vertices one workgroup takes on itself
 #define SK_ITERS_PER_LAUNCH 32
 #define SK_LPATH 1024
 
@@ -418,9 +418,10 @@ __device__ __forceinline__ void sk_finish_branch(const SkArgs& A, int base, int 
 __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
     long long t_last = A.ticks ? wall_clock64() : 0;
     __shared__ unsigned long long s_red[SK_MAX_WAVES];
-    __shared__ unsigned lq[SK_LQ_CLAIM];
     __shared__ int lpath[SK_LPATH];
-    __shared__ unsigned lq_n, lq_base;
+    __shared__ float lpx[SK_LPATH], lpy[SK_LPATH], lpz[SK_LPATH], lpr[SK_LPATH];
+    __shared__ uint32_t row_off[1025], row_first[1024], s_scan[SK_MAX_WAVES + 1];
+    __shared__ int s_lo[3], s_hi[3];
     __shared__ int s_term;
     const int c = blockIdx.x, tid = threadIdx.x;
     if (A.s_done[c]) return;
@@ -494,10 +495,50 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
             rk = k > rk ? k : rk;
         }
         rk = block_max_u64(rk, s_red);
-        const float rp = st_ord2f((unsigned)(rk >> 32));
-        int reach = rp > 0.0f ? (int)ceilf(rp / A.grid->cell) : 0;
+        const float rp = st_ord2f((unsigned)(rk >> 32)), rp2 = rp * rp;
+        const StGrid* g = A.grid;
+        int reach = rp > 0.0f ? (int)ceilf(rp / g->cell) : 0;
         if (reach < 1) reach = 1;
-        const bool small = len <= SK_LPATH && (int64_t)len * (2 * reach + 1) * (2 * reach + 1) <= SK_SMALL_ITEMS;
+        // 4. can this workgroup claim the path's points itself?  Point-centric form of select_path_points
+        //    (path.py:19-46): the candidates are the points of the grid cells around the path; each one
+        //    finds ITS nearest path vertex from LDS -- no atomics, no candidate list.
+        bool small = len <= SK_LPATH;
+        int nrows_s = 0, ncand = 0;
+        if (small) {
+            if (tid < 3) { s_lo[tid] = 0x7fffffff; s_hi[tid] = (int)0x80000000; }
+            __syncthreads();
+            for (int qi = tid; qi < len; qi += blockDim.x) {  // path vertex coordinates / radii into LDS (root side first)
+                const int v = lpath[len - 1 - qi];
+                const float* pv = A.pts + 3 * (int64_t)(base + v);
+                lpx[qi] = pv[0]; lpy[qi] = pv[1]; lpz[qi] = pv[2];
+                lpr[qi] = A.rad[base + v];
+                const int cx = (int)floorf((pv[0] - g->lo[0]) / g->cell), cy = (int)floorf((pv[1] - g->lo[1]) / g->cell),
+                          cz = (int)floorf((pv[2] - g->lo[2]) / g->cell);
+                atomicMin(&s_lo[0], cx); atomicMin(&s_lo[1], cy); atomicMin(&s_lo[2], cz);
+                atomicMax(&s_hi[0], cx); atomicMax(&s_hi[1], cy); atomicMax(&s_hi[2], cz);
+            }
+            __syncthreads();
+            const int x0 = st_max(s_lo[0] - reach, 0), x1 = st_min(s_hi[0] + reach, g->dim[0] - 1);
+            const int y0 = st_max(s_lo[1] - reach, 0), y1 = st_min(s_hi[1] + reach, g->dim[1] - 1);
+            const int z0 = st_max(s_lo[2] - reach, 0), z1 = st_min(s_hi[2] + reach, g->dim[2] - 1);
+            const int nx = x1 - x0 + 1, ny = y1 - y0 + 1;
+            const int nrows = (nx > 0 && ny > 0 && z0 <= z1) ? nx * ny : 0;
+            small = nrows <= (int)blockDim.x;  // one lane per (x, y) row of cells; z is contiguous in memory
+            uint32_t cnt = 0, first = 0;
+            if (small && tid < nrows) {
+                const int64_t row = ((int64_t)(x0 + tid / ny) * g->dim[1] + (y0 + tid % ny)) * g->dim[2];
+                first = A.cell_start[row + z0];
+                cnt = A.cell_start[row + z1 + 1] - first;
+            }
+            uint32_t tot;
+            const uint32_t off = block_exclusive_scan(cnt, s_scan, &tot);
+            ncand = (int)tot;
+            small = small && (int64_t)ncand * len <= SK_SMALL_WORK;
+            if (small && tid < nrows) { row_off[tid] = off; row_first[tid] = first; }
+            if (small && tid == 0) row_off[nrows] = tot;
+            __syncthreads();
+            nrows_s = nrows;
+        }
         const bool keep = len >= 2;  // path.py:125-126: shorter paths still consume their points
         const int id = keep ? nb : -1;
         if (tid == 0 && keep) {
@@ -510,7 +551,7 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
         SK_TICK(3);
         const int cur_off = total;
         if (keep) { nb++; total += len; }
-        if (A.ticks && tid == 0) { A.ticks[8] += 1; A.ticks[9] += small ? 1 : 0; A.ticks[10] += len; }
+        if (A.ticks && tid == 0) { A.ticks[8] += 1; A.ticks[9] += small ? 1 : 0; A.ticks[10] += len; A.ticks[11] += ncand; }
         if (!small) {  // hand the path to k_sk_claim; its points are finished at the next launch (uniform)
             if (tid == 0) {
                 A.s_len[c] = len; A.s_rp[c] = rp; A.s_ntouched[c] = 0u; A.s_cur_off[c] = cur_off; A.s_cur_id[c] = id;
@@ -518,20 +559,38 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
             }
             return;
         }
-        // 4. short path: reverse it in LDS (root side first), claim and finish here
-        __syncthreads();
-        for (int qi = tid; qi < len / 2; qi += blockDim.x) {  // each pair is swapped by exactly one lane
-            const int a = lpath[qi];
-            lpath[qi] = lpath[len - 1 - qi];
-            lpath[len - 1 - qi] = a;
+        __syncthreads();  // the parent lookup above must see the stamps of earlier branches only
+        for (int t = tid; t < ncand; t += blockDim.x) {
+            int lo = 0, hi = nrows_s;  // row r with row_off[r] <= t < row_off[r+1]
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (row_off[mid] <= (uint32_t)t) lo = mid; else hi = mid; }
+            const float4 r4 = A.recs[row_first[lo] + ((uint32_t)t - row_off[lo])];
+            const int p = (int)__float_as_uint(r4.w) - base;
+            if (p < 0 || p >= n) continue;  // other component
+            float bd2 = __uint_as_float(0x7f800000u);
+            int bq = 0;
+            for (int qi = 0; qi < len; qi++) {  // LDS broadcast reads; ascending: ties keep the first path vertex
+                const float dx = r4.x - lpx[qi], dy = r4.y - lpy[qi], dz = r4.z - lpz[qi];
+                float d2 = dx * dx;
+                float tt = dy * dy;
+                d2 = d2 + tt;
+                tt = dz * dz;
+                d2 = d2 + tt;
+                if (d2 < bd2) { bd2 = d2; bq = qi; }
+            }
+            if (bd2 < rp2 && sqrtf(bd2) < lpr[bq]) {  // path.py:35-40
+                A.alloc[base + p] = -1.0f;
+                A.term[base + p] = 1u;
+                if (id >= 0) A.branch_of[base + p] = id;
+            }
         }
-        if (tid == 0) A.s_ntouched[c] = 0u;
+        for (int qi = tid; qi < len; qi += blockDim.x) {  // path.py:112-113,135
+            const int v = lpath[len - 1 - qi];
+            A.alloc[base + v] = -1.0f;
+            A.term[base + v] = 1u;
+            if (id >= 0) A.branch_of[base + v] = id;
+        }
         __syncthreads();
-        const bool local = sk_claim_items(A, c, base, n, len, rp, lpath, true, 0, 1, lq, &lq_n, &lq_base, true);
         SK_TICK(4);
-        if (local) sk_finish_branch(A, base, len, id, lpath, true, lq, true, lq_n);
-        else sk_finish_branch(A, base, len, id, lpath, true, A.touched + base, false, ld(&A.s_ntouched[c]));
-        SK_TICK(5);
     }
     if (tid == 0) { A.s_len[c] = 0; A.s_wide[c] = 0; A.s_cursor[c] = cursor; A.s_total[c] = total; A.s_nb[c] = nb; }
 }

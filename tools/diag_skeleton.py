@@ -37,7 +37,7 @@ L = _lib.lib(); L.st_debug_set_ticks.argtypes=[ctypes.c_void_p]; L.st_debug_set_
 res = run_components(comps, medial, radius, bc.xyz[:,1].contiguous())
 torch.cuda.synchronize(); L.st_debug_set_ticks(None)
 t = ticks.cpu().numpy()
-print('select phases (us, 100MHz ticks): head', t[0]/100, 'cursor', t[1]/100, 'trace', t[2]/100, 'path+record', t[3]/100, 'claim', t[4]/100, 'finish', t[5]/100, '| iterations', t[8], 'small', t[9], 'path verts', t[10])
+print('select phases (us, 100MHz ticks): head', t[0]/100, 'cursor', t[1]/100, 'trace', t[2]/100, 'path+record', t[3]/100, 'claim+finish', t[4]/100, '| iterations', t[8], 'small', t[9], 'path verts', t[10], 'candidates', t[11])
 from smart_tree_amd.skeleton.skeletonize import STAGE_SSSP
 for rep in range(2):
     torch.cuda.synchronize(); t0 = time.perf_counter()
