@@ -12,8 +12,8 @@
 // outlier_removal needs d < r_i): same result, far fewer cells visited for thin branches.
 //
 // Grid: dense cell_start[] over the bounding box (cells capped, cell size doubled until it fits),
-// points counting-sorted by cell into float4 (x, y, z, index) records; one lane per query keeps
-// its top-K in registers (fully unrolled insertion).
+// points counting-sorted by cell into float4 (x, y, z, index) records; a 4-lane group per query, every
+// lane keeps a top-K in registers (fully unrolled insertion), merged by shuffles.
 #include "st_common.h"
 #include "st_grid.h"
 
@@ -118,13 +118,21 @@ int st_grid_build(const float* pts, int64_t n, float cell, int64_t max_cells, St
 __device__ __forceinline__ bool knn_less(float d, int j, float bd, int bj) { return d < bd || (d == bd && j < bj); }
 
 // mode 0: no per-query bound; 1: keep sqrtf(d2) <= bound[i]; 2: keep sqrtf(d2) < bound[i]
+// KNN_LANES lanes work on one query: each takes every KNN_LANES-th (x, y) grid row and keeps its own
+// sorted top-K in registers; the K smallest of the union are then drawn by K rounds of a group-wide
+// minimum (xor shuffles).  With one lane per query a 50k-point cloud is <1 wavefront per SIMD and the
+// candidate loop is one long dependent chain.
+#define KNN_LANES 4
 template <int K>
 __global__ void __launch_bounds__(KNN_BLOCK) k_knn(const float* __restrict__ src, int64_t n1, const StGrid* __restrict__ g,
                                                    const uint32_t* __restrict__ cell_start, const float4* __restrict__ recs,
                                                    float r, const float* __restrict__ bound, int mode,
                                                    int64_t* __restrict__ idx_out, float* __restrict__ dist_out) {
-    int64_t i = (int64_t)blockIdx.x * KNN_BLOCK + threadIdx.x;
-    if (i >= n1) return;
+    const int64_t gid = (int64_t)blockIdx.x * KNN_BLOCK + threadIdx.x;
+    const int sub = (int)(gid & (KNN_LANES - 1));
+    int64_t i = gid / KNN_LANES;
+    const bool valid = i < n1;
+    if (!valid) i = n1 - 1;  // keep the lane in the shuffles below; its result is discarded
     const float px = src[3 * i], py = src[3 * i + 1], pz = src[3 * i + 2];
     const float r2 = r * r;
     float reach_r = r;
@@ -150,49 +158,66 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn(const float* __restrict__ src
     // rows (x, y) farther than the search radius in the xy-plane are skipped and the z-range of the others
     // is clipped to the sphere (a slightly inflated radius keeps the pruning conservative)
     const float rs = reach_r * 1.0001f + 1e-7f, rs2 = rs * rs;
-    for (int x = x0; x <= x1; x++) {
+    const int ny = y1 - y0 + 1, nrows = (x1 - x0 + 1) * ny;
+    for (int rowi = sub; rowi < nrows; rowi += KNN_LANES) {
+        const int x = x0 + rowi / ny, y = y0 + rowi % ny;
         const float cx0 = g->lo[0] + (float)x * cell, ex = px < cx0 ? cx0 - px : (px > cx0 + cell ? px - (cx0 + cell) : 0.0f);
-        for (int y = y0; y <= y1; y++) {
-            const float cy0 = g->lo[1] + (float)y * cell, ey = py < cy0 ? cy0 - py : (py > cy0 + cell ? py - (cy0 + cell) : 0.0f);
-            const float dxy2 = ex * ex + ey * ey;
-            if (dxy2 > rs2) continue;
-            const float rz = sqrtf(rs2 - dxy2);
-            const int za = st_max((int)floorf((pz - rz - g->lo[2]) / cell) - 1, z0), zb = st_min((int)floorf((pz + rz - g->lo[2]) / cell) + 1, z1);
-            if (za > zb) continue;
-            // cells along z are contiguous: one [start, end) range per (x, y) row
-            const int64_t row = ((int64_t)x * g->dim[1] + y) * g->dim[2];
-            const uint32_t s = cell_start[row + za], e = cell_start[row + zb + 1];
-            for (uint32_t t = s; t < e; t++) {
-                const float4 q = recs[t];
-                const float dx = px - q.x, dy = py - q.y, dz = pz - q.z;
-                float d2 = dx * dx;
-                float tt = dy * dy;
-                d2 = d2 + tt;
-                tt = dz * dz;
-                d2 = d2 + tt;
-                if (!(d2 < r2)) continue;
-                if (mode == 1 && !(sqrtf(d2) <= bnd)) continue;
-                if (mode == 2 && !(sqrtf(d2) < bnd)) continue;
-                const int j = (int)__float_as_uint(q.w);
-                if (!knn_less(d2, j, bd[K - 1], bi[K - 1])) continue;
+        const float cy0 = g->lo[1] + (float)y * cell, ey = py < cy0 ? cy0 - py : (py > cy0 + cell ? py - (cy0 + cell) : 0.0f);
+        const float dxy2 = ex * ex + ey * ey;
+        if (dxy2 > rs2) continue;
+        const float rz = sqrtf(rs2 - dxy2);
+        const int za = st_max((int)floorf((pz - rz - g->lo[2]) / cell) - 1, z0), zb = st_min((int)floorf((pz + rz - g->lo[2]) / cell) + 1, z1);
+        if (za > zb) continue;
+        // cells along z are contiguous: one [start, end) range per (x, y) row
+        const int64_t row = ((int64_t)x * g->dim[1] + y) * g->dim[2];
+        const uint32_t s = cell_start[row + za], e = cell_start[row + zb + 1];
+        for (uint32_t t = s; t < e; t++) {
+            const float4 q = recs[t];
+            const float dx = px - q.x, dy = py - q.y, dz = pz - q.z;
+            float d2 = dx * dx;
+            float tt = dy * dy;
+            d2 = d2 + tt;
+            tt = dz * dz;
+            d2 = d2 + tt;
+            if (!(d2 < r2)) continue;
+            if (mode == 1 && !(sqrtf(d2) <= bnd)) continue;
+            if (mode == 2 && !(sqrtf(d2) < bnd)) continue;
+            const int j = (int)__float_as_uint(q.w);
+            if (!knn_less(d2, j, bd[K - 1], bi[K - 1])) continue;
 #pragma unroll
-                for (int p = K - 1; p > 0; p--) {
-                    const bool lt_prev = knn_less(d2, j, bd[p - 1], bi[p - 1]);
-                    const bool lt_cur = knn_less(d2, j, bd[p], bi[p]);
-                    const float nd = lt_prev ? bd[p - 1] : (lt_cur ? d2 : bd[p]);
-                    const int nj = lt_prev ? bi[p - 1] : (lt_cur ? j : bi[p]);
-                    bd[p] = nd;
-                    bi[p] = nj;
-                }
-                if (knn_less(d2, j, bd[0], bi[0])) { bd[0] = d2; bi[0] = j; }
+            for (int p = K - 1; p > 0; p--) {
+                const bool lt_prev = knn_less(d2, j, bd[p - 1], bi[p - 1]);
+                const bool lt_cur = knn_less(d2, j, bd[p], bi[p]);
+                const float nd = lt_prev ? bd[p - 1] : (lt_cur ? d2 : bd[p]);
+                const int nj = lt_prev ? bi[p - 1] : (lt_cur ? j : bi[p]);
+                bd[p] = nd;
+                bi[p] = nj;
             }
+            if (knn_less(d2, j, bd[0], bi[0])) { bd[0] = d2; bi[0] = j; }
         }
     }
+    // merge: K rounds; every lane offers the head of its list, the group minimum is emitted and popped
 #pragma unroll
     for (int q = 0; q < K; q++) {
-        const bool ok = bi[q] != 0x7fffffff;
-        idx_out[i * K + q] = ok ? (int64_t)bi[q] : (int64_t)-1;
-        dist_out[i * K + q] = ok ? sqrtf(bd[q]) : __uint_as_float(0x7fc00000u);
+        float md = bd[0];
+        int mj = bi[0];
+#pragma unroll
+        for (int m = 1; m < KNN_LANES; m <<= 1) {
+            const float od = __shfl_xor(md, m);
+            const int oj = __shfl_xor(mj, m);
+            if (knn_less(od, oj, md, mj)) { md = od; mj = oj; }
+        }
+        if (mj == bi[0] && mj != 0x7fffffff) {  // my head won (indices are unique): pop it
+#pragma unroll
+            for (int p = 0; p < K - 1; p++) { bd[p] = bd[p + 1]; bi[p] = bi[p + 1]; }
+            bd[K - 1] = __uint_as_float(0x7f800000u);
+            bi[K - 1] = 0x7fffffff;
+        }
+        if (sub == 0 && valid) {
+            const bool ok = mj != 0x7fffffff;
+            idx_out[i * K + q] = ok ? (int64_t)mj : (int64_t)-1;
+            dist_out[i * K + q] = ok ? sqrtf(md) : __uint_as_float(0x7fc00000u);
+        }
     }
 }
 
@@ -231,7 +256,7 @@ extern "C" int st_knn_radius(const float* src, int64_t n1, const float* dst, int
         return ST_ERR_WORKSPACE;
     }
     ST_TRY(st_grid_build(dst, n2, cell_hint > 0.0f ? cell_hint : r, KNN_MAX_CELLS, g, cell_start, recs, sub, sub_bytes, stream));
-    dim3 grid((unsigned)st_div_up(n1, KNN_BLOCK)), block(KNN_BLOCK);
+    dim3 grid((unsigned)st_div_up(n1 * KNN_LANES, KNN_BLOCK)), block(KNN_BLOCK);
     if (K == 1)
         hipLaunchKernelGGL((k_knn<1>), grid, block, 0, stream, src, n1, (const StGrid*)g, (const uint32_t*)cell_start,
                            (const float4*)recs, r, bound, bound_mode, idx, dist);
