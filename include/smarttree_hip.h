@@ -73,6 +73,11 @@ int st_build_strided_rulebook(const int32_t* coords, int64_t n, const unsigned l
 int st_sparse_conv_fwd(const float* x0, int c0, const float* x1, int cin, const int32_t* nbr, int K, int64_t n_out,
                        const float* w, int cout, const float* scale, const float* shift, const float* residual,
                        int relu, float* y, void* stream);
+/* same contract; weights pre-permuted to wp[K][cin/16][4][cout][4] = W[k][16c+4kg+s][co]; cin, cout, c0 % 16 == 0.
+ * The per-offset [16 x cin].[cin x cout] contraction runs on v_mfma_f32_16x16x4_f32 (exact fp32). */
+int st_sparse_conv_mfma_fwd(const float* x0, int c0, const float* x1, int cin, const int32_t* nbr, int K, int64_t n_out,
+                            const float* wp, int cout, const float* scale, const float* shift, const float* residual,
+                            int relu, float* y, void* stream);
 int st_head_param_floats(void);
 int st_pointwise_mlp_heads(const float* x, int64_t n, const float* params, float* radius, float* direction,
                            float* class_l, float* medial_vector /*nullable*/, int64_t* class_idx /*nullable*/, void* stream);

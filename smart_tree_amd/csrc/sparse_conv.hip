@@ -88,6 +88,158 @@ static int conv_launch(const float* x0, int c0, const float* x1, const int32_t* 
     return ST_OK;
 }
 
+// ------------------------------------------------------------------------- MFMA rule-GEMM ---
+// For Cin, Cout multiples of 16 the per-offset contraction [16 voxels x Cin] . [Cin x Cout] runs on the
+// matrix cores with v_mfma_f32_16x16x4_f32 (f32 in / f32 accumulate: bit-for-bit a k-ordered fmaf chain,
+// cdna_hip_programming.md section 3), still output-stationary and atomics-free:
+//   wave   = MF_RT row tiles of 16 output voxels x all Cout (Cout/16 column tiles), accumulators in VGPRs
+//   A      = gathered input rows: lane (i = l&15, kg = l>>4) loads ONE float4 = channels 16c+4kg .. +3 of row i
+//            (a 64 B contiguous piece per row and instruction); register s of it feeds MFMA step s
+//   B      = W_k staged once per offset and workgroup in LDS in the matching order
+//            wp[k][c][kg][co][s] = W[k][16c + 4kg + s][co]  (host pre-permuted: a straight float4 copy),
+//            read with one ds_read_b128 per (c, column tile)
+//   D      = lane l holds rows (l>>4)*4 + r, column l&15 of each 16x16 tile: epilogue = BN affine, residual,
+//            ReLU, 64 B row segments stored per instruction.
+typedef float st_v4f __attribute__((ext_vector_type(4)));
+#define MF_BLOCK 256
+
+// RT = row tiles (of 16 output voxels) per wave; LDSW = stage W_k through LDS (one copy per workgroup and
+// offset, two barriers) or let every lane fetch its B float4 straight from the L2-resident weights (no
+// barrier, loads free to run ahead of the MFMAs).
+template <int CIN, int COUT, int RT, bool LDSW>
+__global__ void __launch_bounds__(MF_BLOCK) k_sparse_conv_mfma(const float* __restrict__ x0, int c0, const float* __restrict__ x1,
+                                                               const int32_t* __restrict__ nbr, int K, int64_t n_out,
+                                                               const float* __restrict__ wp, const float* __restrict__ scale,
+                                                               const float* __restrict__ shift, const float* __restrict__ residual,
+                                                               int relu, float* __restrict__ y) {
+    constexpr int CT = COUT / 16, NC = CIN / 16;
+    __shared__ float4 wl[LDSW ? CIN * COUT / 4 : 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i16 = lane & 15, kg = lane >> 4;
+    const int64_t obase = ((int64_t)blockIdx.x * (MF_BLOCK / 64) + wave) * (16 * RT);
+    const int c1 = CIN - c0;
+    st_v4f acc[RT][CT];
+#pragma unroll
+    for (int t = 0; t < RT; t++)
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) acc[t][ct] = st_v4f{0.0f, 0.0f, 0.0f, 0.0f};
+
+    for (int k = 0; k < K; k++) {
+        const float4* wsrc = reinterpret_cast<const float4*>(wp + (int64_t)k * CIN * COUT);
+        if (LDSW) {
+            __syncthreads();  // everyone is done with the previous offset's weights
+            for (int i = tid; i < CIN * COUT / 4; i += MF_BLOCK) wl[i] = wsrc[i];
+        }
+        int idx[RT];
+        bool any = false;
+#pragma unroll
+        for (int t = 0; t < RT; t++) {
+            const int64_t o = obase + t * 16 + i16;
+            idx[t] = o < n_out ? (nbr ? nbr[(int64_t)k * n_out + o] : (int)o) : -1;
+            any = any || idx[t] >= 0;
+        }
+        if (LDSW) __syncthreads();
+        if (__ballot(any) == 0ull) continue;  // no voxel of this wave has a neighbour at offset k (wave-uniform)
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const int ci = 16 * c + 4 * kg;
+            float4 av[RT];
+#pragma unroll
+            for (int t = 0; t < RT; t++) {
+                av[t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (idx[t] >= 0) {
+                    const float* row = ci < c0 ? x0 + (int64_t)idx[t] * c0 + ci : x1 + (int64_t)idx[t] * c1 + (ci - c0);
+                    av[t] = *reinterpret_cast<const float4*>(row);
+                }
+            }
+#pragma unroll
+            for (int ct = 0; ct < CT; ct++) {
+                const int wi = (c * 4 + kg) * COUT + ct * 16 + i16;
+                const float4 bv = LDSW ? wl[wi] : wsrc[wi];
+#pragma unroll
+                for (int t = 0; t < RT; t++) {
+                    acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t].x, bv.x, acc[t][ct], 0, 0, 0);
+                    acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t].y, bv.y, acc[t][ct], 0, 0, 0);
+                    acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t].z, bv.z, acc[t][ct], 0, 0, 0);
+                    acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t].w, bv.w, acc[t][ct], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++) {
+        const int ch = ct * 16 + i16;
+        const float sc = scale ? scale[ch] : 1.0f, sh = scale ? shift[ch] : 0.0f;
+#pragma unroll
+        for (int t = 0; t < RT; t++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int64_t o = obase + t * 16 + kg * 4 + r;
+                if (o >= n_out) continue;
+                float v = acc[t][ct][r];
+                if (scale) v = fmaf(v, sc, sh);
+                if (residual) v += residual[o * COUT + ch];
+                if (relu) v = v > 0.0f ? v : 0.0f;
+                y[o * COUT + ch] = v;
+            }
+    }
+}
+
+static int g_mfma_variant = 0;  // developer knob (st_debug_set_mfma_variant): 0 auto, else RT | (LDSW << 4)
+extern "C" void st_debug_set_mfma_variant(int v) { g_mfma_variant = v; }
+
+template <int CIN, int COUT, int RT, bool LDSW>
+static void conv_launch_mfma_v(const float* x0, int c0, const float* x1, const int32_t* nbr, int K, int64_t n_out, const float* wp,
+                               const float* scale, const float* shift, const float* residual, int relu, float* y,
+                               hipStream_t stream) {
+    const int64_t blocks = st_div_up(n_out, (MF_BLOCK / 64) * 16 * RT);
+    hipLaunchKernelGGL((k_sparse_conv_mfma<CIN, COUT, RT, LDSW>), dim3((unsigned)blocks), dim3(MF_BLOCK), 0, stream, x0, c0, x1,
+                       nbr, K, n_out, wp, scale, shift, residual, relu, y);
+}
+
+template <int CIN, int COUT>
+static int conv_launch_mfma(const float* x0, int c0, const float* x1, const int32_t* nbr, int K, int64_t n_out, const float* wp,
+                            const float* scale, const float* shift, const float* residual, int relu, float* y,
+                            hipStream_t stream) {
+    int v = g_mfma_variant;
+    if (v == 0) v = 1;  // measured on MI355X (tools/bench_conv.py): RT = 1 with direct weight loads wins at every level
+#define MFMA_V(RT_, L_) conv_launch_mfma_v<CIN, COUT, RT_, L_>(x0, c0, x1, nbr, K, n_out, wp, scale, shift, residual, relu, y, stream)
+    switch (v) {
+        case 1: MFMA_V(1, false); break;
+        case 2: MFMA_V(2, false); break;
+        case 17: MFMA_V(1, true); break;
+        default: MFMA_V(2, true); break;
+    }
+#undef MFMA_V
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}
+
+// Same contract as st_sparse_conv_fwd, weights in the MFMA order wp[K][Cin/16][4][Cout][4] (see above).
+// Needs Cin, Cout multiples of 16 and a concat split that is a multiple of 16 (or no concat).
+extern "C" int st_sparse_conv_mfma_fwd(const float* x0, int c0, const float* x1, int cin, const int32_t* nbr, int K,
+                                       int64_t n_out, const float* wp, int cout, const float* scale, const float* shift,
+                                       const float* residual, int relu, float* y, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    ST_REQUIRE(K >= 1 && (nbr != nullptr || K == 1), "conv: a NULL neighbour table means pointwise (K = 1)");
+    ST_REQUIRE(c0 > 0 && c0 <= cin && (c0 == cin || x1 != nullptr), "conv: bad concat split");
+    ST_REQUIRE((scale == nullptr) == (shift == nullptr), "conv: scale and shift go together");
+    ST_REQUIRE(cin % 16 == 0 && cout % 16 == 0 && c0 % 16 == 0, "conv(mfma): channels and concat split must be multiples of 16");
+    if (n_out <= 0) return ST_OK;
+#define MFMA_CASE(CI, CO) \
+    if (cin == CI && cout == CO) return conv_launch_mfma<CI, CO>(x0, c0, x1, nbr, K, n_out, wp, scale, shift, residual, relu, y, stream);
+    MFMA_CASE(16, 16)
+    MFMA_CASE(16, 32)
+    MFMA_CASE(32, 16)
+    MFMA_CASE(32, 32)
+    MFMA_CASE(32, 64)
+    MFMA_CASE(64, 32)
+    MFMA_CASE(64, 64)
+#undef MFMA_CASE
+    st_set_error("conv(mfma): no kernel instance for cin=%d cout=%d", cin, cout);
+    return ST_ERR_INVALID;
+}
+
 // x = cat(x0[:, :c0], x1[:, :cin-c0]) (x1 may be NULL when c0 == cin); w [K][cin][cout];
 // nbr [K][n_out] or NULL (K must be 1: pointwise); scale/shift/residual may be NULL.
 extern "C" int st_sparse_conv_fwd(const float* x0, int c0, const float* x1, int cin, const int32_t* nbr, int K,

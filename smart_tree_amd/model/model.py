@@ -49,10 +49,15 @@ class Smart_Tree:
             self.depth += 1
         self.planes = [sd[f"UNet.{'U.' * l}Head.sequence.0.weight"].shape[0] for l in range(self.depth + 1)]
         self.w: Dict[str, torch.Tensor] = {}
+        self.wp: Dict[str, torch.Tensor] = {}  # MFMA operand order for the Cin, Cout % 16 == 0 convolutions
         self.bn: Dict[str, _Affine] = {}
+        self.use_mfma = True
         for key, t in sd.items():
             if key.endswith(".weight") and t.ndim == 5 and "_head." not in key:
-                self.w[key[: -len(".weight")]] = _conv_weight(t).to(self.device)
+                name = key[: -len(".weight")]
+                self.w[name] = _conv_weight(t).to(self.device)
+                if self.w[name].shape[1] % 16 == 0 and self.w[name].shape[2] % 16 == 0:
+                    self.wp[name] = ops.mfma_weight(self.w[name])
             elif key.endswith(".running_mean") and "_head." not in key:
                 p = key[: -len(".running_mean")]
                 self.bn[p] = _Affine(sd, p, self.device)
@@ -91,7 +96,8 @@ class Smart_Tree:
     def _conv(self, name, x, nbr, n_out, x1=None, bn=None, residual=None, relu=False):
         a = self.bn[bn] if bn else None
         return ops.sparse_conv(x, self.w[name], nbr, n_out, x1=x1, scale=a.scale if a else None,
-                               shift=a.shift if a else None, residual=residual, relu=relu)
+                               shift=a.shift if a else None, residual=residual, relu=relu,
+                               wp=self.wp.get(name) if self.use_mfma else None)
 
     def _res_block(self, prefix, x, nbr, x1=None):
         """ResBlock.forward (model_blocks.py:149-156); x1 != None is the Tail on cat(skip, decoded)."""

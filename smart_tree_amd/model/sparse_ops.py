@@ -100,14 +100,34 @@ def build_pyramid(coords: torch.Tensor, depth: int) -> RulebookPyramid:
     return pyr
 
 
+def mfma_weight(w: torch.Tensor) -> torch.Tensor:
+    """[K, Cin, Cout] -> the MFMA operand order wp[K][Cin/16][4][Cout][4] = W[k][16c + 4kg + s][co]."""
+    K, cin, cout = w.shape
+    return w.reshape(K, cin // 16, 4, 4, cout).permute(0, 1, 2, 4, 3).contiguous()
+
+
+def mfma_eligible(cin: int, cout: int, c0: int) -> bool:
+    return cin % 16 == 0 and cout % 16 == 0 and c0 % 16 == 0
+
+
 def sparse_conv(x0: torch.Tensor, w: torch.Tensor, nbr: Optional[torch.Tensor], n_out: int,
                 x1: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None,
                 shift: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
-                relu: bool = False) -> torch.Tensor:
-    """y = act(bn(sum_k W_k . cat(x0, x1)[nbr[k]]) + residual); w is [K, Cin, Cout]."""
+                relu: bool = False, wp: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = act(bn(sum_k W_k . cat(x0, x1)[nbr[k]]) + residual); w is [K, Cin, Cout].
+    wp (optional): the same weights in MFMA order -> the matrix-core kernel is used."""
     L = _lib.lib()
     K, cin, cout = w.shape
     c0 = x0.shape[1]
+    if wp is not None and mfma_eligible(cin, cout, c0):
+        y = torch.empty((n_out, cout), dtype=torch.float32, device=x0.device)
+        nbytes = (lambda: (_pair_count(nbr) if nbr is not None else n_out) * (cin * 4 + (4 if nbr is not None else 0))
+                  + n_out * cout * 4) if profiling.enabled() else 0
+        with profiling.kernel(f"k_sparse_conv_mfma<{cin},{cout}>" + ("" if nbr is not None else " k1"), nbytes):
+            _lib.check(L.st_sparse_conv_mfma_fwd(_lib.ptr(x0), c0, _lib.ptr(x1), cin, _lib.ptr(nbr), K, n_out, _lib.ptr(wp), cout,
+                                                 _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(residual), int(relu), _lib.ptr(y),
+                                                 _lib.stream(x0.device)))
+        return y
     y = torch.empty((n_out, cout), dtype=torch.float32, device=x0.device)
     # algorithmic bytes (SURVEY.md 8d): P*(Cin*4 + 4) + N*Cout*4 (pointwise: N*(Cin+Cout)*4); the pair count
     # is evaluated lazily, after the timed region

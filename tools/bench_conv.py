@@ -1,0 +1,52 @@
+"""Dev script: per-layer timing of the sparse conv kernels (VALU vs MFMA) on the 1M-point bench cloud."""
+import sys, time
+from pathlib import Path
+ROOT = Path(__file__).resolve().parents[1]; sys.path.insert(0, str(ROOT))
+import torch, numpy as np
+import bench
+from smart_tree_amd.data_types.cloud import Cloud
+from smart_tree_amd.synthetic import sample_tree_cloud
+from smart_tree_amd.dataset.dataset import voxelize_blocks
+from smart_tree_amd.model import sparse_ops as ops
+dev = torch.device("cuda:0")
+pipe = bench.build_pipeline(dev)
+c = sample_tree_cloud(1_000_000, seed=0)
+cloud = pipe.preprocessing(Cloud(xyz=torch.from_numpy(c["xyz"]).to(dev), rgb=torch.from_numpy(c["rgb"]).to(dev)))
+vb = voxelize_blocks(cloud.xyz, cloud.rgb, 0.02)
+pyr = ops.build_pyramid(vb.coords, 3)
+N = [x.shape[0] for x in pyr.coords]
+print("levels", N)
+def timeit(fn, reps=20):
+    fn(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps * 1e3
+planes = [8, 16, 32, 64]
+for lvl in range(4):
+    C = planes[lvl]
+    for (cin, cout, tbl, nout, name) in [(C, C, pyr.subm[lvl], N[lvl], "subm")] + \
+            ([(2 * C, C, pyr.subm[lvl], N[lvl], "tail"), (C, 2 * C, pyr.down[lvl], N[lvl + 1], "down"), (2 * C, C, pyr.up[lvl], N[lvl], "up")] if lvl < 3 else []):
+        nin = N[lvl + 1] if name == "up" else N[lvl]
+        x = torch.randn(nin, cin, device=dev)
+        w = torch.randn(27, cin, cout, device=dev) * 0.05
+        pairs = int((tbl >= 0).sum())
+        bytes_ = pairs * (cin * 4 + 4) + nout * cout * 4
+        flops = 2 * pairs * cin * cout
+        t_valu = timeit(lambda: ops.sparse_conv(x, w, tbl, nout))
+        line = f"L{lvl} {name:5s} {cin:3d}->{cout:3d} N={nout:7d} P={pairs:8d}: VALU {t_valu:7.1f} us ({bytes_/t_valu/1e3:7.1f} GB/s, {flops/t_valu/1e6:6.2f} TF)"
+        if cin % 16 == 0 and cout % 16 == 0:
+            wp = ops.mfma_weight(w)
+            import ctypes
+            from smart_tree_amd import _lib
+            L = _lib.lib(); L.st_debug_set_mfma_variant.argtypes = [ctypes.c_int]
+            ya = ops.sparse_conv(x, w, tbl, nout)
+            for var, tag in ((1, "rt1"), (2, "rt2"), (17, "rt1+lds"), (18, "rt2+lds")):
+                L.st_debug_set_mfma_variant(var)
+                t_m = timeit(lambda: ops.sparse_conv(x, w, tbl, nout, wp=wp))
+                yb = ops.sparse_conv(x, w, tbl, nout, wp=wp)
+                err = (ya - yb).abs().max().item() / (ya.abs().max().item() + 1e-30)
+                line += f" | {tag} {t_m:6.1f} us {flops/t_m/1e6:5.1f} TF e={err:.0e}"
+            L.st_debug_set_mfma_variant(0)
+        print(line)
