@@ -155,39 +155,34 @@ __device__ __forceinline__ int cc_find(int* label, int x) {
     return x;
 }
 __global__ void __launch_bounds__(GR_BLOCK) k_cc_init(int* label, int64_t n) { GR_LOOP(i, n) label[i] = (int)i; }
-__global__ void __launch_bounds__(GR_BLOCK) k_cc_hook(const int64_t* edges, int64_t E, int* label, unsigned* changed) {
+// One pass over the edges (ECL-CC style): the larger root is hooked under the smaller one with a CAS that
+// only succeeds while it is still a root; on failure the walk continues from whatever it was hooked to,
+// so every edge ends up with both ends in one tree -- no outer "until nothing changes" loop, no host sync.
+__global__ void __launch_bounds__(GR_BLOCK) k_cc_hook(const int64_t* edges, int64_t E, int* label) {
     GR_LOOP(e, E) {
         int a = cc_find(label, (int)edges[2 * e]), b = cc_find(label, (int)edges[2 * e + 1]);
-        if (a == b) continue;
-        int hi = a > b ? a : b, lo = a > b ? b : a;
-        // thousands of edges join the same two trees: only the first needs the atomic
-        if (__atomic_load_n(&label[hi], __ATOMIC_RELAXED) > lo) atomicMin(&label[hi], lo);
-        *changed = 1u;
+        while (a != b) {
+            if (a < b) { const int t = a; a = b; b = t; }  // a = larger id
+            const int seen = atomicCAS(&label[a], a, b);
+            if (seen == a) break;  // hooked
+            a = seen;              // a had already been hooked: continue from there
+        }
     }
 }
 __global__ void __launch_bounds__(GR_BLOCK) k_cc_compress(int* label, int64_t n) {
     GR_LOOP(i, n) { int r = cc_find(label, (int)i); label[i] = r; }
 }
 
-// labels [n] int32 out: smallest vertex id of each vertex's component.  scratch: one uint32.
+// labels [n] int32 out: smallest vertex id of each vertex's component.
 extern "C" int st_connected_components(const int64_t* edges, int64_t E, int64_t n, int32_t* labels, void* ws,
                                        int64_t ws_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    (void)ws; (void)ws_bytes;
     ST_REQUIRE(n < (1ll << 31), "cc: too many vertices");
     if (n <= 0) return ST_OK;
-    StArena a(ws, ws_bytes);
-    unsigned* changed = a.take<unsigned>(1);
-    if (!changed) { st_set_error("cc: workspace too small"); return ST_ERR_WORKSPACE; }
     hipLaunchKernelGGL(k_cc_init, dim3(gr_grid(n)), dim3(GR_BLOCK), 0, stream, labels, n);
-    for (int it = 0; it < 64 && E > 0; it++) {
-        (void)hipMemsetAsync(changed, 0, sizeof(unsigned), stream);
-        hipLaunchKernelGGL(k_cc_hook, dim3(gr_grid(E)), dim3(GR_BLOCK), 0, stream, edges, E, labels, changed);
-        hipLaunchKernelGGL(k_cc_compress, dim3(gr_grid(n)), dim3(GR_BLOCK), 0, stream, labels, n);
-        unsigned h = 0;
-        (void)hipMemcpyAsync(&h, changed, sizeof(unsigned), hipMemcpyDeviceToHost, stream);
-        (void)hipStreamSynchronize(stream);
-        if (!h) break;
-    }
+    if (E > 0) hipLaunchKernelGGL(k_cc_hook, dim3(gr_grid(E)), dim3(GR_BLOCK), 0, stream, edges, E, labels);
+    hipLaunchKernelGGL(k_cc_compress, dim3(gr_grid(n)), dim3(GR_BLOCK), 0, stream, labels, n);
     ST_CHECK_LAUNCH();
     return ST_OK;
 }

@@ -51,9 +51,15 @@ __device__ __forceinline__ float pp_dot(const float* a, const float* b) {
     return s + t;
 }
 
+#define PP_LDS_BRANCHES 8192  // branch tables of this size run their sequential chains out of LDS
 __global__ void __launch_bounds__(PP_BLOCK) k_post_process(PpArgs A) {
+    __shared__ int l_parent[PP_LDS_BRANCHES];
+    __shared__ short l_depth[PP_LDS_BRANCHES];
+    __shared__ uint8_t l_keep[PP_LDS_BRANCHES];
     const int tree = blockIdx.x, tid = threadIdx.x;
     const int b0 = A.tree_off[tree], nb = A.tree_off[tree + 1] - b0;
+    const bool in_lds = nb <= PP_LDS_BRANCHES;
+    if (in_lds) for (int b = tid; b < nb; b += PP_BLOCK) l_parent[b] = A.parent[b0 + b];
     // ---- prune (tree 0 only): length / initial radius per branch in parallel, then the keep chain
     for (int b = tid; b < nb; b += PP_BLOCK) A.keep[b0 + b] = 1;
     __syncthreads();
@@ -71,14 +77,25 @@ __global__ void __launch_bounds__(PP_BLOCK) k_post_process(PpArgs A) {
             A.keep[b0 + b] = !(length < A.min_length) && !(initial < A.min_radius);  // own tests (tree.py:113-116)
         }
         __syncthreads();
-        if (tid == 0) {
-            A.keep[b0] = 1;  // the root (smallest id) always stays (tree.py:101-103,120)
-            for (int b = 1; b < nb; b++) {
-                const int p = A.parent[b0 + b];
-                const bool parent_kept = p >= 0 && p < nb && A.keep[b0 + p];
-                if (!parent_kept) A.keep[b0 + b] = 0;  // tree.py:111-112
+        if (in_lds) for (int b = tid; b < nb; b += PP_BLOCK) l_keep[b] = A.keep[b0 + b];
+        __syncthreads();
+        if (tid == 0) {  // the keep chain is sequential (a child needs its parent's verdict): LDS-resident when it fits
+            if (in_lds) {
+                l_keep[0] = 1;  // the root (smallest id) always stays (tree.py:101-103,120)
+                for (int b = 1; b < nb; b++) {
+                    const int p = l_parent[b];
+                    if (!(p >= 0 && p < nb && l_keep[p])) l_keep[b] = 0;  // tree.py:111-112
+                }
+            } else {
+                A.keep[b0] = 1;
+                for (int b = 1; b < nb; b++) {
+                    const int p = A.parent[b0 + b];
+                    if (!(p >= 0 && p < nb && A.keep[b0 + p])) A.keep[b0 + b] = 0;
+                }
             }
         }
+        __syncthreads();
+        if (in_lds) for (int b = tid; b < nb; b += PP_BLOCK) A.keep[b0 + b] = l_keep[b];
         __syncthreads();
     }
     // ---- repair: nearest point on the (already repaired) parent's tube chain.  A branch only needs its
@@ -87,16 +104,24 @@ __global__ void __launch_bounds__(PP_BLOCK) k_post_process(PpArgs A) {
     __shared__ int s_maxdepth;
     int* depth = A.depth + b0;
     for (int b = tid; b < nb; b += PP_BLOCK) A.repaired[b0 + b] = 0;
+    if (in_lds) for (int b = tid; b < nb; b += PP_BLOCK) l_keep[b] = A.keep[b0 + b];
+    __syncthreads();
     if (tid == 0) {
         int md = 0;
         for (int b = 0; b < nb; b++) {  // parents have smaller ids: one forward pass
-            const int p = A.parent[b0 + b];
-            const bool go = A.do_repair && A.keep[b0 + b] && p >= 0 && p < nb && A.keep[b0 + p];  // tree.py:80-82
-            depth[b] = go ? (depth[p] < 0 ? 1 : depth[p] + 1) : -1;  // -1: not repaired; a parent without repair is ready at once
-            if (depth[b] > md) md = depth[b];
+            const int p = in_lds ? l_parent[b] : A.parent[b0 + b];
+            const bool kb = in_lds ? l_keep[b] : A.keep[b0 + b];
+            const bool kp = p >= 0 && p < nb && (in_lds ? l_keep[p] : A.keep[b0 + p]);
+            const bool go = A.do_repair && kb && kp;  // tree.py:80-82
+            const int dp = go ? (in_lds ? (int)l_depth[p] : depth[p]) : -1;
+            const int d = go ? (dp < 0 ? 1 : dp + 1) : -1;  // -1: not repaired; a parent without repair is ready at once
+            if (in_lds) l_depth[b] = (short)(d > 32767 ? 32767 : d); else depth[b] = d;
+            if (d > md) md = d;
         }
-        s_maxdepth = md;
+        s_maxdepth = md > 32767 ? 32767 : md;
     }
+    __syncthreads();
+    if (in_lds) for (int b = tid; b < nb; b += PP_BLOCK) depth[b] = l_depth[b];
     __syncthreads();
     const int maxdepth = s_maxdepth, lane = tid & 63, wave = tid >> 6;
     for (int level = 1; level <= maxdepth; level++) {
