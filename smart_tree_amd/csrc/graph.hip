@@ -172,6 +172,15 @@ __global__ void __launch_bounds__(GR_BLOCK) k_cc_hook(const int64_t* edges, int6
 __global__ void __launch_bounds__(GR_BLOCK) k_cc_compress(int* label, int64_t n) {
     GR_LOOP(i, n) { int r = cc_find(label, (int)i); label[i] = r; }
 }
+// starting forest: every vertex points at its smallest smaller neighbour (a strictly decreasing pointer is
+// always a valid tree edge); most of the hooking work is done before the first find
+__global__ void __launch_bounds__(GR_BLOCK) k_cc_seed(const int64_t* edges, int64_t E, int* label) {
+    GR_LOOP(e, E) {
+        const int a = (int)edges[2 * e], b = (int)edges[2 * e + 1];
+        if (b < a) atomicMin(&label[a], b);
+        else if (a < b) atomicMin(&label[b], a);
+    }
+}
 
 // labels [n] int32 out: smallest vertex id of each vertex's component.
 extern "C" int st_connected_components(const int64_t* edges, int64_t E, int64_t n, int32_t* labels, void* ws,
@@ -181,7 +190,10 @@ extern "C" int st_connected_components(const int64_t* edges, int64_t E, int64_t 
     ST_REQUIRE(n < (1ll << 31), "cc: too many vertices");
     if (n <= 0) return ST_OK;
     hipLaunchKernelGGL(k_cc_init, dim3(gr_grid(n)), dim3(GR_BLOCK), 0, stream, labels, n);
-    if (E > 0) hipLaunchKernelGGL(k_cc_hook, dim3(gr_grid(E)), dim3(GR_BLOCK), 0, stream, edges, E, labels);
+    if (E > 0) {
+        hipLaunchKernelGGL(k_cc_seed, dim3(gr_grid(E)), dim3(GR_BLOCK), 0, stream, edges, E, labels);
+        hipLaunchKernelGGL(k_cc_hook, dim3(gr_grid(E)), dim3(GR_BLOCK), 0, stream, edges, E, labels);
+    }
     hipLaunchKernelGGL(k_cc_compress, dim3(gr_grid(n)), dim3(GR_BLOCK), 0, stream, labels, n);
     ST_CHECK_LAUNCH();
     return ST_OK;

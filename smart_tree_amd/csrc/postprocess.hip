@@ -64,17 +64,25 @@ __global__ void __launch_bounds__(PP_BLOCK) k_post_process(PpArgs A) {
     for (int b = tid; b < nb; b += PP_BLOCK) A.keep[b0 + b] = 1;
     __syncthreads();
     if (A.do_prune && tree == 0 && nb > 0) {
-        for (int b = tid; b < nb; b += PP_BLOCK) {
-            const int s = A.start[b0 + b] + 1, n = A.len[b0 + b];
-            float length = 0.0f;
-            for (int i = 0; i + 1 < n; i++) {
-                const float d[3] = {A.xyz[3 * (s + i + 1)] - A.xyz[3 * (s + i)], A.xyz[3 * (s + i + 1) + 1] - A.xyz[3 * (s + i) + 1],
-                                    A.xyz[3 * (s + i + 1) + 2] - A.xyz[3 * (s + i) + 2]};
-                length = length + sqrtf(pp_dot(d, d));
+        for (int b = tid >> 6; b < nb; b += PP_WAVES) {  // one wavefront per branch
+            const int s = A.start[b0 + b] + 1, n = A.len[b0 + b], ln = tid & 63;
+            float length = 0.0f;  // lanes evaluate 64 segment norms at a time; they are added in path order (sequential float32 sum)
+            for (int i0 = 0; i0 + 1 < n; i0 += 64) {
+                const int i = i0 + ln;
+                float seg = 0.0f;
+                if (i + 1 < n) {
+                    const float d[3] = {A.xyz[3 * (s + i + 1)] - A.xyz[3 * (s + i)], A.xyz[3 * (s + i + 1) + 1] - A.xyz[3 * (s + i) + 1],
+                                        A.xyz[3 * (s + i + 1) + 2] - A.xyz[3 * (s + i) + 2]};
+                    seg = sqrtf(pp_dot(d, d));
+                }
+                const int cnt = (n - 1 - i0) < 64 ? (n - 1 - i0) : 64;
+                for (int j = 0; j < cnt; j++) length = length + __shfl(seg, j);
             }
-            const float r0 = A.rad_in[s], r1 = A.rad_in[s + n - 1];
-            const float initial = r0 > r1 ? r0 : r1;
-            A.keep[b0 + b] = !(length < A.min_length) && !(initial < A.min_radius);  // own tests (tree.py:113-116)
+            if (ln == 0) {
+                const float r0 = A.rad_in[s], r1 = A.rad_in[s + n - 1];
+                const float initial = r0 > r1 ? r0 : r1;
+                A.keep[b0 + b] = !(length < A.min_length) && !(initial < A.min_radius);  // own tests (tree.py:113-116)
+            }
         }
         __syncthreads();
         if (in_lds) for (int b = tid; b < nb; b += PP_BLOCK) l_keep[b] = A.keep[b0 + b];
