@@ -155,12 +155,23 @@ __device__ __forceinline__ int cc_find(int* label, int x) {
     return x;
 }
 __global__ void __launch_bounds__(GR_BLOCK) k_cc_init(int* label, int64_t n) { GR_LOOP(i, n) label[i] = (int)i; }
-// One pass over the edges (ECL-CC style): the larger root is hooked under the smaller one with a CAS that
-// only succeeds while it is still a root; on failure the walk continues from whatever it was hooked to,
-// so every edge ends up with both ends in one tree -- no outer "until nothing changes" loop, no host sync.
-__global__ void __launch_bounds__(GR_BLOCK) k_cc_hook(const int64_t* edges, int64_t E, int* label) {
+// Hooking (ECL-CC style): the larger root is hooked under the smaller one with a CAS that only succeeds
+// while it is still a root; on failure the walk continues from whatever it was hooked to, so every
+// processed edge ends up with both ends in one tree -- no "until nothing changes" loop, no host sync.
+// Afforest-style schedule: a sampled eighth of the edges is linked first, the forest is flattened, and
+// the full pass then dismisses almost every edge with two loads (both ends already carry the same root:
+// a tree cloud is one giant component) instead of chasing pointers for it.
+__global__ void __launch_bounds__(GR_BLOCK) k_cc_hook(const int64_t* edges, int64_t E, int* label, int sample) {
     GR_LOOP(e, E) {
-        int a = cc_find(label, (int)edges[2 * e]), b = cc_find(label, (int)edges[2 * e + 1]);
+        if (sample && (e & 7) != 0) continue;
+        int a = (int)edges[2 * e], b = (int)edges[2 * e + 1];
+        if (a == b) continue;
+        if (!sample) {  // labels were flattened by the preceding compress
+            const int la = __atomic_load_n(&label[a], __ATOMIC_RELAXED), lb = __atomic_load_n(&label[b], __ATOMIC_RELAXED);
+            if (la == lb) continue;
+        }
+        a = cc_find(label, a);
+        b = cc_find(label, b);
         while (a != b) {
             if (a < b) { const int t = a; a = b; b = t; }  // a = larger id
             const int seen = atomicCAS(&label[a], a, b);
@@ -172,15 +183,6 @@ __global__ void __launch_bounds__(GR_BLOCK) k_cc_hook(const int64_t* edges, int6
 __global__ void __launch_bounds__(GR_BLOCK) k_cc_compress(int* label, int64_t n) {
     GR_LOOP(i, n) { int r = cc_find(label, (int)i); label[i] = r; }
 }
-// starting forest: every vertex points at its smallest smaller neighbour (a strictly decreasing pointer is
-// always a valid tree edge); most of the hooking work is done before the first find
-__global__ void __launch_bounds__(GR_BLOCK) k_cc_seed(const int64_t* edges, int64_t E, int* label) {
-    GR_LOOP(e, E) {
-        const int a = (int)edges[2 * e], b = (int)edges[2 * e + 1];
-        if (b < a) atomicMin(&label[a], b);
-        else if (a < b) atomicMin(&label[b], a);
-    }
-}
 
 // labels [n] int32 out: smallest vertex id of each vertex's component.
 extern "C" int st_connected_components(const int64_t* edges, int64_t E, int64_t n, int32_t* labels, void* ws,
@@ -191,8 +193,9 @@ extern "C" int st_connected_components(const int64_t* edges, int64_t E, int64_t 
     if (n <= 0) return ST_OK;
     hipLaunchKernelGGL(k_cc_init, dim3(gr_grid(n)), dim3(GR_BLOCK), 0, stream, labels, n);
     if (E > 0) {
-        hipLaunchKernelGGL(k_cc_seed, dim3(gr_grid(E)), dim3(GR_BLOCK), 0, stream, edges, E, labels);
-        hipLaunchKernelGGL(k_cc_hook, dim3(gr_grid(E)), dim3(GR_BLOCK), 0, stream, edges, E, labels);
+        hipLaunchKernelGGL(k_cc_hook, dim3(gr_grid(E)), dim3(GR_BLOCK), 0, stream, edges, E, labels, 1);
+        hipLaunchKernelGGL(k_cc_compress, dim3(gr_grid(n)), dim3(GR_BLOCK), 0, stream, labels, n);
+        hipLaunchKernelGGL(k_cc_hook, dim3(gr_grid(E)), dim3(GR_BLOCK), 0, stream, edges, E, labels, 0);
     }
     hipLaunchKernelGGL(k_cc_compress, dim3(gr_grid(n)), dim3(GR_BLOCK), 0, stream, labels, n);
     ST_CHECK_LAUNCH();

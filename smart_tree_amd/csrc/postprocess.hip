@@ -18,7 +18,7 @@
 // radius, tree.py:92), the extracted path sits in start[b]+1 ...
 #include "st_common.h"
 
-#define PP_BLOCK 256
+#define PP_BLOCK 1024  // 16 wavefronts: the per-branch work is a chain of dependent loads, more waves = more branches in flight
 #define PP_WAVES (PP_BLOCK / 64)
 
 struct PpArgs {
@@ -134,7 +134,7 @@ __global__ void __launch_bounds__(PP_BLOCK) k_post_process(PpArgs A) {
     const int maxdepth = s_maxdepth, lane = tid & 63, wave = tid >> 6;
     for (int level = 1; level <= maxdepth; level++) {
         for (int b = wave; b < nb; b += PP_WAVES) {  // wave-uniform
-            if (depth[b] != level) continue;
+            if ((in_lds ? (int)l_depth[b] : depth[b]) != level) continue;
             const int p = A.parent[b0 + b];
             const int prep = __hip_atomic_load(&A.repaired[b0 + p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int ps = A.start[b0 + p] + (prep ? 0 : 1);
@@ -146,8 +146,10 @@ __global__ void __launch_bounds__(PP_BLOCK) k_post_process(PpArgs A) {
             for (int i = lane; i + 1 < pn; i += 64) {
                 float a[3], bb[3];
                 for (int k = 0; k < 3; k++) {
-                    a[k] = pp_ldf(&A.xyz[3 * (ps + i) + k]);
-                    bb[k] = pp_ldf(&A.xyz[3 * (ps + i + 1) + k]);
+                    // only the parent's connection point (slot 0, written one level earlier by another wavefront)
+                    // needs the L2-coherent load; the extracted path is immutable input
+                    a[k] = (prep && i == 0) ? pp_ldf(&A.xyz[3 * ps + k]) : A.xyz[3 * (ps + i) + k];
+                    bb[k] = A.xyz[3 * (ps + i + 1) + k];
                 }
                 const float ab[3] = {bb[0] - a[0], bb[1] - a[1], bb[2] - a[2]};
                 const float ap[3] = {pt[0] - a[0], pt[1] - a[1], pt[2] - a[2]};
@@ -169,8 +171,8 @@ __global__ void __launch_bounds__(PP_BLOCK) k_post_process(PpArgs A) {
                 const int i = (int)(0xffffffffu - (unsigned)(key & 0xffffffffu));
                 float a[3], bb[3];
                 for (int k = 0; k < 3; k++) {
-                    a[k] = pp_ldf(&A.xyz[3 * (ps + i) + k]);
-                    bb[k] = pp_ldf(&A.xyz[3 * (ps + i + 1) + k]);
+                    a[k] = (prep && i == 0) ? pp_ldf(&A.xyz[3 * ps + k]) : A.xyz[3 * (ps + i) + k];
+                    bb[k] = A.xyz[3 * (ps + i + 1) + k];
                 }
                 const float ab[3] = {bb[0] - a[0], bb[1] - a[1], bb[2] - a[2]};
                 const float ap[3] = {pt[0] - a[0], pt[1] - a[1], pt[2] - a[2]};
