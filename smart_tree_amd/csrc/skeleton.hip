@@ -33,7 +33,8 @@
 #define SK_WIDE_BLOCK 256  // block size of the vertex / frontier kernels
 #define SK_SSSP_BLOCKS 256  // upper bound; small graphs launch fewer (one wave per frontier vertex)
 #define SK_MARK 0xfffffffeu
-#define SK_ANC 64  // direct ancestors kept per vertex
+#define SK_ANC 64  // direct ancestors kept per vertex; longer walks hop 64 levels at a time (16 measured slower: every lane
+                   // of a 1024-wide chunk hops j/SK_ANC times, so the chunk costs as much as its farthest lane)
 
 struct SkArgs {
     int C;
@@ -69,7 +70,7 @@ struct SkArgs {
     unsigned* term;   // termination set
     unsigned long long* best;  // claim race: (d2 bits << 32) | path position
     unsigned* touched;
-    int* anc;         // [m][64] direct ancestor table (component-local ids)
+    int* anc;         // [m][SK_ANC] direct ancestor table (component-local ids)
     // global counters: [0..2] rotating frontier counts, [3] unresolved, [4] plateau progress, [5] components done
     unsigned* cnt;
     // per-component sample_tree state [C]
@@ -301,10 +302,10 @@ __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_order_init(SkArgs A, float
     SK_VERTEX_LOOP(j) order_init[j] = A.alloc[A.order[j]];
 }
 
-// Ancestor table: anc[v*64 + k] = (k+1)-th ancestor of v (component-local id, -1 past the root).
-// k = 0 is written by k_sk_lift_init; pass `span` (1, 2, 4, .. 32) fills entries [span, 2*span) from
-// the table of the span-th ancestor.  A lane then reads "my j-th ancestor" with ONE load for j <= 64
-// and hops 64 levels at a time beyond (the trace of trace_route, path.py:9-16, without a pointer chase).
+// Ancestor table: anc[v*SK_ANC + k] = (k+1)-th ancestor of v (component-local id, -1 past the root).
+// k = 0 is written by k_sk_lift_init; pass `span` (1, 2, 4, ..) fills entries [span, 2*span) from
+// the table of the span-th ancestor.  A lane then reads "my j-th ancestor" with ONE load for j <= SK_ANC
+// and hops SK_ANC levels at a time beyond (the trace of trace_route, path.py:9-16, without a pointer chase).
 __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_anc_pass(SkArgs A, int span) {
     const int64_t total = A.m * span;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -316,11 +317,11 @@ __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_anc_pass(SkArgs A, int spa
     }
 }
 
-// j-th ancestor of `far` (j = 0: itself); lanes of one 64-chunk share the hop chain (broadcast loads)
+// j-th ancestor of `far` (j = 0: itself); lanes of one SK_ANC-chunk share the hop chain (broadcast loads)
 __device__ __forceinline__ int sk_ancestor(const SkArgs& A, int base, int far, unsigned j) {
     int cur = far;
-    for (unsigned h = j >> 6; h > 0 && cur >= 0; h--) cur = A.anc[(int64_t)(base + cur) * SK_ANC + (SK_ANC - 1)];
-    const unsigned rem = j & 63u;
+    for (unsigned h = j / SK_ANC; h > 0 && cur >= 0; h--) cur = A.anc[(int64_t)(base + cur) * SK_ANC + (SK_ANC - 1)];
+    const unsigned rem = j % SK_ANC;
     if (rem == 0u || cur < 0) return cur;
     return A.anc[(int64_t)(base + cur) * SK_ANC + rem - 1];
 }
@@ -633,7 +634,7 @@ static void sk_layout(StArena& a, int64_t m, int64_t C, SkLayout* s) {
     s->touched = a.take<unsigned>(m);
     s->alloc = a.take<float>(m);
     s->best = a.take<unsigned long long>(m);
-    s->anc = a.take<int>((int64_t)64 * m);
+    s->anc = a.take<int>((int64_t)SK_ANC * m);
     s->comp_of = a.take<int>(m);
     s->cnt = a.take<unsigned>(8);
     s->s_done = a.take<int>(C);
@@ -793,7 +794,7 @@ extern "C" int st_skeleton_components(int n_comp, const int32_t* comp_off, const
         (void)hipMemsetAsync(&s.cnt[5], 0, sizeof(unsigned), stream);
         hipLaunchKernelGGL(k_sk_lift_init, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A,
                            (const float*)((stages & 2) ? tree_dist : dist));
-        for (int span = 1; span < SK_ANC; span *= 2)  // direct ancestor table by doubling (6 passes)
+        for (int span = 1; span < SK_ANC; span *= 2)  // direct ancestor table by doubling
             hipLaunchKernelGGL(k_sk_anc_pass, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A, span);
         // order the vertices of every component by distance, once: the per-branch argmax becomes a cursor
         hipLaunchKernelGGL(k_sk_sort_keys, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A, s.sort_keys, s.order, 0);

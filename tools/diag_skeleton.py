@@ -24,7 +24,7 @@ print("after outlier", len(bc), "radius q", torch.quantile(radius, torch.tensor(
 g = G.nn_graph(medial, radius.clamp(min=0.02), K=16)
 comps = g.connected_cugraph_components(32)
 print("edges", g.edges.shape[0], "comps", comps.n_components, comps.comp_size[:8].tolist())
-for bt in (256, 1024):
+for bt in (256, 512, 1024):
     for rep in range(3):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         res = run_components(comps, medial, radius, bc.xyz[:,1].contiguous(), block_threads=bt)
