@@ -123,7 +123,8 @@ def sparse_conv(x0: torch.Tensor, w: torch.Tensor, nbr: Optional[torch.Tensor], 
         y = torch.empty((n_out, cout), dtype=torch.float32, device=x0.device)
         nbytes = (lambda: (_pair_count(nbr) if nbr is not None else n_out) * (cin * 4 + (4 if nbr is not None else 0))
                   + n_out * cout * 4) if profiling.enabled() else 0
-        with profiling.kernel(f"k_sparse_conv_mfma<{cin},{cout}>" + ("" if nbr is not None else " k1"), nbytes):
+        nflops = (lambda: 2.0 * (_pair_count(nbr) if nbr is not None else n_out) * cin * cout) if profiling.enabled() else 0
+        with profiling.kernel(f"k_sparse_conv_mfma<{cin},{cout}>" + ("" if nbr is not None else " k1"), nbytes, nflops):
             _lib.check(L.st_sparse_conv_mfma_fwd(_lib.ptr(x0), c0, _lib.ptr(x1), cin, _lib.ptr(nbr), K, n_out, _lib.ptr(wp), cout,
                                                  _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(residual), int(relu), _lib.ptr(y),
                                                  _lib.stream(x0.device)))
@@ -133,7 +134,8 @@ def sparse_conv(x0: torch.Tensor, w: torch.Tensor, nbr: Optional[torch.Tensor], 
     # is evaluated lazily, after the timed region
     nbytes = (lambda: (_pair_count(nbr) if nbr is not None else n_out) * (cin * 4 + (4 if nbr is not None else 0))
               + n_out * cout * 4) if profiling.enabled() else 0
-    with profiling.kernel(f"k_sparse_conv<{cin},{cout}>" + ("" if nbr is not None else " k1"), nbytes):
+    nflops = (lambda: 2.0 * (_pair_count(nbr) if nbr is not None else n_out) * cin * cout) if profiling.enabled() else 0
+    with profiling.kernel(f"k_sparse_conv<{cin},{cout}>" + ("" if nbr is not None else " k1"), nbytes, nflops):
       _lib.check(L.st_sparse_conv_fwd(_lib.ptr(x0), c0, _lib.ptr(x1), cin, _lib.ptr(nbr), K, n_out, _lib.ptr(w), cout,
                                     _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(residual), int(relu), _lib.ptr(y),
                                     _lib.stream(x0.device)))

@@ -15,7 +15,7 @@ import torch
 from . import profiling
 from .data_types.cloud import Cloud
 from .data_types.tree import DisjointTreeSkeleton
-from .util.file import load_cloud, save_skeleton_npz
+from .util.file import load_cloud, save_skeleton_npz, write_ply_points, write_ply_skeleton
 
 
 class Pipeline:
@@ -56,8 +56,11 @@ class Pipeline:
             skeleton.skeletons  # materialise: device post-processing kernel, one D->H copy, BranchSkeleton objects
         if self.view_model_output or self.view_skeletons:
             raise NotImplementedError("viewing needs open3d, which is out of scope of smart_tree_amd")
-        if self.save_outputs:
-            save_skeleton_npz(Path(self.save_path) / "skeleton.npz", skeleton)
+        if self.save_outputs:  # reference pipeline.py:85-93 (skeleton.ply / cloud.ply; meshes need open3d)
+            sp = Path(self.save_path)
+            save_skeleton_npz(sp / "skeleton.npz", skeleton)
+            write_ply_skeleton(sp / "skeleton.ply", skeleton)
+            write_ply_points(sp / "cloud.ply", lc.xyz.cpu().numpy(), lc.rgb.cpu().numpy() if lc.rgb is not None else None)
         return skeleton
 
     def post_process(self, skeleton: DisjointTreeSkeleton) -> None:

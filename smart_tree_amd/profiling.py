@@ -44,7 +44,7 @@ def stage(name: str):
 
 
 @contextmanager
-def kernel(name: str, algorithmic_bytes: float):
+def kernel(name: str, algorithmic_bytes, flops=0):
     if not _enabled:
         yield
         return
@@ -54,7 +54,7 @@ def kernel(name: str, algorithmic_bytes: float):
         yield
     finally:
         b.record()
-        _kernels[name].append((a, b, algorithmic_bytes))  # a number, or a thunk evaluated after the timed region
+        _kernels[name].append((a, b, algorithmic_bytes, flops))  # numbers, or thunks evaluated after the timed region
 
 
 _external = defaultdict(list)  # name -> [(total_ms, launches, bytes_thunk)] measured by the library itself
@@ -75,28 +75,60 @@ def kernel_table():
     torch.cuda.synchronize()
     rows = {}
     for name, recs in _kernels.items():
-        ms = [a.elapsed_time(b) for a, b, _ in recs]
+        ms = [r[0].elapsed_time(r[1]) for r in recs]
         nbytes = [float(r[2]() if callable(r[2]) else r[2]) for r in recs]
+        nflops = [float(r[3]() if callable(r[3]) else r[3]) for r in recs]
         rows[name] = {"launches": len(recs), "total_ms": sum(ms), "avg_us": 1e3 * sum(ms) / len(ms),
-                      "bytes_per_launch": sum(nbytes) / len(recs)}
+                      "bytes_per_launch": sum(nbytes) / len(recs), "flops_per_launch": sum(nflops) / len(recs)}
     for name, recs in _external.items():
         launches = sum(r[1] for r in recs)
         total = sum(r[0] for r in recs)
         nbytes = sum(float(r[2]() if callable(r[2]) else r[2]) for r in recs)
         rows[name] = {"launches": launches, "total_ms": total, "avg_us": 1e3 * total / max(launches, 1),
-                      "bytes_per_launch": nbytes / max(launches, 1)}
+                      "bytes_per_launch": nbytes / max(launches, 1), "flops_per_launch": 0.0}
     return rows
 
 
-def roofline(peak_gbs: float):
-    """Roofline entry of the kernel class with the largest total time in the timed region."""
+def _pmc_traffic(kernel_name: str):
+    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC summary (profiles/*_pmc_summary.csv:
+    FETCH_SIZE + WRITE_SIZE, KB per dispatch), or None.  PMC counters cannot be read from inside the process."""
+    import csv
+    from pathlib import Path
+
+    files = sorted((Path(__file__).resolve().parents[1] / "profiles").glob("*_pmc_summary.csv"))
+    if not files:
+        return None
+    for row in csv.DictReader(open(files[-1])):
+        if row["kernel"].split("(")[0].strip().endswith(kernel_name.split("<")[0]):
+            fetch = float(row["FETCH_SIZE_KB_per_launch"] or 0)
+            write = float(row["WRITE_SIZE_KB_per_launch"] or 0)
+            return (fetch + write) * 1024.0
+    return None
+
+
+def roofline(peak_gbs: float, peak_f32_tflops: float = 157.3):
+    """Roofline entry of the kernel class with the largest total time in the timed region, plus (as
+    `gather_gemm`) the sparse-conv kernel with the largest total time: the gather/GEMM the path is named for."""
     rows = kernel_table()
     if not rows:
         return None
     name = max(rows, key=lambda k: rows[k]["total_ms"])
     r = rows[name]
     achieved = r["bytes_per_launch"] / (r["avg_us"] * 1e-6) / 1e9
-    return {"kernel": name, "bound": "hbm", "achieved": achieved, "peak": peak_gbs, "unit": "GB/s",
-            "frac": achieved / peak_gbs, "traffic": None, "launches": r["launches"], "avg_us": r["avg_us"],
-            "algorithmic_bytes_per_launch": r["bytes_per_launch"],
-            "all_kernels": {k: {"total_ms": round(v["total_ms"], 3), "launches": v["launches"]} for k, v in rows.items()}}
+    out = {"kernel": name, "bound": "hbm", "achieved": achieved, "peak": peak_gbs, "unit": "GB/s",
+           "frac": achieved / peak_gbs, "traffic": _pmc_traffic(name), "launches": r["launches"], "avg_us": r["avg_us"],
+           "algorithmic_bytes_per_launch": r["bytes_per_launch"],
+           "note": "latency-bound branch selection (one workgroup per tree component, ~16 us of dependent L2 round trips per "
+                   "branch); bytes = path*24 + claimed*16 + 8*vertices per tree, divided over its launches" if name == "k_sk_select" else ""}
+    convs = {k: v for k, v in rows.items() if k.startswith("k_sparse_conv")}
+    if convs:
+        cname = max(convs, key=lambda k: convs[k]["total_ms"])
+        c = convs[cname]
+        gbs = c["bytes_per_launch"] / (c["avg_us"] * 1e-6) / 1e9
+        tfs = c["flops_per_launch"] / (c["avg_us"] * 1e-6) / 1e12
+        out["gather_gemm"] = {"kernel": cname, "avg_us": c["avg_us"], "launches": c["launches"],
+                              "algorithmic_bytes_per_launch": c["bytes_per_launch"], "achieved_GBps": gbs,
+                              "hbm_frac": gbs / peak_gbs, "useful_TFLOPs": tfs, "f32_matrix_frac": tfs / peak_f32_tflops}
+    out["all_kernels"] = {k: {"total_ms": round(v["total_ms"], 3), "launches": v["launches"],
+                              "GBps": round(v["bytes_per_launch"] / (v["avg_us"] * 1e-6) / 1e9, 1)} for k, v in rows.items()}
+    return out

@@ -1,0 +1,53 @@
+"""Cloud / skeleton file formats: .npz keys, PLY round trips, CLI overrides."""
+import numpy as np
+import torch
+
+from smart_tree_amd import cli
+from smart_tree_amd.data_types.branch import BranchSkeleton
+from smart_tree_amd.data_types.cloud import Cloud
+from smart_tree_amd.data_types.tree import DisjointTreeSkeleton, TreeSkeleton
+from smart_tree_amd.util import file as F
+
+
+def test_npz_cloud_roundtrip_and_legacy_key(tmp_path):
+    rng = np.random.RandomState(0)
+    xyz, mv = rng.rand(50, 3).astype(np.float32), rng.rand(50, 3).astype(np.float32)
+    np.savez(tmp_path / "legacy.npz", xyz=xyz, rgb=xyz, vector=mv, class_l=np.zeros((50, 1)))
+    c = F.load_cloud(tmp_path / "legacy.npz")
+    assert torch.equal(c.medial_vector, torch.from_numpy(mv)) and c.class_l.shape == (50, 1) and c.filename.name == "legacy.npz"
+    F.save_cloud(tmp_path / "again.npz", c)
+    c2 = F.load_cloud(tmp_path / "again.npz")
+    assert torch.equal(c2.xyz, c.xyz) and torch.equal(c2.medial_vector, c.medial_vector)
+
+
+def test_ply_points_binary_and_ascii(tmp_path):
+    rng = np.random.RandomState(1)
+    xyz, rgb = rng.rand(20, 3).astype(np.float32), (rng.randint(0, 256, (20, 3)) / 255.0).astype(np.float32)
+    F.write_ply_points(tmp_path / "c.ply", xyz, rgb)
+    c = F.load_cloud(tmp_path / "c.ply")
+    np.testing.assert_array_equal(c.xyz.numpy(), xyz)
+    np.testing.assert_allclose(c.rgb.numpy(), rgb, atol=1 / 255)
+    lines = ["ply", "format ascii 1.0", "element vertex 3", "property float x", "property float y", "property float z",
+             "end_header", "0 1 2", "3 4 5", "6 7 8"]
+    (tmp_path / "a.ply").write_text("\n".join(lines) + "\n")
+    xyz2, rgb2 = F.read_ply_points(tmp_path / "a.ply")
+    assert rgb2 is None and xyz2.tolist() == [[0, 1, 2], [3, 4, 5], [6, 7, 8]]
+
+
+def test_skeleton_outputs(tmp_path):
+    b0 = BranchSkeleton(0, -1, torch.rand(4, 3), torch.rand(4, 1))
+    b1 = BranchSkeleton(1, 0, torch.rand(3, 3), torch.rand(3, 1))
+    b1.radii = b1.radii.reshape(-1)  # smoothed branches carry 1-D radii (tree.py:130-134)
+    sk = DisjointTreeSkeleton([TreeSkeleton(0, {0: b0, 1: b1})])
+    F.save_skeleton_npz(tmp_path / "s.npz", sk)
+    z = np.load(tmp_path / "s.npz")
+    assert z["branches"].tolist() == [[0, 0, -1, 0, 4], [0, 1, 0, 4, 3]] and z["xyz"].shape == (7, 3)
+    F.write_ply_skeleton(tmp_path / "s.ply", sk)
+    head = (tmp_path / "s.ply").read_bytes().split(b"end_header")[0].decode()
+    assert "element vertex 7" in head and "element edge 5" in head
+
+
+def test_cli_overrides():
+    cfg = cli.load_config(["+path=tree.npz", "pipeline.skeletonizer.K=8", "pipeline.repair_skeletons=False"])
+    assert cfg["path"] == "tree.npz" and cfg["pipeline"]["skeletonizer"]["K"] == 8
+    assert cfg["pipeline"]["repair_skeletons"] is False and cfg["pipeline"]["model_inference"]["block_size"] == 4
