@@ -218,34 +218,31 @@ class DeviceSkeleton(DisjointTreeSkeleton):
                                      _lib.ptr(depth), int(pr is not None), pr[0] if pr else 0.0, pr[1] if pr else 0.0,
                                      int("repair" in self._ops), int("smooth" in self._ops), self._ops.get("smooth", 0),
                                      _lib.stream(dev)))
-        # two copies (geometry, branch table), then views: torch.split builds every slice in one C++ call
-        geom = torch.cat((xyz, rad_out.unsqueeze(1)), dim=1).cpu()
-        table = torch.stack((parent, start, length, keep.int(), repaired.int(), smoothed.int()), dim=1).cpu()
+        # two copies (geometry, branch table); torch.split then builds every per-branch view in one C++ call
+        xyz_h, rad_h = xyz.cpu(), rad_out.cpu()
+        rows = torch.stack((parent, start, length, keep.int(), repaired.int(), smoothed.int()), dim=1).cpu().tolist()
         offs = tree_off.cpu().tolist()
-        rep = table[:, 4]
-        first = (table[:, 1] + 1 - rep).tolist()
-        count = (table[:, 2] + rep).tolist()
-        # slots are laid out back to back: [start_b + 1 - rep_b, start_b + 1 + len_b) with one unused slot when not repaired
+        # slots are laid out back to back: [start_b + 1 - rep_b, start_b + 1 + len_b), plus one unused slot when not repaired
         sizes = []
-        for b in range(B):
-            if not table[b, 4]:
-                sizes.append(1)  # the reserved, unused slot
-            sizes.append(count[b])
-        pieces = iter(torch.split(geom, sizes))
-        rows = table.tolist()
+        for _, _, ln, _, rp, _ in rows:
+            if not rp:
+                sizes.append(1)
+            sizes.append(ln + rp)
+        xyz_pieces = iter(xyz_h.split(sizes))
+        rad1 = iter(rad_h.split(sizes))                # smooth flattens radii to 1-D (tree.py:130-134)
+        rad2 = iter(rad_h.unsqueeze(1).split(sizes))   # everything else keeps [n,1]
+        new, fill = BranchSkeleton.__new__, dict.update
         trees = []
         for t in range(T):
             branches = {}
             for b in range(offs[t], offs[t + 1]):
-                par, st, ln, kp, rp, sm = rows[b]
+                par, _, _, kp, rp, sm = rows[b]
                 if not rp:
-                    next(pieces)
-                g = next(pieces)
-                if not kp:
-                    continue
-                obj = BranchSkeleton.__new__(BranchSkeleton)
-                # smooth flattens radii to 1-D (tree.py:130-134)
-                obj.__dict__.update(_id=b - offs[t], parent_id=par, xyz=g[:, :3], radii=g[:, 3] if sm else g[:, 3:4], child_id=None)
-                branches[b - offs[t]] = obj
+                    next(xyz_pieces), next(rad1), next(rad2)
+                gx, r1, r2 = next(xyz_pieces), next(rad1), next(rad2)
+                if kp:
+                    obj = new(BranchSkeleton)
+                    fill(obj.__dict__, _id=b - offs[t], parent_id=par, xyz=gx, radii=r1 if sm else r2, child_id=None)
+                    branches[b - offs[t]] = obj
             trees.append(TreeSkeleton(t, branches))
         return trees

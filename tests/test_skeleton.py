@@ -137,3 +137,45 @@ def test_skeletonizer_empty_cloud(backend):
     assert sk.forward(empty).skeletons == []
     few = Cloud(xyz=torch.rand((10, 3), device=backend), medial_vector=torch.rand((10, 3), device=backend) * 0.01)
     assert sk.forward(few).skeletons == []
+
+
+def test_sample_tree_reference_signature(backend):
+    """skeleton/path.py sample_tree(medial_pts, medial_radii, preds, distances, all_points) on one component."""
+    from smart_tree_amd.skeleton.path import sample_tree
+
+    pts, mv = _tree(n=2000, seed=12)
+    ref = so.skeletonize(pts, mv)
+    comp = ref.components[0]
+    kept = np.nonzero(ref.keep_mask)[0]
+    medial = (pts + mv)[kept][comp.vertex_ids]
+    radius = np.sqrt(((mv * mv)[:, 0] + (mv * mv)[:, 1]) + (mv * mv)[:, 2]).astype(np.float32)[kept][comp.vertex_ids]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(backend)
+    got = sample_tree(t(medial), t(radius).unsqueeze(1), t(comp.preds), t(comp.tree_dist), t(medial),
+                      block_threads=128 if backend.type == "cpu" else 0)
+    assert list(got) == [b.branch_id for b in comp.branches]
+    for b in comp.branches:
+        assert got[b.branch_id].parent_id == b.parent_id
+        np.testing.assert_array_equal(got[b.branch_id].xyz.numpy(), medial[b.verts])
+        np.testing.assert_array_equal(got[b.branch_id].radii.numpy()[:, 0], radius[b.verts])
+
+
+def test_shortest_paths_reference_signature(backend):
+    """skeleton/shortest_path.py shortest_paths(root, edges, edge_weights) vs the oracle's float32 Dijkstra."""
+    from smart_tree_amd.skeleton.shortest_path import shortest_paths
+
+    rng = np.random.RandomState(3)
+    n = 400
+    pts = rng.rand(n, 3).astype(np.float32)
+    idx, dist = so.knn(pts, pts, 8, 0.5)
+    src = np.repeat(np.arange(n), 8)
+    ok = (idx.reshape(-1) >= 0) & (idx.reshape(-1) != src)
+    edges = np.stack([src[ok], idx.reshape(-1)[ok]], axis=1).astype(np.int64)
+    w = dist.reshape(-1)[ok].astype(np.float32)
+    root = 17
+    ref_d, ref_p = so.sssp(n, edges, w, root)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(backend)
+    verts, preds, d = shortest_paths(root, t(edges), t(w), points=t(pts))
+    np.testing.assert_array_equal(verts.cpu().numpy(), np.arange(n))
+    reach = np.isfinite(ref_d)
+    np.testing.assert_array_equal(d.cpu().numpy()[reach], ref_d[reach])
+    np.testing.assert_array_equal(preds.cpu().numpy()[reach], ref_p[reach])
