@@ -152,6 +152,12 @@ __global__ void __launch_bounds__(1024) k_sk_roots(SkArgs A) {
     }
 }
 
+// comp_of[] alone (callers that bring their own predecessors skip the root / SSSP stage)
+__global__ void __launch_bounds__(1024) k_sk_fill_comp_of(SkArgs A) {
+    const int c = blockIdx.x, base = A.comp_off[c], n = A.comp_off[c + 1] - base;
+    for (int v = threadIdx.x; v < n; v += blockDim.x) A.comp_of[base + v] = c;
+}
+
 // ------------------------------------------------------------------------------------ SSSP ---
 // round r: frontier r%2 -> (r+1)%2; counts rotate through cnt[0..2]
 #define SK_LQ 2048  // workgroup-local queue entries staged in LDS before one global reservation
@@ -762,6 +768,7 @@ extern "C" int st_skeleton_components(int n_comp, const int32_t* comp_off, const
         }
         if (stats_host) { stats_host[0] = sssp_rounds; stats_host[1] = round - 2; }
     }
+    if (!(stages & 1)) hipLaunchKernelGGL(k_sk_fill_comp_of, dim3((unsigned)n_comp), dim3((unsigned)block_threads), 0, stream, A);
     if (stages & 2) {
         hipLaunchKernelGGL(k_sk_td_init, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A);
         hipLaunchKernelGGL(k_sk_td_roots, dim3(1), dim3(SK_WIDE_BLOCK), 0, stream, A);
