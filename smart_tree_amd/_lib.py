@@ -109,4 +109,7 @@ def stream(device=None):
 
 
 def workspace(nbytes: int, device) -> torch.Tensor:
-    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+    ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+    if _ALLOW_HOST_POINTERS:
+        ws.fill_(0xCD)  # sanitizer build only: poison scratch so reads of never-written words cannot pass by luck
+    return ws
