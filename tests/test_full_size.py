@@ -96,3 +96,27 @@ def test_config3_dense_canopy_properties():
     for tree in sk.skeletons:
         for b in tree.branches.values():
             assert b.parent_id < b._id and b.xyz.shape[0] == b.radii.shape[0] and torch.isfinite(b.xyz).all()
+
+
+def test_config1_ground_truth_medial_many_components():
+    """The 1M-point tree's voxel representatives with EXACT medial vectors: ~70k graph vertices in dozens of
+    components of very different sizes -- all advanced in lockstep by the skeleton kernels; must equal the oracle."""
+    dev = torch.device("cuda:0")
+    c = sample_tree_cloud(1_000_000, seed=0)
+    vx = vo.voxelize_cloud(vo.centre_cloud(c["xyz"]), c["rgb"], 0.02)
+    m = vx["mask"]
+    pts, mv = vx["feats"][m, :3], c["medial_vector"][vx["point"][m]]
+    ref = so.skeletonize(pts, mv)
+    assert len(ref.components) > 10
+    sk = Skeletonizer(K=16, min_connection_length=0.02, minimum_graph_vertices=32, device=dev)
+    for _ in range(2):  # twice: results must not depend on scheduling
+        out = sk.forward(Cloud(xyz=torch.from_numpy(pts).to(dev), medial_vector=torch.from_numpy(mv).to(dev)))
+        assert len(out.skeletons) == len(ref.components)
+        kept = np.nonzero(ref.keep_mask)[0]
+        medial = (pts + mv)[kept]
+        for tree, rc in zip(out.skeletons, ref.components):
+            assert list(tree.branches) == [b.branch_id for b in rc.branches]
+            for b in rc.branches:
+                g = tree.branches[b.branch_id]
+                assert g.parent_id == b.parent_id
+                np.testing.assert_array_equal(g.xyz.numpy(), medial[rc.vertex_ids[b.verts]])
