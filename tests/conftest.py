@@ -22,7 +22,10 @@ def emu_lib():
 
     from smart_tree_amd import _lib
 
-    return _lib.declare(ctypes.CDLL(str(emu_build.build())))
+    import os
+
+    path = os.environ.get("SMARTTREE_EMU_LIB") or str(emu_build.build())  # sanitize.py points at its ASan/UBSan build
+    return _lib.declare(ctypes.CDLL(path))
 
 
 @pytest.fixture(params=["emu", pytest.param("hip", marks=pytest.mark.gpu)])

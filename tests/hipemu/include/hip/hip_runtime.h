@@ -233,7 +233,7 @@ inline T from_bits(uint64_t u) {
 #define warpSize 64
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
-    hipemu::launch(dim3(grid), dim3(block), [=]() { kernel(__VA_ARGS__); })
+    ((void)(stream), (void)(shmem), hipemu::launch(dim3(grid), dim3(block), [=]() { kernel(__VA_ARGS__); }))
 
 inline void __syncthreads() { hipemu::yield_to_sched(hipemu::AT_BARRIER); }
 inline void __threadfence() {}
