@@ -86,6 +86,7 @@ struct SkArgs {
     int* s_wide;     // this launch's path is long: the chip-wide claim kernel handles it
     const unsigned* order;  // [m] vertices of each component by distance descending (ties: index ascending)
     const float* order_init;  // [m] initial distance of order[j] (<= 0 marks the tail of never-selectable vertices)
+    const int* pos;           // [m] inverse of `order`, component-local position
     // claim grid: workgroup b works for component blk_comp[b], as slice (b - blk_first[c]) of blk_count[c]
     const int* blk_comp;
     const int* blk_first;
@@ -304,8 +305,12 @@ __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_sort_keys(SkArgs A, uint32
     }
 }
 
-__global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_order_init(SkArgs A, float* order_init) {
-    SK_VERTEX_LOOP(j) order_init[j] = A.alloc[A.order[j]];
+__global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_order_init(SkArgs A, float* order_init, int* pos) {
+    SK_VERTEX_LOOP(j) {
+        const unsigned v = A.order[j];
+        order_init[j] = A.alloc[v];
+        pos[v] = (int)(j - A.comp_off[A.comp_of[v]]);
+    }
 }
 
 // Ancestor table: anc[v*SK_ANC + k] = (k+1)-th ancestor of v (component-local id, -1 past the root).
@@ -428,13 +433,16 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
     __shared__ int lpath[SK_LPATH];
     __shared__ float lpx[SK_LPATH], lpy[SK_LPATH], lpz[SK_LPATH], lpr[SK_LPATH];
     __shared__ uint32_t row_off[1025], row_first[1024], s_scan[SK_MAX_WAVES + 1];
+    __shared__ unsigned char win_live[1024];  // candidate window: "still unallocated" flag of order[win_base + lane]
     __shared__ int s_lo[3], s_hi[3];
     __shared__ int s_term;
-    const int c = blockIdx.x, tid = threadIdx.x;
+    const int c = blockIdx.x, tid = threadIdx.x, W = (int)blockDim.x;
     if (A.s_done[c]) return;
     const int base = A.comp_off[c], n = A.comp_off[c + 1] - base;
     const unsigned* order = A.order + base;
+    const int* pos = A.pos + base;
     unsigned* tmp = A.q0 + base;
+    const StGrid* g = A.grid;
     // a long path left over from the previous launch: k_sk_claim filled `touched`
     {
         const int plen = A.s_len[c];
@@ -443,28 +451,39 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
                              A.s_ntouched[c]);
     }
     SK_TICK(0);
-    int cursor = A.s_cursor[c], total = A.s_total[c], nb = A.s_nb[c];  // per-component state lives in registers
+    int win_base = A.s_cursor[c], total = A.s_total[c], nb = A.s_nb[c];  // per-component state lives in registers
+    int wv = -1;         // my window entry: component-local vertex, -1 = none
+    bool wtail = false;  // my entry marks the end of the selectable vertices (initial distance <= 0, or end of the list)
+    bool need_fill = true;
     for (int iter = 0; iter < SK_ITERS_PER_LAUNCH; iter++) {
-        // 1. farthest unallocated vertex: first live entry of the sorted order at or after the cursor
+        // 1. farthest unallocated vertex (path.py:92) = first live entry of the distance-sorted order.  A window
+        //    of W entries is held in registers/LDS; its flags are cleared as points get allocated, so finding the
+        //    next tip costs no global access until the window is used up.
         int far = -1;
         bool exhausted = false;
-        for (; far < 0 && !exhausted; cursor += blockDim.x) {
-            const int j = cursor + tid;
+        while (far < 0 && !exhausted) {
+            if (need_fill) {
+                const int j = win_base + tid;
+                wv = -1; wtail = false;
+                bool live = false;
+                if (j < n) {
+                    wv = (int)order[j] - base;
+                    wtail = !(A.order_init[base + j] > 0.0f);
+                    live = !wtail && ld(&A.alloc[base + wv]) > 0.0f;
+                } else if (j == n) {
+                    wtail = true;
+                }
+                win_live[tid] = live ? 1 : 0;
+                need_fill = false;
+                __syncthreads();
+            }
             unsigned long long k = 0;
-            if (j < n) {
-                const int v = (int)order[j] - base;
-                const bool live = ld(&A.alloc[base + v]) > 0.0f;
-                const bool tail = !(A.order_init[base + j] > 0.0f);  // sorted by INITIAL distance: first non-positive ends the list
-                if (live || tail) k = ((unsigned long long)(0xffffffffu - (unsigned)j) << 32) | (tail ? 0u : (unsigned)v + 1u);
-            } else if (j == n) {
-                k = ((unsigned long long)(0xffffffffu - (unsigned)j) << 32);  // end of the component
-            }
+            if (wtail) k = ((unsigned long long)(0xffffffffu - (unsigned)tid) << 32);
+            else if (win_live[tid]) k = ((unsigned long long)(0xffffffffu - (unsigned)tid) << 32) | ((unsigned)wv + 1u);
             k = block_max_u64(k, s_red);
-            if (k != 0ull) {
-                const unsigned lowv = (unsigned)(k & 0xffffffffu);
-                if (lowv == 0u) exhausted = true;
-                else { far = (int)lowv - 1; cursor = (int)(0xffffffffu - (unsigned)(k >> 32)) + 1 - (int)blockDim.x; }
-            }
+            if (k == 0ull) { win_base += W; need_fill = true; continue; }  // nothing left in this window
+            const unsigned lowv = (unsigned)(k & 0xffffffffu);
+            if (lowv == 0u) exhausted = true; else far = (int)lowv - 1;
         }
         SK_TICK(1);
         if (far < 0) {  // path.py:94-95 (uniform)
@@ -489,42 +508,46 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
                 if (tid == 0) s_term = (int)(unsigned)(k & 0xffffffffu) - 1;
             }
         }
+        if (tid < 3) { s_lo[tid] = 0x7fffffff; s_hi[tid] = (int)0x80000000; }
         __syncthreads();
         SK_TICK(2);
-        // 3. path root side first (global: it is an output); r = max radius on the path (path.py:31)
+        // 3. one pass over the path: output (root side first), radius maximum (path.py:31), and -- when it fits --
+        //    coordinates / radii / cell bounding box into LDS for the claim below.  The parent lookup rides along:
+        //    it is read BEFORE this branch stamps anything (path.py:128-136); termination -1 reads
+        //    branch_ids[-1] = the last vertex (quirk kept).
+        const bool keep = len >= 2;  // path.py:125-126: shorter paths still consume their points
+        int parent = -1;
+        if (tid == 0 && keep) parent = ld(&A.branch_of[base + (s_term < 0 ? n - 1 : s_term)]);
         int* path_out = A.path_verts + base + total;
+        const bool fits = len <= SK_LPATH;
         unsigned long long rk = 0;
         for (int qi = tid; qi < len; qi += blockDim.x) {
             const int w = len - 1 - qi;  // walk order -> root side first
             const int v = w < SK_LPATH ? lpath[w] : (int)ld(&tmp[w]);
             path_out[qi] = v;
-            const unsigned long long k = (unsigned long long)st_f2ord(A.rad[base + v]) << 32;
+            const float r = A.rad[base + v];
+            const unsigned long long k = (unsigned long long)st_f2ord(r) << 32;
             rk = k > rk ? k : rk;
+            if (fits) {
+                const float* pv = A.pts + 3 * (int64_t)(base + v);
+                const float x = pv[0], y = pv[1], z = pv[2];
+                lpx[qi] = x; lpy[qi] = y; lpz[qi] = z; lpr[qi] = r;
+                const int cx = (int)floorf((x - g->lo[0]) / g->cell), cy = (int)floorf((y - g->lo[1]) / g->cell),
+                          cz = (int)floorf((z - g->lo[2]) / g->cell);
+                atomicMin(&s_lo[0], cx); atomicMin(&s_lo[1], cy); atomicMin(&s_lo[2], cz);
+                atomicMax(&s_hi[0], cx); atomicMax(&s_hi[1], cy); atomicMax(&s_hi[2], cz);
+            }
         }
-        rk = block_max_u64(rk, s_red);
+        rk = block_max_u64(rk, s_red);  // (its barriers also publish lp*, s_lo / s_hi)
         const float rp = st_ord2f((unsigned)(rk >> 32)), rp2 = rp * rp;
-        const StGrid* g = A.grid;
         int reach = rp > 0.0f ? (int)ceilf(rp / g->cell) : 0;
         if (reach < 1) reach = 1;
         // 4. can this workgroup claim the path's points itself?  Point-centric form of select_path_points
         //    (path.py:19-46): the candidates are the points of the grid cells around the path; each one
         //    finds ITS nearest path vertex from LDS -- no atomics, no candidate list.
-        bool small = len <= SK_LPATH;
+        bool small = fits;
         int nrows_s = 0, ncand = 0;
         if (small) {
-            if (tid < 3) { s_lo[tid] = 0x7fffffff; s_hi[tid] = (int)0x80000000; }
-            __syncthreads();
-            for (int qi = tid; qi < len; qi += blockDim.x) {  // path vertex coordinates / radii into LDS (root side first)
-                const int v = lpath[len - 1 - qi];
-                const float* pv = A.pts + 3 * (int64_t)(base + v);
-                lpx[qi] = pv[0]; lpy[qi] = pv[1]; lpz[qi] = pv[2];
-                lpr[qi] = A.rad[base + v];
-                const int cx = (int)floorf((pv[0] - g->lo[0]) / g->cell), cy = (int)floorf((pv[1] - g->lo[1]) / g->cell),
-                          cz = (int)floorf((pv[2] - g->lo[2]) / g->cell);
-                atomicMin(&s_lo[0], cx); atomicMin(&s_lo[1], cy); atomicMin(&s_lo[2], cz);
-                atomicMax(&s_hi[0], cx); atomicMax(&s_hi[1], cy); atomicMax(&s_hi[2], cz);
-            }
-            __syncthreads();
             const int x0 = st_max(s_lo[0] - reach, 0), x1 = st_min(s_hi[0] + reach, g->dim[0] - 1);
             const int y0 = st_max(s_lo[1] - reach, 0), y1 = st_min(s_hi[1] + reach, g->dim[1] - 1);
             const int z0 = st_max(s_lo[2] - reach, 0), z1 = st_min(s_hi[2] + reach, g->dim[2] - 1);
@@ -546,12 +569,9 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
             __syncthreads();
             nrows_s = nrows;
         }
-        const bool keep = len >= 2;  // path.py:125-126: shorter paths still consume their points
         const int id = keep ? nb : -1;
         if (tid == 0 && keep) {
-            // parent id is read BEFORE this branch stamps anything (path.py:128-136);
-            // termination -1 reads branch_ids[-1] = the last vertex (quirk kept)
-            A.branch_parent[base + nb] = ld(&A.branch_of[base + (s_term < 0 ? n - 1 : s_term)]);
+            A.branch_parent[base + nb] = parent;
             A.branch_off[base + nb] = total;
             A.branch_len[base + nb] = len;
         }
@@ -562,11 +582,10 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
         if (!small) {  // hand the path to k_sk_claim; its points are finished at the next launch (uniform)
             if (tid == 0) {
                 A.s_len[c] = len; A.s_rp[c] = rp; A.s_ntouched[c] = 0u; A.s_cur_off[c] = cur_off; A.s_cur_id[c] = id;
-                A.s_wide[c] = 1; A.s_cursor[c] = cursor; A.s_total[c] = total; A.s_nb[c] = nb;
+                A.s_wide[c] = 1; A.s_cursor[c] = win_base; A.s_total[c] = total; A.s_nb[c] = nb;
             }
             return;
         }
-        __syncthreads();  // the parent lookup above must see the stamps of earlier branches only
         for (int t = tid; t < ncand; t += blockDim.x) {
             int lo = 0, hi = nrows_s;  // row r with row_off[r] <= t < row_off[r+1]
             while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (row_off[mid] <= (uint32_t)t) lo = mid; else hi = mid; }
@@ -588,6 +607,8 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
                 A.alloc[base + p] = -1.0f;
                 A.term[base + p] = 1u;
                 if (id >= 0) A.branch_of[base + p] = id;
+                const unsigned q = (unsigned)(pos[p] - win_base);
+                if (q < (unsigned)W) win_live[q] = 0;
             }
         }
         for (int qi = tid; qi < len; qi += blockDim.x) {  // path.py:112-113,135
@@ -595,11 +616,13 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
             A.alloc[base + v] = -1.0f;
             A.term[base + v] = 1u;
             if (id >= 0) A.branch_of[base + v] = id;
+            const unsigned q = (unsigned)(pos[v] - win_base);
+            if (q < (unsigned)W) win_live[q] = 0;
         }
         __syncthreads();
         SK_TICK(4);
     }
-    if (tid == 0) { A.s_len[c] = 0; A.s_wide[c] = 0; A.s_cursor[c] = cursor; A.s_total[c] = total; A.s_nb[c] = nb; }
+    if (tid == 0) { A.s_len[c] = 0; A.s_wide[c] = 0; A.s_cursor[c] = win_base; A.s_total[c] = total; A.s_nb[c] = nb; }
 }
 
 __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_claim(SkArgs A) {
@@ -619,7 +642,7 @@ __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_claim(SkArgs A) {
 struct SkLayout {
     unsigned *dist_ord, *stamp, *q0, *q1, *term, *touched, *cnt, *s_ntouched, *sort_keys, *order;
     float *alloc, *s_rp, *order_init;
-    int *s_cursor, *s_wide;
+    int *s_cursor, *s_wide, *pos;
     char* sort_ws;
     int64_t sort_bytes;
     unsigned long long* best;
@@ -656,6 +679,7 @@ static void sk_layout(StArena& a, int64_t m, int64_t C, SkLayout* s) {
     s->sort_keys = a.take<unsigned>(m);
     s->order = a.take<unsigned>(m);
     s->order_init = a.take<float>(m);
+    s->pos = a.take<int>(m);
     s->sort_bytes = st_sort_ws_bytes(m);
     s->sort_ws = a.take<char>(s->sort_bytes);
     s->blk_first = a.take<int>(C);
@@ -736,7 +760,7 @@ extern "C" int st_skeleton_components(int n_comp, const int32_t* comp_off, const
     A.s_done = s.s_done; A.s_len = s.s_len; A.s_cur_id = s.s_cur_id; A.s_cur_off = s.s_cur_off; A.s_nb = s.s_nb;
     A.s_total = s.s_total; A.s_rp = s.s_rp; A.s_ntouched = s.s_ntouched;
     A.blk_comp = s.blk_comp; A.blk_first = s.blk_first; A.blk_count = s.blk_count;
-    A.s_cursor = s.s_cursor; A.s_wide = s.s_wide; A.order = s.order; A.order_init = s.order_init;
+    A.s_cursor = s.s_cursor; A.s_wide = s.s_wide; A.order = s.order; A.order_init = s.order_init; A.pos = s.pos;
     A.ticks = g_debug_ticks;
 
     const unsigned vg = sk_vgrid(m);
@@ -812,7 +836,7 @@ extern "C" int st_skeleton_components(int n_comp, const int32_t* comp_off, const
             hipLaunchKernelGGL(k_sk_sort_keys, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A, s.sort_keys, s.order, 1);
             ST_TRY(st_radix_sort_pairs_u32(s.sort_keys, s.order, m, bits, s.sort_ws, s.sort_bytes, stream));
         }
-        hipLaunchKernelGGL(k_sk_order_init, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A, s.order_init);
+        hipLaunchKernelGGL(k_sk_order_init, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A, s.order_init, s.pos);
         int64_t iters = 0;
         hipEvent_t ev[32];
         if (time_select) for (int i = 0; i < 32; i++) (void)hipEventCreate(&ev[i]);
