@@ -91,6 +91,11 @@ struct SkArgs {
     const int* blk_comp;
     const int* blk_first;
     const int* blk_count;
+    float prune_factor;  // select: an entry within prune_factor x radius of an earlier chosen tip gets no wavefront
+    int small_work;      // select: candidate points x path vertices one workgroup takes on itself (beyond: k_sk_claim)
+    int iters_per_launch;
+    int wave_work;       // select: candidate points x path vertices of one speculative branch (beyond: whole workgroup)
+    int local_items;     // select: (path vertex, cell row) pairs one workgroup claims path-centric by itself
     long long* ticks;  // optional developer aid: per-phase wall_clock64 sums of k_sk_select (st_debug_set_ticks)
 };
 
@@ -98,6 +103,8 @@ struct SkArgs {
 template <class T>
 __device__ __forceinline__ T ld(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float ld(const float* p) { return __uint_as_float(ld((const unsigned*)p)); }
+// workgroup-scope load: may be served by this CU's L1 / this XCD's L2
+__device__ __forceinline__ unsigned ld_wg(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 // workgroup-wide max of a 64-bit key; every thread must call; lds needs SK_MAX_WAVES words
 __device__ __forceinline__ unsigned long long block_max_u64(unsigned long long v, unsigned long long* lds) {
@@ -292,6 +299,7 @@ __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_lift_init(SkArgs A, const 
         A.term[v] = 0u;
         A.branch_of[v] = -1;
         A.best[v] = SK_EMPTY64;
+        A.stamp[v] = 0u;  // speculation marks of k_sk_select
     }
     if (blockIdx.x == 0)
         for (int c = threadIdx.x; c < A.C; c += blockDim.x) { A.s_done[c] = 0; A.s_nb[c] = 0; A.s_total[c] = 0; A.s_len[c] = 0; A.s_cursor[c] = 0; A.s_wide[c] = 0; }
@@ -398,7 +406,7 @@ __device__ __forceinline__ bool sk_claim_items(const SkArgs& A, int c, int base,
 // nothing is ever re-scanned), trace its route through the ancestor table, record the branch; a
 // short path is claimed and finished right here (state, path and touched list stay in LDS), a long
 // one is left to the chip-wide k_sk_claim and finished at the head of the next launch.
-#define SK_SMALL_WORK (4 << 20)  // candidate points x path vertices one workgroup takes on itself
+#define SK_SMALL_WORK (1 << 18)  // candidate points x path vertices one workgroup takes on itself
 #define SK_ITERS_PER_LAUNCH 32
 #define SK_LPATH 1024
 
@@ -426,22 +434,93 @@ __device__ __forceinline__ void sk_finish_branch(const SkArgs& A, int base, int 
     __syncthreads();  // stores drained (vmcnt) before anyone re-reads through L2
 }
 
-#define SK_TICK(i) do { if (A.ticks && tid == 0) { const long long now_ = wall_clock64(); A.ticks[i] += now_ - t_last; t_last = now_; } } while (0)
+#define SK_TICK(i) do { if (A.ticks && tid == 0) { const long long now_ = wall_clock64(); tk[i] += now_ - t_last; t_last = now_; } } while (0)
+#define SK_TICK_FLUSH() do { if (A.ticks && tid == 0) for (int i_ = 0; i_ < 8; i_++) A.ticks[i_] += tk[i_]; } while (0)
+
+// ---- wavefront helpers (all 64 lanes must call) ----
+__device__ __forceinline__ float wave_readlane_f(float v, int src) { return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), src)); }
+__device__ __forceinline__ int wave_min_i(int v) { for (int d = 32; d > 0; d >>= 1) { const int o = __shfl_xor(v, d); v = o < v ? o : v; } return v; }
+__device__ __forceinline__ int wave_max_i(int v) { for (int d = 32; d > 0; d >>= 1) { const int o = __shfl_xor(v, d); v = o > v ? o : v; } return v; }
+__device__ __forceinline__ unsigned wave_max_u(unsigned v) { for (int d = 32; d > 0; d >>= 1) { const unsigned o = __shfl_xor(v, d); v = o > v ? o : v; } return v; }
+__device__ __forceinline__ unsigned wave_or_u(unsigned v) { for (int d = 32; d > 0; d >>= 1) v |= __shfl_xor(v, d); return v; }
+__device__ __forceinline__ unsigned wave_incl_scan_u(unsigned v, int lane) {
+    for (int d = 1; d < 64; d <<= 1) { const unsigned o = __shfl_up(v, (unsigned)d); if (lane >= d) v += o; }
+    return v;
+}
+
+// LDS of k_sk_select.  Two modes share the space: `one` = a single branch worked on by the whole workgroup
+// (paths up to SK_LPATH vertices), `slot[]` = one speculative branch per wavefront (short paths).
+#define SK_WSLOTS 16   // = SK_MAX_WAVES
+#define SK_WENT 32     // window entries looked at per round (those predicted to be swallowed get no slot)
+#define SK_WPATH 64    // a speculative walk is ONE row of the ancestor table
+#define SK_WROWS 128   // (x, y) cell rows around a speculative path: two per lane
+#define SK_WAVE_WORK (1 << 20)  // candidate points x path vertices per speculative branch
+#define SK_WAVE_CAND 16384
+#define SK_ROUND_ITEMS 32       // candidates per thread and round
+#define SK_CL_KEEP 4            // claimed points a thread remembers in LDS; further ones are found again through a bit mask
+struct SkSelOne {
+    int lpath[SK_LPATH];
+    float lpx[SK_LPATH], lpy[SK_LPATH], lpz[SK_LPATH], lpr[SK_LPATH];
+    uint32_t row_off[1025], row_first[1024];
+};
+struct SkSelSlot {
+    int path[SK_WPATH];  // root side first
+    float x[SK_WPATH], y[SK_WPATH], z[SK_WPATH], r[SK_WPATH];
+    uint32_t row_off[SK_WROWS + 1], row_first[SK_WROWS];
+    int lo[3], hi[3];  // cell bounding box of the path (LDS min / max)
+    unsigned rk;       // ordered bits of the largest radius
+};
+union SkSelLds {
+    SkSelOne one;
+    SkSelSlot slot[SK_WSLOTS];
+};
+
+// row r with row_off[r] <= t < row_off[r+1]
+__device__ __forceinline__ int sk_find_row(const uint32_t* row_off, int nrows, uint32_t t) {
+    int lo = 0, hi = nrows;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (row_off[mid] <= t) lo = mid; else hi = mid; }
+    return lo;
+}
+
+// select: one workgroup per component.  sample_tree (path.py:49-140) is a sequential greedy loop -- take the
+// farthest unallocated vertex, walk to the skeleton, claim the points within the path's radius -- but
+// branches far apart do not interact, so each ROUND speculates: wavefront s takes the s-th farthest
+// unallocated vertex, walks it and marks (bit s of cmask[]) every point its branch would allocate, all
+// against the state at the start of the round.  A scan in order then replays the sequential semantics from
+// the marks: a tip already marked by an accepted earlier slot would never have been selected (skipped); a
+// walk (or the vertex the parent id is read from) touched by an accepted earlier slot would have come out
+// differently -- the round stops there and the rest is retried next round; everything else is exactly what the
+// sequential loop produces and is committed (ids / offsets by prefix over the accepted slots;
+// branch_of = max id = last writer).  Slot 0 is always accepted, so every round makes progress.  A path
+// too long for one wavefront is worked on by the whole workgroup (`one` mode); one too long even for that
+// is handed to the chip-wide k_sk_claim and finished at the head of the next launch.
 __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
     long long t_last = A.ticks ? wall_clock64() : 0;
+    long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     __shared__ unsigned long long s_red[SK_MAX_WAVES];
-    __shared__ int lpath[SK_LPATH];
-    __shared__ float lpx[SK_LPATH], lpy[SK_LPATH], lpz[SK_LPATH], lpr[SK_LPATH];
-    __shared__ uint32_t row_off[1025], row_first[1024], s_scan[SK_MAX_WAVES + 1];
+    __shared__ SkSelLds L;
+    __shared__ unsigned cl_list[SK_CL_KEEP][1024];  // claimed points of this round, SK_CL_KEEP private entries per thread
+    __shared__ uint32_t s_scan[SK_MAX_WAVES + 1];
     __shared__ unsigned char win_live[1024];  // candidate window: "still unallocated" flag of order[win_base + lane]
     __shared__ int s_lo[3], s_hi[3];
     __shared__ int s_term;
+    __shared__ int w_cnt[SK_WSLOTS], w_tail[SK_WSLOTS], cand_v[SK_WENT];  // the round's entries: first live window vertices
+    __shared__ float4 cand_p[SK_WENT];
+    __shared__ int sl_ent[SK_WSLOTS], s_nb2, s_tot2;
+    __shared__ unsigned s_alive;
+    __shared__ int sl_len[SK_WSLOTS], sl_term[SK_WSLOTS], sl_parent[SK_WSLOTS], sl_nrows[SK_WSLOTS], sl_ncand[SK_WSLOTS],
+        sl_big[SK_WSLOTS], sl_id[SK_WSLOTS], sl_off[SK_WSLOTS];
+    __shared__ float sl_rp[SK_WSLOTS];
+    __shared__ unsigned sl_walkm[SK_WSLOTS];
     const int c = blockIdx.x, tid = threadIdx.x, W = (int)blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, nw = (W + 63) >> 6;
     if (A.s_done[c]) return;
     const int base = A.comp_off[c], n = A.comp_off[c + 1] - base;
     const unsigned* order = A.order + base;
     const int* pos = A.pos + base;
     unsigned* tmp = A.q0 + base;
+    unsigned* cmask = A.stamp + base;  // speculation marks (zeroed by k_sk_lift_init, zero again after every round)
+    const float4* __restrict__ recs = A.recs;
     const StGrid* g = A.grid;
     // a long path left over from the previous launch: k_sk_claim filled `touched`
     {
@@ -453,15 +532,16 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
     SK_TICK(0);
     int win_base = A.s_cursor[c], total = A.s_total[c], nb = A.s_nb[c];  // per-component state lives in registers
     int wv = -1;         // my window entry: component-local vertex, -1 = none
+    float wx = 0.0f, wy = 0.0f, wz = 0.0f, wr = 0.0f;  // ... its position and radius (for step 1b)
     bool wtail = false;  // my entry marks the end of the selectable vertices (initial distance <= 0, or end of the list)
     bool need_fill = true;
-    for (int iter = 0; iter < SK_ITERS_PER_LAUNCH; iter++) {
-        // 1. farthest unallocated vertex (path.py:92) = first live entry of the distance-sorted order.  A window
-        //    of W entries is held in registers/LDS; its flags are cleared as points get allocated, so finding the
-        //    next tip costs no global access until the window is used up.
-        int far = -1;
+    for (int iter = 0; iter < A.iters_per_launch; iter++) {
+        // 1. the farthest unallocated vertices (path.py:92) = the first live entries of the distance-sorted order.
+        //    A window of W entries is held in registers / LDS; its flags are cleared as points get allocated, so
+        //    finding the next tips costs no global access until the window is used up.
+        int nc = 0, ne = 0;
         bool exhausted = false;
-        while (far < 0 && !exhausted) {
+        for (;;) {
             if (need_fill) {
                 const int j = win_base + tid;
                 wv = -1; wtail = false;
@@ -470,6 +550,10 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
                     wv = (int)order[j] - base;
                     wtail = !(A.order_init[base + j] > 0.0f);
                     live = !wtail && ld(&A.alloc[base + wv]) > 0.0f;
+                    if (live) {
+                        const float* pv = A.pts + 3 * (int64_t)(base + wv);
+                        wx = pv[0]; wy = pv[1]; wz = pv[2]; wr = A.rad[base + wv];
+                    }
                 } else if (j == n) {
                     wtail = true;
                 }
@@ -477,30 +561,325 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
                 need_fill = false;
                 __syncthreads();
             }
-            unsigned long long k = 0;
-            if (wtail) k = ((unsigned long long)(0xffffffffu - (unsigned)tid) << 32);
-            else if (win_live[tid]) k = ((unsigned long long)(0xffffffffu - (unsigned)tid) << 32) | ((unsigned)wv + 1u);
-            k = block_max_u64(k, s_red);
-            if (k == 0ull) { win_base += W; need_fill = true; continue; }  // nothing left in this window
-            const unsigned lowv = (unsigned)(k & 0xffffffffu);
-            if (lowv == 0u) exhausted = true; else far = (int)lowv - 1;
+            const bool live = win_live[tid] != 0;
+            const unsigned long long lb = __ballot(live), tb = __ballot(wtail);
+            if (lane == 0) { w_cnt[wave] = __popcll(lb); w_tail[wave] = tb != 0ull; }
+            __syncthreads();
+            int before = 0, tot = 0, anytail = 0;
+            for (int w = 0; w < nw; w++) { const int k = w_cnt[w]; before += w < wave ? k : 0; tot += k; anytail |= w_tail[w]; }
+            if (tot == 0) {
+                if (anytail) { exhausted = true; break; }
+                win_base += W; need_fill = true;  // nothing left in this window
+                __syncthreads();
+                continue;
+            }
+            const int rank = before + __popcll(lb & ((1ull << lane) - 1ull));
+            if (live && rank < SK_WENT) { cand_v[rank] = wv; cand_p[rank] = make_float4(wx, wy, wz, wr); }
+            ne = tot < SK_WENT ? tot : SK_WENT;
+            __syncthreads();
+            break;
         }
-        SK_TICK(1);
-        if (far < 0) {  // path.py:94-95 (uniform)
+        if (exhausted) {  // path.py:94-95 (uniform)
             if (tid == 0) {
                 A.s_done[c] = 1; A.s_len[c] = 0; A.s_wide[c] = 0; A.n_branches[c] = nb; A.s_nb[c] = nb; A.s_total[c] = total;
                 atomicAdd(&A.cnt[5], 1u);
             }
+            SK_TICK_FLUSH();
             return;
         }
-        // 2. trace_route (path.py:9-16): lane j inspects the j-th ancestor; the first allocated one
-        //    (or the step past the root) ends the walk
+        SK_TICK(7);
+        // 1b. which entries get a wavefront?  A tip within the radius of an earlier chosen tip will almost surely
+        //     be swallowed by that branch: it gets no slot (if the guess is wrong the replay below simply stops
+        //     there).  Every wavefront runs this little greedy pass itself -- no barrier, no LDS.
+        int my_slot = -1;  // lane e < ne: slot of entry e (-1: none)
+        int my_ent = 0;    // the entry this wavefront speculates on (wave < nc)
+        int ent_v = -1;
+        {
+            float ex = 0.0f, ey = 0.0f, ez = 0.0f, er = 0.0f;
+            if (lane < ne) {
+                ent_v = cand_v[lane];
+                const float4 e4 = cand_p[lane];
+                ex = e4.x; ey = e4.y; ez = e4.z; er = e4.w * A.prune_factor;
+            }
+            int shadowed = 0, chosen = 0;
+            for (int u = 0; u < ne; u++) {
+                if (__builtin_amdgcn_readlane(shadowed, u)) continue;
+                if (chosen == nw) { ne = u; break; }  // out of wavefronts: the round ends before this entry
+                chosen++;
+                const float ux = wave_readlane_f(ex, u), uy = wave_readlane_f(ey, u), uz = wave_readlane_f(ez, u),
+                            ur = wave_readlane_f(er, u);
+                const float dx = ex - ux, dy = ey - uy, dz = ez - uz;
+                if (lane > u && dx * dx + dy * dy + dz * dz < ur * ur) shadowed = 1;
+            }
+            const unsigned long long cb = __ballot(lane < ne && !shadowed);
+            nc = __popcll(cb);
+            if (lane < ne && !shadowed) my_slot = __popcll(cb & ((1ull << lane) - 1ull));
+            unsigned long long rest = cb;
+            for (int k = 0; k < wave && rest; k++) rest &= rest - 1ull;
+            my_ent = rest ? __ffsll(rest) - 1 : 0;
+        }
+        SK_TICK(1);
+        // 2. speculative walks: wavefront s traces its entry through ONE ancestor-table row (trace_route,
+        //    path.py:9-16: lane j inspects the j-th ancestor; the first allocated one, or the step past the root,
+        //    ends the walk), then gathers radius / position of its path, the (x, y) rows of grid cells around it
+        //    and how many candidate points they hold.
+        if (wave < nc) {
+            SkSelSlot& S = L.slot[wave];
+            const int tip = cand_v[my_ent];
+            const int node = lane == 0 ? tip : A.anc[(int64_t)(base + tip) * SK_ANC + lane - 1];
+            const bool end = node < 0 || ld(&A.term[base + node]) != 0u;
+            const unsigned long long eb = __ballot(end);
+            int big = eb == 0ull, len = 0, termv = -1, nrows = 0, ncand = 0, parent = -1;
+            float rp = 0.0f;
+            if (!big) {
+                len = __ffsll(eb) - 1;
+                termv = __shfl(node, len);
+                const int qi = len - 1 - lane;  // walk order -> root side first
+                if (lane < 3) { S.lo[lane] = 0x7fffffff; S.hi[lane] = (int)0x80000000; }
+                if (lane == 3) S.rk = 0u;
+                __builtin_amdgcn_wave_barrier();
+                // the parent id is read BEFORE anything is stamped (path.py:128-136); termination -1 reads
+                // branch_ids[-1] = the last vertex (quirk kept)
+                if (lane == 0 && len >= 2) parent = ld(&A.branch_of[base + (termv < 0 ? n - 1 : termv)]);
+                if (lane < len) {
+                    const float r = A.rad[base + node];
+                    const float* pv = A.pts + 3 * (int64_t)(base + node);
+                    const float x = pv[0], y = pv[1], z = pv[2];
+                    S.path[qi] = node; S.x[qi] = x; S.y[qi] = y; S.z[qi] = z; S.r[qi] = r;
+                    const int cx = (int)floorf((x - g->lo[0]) / g->cell), cy = (int)floorf((y - g->lo[1]) / g->cell),
+                              cz = (int)floorf((z - g->lo[2]) / g->cell);
+                    atomicMax(&S.rk, st_f2ord(r));  // path.py:31
+                    atomicMin(&S.lo[0], cx); atomicMin(&S.lo[1], cy); atomicMin(&S.lo[2], cz);
+                    atomicMax(&S.hi[0], cx); atomicMax(&S.hi[1], cy); atomicMax(&S.hi[2], cz);
+                }
+                __builtin_amdgcn_wave_barrier();
+                rp = st_ord2f(S.rk);
+                int reach = rp > 0.0f ? (int)ceilf(rp / g->cell) : 0;
+                if (reach < 1) reach = 1;
+                const int x0 = st_max(S.lo[0] - reach, 0), x1 = st_min(S.hi[0] + reach, g->dim[0] - 1);
+                const int y0 = st_max(S.lo[1] - reach, 0), y1 = st_min(S.hi[1] + reach, g->dim[1] - 1);
+                const int z0 = st_max(S.lo[2] - reach, 0), z1 = st_min(S.hi[2] + reach, g->dim[2] - 1);
+                const int nx = x1 - x0 + 1, ny = y1 - y0 + 1;
+                nrows = (nx > 0 && ny > 0 && z0 <= z1) ? nx * ny : 0;
+                big = nrows > SK_WROWS;
+                if (!big) {
+                    uint32_t cnt0 = 0, first0 = 0, cnt1 = 0, first1 = 0;
+                    if (lane < nrows) {
+                        const int64_t row = ((int64_t)(x0 + lane / ny) * g->dim[1] + (y0 + lane % ny)) * g->dim[2];
+                        first0 = A.cell_start[row + z0];
+                        cnt0 = A.cell_start[row + z1 + 1] - first0;
+                    }
+                    if (lane + 64 < nrows) {
+                        const int r1 = lane + 64;
+                        const int64_t row = ((int64_t)(x0 + r1 / ny) * g->dim[1] + (y0 + r1 % ny)) * g->dim[2];
+                        first1 = A.cell_start[row + z0];
+                        cnt1 = A.cell_start[row + z1 + 1] - first1;
+                    }
+                    const uint32_t in0 = wave_incl_scan_u(cnt0, lane), tot0 = __shfl(in0, 63);
+                    uint32_t in1 = 0u, tot1 = 0u;
+                    if (nrows > 64) { in1 = wave_incl_scan_u(cnt1, lane); tot1 = __shfl(in1, 63); }
+                    if (lane < nrows) { S.row_off[lane] = in0 - cnt0; S.row_first[lane] = first0; }
+                    if (lane + 64 < nrows) { S.row_off[lane + 64] = tot0 + in1 - cnt1; S.row_first[lane + 64] = first1; }
+                    ncand = (int)(tot0 + tot1);
+                    if (lane == 0) S.row_off[nrows] = (uint32_t)ncand;
+                    big = ncand > SK_WAVE_CAND || ncand > SK_ROUND_ITEMS * W || (int64_t)ncand * len > A.wave_work;
+                }
+            }
+            if (lane == 0) {
+                sl_len[wave] = len; sl_term[wave] = termv; sl_parent[wave] = parent; sl_nrows[wave] = nrows; sl_ncand[wave] = ncand;
+                sl_big[wave] = big; sl_rp[wave] = rp; sl_ent[wave] = my_ent;
+            }
+        }
+        __syncthreads();
+        SK_TICK(2);
+        if (!sl_big[0]) {
+            // slots after the first oversized one (or past the per-round item budget) wait for a later round.
+            // pre[k] = candidates of the slots before k: workgroup-uniform, so it lives in scalar registers.
+            int pre[SK_WSLOTS + 1];
+            pre[0] = 0;
+            {
+                bool open = true;
+                int k_cut = nc;
+#pragma unroll
+                for (int k = 0; k < SK_WSLOTS; k++) {
+                    int add = 0;
+                    if (k < nc && open) {
+                        const int cand_k = __builtin_amdgcn_readfirstlane(sl_ncand[k]), big_k = __builtin_amdgcn_readfirstlane(sl_big[k]);
+                        if (big_k || pre[k] + cand_k > SK_ROUND_ITEMS * W) { open = false; k_cut = k; }
+                        else add = cand_k;
+                    }
+                    pre[k + 1] = pre[k] + add;
+                }
+                if (k_cut < nc) { ne = __builtin_amdgcn_readfirstlane(sl_ent[k_cut]); nc = k_cut; }
+            }
+            const int T = pre[SK_WSLOTS];
+            // 3. claims (select_path_points, path.py:19-46), point-centric: the candidates of ALL slots are dealt
+            //    out over the workgroup; each finds ITS nearest path vertex from LDS -- no atomics but the mark.
+            if (wave < nc && lane < sl_len[wave]) atomicOr(&cmask[L.slot[wave].path[lane]], 1u << wave);
+            unsigned cl_bits = 0u;  // bit k: my k-th item was claimed but did not fit cl_list
+            int cl_n = 0;
+            const int nround = (T + W - 1) / W;
+            for (int k0 = 0; k0 < nround; k0 += 4) {
+                float4 r4[4];
+                int ss[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int gi = (k0 + u) * W + tid;
+                    ss[u] = -1;
+                    r4[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    if (k0 + u < nround && gi < T) {
+                        int sidx = 0, acc = 0;
+#pragma unroll
+                        for (int k = 1; k < SK_WSLOTS; k++)
+                            if (gi >= pre[k]) { sidx = k; acc = pre[k]; }  // pre[] is non-decreasing and ends at T > gi
+                        const SkSelSlot& S = L.slot[sidx];
+                        const uint32_t t = (uint32_t)(gi - acc);
+                        const int row = sk_find_row(S.row_off, sl_nrows[sidx], t);
+                        r4[u] = recs[S.row_first[row] + (t - S.row_off[row])];
+                        ss[u] = sidx;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (ss[u] < 0) continue;
+                    const int p = (int)__float_as_uint(r4[u].w) - base;
+                    if (p < 0 || p >= n) continue;  // other component
+                    const SkSelSlot& S = L.slot[ss[u]];
+                    const int len = sl_len[ss[u]];
+                    const float rp = sl_rp[ss[u]];
+                    float bd2 = __uint_as_float(0x7f800000u);
+                    int bq = 0;
+                    for (int qi = 0; qi < len; qi++) {  // ascending: ties keep the first path vertex
+                        const float dx = r4[u].x - S.x[qi], dy = r4[u].y - S.y[qi], dz = r4[u].z - S.z[qi];
+                        float d2 = dx * dx;
+                        float tt = dy * dy;
+                        d2 = d2 + tt;
+                        tt = dz * dz;
+                        d2 = d2 + tt;
+                        if (d2 < bd2) { bd2 = d2; bq = qi; }
+                    }
+                    if (bd2 < rp * rp && sqrtf(bd2) < S.r[bq]) {  // path.py:35-40
+                        atomicOr(&cmask[p], 1u << ss[u]);
+                        if (cl_n < SK_CL_KEEP) cl_list[cl_n][tid] = (unsigned)p | ((unsigned)ss[u] << 28);
+                        else cl_bits |= 1u << (k0 + u);
+                        cl_n++;
+                    }
+                }
+            }
+            __syncthreads();  // all marks are in L2
+            SK_TICK(3);
+            // 4. what did the earlier slots touch?  (walk + the vertex the parent id was read from; tip of every entry)
+            if (wave < nc) {
+                const SkSelSlot& S = L.slot[wave];
+                const int len = sl_len[wave], termv = sl_term[wave];
+                unsigned mk = 0u;
+                if (lane < len) mk = ld(&cmask[S.path[lane]]);
+                else if (lane == len) mk = ld(&cmask[termv < 0 ? n - 1 : termv]);
+                const unsigned walkm = wave_or_u(mk);
+                if (lane == 0) sl_walkm[wave] = walkm;
+            }
+            unsigned etip = 0u;
+            if (wave == 0 && lane < ne) etip = ld(&cmask[ent_v]);
+            __syncthreads();
+            if (wave == 0) {  // the sequential replay over the entries, lane e holding entry e
+                if (my_slot >= nc) my_slot = -1;
+                const unsigned walkm = my_slot >= 0 ? sl_walkm[my_slot] : 0u;
+                const int mylen = my_slot >= 0 ? sl_len[my_slot] : 0;
+                unsigned alive = 0u;
+                int nb2 = nb, tot2 = total, commits = 0, my_id = -2, my_off = 0;
+                for (int e = 0; e < ne; e++) {
+                    if ((unsigned)__builtin_amdgcn_readlane((int)etip, e) & alive) continue;  // never selected
+                    const int sl = __builtin_amdgcn_readlane(my_slot, e);
+                    if (sl < 0) break;                                                         // guessed wrong: it lives
+                    if ((unsigned)__builtin_amdgcn_readlane((int)walkm, e) & alive) break;     // depends on an accepted slot
+                    alive |= 1u << sl;
+                    const int l = __builtin_amdgcn_readlane(mylen, e);
+                    const bool keep = l >= 2;  // path.py:125-126: shorter paths still consume their points
+                    if (lane == e) { my_id = keep ? nb2 : -1; my_off = tot2; }
+                    if (keep) { nb2++; tot2 += l; }
+                    commits++;
+                }
+                if (my_slot >= 0) { sl_id[my_slot] = my_id; sl_off[my_slot] = my_off; }
+                if (lane == 0) {
+                    s_alive = alive; s_nb2 = nb2; s_tot2 = tot2;
+                    if (A.ticks) { A.ticks[8] += 1; A.ticks[12] += commits; A.ticks[13] += nc; A.ticks[11] += T; }
+                }
+            }
+            __syncthreads();
+            const unsigned alive = s_alive;
+            nb = s_nb2; total = s_tot2;
+            // 5. commit the accepted slots (path.py:112-136), wipe every mark
+            if (wave < nc) {
+                const SkSelSlot& S = L.slot[wave];
+                const int len = sl_len[wave], id = sl_id[wave];
+                if (lane < len) {
+                    const int v = S.path[lane];
+                    atomicAnd(&cmask[v], ~(1u << wave));
+                    if (id != -2) {
+                        if (id >= 0) A.path_verts[base + sl_off[wave] + lane] = v;  // (a dropped path shares its offset with the next one)
+                        A.alloc[base + v] = -1.0f;
+                        A.term[base + v] = 1u;
+                        if (id >= 0) atomicMax(&A.branch_of[base + v], id);
+                        const unsigned q = (unsigned)(pos[v] - win_base);
+                        if (q < (unsigned)W) win_live[q] = 0;
+                    }
+                }
+                if (lane == 0 && id >= 0) {
+                    A.branch_parent[base + id] = sl_parent[wave];
+                    A.branch_off[base + id] = sl_off[wave];
+                    A.branch_len[base + id] = len;
+                    if (A.ticks) A.ticks[10] += len;
+                }
+            }
+            const int kept_n = cl_n < SK_CL_KEEP ? cl_n : SK_CL_KEEP;
+            for (int j = 0; j < kept_n; j++) {
+                const unsigned e = cl_list[j][tid];
+                const int p = (int)(e & 0x0fffffffu), sidx = (int)(e >> 28);
+                atomicAnd(&cmask[p], ~(1u << sidx));
+                if ((alive >> sidx) & 1u) {
+                    const int id = sl_id[sidx];
+                    A.alloc[base + p] = -1.0f;
+                    A.term[base + p] = 1u;
+                    if (id >= 0) atomicMax(&A.branch_of[base + p], id);
+                    const unsigned q = (unsigned)(pos[p] - win_base);
+                    if (q < (unsigned)W) win_live[q] = 0;
+                }
+            }
+            while (cl_bits) {  // the overflow: find the point again
+                const int k = __ffs(cl_bits) - 1;
+                cl_bits &= cl_bits - 1u;
+                const int gi = k * W + tid;
+                int sidx = 0, acc = 0;
+#pragma unroll
+                for (int k2 = 1; k2 < SK_WSLOTS; k2++)
+                    if (gi >= pre[k2]) { sidx = k2; acc = pre[k2]; }
+                const SkSelSlot& S = L.slot[sidx];
+                const uint32_t t = (uint32_t)(gi - acc);
+                const int row = sk_find_row(S.row_off, sl_nrows[sidx], t);
+                const int p = (int)__float_as_uint(recs[S.row_first[row] + (t - S.row_off[row])].w) - base;
+                atomicAnd(&cmask[p], ~(1u << sidx));
+                if ((alive >> sidx) & 1u) {
+                    const int id = sl_id[sidx];
+                    A.alloc[base + p] = -1.0f;
+                    A.term[base + p] = 1u;
+                    if (id >= 0) atomicMax(&A.branch_of[base + p], id);
+                    const unsigned q = (unsigned)(pos[p] - win_base);
+                    if (q < (unsigned)W) win_live[q] = 0;
+                }
+            }
+            __syncthreads();  // (also: LDS of this round is dead)
+            SK_TICK(4);
+            continue;
+        }
+        // ---- `one` mode: candidate 0 needs the whole workgroup ----
+        const int far = cand_v[0];
+        __syncthreads();  // slot data is dead; its space is reused below
         int len = -1;
         for (unsigned chunk = 0; len < 0; chunk += blockDim.x) {
             const unsigned j = chunk + tid;
             const int node = sk_ancestor(A, base, far, j);
             const bool end = node < 0 || ld(&A.term[base + node]) != 0u;
-            if (!end) { if (j < SK_LPATH) lpath[j] = node; else tmp[j] = (unsigned)node; }
+            if (!end) { if (j < SK_LPATH) L.one.lpath[j] = node; else tmp[j] = (unsigned)node; }
             unsigned long long k = end ? ((unsigned long long)(0xffffffffu - j) << 32) | (unsigned)(node + 1) : 0ull;
             k = block_max_u64(k, s_red);
             if (k != 0ull) {
@@ -510,12 +889,9 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
         }
         if (tid < 3) { s_lo[tid] = 0x7fffffff; s_hi[tid] = (int)0x80000000; }
         __syncthreads();
-        SK_TICK(2);
-        // 3. one pass over the path: output (root side first), radius maximum (path.py:31), and -- when it fits --
-        //    coordinates / radii / cell bounding box into LDS for the claim below.  The parent lookup rides along:
-        //    it is read BEFORE this branch stamps anything (path.py:128-136); termination -1 reads
-        //    branch_ids[-1] = the last vertex (quirk kept).
-        const bool keep = len >= 2;  // path.py:125-126: shorter paths still consume their points
+        // one pass over the path: output (root side first), radius maximum (path.py:31), and -- when it fits --
+        // coordinates / radii / cell bounding box into LDS for the claim below.
+        const bool keep = len >= 2;
         int parent = -1;
         if (tid == 0 && keep) parent = ld(&A.branch_of[base + (s_term < 0 ? n - 1 : s_term)]);
         int* path_out = A.path_verts + base + total;
@@ -523,7 +899,7 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
         unsigned long long rk = 0;
         for (int qi = tid; qi < len; qi += blockDim.x) {
             const int w = len - 1 - qi;  // walk order -> root side first
-            const int v = w < SK_LPATH ? lpath[w] : (int)ld(&tmp[w]);
+            const int v = w < SK_LPATH ? L.one.lpath[w] : (int)ld(&tmp[w]);
             path_out[qi] = v;
             const float r = A.rad[base + v];
             const unsigned long long k = (unsigned long long)st_f2ord(r) << 32;
@@ -531,7 +907,7 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
             if (fits) {
                 const float* pv = A.pts + 3 * (int64_t)(base + v);
                 const float x = pv[0], y = pv[1], z = pv[2];
-                lpx[qi] = x; lpy[qi] = y; lpz[qi] = z; lpr[qi] = r;
+                L.one.lpx[qi] = x; L.one.lpy[qi] = y; L.one.lpz[qi] = z; L.one.lpr[qi] = r;
                 const int cx = (int)floorf((x - g->lo[0]) / g->cell), cy = (int)floorf((y - g->lo[1]) / g->cell),
                           cz = (int)floorf((z - g->lo[2]) / g->cell);
                 atomicMin(&s_lo[0], cx); atomicMin(&s_lo[1], cy); atomicMin(&s_lo[2], cz);
@@ -542,9 +918,6 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
         const float rp = st_ord2f((unsigned)(rk >> 32)), rp2 = rp * rp;
         int reach = rp > 0.0f ? (int)ceilf(rp / g->cell) : 0;
         if (reach < 1) reach = 1;
-        // 4. can this workgroup claim the path's points itself?  Point-centric form of select_path_points
-        //    (path.py:19-46): the candidates are the points of the grid cells around the path; each one
-        //    finds ITS nearest path vertex from LDS -- no atomics, no candidate list.
         bool small = fits;
         int nrows_s = 0, ncand = 0;
         if (small) {
@@ -563,9 +936,9 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
             uint32_t tot;
             const uint32_t off = block_exclusive_scan(cnt, s_scan, &tot);
             ncand = (int)tot;
-            small = small && (int64_t)ncand * len <= SK_SMALL_WORK;
-            if (small && tid < nrows) { row_off[tid] = off; row_first[tid] = first; }
-            if (small && tid == 0) row_off[nrows] = tot;
+            small = small && (int64_t)ncand * len <= A.small_work;
+            if (small && tid < nrows) { L.one.row_off[tid] = off; L.one.row_first[tid] = first; }
+            if (small && tid == 0) L.one.row_off[nrows] = tot;
             __syncthreads();
             nrows_s = nrows;
         }
@@ -575,27 +948,44 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
             A.branch_off[base + nb] = total;
             A.branch_len[base + nb] = len;
         }
-        SK_TICK(3);
         const int cur_off = total;
         if (keep) { nb++; total += len; }
-        if (A.ticks && tid == 0) { A.ticks[8] += 1; A.ticks[9] += small ? 1 : 0; A.ticks[10] += len; A.ticks[11] += ncand; }
+        // too much work point-centric (every candidate against every path vertex)?  Path-centric then: every
+        // (path vertex, cell row) pair offers itself to the points of its cells -- here if the path is of moderate
+        // length, chip-wide (k_sk_claim) otherwise.
+        const int side = 2 * reach + 1;
+        const bool local = !small && (int64_t)len * side * side <= A.local_items;
+        if (A.ticks && tid == 0) { A.ticks[9] += 1; A.ticks[10] += len; A.ticks[14] += (small || local) ? 0 : 1; A.ticks[15] += local ? 1 : 0; }
+        if (local) {
+            if (tid == 0) A.s_ntouched[c] = 0u;
+            __syncthreads();  // (LDS path coordinates are dead: the staging list takes their place)
+            unsigned* lq = (unsigned*)L.one.lpx;  // SK_LQ_CLAIM words = lpx + lpy
+            unsigned* lq_ctl = (unsigned*)L.one.lpz;
+            const bool in_lds = sk_claim_items(A, c, base, n, len, rp, path_out, false, 0, 1, lq, &lq_ctl[0], &lq_ctl[1], true);
+            __syncthreads();
+            sk_finish_branch(A, base, len, id, path_out, false, in_lds ? lq : A.touched + base, in_lds,
+                             in_lds ? lq_ctl[0] : ld(&A.s_ntouched[c]));
+            need_fill = true;  // the window flags are rebuilt from the allocation state
+            SK_TICK(6);
+            continue;
+        }
         if (!small) {  // hand the path to k_sk_claim; its points are finished at the next launch (uniform)
             if (tid == 0) {
                 A.s_len[c] = len; A.s_rp[c] = rp; A.s_ntouched[c] = 0u; A.s_cur_off[c] = cur_off; A.s_cur_id[c] = id;
                 A.s_wide[c] = 1; A.s_cursor[c] = win_base; A.s_total[c] = total; A.s_nb[c] = nb;
             }
+            SK_TICK_FLUSH();
             return;
         }
         for (int t = tid; t < ncand; t += blockDim.x) {
-            int lo = 0, hi = nrows_s;  // row r with row_off[r] <= t < row_off[r+1]
-            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (row_off[mid] <= (uint32_t)t) lo = mid; else hi = mid; }
-            const float4 r4 = A.recs[row_first[lo] + ((uint32_t)t - row_off[lo])];
+            const int row = sk_find_row(L.one.row_off, nrows_s, (uint32_t)t);
+            const float4 r4 = recs[L.one.row_first[row] + ((uint32_t)t - L.one.row_off[row])];
             const int p = (int)__float_as_uint(r4.w) - base;
             if (p < 0 || p >= n) continue;  // other component
             float bd2 = __uint_as_float(0x7f800000u);
             int bq = 0;
             for (int qi = 0; qi < len; qi++) {  // LDS broadcast reads; ascending: ties keep the first path vertex
-                const float dx = r4.x - lpx[qi], dy = r4.y - lpy[qi], dz = r4.z - lpz[qi];
+                const float dx = r4.x - L.one.lpx[qi], dy = r4.y - L.one.lpy[qi], dz = r4.z - L.one.lpz[qi];
                 float d2 = dx * dx;
                 float tt = dy * dy;
                 d2 = d2 + tt;
@@ -603,7 +993,7 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
                 d2 = d2 + tt;
                 if (d2 < bd2) { bd2 = d2; bq = qi; }
             }
-            if (bd2 < rp2 && sqrtf(bd2) < lpr[bq]) {  // path.py:35-40
+            if (bd2 < rp2 && sqrtf(bd2) < L.one.lpr[bq]) {  // path.py:35-40
                 A.alloc[base + p] = -1.0f;
                 A.term[base + p] = 1u;
                 if (id >= 0) A.branch_of[base + p] = id;
@@ -612,7 +1002,7 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
             }
         }
         for (int qi = tid; qi < len; qi += blockDim.x) {  // path.py:112-113,135
-            const int v = lpath[len - 1 - qi];
+            const int v = L.one.lpath[len - 1 - qi];
             A.alloc[base + v] = -1.0f;
             A.term[base + v] = 1u;
             if (id >= 0) A.branch_of[base + v] = id;
@@ -620,9 +1010,10 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
             if (q < (unsigned)W) win_live[q] = 0;
         }
         __syncthreads();
-        SK_TICK(4);
+        SK_TICK(5);
     }
     if (tid == 0) { A.s_len[c] = 0; A.s_wide[c] = 0; A.s_cursor[c] = win_base; A.s_total[c] = total; A.s_nb[c] = nb; }
+    SK_TICK_FLUSH();
 }
 
 __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_claim(SkArgs A) {
@@ -693,6 +1084,22 @@ static void sk_layout(StArena& a, int64_t m, int64_t C, SkLayout* s) {
 }
 
 static long long* g_debug_ticks = nullptr;
+static float g_prune_factor = 1.0f;
+static int g_small_work = SK_SMALL_WORK, g_iters_per_launch = SK_ITERS_PER_LAUNCH, g_launch_batch = 16, g_local_items = 0, g_wave_work = SK_WAVE_WORK;
+// developer aid / test hook (forces every claim strategy): 0 prune factor (x1000), 1 small_work, 2 rounds per launch,
+// 3 launches per host read-back, 4 local_items, 5 wave_work; a negative `which` restores the defaults
+extern "C" void st_debug_set_skeleton_param(int which, int value) {
+    if (which < 0) {
+        g_prune_factor = 1.0f; g_small_work = SK_SMALL_WORK; g_iters_per_launch = SK_ITERS_PER_LAUNCH; g_launch_batch = 16;
+        g_local_items = 0; g_wave_work = SK_WAVE_WORK;
+    }
+    if (which == 0) g_prune_factor = value / 1000.0f;
+    if (which == 1) g_small_work = value;
+    if (which == 2) g_iters_per_launch = value;
+    if (which == 3) g_launch_batch = value < 1 ? 1 : (value > 16 ? 16 : value);
+    if (which == 4) g_local_items = value;
+    if (which == 5) g_wave_work = value;
+}
 extern "C" void st_debug_set_ticks(long long* device_ptr) { g_debug_ticks = device_ptr; }
 
 extern "C" int64_t st_skeleton_workspace_bytes(int64_t m, int64_t n_comp) {
@@ -741,6 +1148,7 @@ extern "C" int st_skeleton_components(int n_comp, const int32_t* comp_off, const
     ST_REQUIRE(!(stages & 2) || tree_dist != nullptr, "skeleton: stage 2 needs a tree_dist buffer");
     if (block_threads <= 0) block_threads = 1024;
     ST_REQUIRE(block_threads % 64 == 0 && block_threads <= 1024, "skeleton: block_threads must be a multiple of 64, <= 1024");
+    ST_REQUIRE(m < (1ll << 28), "skeleton: at most 2^28 graph vertices");
     StArena a(ws, ws_bytes);
     SkLayout s;
     sk_layout(a, m, n_comp, &s);
@@ -762,6 +1170,7 @@ extern "C" int st_skeleton_components(int n_comp, const int32_t* comp_off, const
     A.blk_comp = s.blk_comp; A.blk_first = s.blk_first; A.blk_count = s.blk_count;
     A.s_cursor = s.s_cursor; A.s_wide = s.s_wide; A.order = s.order; A.order_init = s.order_init; A.pos = s.pos;
     A.ticks = g_debug_ticks;
+    A.prune_factor = g_prune_factor; A.small_work = g_small_work; A.iters_per_launch = g_iters_per_launch; A.local_items = g_local_items; A.wave_work = g_wave_work;
 
     const unsigned vg = sk_vgrid(m);
     const unsigned fg = (unsigned)st_min64(st_div_up(m, SK_WIDE_BLOCK), SK_SSSP_BLOCKS);
@@ -842,7 +1251,7 @@ extern "C" int st_skeleton_components(int n_comp, const int32_t* comp_off, const
         if (time_select) for (int i = 0; i < 32; i++) (void)hipEventCreate(&ev[i]);
         double select_ms = 0.0;
         for (;;) {  // batches of 16 launch pairs (each select runs up to 32 short-path branches itself)
-            for (int b = 0; b < 16; b++, iters++) {
+            for (int b = 0; b < g_launch_batch; b++, iters++) {
                 if (time_select) (void)hipEventRecord(ev[2 * b], stream);
                 hipLaunchKernelGGL(k_sk_select, dim3((unsigned)n_comp), dim3((unsigned)block_threads), 0, stream, A);
                 if (time_select) (void)hipEventRecord(ev[2 * b + 1], stream);
@@ -850,7 +1259,7 @@ extern "C" int st_skeleton_components(int n_comp, const int32_t* comp_off, const
             }
             ST_TRY(sk_read(h, s.cnt, sizeof(unsigned) * 8, stream));
             if (time_select)
-                for (int b = 0; b < 16; b++) {
+                for (int b = 0; b < g_launch_batch; b++) {
                     float ms = 0.0f;
                     (void)hipEventElapsedTime(&ms, ev[2 * b], ev[2 * b + 1]);
                     select_ms += ms;

@@ -108,6 +108,11 @@ inline void fiber_entry() {
     swapcontext(&r.cur->ctx, &r.sched);
 }
 
+inline int sched_order() {
+    static const int v = [] { const char* e = getenv("HIPEMU_ORDER"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
 [[noreturn]] inline void die(const char* msg) {
     fprintf(stderr, "hipemu: %s\n", msg);
     abort();
@@ -130,8 +135,20 @@ inline void run_block(unsigned nthreads) {
         f.state = READY;
         f.tid = dim3(t);
     }
+    const int order = sched_order();
+    uint64_t lcg = 0x9e3779b97f4a7c15ull * (uint64_t)(order + 1) + r.bid.x;
     for (;;) {
-        for (unsigned t = 0; t < nthreads; t++) {
+        // HIPEMU_ORDER: 0 ascending (default), 1 descending, >= 2 a pseudo-random rotation + direction per pass.
+        // Results must not depend on it -- a cheap detector for races between lanes / waves of a workgroup.
+        unsigned start = 0;
+        bool down = order == 1;
+        if (order >= 2) {
+            lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+            start = (unsigned)((lcg >> 33) % nthreads);
+            down = (lcg >> 20) & 1;
+        }
+        for (unsigned i = 0; i < nthreads; i++) {
+            const unsigned t = down ? (start + nthreads - i) % nthreads : (start + i) % nthreads;
             Fiber& f = r.fibers[t];
             if (f.state != READY) continue;
             r.cur = &f;
@@ -185,8 +202,8 @@ inline void launch(dim3 grid, dim3 block, F&& body) {
     r.gdim = grid;
     r.bdim = block;
     r.body = body;
-    for (unsigned b = 0; b < grid.x; b++) {
-        r.bid = dim3(b);
+    for (unsigned i = 0; i < grid.x; i++) {
+        r.bid = dim3(sched_order() == 0 ? i : grid.x - 1 - i);
         run_block(block.x);
     }
 }
@@ -284,6 +301,12 @@ inline int __builtin_amdgcn_readfirstlane(int x) {
     auto v = hipemu::wave_exchange((uint64_t)(uint32_t)x);
     return (int)(uint32_t)v.lo(__builtin_ctzll(v.mask));
 }
+inline int __builtin_amdgcn_readlane(int x, int src) {
+    auto v = hipemu::wave_exchange((uint64_t)(uint32_t)x);
+    return (int)(uint32_t)v.lo((unsigned)src & 63u);
+}
+// hardware: a scheduling fence (lanes run in lockstep); here lanes are fibers, so it must be a rendezvous
+inline void __builtin_amdgcn_wave_barrier() { (void)hipemu::wave_exchange((uint64_t)0); }
 inline unsigned __lane_id() { return threadIdx.x % 64; }
 
 typedef float hipemu_v4f __attribute__((ext_vector_type(4)));

@@ -106,6 +106,28 @@ def test_components_match_oracle(backend):
     assert _compare_components(backend, pts, mv, block_threads=128) >= 2
 
 
+@pytest.mark.parametrize("params", [
+    {0: 0},                      # no pruning: every live window entry speculates
+    {0: 4000},                   # aggressive pruning: wrong guesses stop the replay
+    {2: 1, 3: 1},                # one round per launch, host read-back after every launch
+    {5: -1},                     # no speculation: the whole workgroup per branch, point-centric
+    {5: -1, 1: -1, 4: 1 << 30},  # ... path-centric inside the workgroup
+    {5: -1, 1: -1, 4: -1},       # ... handed to the chip-wide claim kernel
+    {5: 300, 1: 2000, 4: 200},   # a mix of all of them
+], ids=["noprune", "prune4", "relaunch", "one", "local", "wide", "mixed"])
+def test_sample_tree_strategies_agree(backend, params):
+    """Branch selection has four claim strategies picked by size; each one alone must reproduce the oracle."""
+    from smart_tree_amd import _lib
+    hook = _lib.lib().st_debug_set_skeleton_param
+    pts, mv = _tree()
+    try:
+        for k, v in params.items():
+            hook(int(k), int(v))
+        assert _compare_components(backend, pts, mv, block_threads=256) >= 2
+    finally:
+        hook(-1, 0)
+
+
 def test_components_with_duplicates_and_plateaus(backend):
     pts, mv = _tree(n=2000, seed=8, exact_medial=True)
     _compare_components(backend, pts, mv, block_threads=64)

@@ -24,23 +24,34 @@ print("after outlier", len(bc), "radius q", torch.quantile(radius, torch.tensor(
 g = G.nn_graph(medial, radius.clamp(min=0.02), K=16)
 comps = g.connected_cugraph_components(32)
 print("edges", g.edges.shape[0], "comps", comps.n_components, comps.comp_size[:8].tolist())
-for bt in (256, 512, 1024):
-    for rep in range(3):
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        res = run_components(comps, medial, radius, bc.xyz[:,1].contiguous(), block_threads=bt)
-        torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print(f"select block {bt}: total {dt*1e3:.2f} ms; stats {res.stats}; branches {int(res.n_branches[0])}")
 import ctypes
 from smart_tree_amd import _lib
-ticks = torch.zeros(16, dtype=torch.int64, device=dev)
-L = _lib.lib(); L.st_debug_set_ticks.argtypes=[ctypes.c_void_p]; L.st_debug_set_ticks(ticks.data_ptr())
-res = run_components(comps, medial, radius, bc.xyz[:,1].contiguous())
-torch.cuda.synchronize(); L.st_debug_set_ticks(None)
-t = ticks.cpu().numpy()
-print('select phases (us, 100MHz ticks): head', t[0]/100, 'cursor', t[1]/100, 'trace', t[2]/100, 'path+record', t[3]/100, 'claim+finish', t[4]/100, '| iterations', t[8], 'small', t[9], 'path verts', t[10], 'candidates', t[11])
 from smart_tree_amd.skeleton.skeletonize import STAGE_SSSP
-for rep in range(2):
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    res = run_components(comps, medial, radius, bc.xyz[:,1].contiguous(), stages=STAGE_SSSP)
-    torch.cuda.synchronize(); dt = time.perf_counter() - t0
-print(f"sssp+preds only: {dt*1e3:.2f} ms {res.stats}")
+L = _lib.lib(); L.st_debug_set_ticks.argtypes = [ctypes.c_void_p]
+def timed(**kw):
+    for rep in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        res = run_components(comps, medial, radius, bc.xyz[:,1].contiguous(), **kw)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    return dt * 1e3, res
+base_ms, _ = timed(stages=STAGE_SSSP)
+print(f"sssp+preds only: {base_ms:.2f} ms")
+def phases(tag):
+    ticks = torch.zeros(16, dtype=torch.int64, device=dev)
+    L.st_debug_set_ticks(ticks.data_ptr())
+    run_components(comps, medial, radius, bc.xyz[:,1].contiguous())
+    torch.cuda.synchronize(); L.st_debug_set_ticks(None)
+    t = ticks.cpu().numpy()
+    print(f'  {tag} phases us: head {t[0]/100:.0f} rank {t[7]/100:.0f} prune {t[1]/100:.0f} walk+rows {t[2]/100:.0f} claim {t[3]/100:.0f} validate+commit {t[4]/100:.0f} one-mode {t[5]/100:.0f} local {t[6]/100:.0f} ({t[15]}) | rounds {t[8]} slots {t[13]} commits {t[12]} one-mode iters {t[9]} wide {t[14]} cand {t[11]}')
+DEF = {0: 1000, 1: 4 << 20, 2: 32, 3: 16, 4: 0}
+def setp(kw={}):
+    for k, v in {**DEF, **kw}.items(): L.st_debug_set_skeleton_param(int(k), int(v))
+for name, kw in [("small 64k", {1: 1 << 16}), ("small 64k wave 256k", {1: 1 << 16, 5: 1 << 18}), ("small 64k wave 1M", {1: 1 << 16, 5: 1 << 20}), ("small 64k wave 4M", {1: 1 << 16, 5: 1 << 22}), ("small 256k wave 1M", {1: 1 << 18, 5: 1 << 20}), ("small 1M wave 1M", {1: 1 << 20, 5: 1 << 20})]:
+    setp(kw)
+    ms, res = timed()
+    print(f"{name}: total {ms:.2f} ms  (select part {ms - base_ms:.2f}); stats {res.stats}; branches {int(res.n_branches[0])}")
+    phases(name)
+setp()
+for bt in (256, 512):
+    ms, res = timed(block_threads=bt)
+    print(f"select block {bt}: total {ms:.2f} ms; branches {int(res.n_branches[0])}")
