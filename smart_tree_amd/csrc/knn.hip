@@ -12,8 +12,8 @@
 // outlier_removal needs d < r_i): same result, far fewer cells visited for thin branches.
 //
 // Grid: dense cell_start[] over the bounding box (cells capped, cell size doubled until it fits),
-// points counting-sorted by cell into float4 (x, y, z, index) records; a 4-lane group per query, every
-// lane keeps a top-K in registers (fully unrolled insertion), merged by shuffles.
+// points counting-sorted by cell into float4 (x, y, z, index) records; one wavefront per query, the K nearest
+// drawn from an LDS candidate list by rank counting.
 #include "st_common.h"
 #include "st_grid.h"
 
@@ -115,24 +115,66 @@ int st_grid_build(const float* pts, int64_t n, float cell, int64_t max_cells, St
 }
 
 // ----------------------------------------------------------------------------------- search ---
-__device__ __forceinline__ bool knn_less(float d, int j, float bd, int bj) { return d < bd || (d == bd && j < bj); }
 
 // mode 0: no per-query bound; 1: keep sqrtf(d2) <= bound[i]; 2: keep sqrtf(d2) < bound[i]
-// KNN_LANES lanes work on one query: each takes every KNN_LANES-th (x, y) grid row and keeps its own
-// sorted top-K in registers; the K smallest of the union are then drawn by K rounds of a group-wide
-// minimum (xor shuffles).  With one lane per query a 50k-point cloud is <1 wavefront per SIMD and the
-// candidate loop is one long dependent chain.
-#define KNN_LANES 4
+//
+// One WAVEFRONT per query.  A 50k-point cloud with a lane (or a few lanes) per query is a handful of
+// wavefronts per SIMD, each walking a long chain of dependent loads; with a wavefront per query there are
+// 50k of them and every step is 64 wide:
+//   1. lanes take the (x, y) rows of grid cells around the query (cells along z are contiguous in memory, so a
+//      row is ONE [start, end) range, clipped to the search sphere) and scan their sizes;
+//   2. the candidates of all rows are dealt out one per lane (coalesced float4 records), tested against r and
+//      the per-query bound, and the survivors appended to a list in LDS as 64-bit keys (d2 bits, index);
+//   3. every survivor counts the keys smaller than its own (LDS broadcast reads): that count IS its output
+//      slot -- the K nearest come out sorted by (d2, index) without a sort.  If the list fills up it is cut
+//      back to its K smallest the same way and the scan goes on.
+#define KNN_WAVES (KNN_BLOCK / 64)
+#define KNN_CAP 256  // keys per query held in LDS between cuts
+
+__device__ __forceinline__ uint32_t knn_wave_scan(uint32_t v, int lane) {  // inclusive
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(v, (unsigned)d); if (lane >= d) v += o; }
+    return v;
+}
+
+// Keep the K smallest of keys[0..n): rank = number of smaller keys (keys are unique: the index is part of them).
+// Returns the new count.  All 64 lanes call.
+template <int K>
+__device__ __forceinline__ int knn_cut(unsigned long long* keys, int n, int lane) {
+    __builtin_amdgcn_wave_barrier();
+    unsigned long long mine[KNN_CAP / 64];
+    int rank[KNN_CAP / 64];
+#pragma unroll
+    for (int c = 0; c < KNN_CAP / 64; c++) {
+        const int j = c * 64 + lane;
+        mine[c] = j < n ? keys[j] : ~0ull;
+        rank[c] = 0;
+    }
+    for (int t = 0; t < n; t++) {
+        const unsigned long long kt = keys[t];  // same address in every lane: a broadcast
+#pragma unroll
+        for (int c = 0; c < KNN_CAP / 64; c++) rank[c] += kt < mine[c] ? 1 : 0;
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int c = 0; c < KNN_CAP / 64; c++)
+        if (c * 64 + lane < n && rank[c] < K) keys[rank[c]] = mine[c];
+    __builtin_amdgcn_wave_barrier();
+    return n < K ? n : K;
+}
+
 template <int K>
 __global__ void __launch_bounds__(KNN_BLOCK) k_knn(const float* __restrict__ src, int64_t n1, const StGrid* __restrict__ g,
                                                    const uint32_t* __restrict__ cell_start, const float4* __restrict__ recs,
                                                    float r, const float* __restrict__ bound, int mode,
                                                    int64_t* __restrict__ idx_out, float* __restrict__ dist_out) {
-    const int64_t gid = (int64_t)blockIdx.x * KNN_BLOCK + threadIdx.x;
-    const int sub = (int)(gid & (KNN_LANES - 1));
-    int64_t i = gid / KNN_LANES;
-    const bool valid = i < n1;
-    if (!valid) i = n1 - 1;  // keep the lane in the shuffles below; its result is discarded
+    __shared__ uint32_t s_roff[KNN_WAVES][65], s_rfirst[KNN_WAVES][64];
+    __shared__ unsigned long long s_keys[KNN_WAVES][KNN_CAP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * KNN_WAVES + wave;
+    if (i >= n1) return;  // wave-uniform; the kernel has no workgroup barrier
+    uint32_t* roff = s_roff[wave];
+    uint32_t* rfirst = s_rfirst[wave];
+    unsigned long long* keys = s_keys[wave];
     const float px = src[3 * i], py = src[3 * i + 1], pz = src[3 * i + 2];
     const float r2 = r * r;
     float reach_r = r;
@@ -141,82 +183,95 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn(const float* __restrict__ src
         bnd = bound[i];
         if (bnd < reach_r) reach_r = bnd;
     }
-    float bd[K];
-    int bi[K];
-#pragma unroll
-    for (int q = 0; q < K; q++) { bd[q] = __uint_as_float(0x7f800000u); bi[q] = 0x7fffffff; }
     const float cell = g->cell;
     int reach = reach_r > 0.0f ? (int)ceilf(reach_r / cell) : 0;
     if (reach < 1) reach = 1;
-    int c0[3];
-    c0[0] = (int)floorf((px - g->lo[0]) / cell);
-    c0[1] = (int)floorf((py - g->lo[1]) / cell);
-    c0[2] = (int)floorf((pz - g->lo[2]) / cell);
-    const int x0 = st_max(c0[0] - reach, 0), x1 = st_min(c0[0] + reach, g->dim[0] - 1);
-    const int y0 = st_max(c0[1] - reach, 0), y1 = st_min(c0[1] + reach, g->dim[1] - 1);
-    const int z0 = st_max(c0[2] - reach, 0), z1 = st_min(c0[2] + reach, g->dim[2] - 1);
+    const int cx = (int)floorf((px - g->lo[0]) / cell), cy = (int)floorf((py - g->lo[1]) / cell), cz = (int)floorf((pz - g->lo[2]) / cell);
+    const int x0 = st_max(cx - reach, 0), x1 = st_min(cx + reach, g->dim[0] - 1);
+    const int y0 = st_max(cy - reach, 0), y1 = st_min(cy + reach, g->dim[1] - 1);
+    const int z0 = st_max(cz - reach, 0), z1 = st_min(cz + reach, g->dim[2] - 1);
     // rows (x, y) farther than the search radius in the xy-plane are skipped and the z-range of the others
     // is clipped to the sphere (a slightly inflated radius keeps the pruning conservative)
     const float rs = reach_r * 1.0001f + 1e-7f, rs2 = rs * rs;
-    const int ny = y1 - y0 + 1, nrows = (x1 - x0 + 1) * ny;
-    for (int rowi = sub; rowi < nrows; rowi += KNN_LANES) {
-        const int x = x0 + rowi / ny, y = y0 + rowi % ny;
-        const float cx0 = g->lo[0] + (float)x * cell, ex = px < cx0 ? cx0 - px : (px > cx0 + cell ? px - (cx0 + cell) : 0.0f);
-        const float cy0 = g->lo[1] + (float)y * cell, ey = py < cy0 ? cy0 - py : (py > cy0 + cell ? py - (cy0 + cell) : 0.0f);
-        const float dxy2 = ex * ex + ey * ey;
-        if (dxy2 > rs2) continue;
-        const float rz = sqrtf(rs2 - dxy2);
-        const int za = st_max((int)floorf((pz - rz - g->lo[2]) / cell) - 1, z0), zb = st_min((int)floorf((pz + rz - g->lo[2]) / cell) + 1, z1);
-        if (za > zb) continue;
-        // cells along z are contiguous: one [start, end) range per (x, y) row
-        const int64_t row = ((int64_t)x * g->dim[1] + y) * g->dim[2];
-        const uint32_t s = cell_start[row + za], e = cell_start[row + zb + 1];
-        for (uint32_t t = s; t < e; t++) {
-            const float4 q = recs[t];
-            const float dx = px - q.x, dy = py - q.y, dz = pz - q.z;
-            float d2 = dx * dx;
-            float tt = dy * dy;
-            d2 = d2 + tt;
-            tt = dz * dz;
-            d2 = d2 + tt;
-            if (!(d2 < r2)) continue;
-            if (mode == 1 && !(sqrtf(d2) <= bnd)) continue;
-            if (mode == 2 && !(sqrtf(d2) < bnd)) continue;
-            const int j = (int)__float_as_uint(q.w);
-            if (!knn_less(d2, j, bd[K - 1], bi[K - 1])) continue;
-#pragma unroll
-            for (int p = K - 1; p > 0; p--) {
-                const bool lt_prev = knn_less(d2, j, bd[p - 1], bi[p - 1]);
-                const bool lt_cur = knn_less(d2, j, bd[p], bi[p]);
-                const float nd = lt_prev ? bd[p - 1] : (lt_cur ? d2 : bd[p]);
-                const int nj = lt_prev ? bi[p - 1] : (lt_cur ? j : bi[p]);
-                bd[p] = nd;
-                bi[p] = nj;
+    const int ny = y1 - y0 + 1, nrows = (x1 >= x0 && ny > 0 && z1 >= z0) ? (x1 - x0 + 1) * ny : 0;
+    int nkeys = 0;  // wave-uniform
+    for (int rbase = 0; rbase < nrows; rbase += 64) {
+        const int rowi = rbase + lane;
+        uint32_t first = 0, cnt = 0;
+        if (rowi < nrows) {
+            const int x = x0 + rowi / ny, y = y0 + rowi % ny;
+            const float cx0 = g->lo[0] + (float)x * cell, ex = px < cx0 ? cx0 - px : (px > cx0 + cell ? px - (cx0 + cell) : 0.0f);
+            const float cy0 = g->lo[1] + (float)y * cell, ey = py < cy0 ? cy0 - py : (py > cy0 + cell ? py - (cy0 + cell) : 0.0f);
+            const float dxy2 = ex * ex + ey * ey;
+            if (!(dxy2 > rs2)) {
+                const float rz = sqrtf(rs2 - dxy2);
+                const int za = st_max((int)floorf((pz - rz - g->lo[2]) / cell) - 1, z0),
+                          zb = st_min((int)floorf((pz + rz - g->lo[2]) / cell) + 1, z1);
+                if (za <= zb) {
+                    const int64_t row = ((int64_t)x * g->dim[1] + y) * g->dim[2];
+                    first = cell_start[row + za];
+                    cnt = cell_start[row + zb + 1] - first;
+                }
             }
-            if (knn_less(d2, j, bd[0], bi[0])) { bd[0] = d2; bi[0] = j; }
+        }
+        const uint32_t incl = knn_wave_scan(cnt, lane);
+        const int total = (int)__shfl(incl, 63);
+        __builtin_amdgcn_wave_barrier();  // the previous chunk's reads of roff / rfirst are done
+        roff[lane] = incl - cnt;
+        rfirst[lane] = first;
+        if (lane == 63) roff[64] = incl;
+        __builtin_amdgcn_wave_barrier();
+        for (int cb = 0; cb < total; cb += 64) {
+            const int t = cb + lane;
+            bool ok = false;
+            unsigned long long key = 0ull;
+            if (t < total) {
+                int lo = 0, hi = 64;  // row with roff[row] <= t < roff[row + 1]
+                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (roff[mid] <= (uint32_t)t) lo = mid; else hi = mid; }
+                const float4 q = recs[rfirst[lo] + ((uint32_t)t - roff[lo])];
+                const float dx = px - q.x, dy = py - q.y, dz = pz - q.z;
+                float d2 = dx * dx;
+                float tt = dy * dy;
+                d2 = d2 + tt;
+                tt = dz * dz;
+                d2 = d2 + tt;
+                ok = d2 < r2;
+                if (mode == 1) ok = ok && sqrtf(d2) <= bnd;
+                if (mode == 2) ok = ok && sqrtf(d2) < bnd;
+                key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned long long)__float_as_uint(q.w);  // d2 >= 0: bits order like values
+            }
+            const unsigned long long bal = __ballot(ok);
+            if (ok) keys[nkeys + __popcll(bal & ((1ull << lane) - 1ull))] = key;
+            nkeys += __popcll(bal);
+            if (nkeys > KNN_CAP - 64) nkeys = knn_cut<K>(keys, nkeys, lane);
         }
     }
-    // merge: K rounds; every lane offers the head of its list, the group minimum is emitted and popped
+    // output: rank = slot.  (d2, index) ascending, -1 / NaN padding.
+    __builtin_amdgcn_wave_barrier();
+    {
+        unsigned long long mine[KNN_CAP / 64];
+        int rank[KNN_CAP / 64];
 #pragma unroll
-    for (int q = 0; q < K; q++) {
-        float md = bd[0];
-        int mj = bi[0];
-#pragma unroll
-        for (int m = 1; m < KNN_LANES; m <<= 1) {
-            const float od = __shfl_xor(md, m);
-            const int oj = __shfl_xor(mj, m);
-            if (knn_less(od, oj, md, mj)) { md = od; mj = oj; }
+        for (int c = 0; c < KNN_CAP / 64; c++) {
+            const int j = c * 64 + lane;
+            mine[c] = j < nkeys ? keys[j] : ~0ull;
+            rank[c] = 0;
         }
-        if (mj == bi[0] && mj != 0x7fffffff) {  // my head won (indices are unique): pop it
+        for (int t = 0; t < nkeys; t++) {
+            const unsigned long long kt = keys[t];
 #pragma unroll
-            for (int p = 0; p < K - 1; p++) { bd[p] = bd[p + 1]; bi[p] = bi[p + 1]; }
-            bd[K - 1] = __uint_as_float(0x7f800000u);
-            bi[K - 1] = 0x7fffffff;
+            for (int c = 0; c < KNN_CAP / 64; c++) rank[c] += kt < mine[c] ? 1 : 0;
         }
-        if (sub == 0 && valid) {
-            const bool ok = mj != 0x7fffffff;
-            idx_out[i * K + q] = ok ? (int64_t)mj : (int64_t)-1;
-            dist_out[i * K + q] = ok ? sqrtf(md) : __uint_as_float(0x7fc00000u);
+#pragma unroll
+        for (int c = 0; c < KNN_CAP / 64; c++)
+            if (c * 64 + lane < nkeys && rank[c] < K) {
+                idx_out[i * K + rank[c]] = (int64_t)(unsigned)(mine[c] & 0xffffffffull);
+                dist_out[i * K + rank[c]] = sqrtf(__uint_as_float((unsigned)(mine[c] >> 32)));
+            }
+        const int found = nkeys < K ? nkeys : K;
+        if (lane >= found && lane < K) {
+            idx_out[i * K + lane] = (int64_t)-1;
+            dist_out[i * K + lane] = __uint_as_float(0x7fc00000u);
         }
     }
 }
@@ -256,7 +311,7 @@ extern "C" int st_knn_radius(const float* src, int64_t n1, const float* dst, int
         return ST_ERR_WORKSPACE;
     }
     ST_TRY(st_grid_build(dst, n2, cell_hint > 0.0f ? cell_hint : r, KNN_MAX_CELLS, g, cell_start, recs, sub, sub_bytes, stream));
-    dim3 grid((unsigned)st_div_up(n1 * KNN_LANES, KNN_BLOCK)), block(KNN_BLOCK);
+    dim3 grid((unsigned)st_div_up(n1, KNN_WAVES)), block(KNN_BLOCK);
     if (K == 1)
         hipLaunchKernelGGL((k_knn<1>), grid, block, 0, stream, src, n1, (const StGrid*)g, (const uint32_t*)cell_start,
                            (const float4*)recs, r, bound, bound_mode, idx, dist);

@@ -167,43 +167,82 @@ __global__ void __launch_bounds__(1024) k_sk_fill_comp_of(SkArgs A) {
 }
 
 // ------------------------------------------------------------------------------------ SSSP ---
-// round r: frontier r%2 -> (r+1)%2; counts rotate through cnt[0..2]
-#define SK_LQ 2048  // workgroup-local queue entries staged in LDS before one global reservation
-__global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_sssp_round(SkArgs A, int r) {
-    __shared__ unsigned lq[SK_LQ];
-    __shared__ unsigned lq_n, lq_base;
+// Launch r: global frontier r%2 -> (r+1)%2; counts rotate through cnt[0..2].  The frontier of a tree-shaped graph
+// is small (a few hundred vertices) and hundreds of levels deep, so a launch per level is bound by launch latency.
+// Each workgroup therefore keeps relaxing what IT improved for up to `hops` further levels from a queue in LDS
+// before handing the rest to the next launch.  The distances are the least fixed point of d[v] = min(d[u] + w)
+// whatever the order of relaxations (atomicMin; every improvement is queued again), so the result is the same
+// as one level per launch -- at 1/hops of the launches.
+#define SK_LQ 1024  // entries per local generation; overflow goes straight to the global queue
+__global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_sssp_round(SkArgs A, int r, int hops, int glanes) {
+    __shared__ unsigned lq[2][SK_LQ];
+    __shared__ unsigned ln[3], lq_base;  // generation h fills lq[h & 1], counted by ln[h % 3]
     const unsigned count = A.cnt[r % 3];
     if (blockIdx.x == 0 && threadIdx.x == 0) A.cnt[(r + 2) % 3] = 0u;
     if (count == 0) return;
-    if (threadIdx.x == 0) lq_n = 0;
+    if (threadIdx.x < 3) ln[threadIdx.x] = 0;
     __syncthreads();
     const unsigned* q = (r & 1) ? A.q1 : A.q0;
     unsigned* qn = (r & 1) ? A.q0 : A.q1;
     unsigned* cnt_out = &A.cnt[(r + 1) % 3];
-    const unsigned round = (unsigned)r + 1u;
-    const int lane = threadIdx.x & 63;
-    const unsigned gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, tw = (gridDim.x * blockDim.x) >> 6;
-    for (unsigned f = gw; f < count; f += tw) {  // wave-uniform
+    const unsigned round = (unsigned)r + 1u;  // stamp[v] == round: v already sits in the next global frontier
+    const int lane = threadIdx.x & (glanes - 1);  // `glanes` lanes share one vertex (rows hold ~16 edges)
+    const unsigned wave = threadIdx.x / glanes, nwv = blockDim.x / glanes;
+    const unsigned gw = blockIdx.x * nwv + wave, tw = gridDim.x * nwv;
+    // one lane group per vertex: relax its edges; improved neighbours go to the local generation `out`
+#define SK_RELAX(u, du, out, out_n)                                                                        \
+    {                                                                                                      \
+        const uint32_t s_ = A.row_off[u], e_ = A.row_off[(u) + 1];                                         \
+        for (uint32_t t = s_ + lane; t < e_; t += glanes) {                                                    \
+            const unsigned v = A.col[t];                                                                   \
+            const unsigned o = st_f2ord((du) + A.wgt[t]);                                                  \
+            const unsigned old = atomicMin(&A.dist_ord[v], o);                                             \
+            if (o < old) {                                                                                 \
+                const unsigned slot = atomicAdd(out_n, 1u);                                                \
+                if (slot < SK_LQ) (out)[slot] = v;                                                         \
+                else if (atomicExch(&A.stamp[v], round) != round) qn[atomicAdd(cnt_out, 1u)] = v;          \
+            }                                                                                              \
+        }                                                                                                  \
+    }
+    for (unsigned f = gw; f < count; f += tw) {
         const unsigned u = q[f];
-        const float du = st_ord2f(A.dist_ord[u]);
-        const uint32_t s = A.row_off[u], e = A.row_off[u + 1];
-        for (uint32_t t = s + lane; t < e; t += 64) {
-            const unsigned v = A.col[t];
-            const unsigned o = st_f2ord(du + A.wgt[t]);
-            const unsigned old = atomicMin(&A.dist_ord[v], o);
-            if (o < old && atomicExch(&A.stamp[v], round) != round) {
-                // stage in LDS (a frontier of thousands pushing on ONE global counter serialises the
-                // round); overflow goes straight to the global queue
-                const unsigned slot = atomicAdd(&lq_n, 1u);
-                if (slot < SK_LQ) lq[slot] = v; else qn[atomicAdd(cnt_out, 1u)] = v;
-            }
+        const float du = st_ord2f(A.dist_ord[u]);  // written before this launch
+        SK_RELAX(u, du, lq[0], &ln[0]);
+    }
+    int h = 1;  // generation being read: lq[(h - 1) & 1], ln[(h - 1) % 3]
+    for (; h < hops; h++) {
+        __syncthreads();  // generation h-1 is complete; nobody still reads generation h-2
+        const unsigned have = ln[(h - 1) % 3];
+        const unsigned ncur = have < SK_LQ ? have : SK_LQ;
+        if (ncur == 0) break;  // uniform
+        if (threadIdx.x == 0) ln[(h + 1) % 3] = 0;  // counter of the generation after this one (last read two barriers ago)
+        const unsigned* in = lq[(h - 1) & 1];
+        unsigned* out = lq[h & 1];
+        for (unsigned i = wave; i < ncur; i += nwv) {
+            const unsigned u = in[i];
+            const float du = st_ord2f(ld(&A.dist_ord[u]));  // improved during this launch: read it where the atomics act
+            SK_RELAX(u, du, out, &ln[h % 3]);
         }
     }
+#undef SK_RELAX
     __syncthreads();
-    const unsigned nloc = lq_n < SK_LQ ? lq_n : SK_LQ;
+    // what is left joins the next global frontier (once per vertex: stamp)
+    const unsigned have = ln[(h - 1) % 3];
+    const unsigned nrem = have < SK_LQ ? have : SK_LQ;
+    const unsigned* rem = lq[(h - 1) & 1];
+    unsigned* keep = lq[h & 1];
+    unsigned* keep_n = &ln[h % 3];
+    if (threadIdx.x == 0) *keep_n = 0;
+    __syncthreads();
+    for (unsigned i = threadIdx.x; i < nrem; i += blockDim.x) {
+        const unsigned v = rem[i];
+        if (atomicExch(&A.stamp[v], round) != round) keep[atomicAdd(keep_n, 1u)] = v;
+    }
+    __syncthreads();
+    const unsigned nloc = *keep_n;
     if (threadIdx.x == 0 && nloc) lq_base = atomicAdd(cnt_out, nloc);
     __syncthreads();
-    for (unsigned i = threadIdx.x; i < nloc; i += blockDim.x) qn[lq_base + i] = lq[i];
+    for (unsigned i = threadIdx.x; i < nloc; i += blockDim.x) qn[lq_base + i] = keep[i];
 }
 
 __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_dist_out(SkArgs A) {
@@ -1085,13 +1124,14 @@ static void sk_layout(StArena& a, int64_t m, int64_t C, SkLayout* s) {
 
 static long long* g_debug_ticks = nullptr;
 static float g_prune_factor = 1.0f;
+static int g_sssp_hops = 4, g_sssp_batch = 16, g_sssp_lanes = 64;
 static int g_small_work = SK_SMALL_WORK, g_iters_per_launch = SK_ITERS_PER_LAUNCH, g_launch_batch = 16, g_local_items = 0, g_wave_work = SK_WAVE_WORK;
 // developer aid / test hook (forces every claim strategy): 0 prune factor (x1000), 1 small_work, 2 rounds per launch,
-// 3 launches per host read-back, 4 local_items, 5 wave_work; a negative `which` restores the defaults
+// 3 launches per host read-back, 4 local_items, 5 wave_work, 6 SSSP levels per launch, 7 SSSP launches per read-back; a negative `which` restores the defaults
 extern "C" void st_debug_set_skeleton_param(int which, int value) {
     if (which < 0) {
         g_prune_factor = 1.0f; g_small_work = SK_SMALL_WORK; g_iters_per_launch = SK_ITERS_PER_LAUNCH; g_launch_batch = 16;
-        g_local_items = 0; g_wave_work = SK_WAVE_WORK;
+        g_local_items = 0; g_wave_work = SK_WAVE_WORK; g_sssp_hops = 4; g_sssp_batch = 16; g_sssp_lanes = 64;
     }
     if (which == 0) g_prune_factor = value / 1000.0f;
     if (which == 1) g_small_work = value;
@@ -1099,6 +1139,9 @@ extern "C" void st_debug_set_skeleton_param(int which, int value) {
     if (which == 3) g_launch_batch = value < 1 ? 1 : (value > 16 ? 16 : value);
     if (which == 4) g_local_items = value;
     if (which == 5) g_wave_work = value;
+    if (which == 6) g_sssp_hops = value < 1 ? 1 : value;
+    if (which == 8) g_sssp_lanes = value == 64 ? 64 : (value == 32 ? 32 : 16);
+    if (which == 7) g_sssp_batch = value < 1 ? 1 : (value > 64 ? 64 : value);
 }
 extern "C" void st_debug_set_ticks(long long* device_ptr) { g_debug_ticks = device_ptr; }
 
@@ -1180,8 +1223,8 @@ extern "C" int st_skeleton_components(int n_comp, const int32_t* comp_off, const
         hipLaunchKernelGGL(k_sk_init, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A);
         hipLaunchKernelGGL(k_sk_roots, dim3((unsigned)n_comp), dim3((unsigned)block_threads), 0, stream, A);
         for (int r = 0;;) {  // frontier rounds in batches of 32 launches, one counter read-back per batch
-            for (int b = 0; b < 32; b++, r++)
-                hipLaunchKernelGGL(k_sk_sssp_round, dim3(fg), dim3(SK_WIDE_BLOCK), 0, stream, A, r);
+            for (int b = 0; b < g_sssp_batch; b++, r++)
+                hipLaunchKernelGGL(k_sk_sssp_round, dim3(fg), dim3(SK_WIDE_BLOCK), 0, stream, A, r, g_sssp_hops, g_sssp_lanes);
             ST_TRY(sk_read(h, s.cnt, sizeof(unsigned) * 8, stream));
             sssp_rounds = r;
             if (h[r % 3] == 0) break;

@@ -34,8 +34,13 @@ def timed(**kw):
         res = run_components(comps, medial, radius, bc.xyz[:,1].contiguous(), **kw)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
     return dt * 1e3, res
+for rep in range(2):
+  for hops, batch, lanes in [(1, 32, 64), (1, 32, 16), (2, 32, 64), (2, 32, 16), (4, 16, 64), (4, 16, 16), (4, 16, 32), (8, 16, 64), (8, 16, 16), (16, 8, 16)]:
+    L.st_debug_set_skeleton_param(6, hops); L.st_debug_set_skeleton_param(7, batch); L.st_debug_set_skeleton_param(8, lanes)
+    ms, res = timed(stages=STAGE_SSSP)
+    print(f"sssp+preds hops {hops} batch {batch} lanes {lanes}: {ms:.2f} ms  rounds {res.stats['sssp_rounds']}")
+L.st_debug_set_skeleton_param(-1, 0)
 base_ms, _ = timed(stages=STAGE_SSSP)
-print(f"sssp+preds only: {base_ms:.2f} ms")
 def phases(tag):
     ticks = torch.zeros(16, dtype=torch.int64, device=dev)
     L.st_debug_set_ticks(ticks.data_ptr())
@@ -43,10 +48,10 @@ def phases(tag):
     torch.cuda.synchronize(); L.st_debug_set_ticks(None)
     t = ticks.cpu().numpy()
     print(f'  {tag} phases us: head {t[0]/100:.0f} rank {t[7]/100:.0f} prune {t[1]/100:.0f} walk+rows {t[2]/100:.0f} claim {t[3]/100:.0f} validate+commit {t[4]/100:.0f} one-mode {t[5]/100:.0f} local {t[6]/100:.0f} ({t[15]}) | rounds {t[8]} slots {t[13]} commits {t[12]} one-mode iters {t[9]} wide {t[14]} cand {t[11]}')
-DEF = {0: 1000, 1: 4 << 20, 2: 32, 3: 16, 4: 0}
+DEF = {0: 1000, 1: 1 << 18, 2: 32, 3: 16, 4: 0, 5: 1 << 20}
 def setp(kw={}):
     for k, v in {**DEF, **kw}.items(): L.st_debug_set_skeleton_param(int(k), int(v))
-for name, kw in [("small 64k", {1: 1 << 16}), ("small 64k wave 256k", {1: 1 << 16, 5: 1 << 18}), ("small 64k wave 1M", {1: 1 << 16, 5: 1 << 20}), ("small 64k wave 4M", {1: 1 << 16, 5: 1 << 22}), ("small 256k wave 1M", {1: 1 << 18, 5: 1 << 20}), ("small 1M wave 1M", {1: 1 << 20, 5: 1 << 20})]:
+for name, kw in [("default", {})]:
     setp(kw)
     ms, res = timed()
     print(f"{name}: total {ms:.2f} ms  (select part {ms - base_ms:.2f}); stats {res.stats}; branches {int(res.n_branches[0])}")
