@@ -92,6 +92,8 @@ int st_pointwise_mlp_heads(const float* x, int64_t n, const float* params, float
  * st_skeleton_components (stages 1|2|4) and its single-stage forms st_sssp / st_tree_distance / st_sample_tree
  *                   replace: cugraph.sssp (skeleton/shortest_path.py:12-21), pred_graph + second sssp
  *                            (shortest_path.py:46-55, skeletonize.py:80-85), sample_tree (skeleton/path.py:9-140)
+ * st_assemble_branches replaces: the BranchSkeleton / TreeSkeleton construction of skeleton/path.py:128-140 and
+ *                   skeletonize.py:86-95 (flat layout consumed by st_post_process)
  * st_post_process   replaces: pipeline.py:95-106 over data_types/tree.py:73-134,164-176 (+ util/queries.py:89-133) */
 /* st_centre_cloud replaces: dataset/augmentations.py:38-41 (CentreCloud over Cloud.bbox, data_types/cloud.py:222-227) */
 int st_centre_cloud(const float* xyz, int64_t n, float* out, void* ws, int64_t ws_bytes, void* stream);
@@ -126,6 +128,12 @@ int st_skeleton_components(int n_comp, const int32_t* comp_off, const int32_t* c
 int st_sssp(ST_SKELETON_STAGE_ARGS);
 int st_tree_distance(ST_SKELETON_STAGE_ARGS);
 int st_sample_tree(ST_SKELETON_STAGE_ARGS);
+int64_t st_assemble_workspace_bytes(int64_t cap_b);
+int st_assemble_branches(int n_comp, const int32_t* comp_off, const int32_t* n_branches, const int32_t* branch_parent,
+                         const int32_t* branch_off, const int32_t* branch_len, const int32_t* path_verts,
+                         const int32_t* vert_order, const float* medial, const float* radius, int32_t* tree_off,
+                         int32_t* parent, int32_t* start, int32_t* length, float* xyz, float* rad, int64_t cap_b,
+                         int64_t cap_p, int64_t* counts_host, void* ws, int64_t ws_bytes, void* stream);
 int st_post_process(int n_trees, const int32_t* tree_off, const int32_t* parent, const int32_t* start, const int32_t* len,
                     float* xyz, const float* rad_in, float* rad_out, uint8_t* keep, uint8_t* repaired, uint8_t* smoothed,
                     int32_t* depth_scratch, int do_prune, float min_radius, float min_length, int do_repair, int do_smooth, int kernel_size,

@@ -225,3 +225,126 @@ extern "C" int st_post_process(int n_trees, const int32_t* tree_off, const int32
     ST_CHECK_LAUNCH();
     return ST_OK;
 }
+
+
+// ------------------------------------------------------------------ branch assembly ---
+// sample_tree's per-component output (branch table + path vertex lists, skeleton.hip) -> the flat branch
+// layout st_post_process works on: BranchSkeleton construction of skeleton/path.py:128-133 for every tree
+// at once.  Branch k owns geometry slots [start[k], start[k] + len[k] + 1); slot start[k] is reserved for the
+// connection point `repair` prepends and is pre-filled with the branch's first vertex (tree.py:92 reads
+// its radius).
+struct AsmArgs {
+    int C;
+    const int32_t *comp_off, *n_branches, *branch_parent, *branch_off, *branch_len, *path_verts, *vert_order;
+    const float *medial, *radius;
+    int32_t *tree_off, *parent, *start, *length;
+    float *xyz, *rad;
+    uint32_t *len1, *src0, *vbase;  // scratch [cap_b]
+    int64_t cap_b, cap_p;
+    int64_t* counts;  // device: B, P
+};
+
+__global__ void __launch_bounds__(1024) k_asm_trees(AsmArgs A) {  // one workgroup: tree_off = scan of the branch counts
+    __shared__ uint32_t s_scan[17];
+    __shared__ uint32_t s_carry;
+    if (threadIdx.x == 0) s_carry = 0u;
+    __syncthreads();
+    for (int c0 = 0; c0 < A.C; c0 += (int)blockDim.x) {
+        const int c = c0 + (int)threadIdx.x;
+        const uint32_t v = c < A.C ? (uint32_t)A.n_branches[c] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_exclusive_scan(v, s_scan, &tot);
+        const uint32_t carry = s_carry;
+        if (c < A.C) A.tree_off[c] = (int32_t)(carry + ex);
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry = carry + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { A.tree_off[A.C] = (int32_t)s_carry; A.counts[0] = (int64_t)s_carry; }
+}
+
+__global__ void __launch_bounds__(256) k_asm_branches(AsmArgs A) {
+    const int64_t B = A.tree_off[A.C];
+    for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < A.cap_b; b += (int64_t)gridDim.x * blockDim.x) {
+        if (b >= B) { A.len1[b] = 0u; continue; }
+        int lo = 0, hi = A.C;  // tree with tree_off[c] <= b < tree_off[c + 1] (empty trees have equal offsets: take the last)
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int64_t)A.tree_off[mid] <= b) lo = mid; else hi = mid; }
+        const int base = A.comp_off[lo];
+        const int slot = base + (int)(b - A.tree_off[lo]);
+        const int len = A.branch_len[slot];
+        A.parent[b] = A.branch_parent[slot];
+        A.length[b] = len;
+        A.len1[b] = (uint32_t)(len + 1);
+        A.src0[b] = (uint32_t)(base + A.branch_off[slot]);
+        A.vbase[b] = (uint32_t)base;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_asm_geometry(AsmArgs A) {
+    const int64_t B = A.tree_off[A.C];
+    const int64_t P = B > 0 ? (int64_t)A.start[B - 1] + A.length[B - 1] + 1 : 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) A.counts[1] = P;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < P && k < A.cap_p; k += (int64_t)gridDim.x * blockDim.x) {
+        int64_t lo = 0, hi = B;  // branch with start[b] <= k
+        while (hi - lo > 1) { const int64_t mid = (lo + hi) >> 1; if ((int64_t)A.start[mid] <= k) lo = mid; else hi = mid; }
+        const int64_t j = k - A.start[lo];  // 0 = the reserved slot
+        const int64_t src = (int64_t)A.src0[lo] + (j > 0 ? j - 1 : 0);
+        const int64_t id = A.vert_order[(int64_t)A.path_verts[src] + A.vbase[lo]];
+        A.xyz[3 * k] = A.medial[3 * id]; A.xyz[3 * k + 1] = A.medial[3 * id + 1]; A.xyz[3 * k + 2] = A.medial[3 * id + 2];
+        A.rad[k] = A.radius[id];
+    }
+}
+
+static void asm_layout(StArena& a, int64_t cap_b, uint32_t** len1, uint32_t** src0, uint32_t** vbase, int64_t** counts, char** scan_ws,
+                       int64_t* scan_bytes) {
+    *len1 = a.take<uint32_t>(cap_b);
+    *src0 = a.take<uint32_t>(cap_b);
+    *vbase = a.take<uint32_t>(cap_b);
+    *counts = a.take<int64_t>(2);
+    *scan_bytes = st_scan_ws_bytes(cap_b);
+    *scan_ws = a.take<char>(*scan_bytes);
+}
+
+extern "C" int64_t st_assemble_workspace_bytes(int64_t cap_b) {
+    StArena a(nullptr, 0);
+    uint32_t *l, *s0, *vb; int64_t* cn; char* sw; int64_t sb;
+    asm_layout(a, cap_b, &l, &s0, &vb, &cn, &sw, &sb);
+    return a.used;
+}
+
+// Outputs are sized by the caller to the capacities cap_b (branches; every component-local branch slot is enough:
+// cap_b = m) and cap_p (geometry slots; path vertices + branches <= 2 m); counts_host receives the numbers used.
+extern "C" int st_assemble_branches(int n_comp, const int32_t* comp_off, const int32_t* n_branches, const int32_t* branch_parent,
+                                    const int32_t* branch_off, const int32_t* branch_len, const int32_t* path_verts,
+                                    const int32_t* vert_order, const float* medial, const float* radius, int32_t* tree_off,
+                                    int32_t* parent, int32_t* start, int32_t* length, float* xyz, float* rad, int64_t cap_b,
+                                    int64_t cap_p, int64_t* counts_host, void* ws, int64_t ws_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    counts_host[0] = counts_host[1] = 0;
+    if (n_comp <= 0) return ST_OK;
+    ST_REQUIRE(cap_b >= 1 && cap_p >= 1, "assemble: empty capacity");
+    StArena a(ws, ws_bytes);
+    AsmArgs A;
+    char* scan_ws; int64_t scan_bytes;
+    asm_layout(a, cap_b, &A.len1, &A.src0, &A.vbase, &A.counts, &scan_ws, &scan_bytes);
+    if (!a.ok() || !scan_ws) {
+        st_set_error("assemble: workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)a.used);
+        return ST_ERR_WORKSPACE;
+    }
+    A.C = n_comp; A.comp_off = comp_off; A.n_branches = n_branches; A.branch_parent = branch_parent; A.branch_off = branch_off;
+    A.branch_len = branch_len; A.path_verts = path_verts; A.vert_order = vert_order; A.medial = medial; A.radius = radius;
+    A.tree_off = tree_off; A.parent = parent; A.start = start; A.length = length; A.xyz = xyz; A.rad = rad;
+    A.cap_b = cap_b; A.cap_p = cap_p;
+    hipLaunchKernelGGL(k_asm_trees, dim3(1), dim3(1024), 0, stream, A);
+    const unsigned gb = (unsigned)(st_div_up(cap_b, 256) < 1024 ? st_div_up(cap_b, 256) : 1024),
+                   gp = (unsigned)(st_div_up(cap_p, 256) < 2048 ? st_div_up(cap_p, 256) : 2048);
+    hipLaunchKernelGGL(k_asm_branches, dim3(gb), dim3(256), 0, stream, A);
+    ST_TRY(st_exclusive_scan_u32(A.len1, (uint32_t*)start, cap_b, nullptr, scan_ws, scan_bytes, stream));
+    hipLaunchKernelGGL(k_asm_geometry, dim3(gp), dim3(256), 0, stream, A);
+    (void)hipMemcpyAsync(counts_host, A.counts, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, stream);
+    (void)hipStreamSynchronize(stream);
+    ST_CHECK_LAUNCH();
+    ST_REQUIRE(counts_host[0] <= cap_b && counts_host[1] <= cap_p, "assemble: capacity exceeded (%lld branches, %lld slots)",
+               (long long)counts_host[0], (long long)counts_host[1]);
+    return ST_OK;
+}

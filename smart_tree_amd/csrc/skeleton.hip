@@ -1124,14 +1124,14 @@ static void sk_layout(StArena& a, int64_t m, int64_t C, SkLayout* s) {
 
 static long long* g_debug_ticks = nullptr;
 static float g_prune_factor = 1.0f;
-static int g_sssp_hops = 4, g_sssp_batch = 16, g_sssp_lanes = 64;
+static int g_sssp_hops = 4, g_sssp_batch = 32, g_sssp_lanes = 64;
 static int g_small_work = SK_SMALL_WORK, g_iters_per_launch = SK_ITERS_PER_LAUNCH, g_launch_batch = 16, g_local_items = 0, g_wave_work = SK_WAVE_WORK;
 // developer aid / test hook (forces every claim strategy): 0 prune factor (x1000), 1 small_work, 2 rounds per launch,
 // 3 launches per host read-back, 4 local_items, 5 wave_work, 6 SSSP levels per launch, 7 SSSP launches per read-back; a negative `which` restores the defaults
 extern "C" void st_debug_set_skeleton_param(int which, int value) {
     if (which < 0) {
         g_prune_factor = 1.0f; g_small_work = SK_SMALL_WORK; g_iters_per_launch = SK_ITERS_PER_LAUNCH; g_launch_batch = 16;
-        g_local_items = 0; g_wave_work = SK_WAVE_WORK; g_sssp_hops = 4; g_sssp_batch = 16; g_sssp_lanes = 64;
+        g_local_items = 0; g_wave_work = SK_WAVE_WORK; g_sssp_hops = 4; g_sssp_batch = 32; g_sssp_lanes = 64;
     }
     if (which == 0) g_prune_factor = value / 1000.0f;
     if (which == 1) g_small_work = value;
@@ -1293,8 +1293,9 @@ extern "C" int st_skeleton_components(int n_comp, const int32_t* comp_off, const
         hipEvent_t ev[32];
         if (time_select) for (int i = 0; i < 32; i++) (void)hipEventCreate(&ev[i]);
         double select_ms = 0.0;
-        for (;;) {  // batches of 16 launch pairs (each select runs up to 32 short-path branches itself)
-            for (int b = 0; b < g_launch_batch; b++, iters++) {
+        for (int batch = g_launch_batch;; batch = batch > 4 ? 4 : batch) {  // launch pairs per counter read-back: a long first
+            // batch, short ones for the stragglers (a finished launch pair still costs its ~10 us of launch latency)
+            for (int b = 0; b < batch; b++, iters++) {
                 if (time_select) (void)hipEventRecord(ev[2 * b], stream);
                 hipLaunchKernelGGL(k_sk_select, dim3((unsigned)n_comp), dim3((unsigned)block_threads), 0, stream, A);
                 if (time_select) (void)hipEventRecord(ev[2 * b + 1], stream);
@@ -1302,7 +1303,7 @@ extern "C" int st_skeleton_components(int n_comp, const int32_t* comp_off, const
             }
             ST_TRY(sk_read(h, s.cnt, sizeof(unsigned) * 8, stream));
             if (time_select)
-                for (int b = 0; b < g_launch_batch; b++) {
+                for (int b = 0; b < batch; b++) {
                     float ms = 0.0f;
                     (void)hipEventElapsedTime(&ms, ev[2 * b], ev[2 * b + 1]);
                     select_ms += ms;

@@ -52,7 +52,9 @@ class Cloud:
     def filter(self, mask) -> "Cloud":
         """Boolean-mask or index gather of every per-point field (reference cloud.py:72-95)."""
         mask = mask.to(self.xyz.device)
-        return self._map(lambda t: t[mask])
+        if mask.dtype == torch.bool:  # one compaction (one host sync) for all fields instead of one per field
+            mask = mask.nonzero().view(-1)
+        return self._map(lambda t: t.index_select(0, mask))
 
     def filter_by_class(self, classes) -> "Cloud":
         wanted = torch.as_tensor(classes, device=self.class_l.device)

@@ -103,8 +103,9 @@ class Skeletonizer:
         with profiling.stage("outlier_removal"):
             medial, radius = medial_points(cloud.xyz, cloud.medial_vector)
             mask = outlier_removal(medial, radius.unsqueeze(1), nb_points=8)
-            cloud = cloud.filter(mask)
-            medial, radius = medial[mask], radius[mask]
+            keep = mask.nonzero().view(-1)  # one compaction (one host sync) shared by every field
+            cloud = cloud.filter(keep)
+            medial, radius = medial.index_select(0, keep), radius.index_select(0, keep)
         with profiling.stage("nn_graph"):
             graph = nn_graph(medial, radius.clamp(min=self.min_connection_length), K=self.K)
         with profiling.stage("components"):
@@ -148,23 +149,23 @@ class DeviceSkeleton(DisjointTreeSkeleton):
         if C == 0:
             z = torch.zeros(0, **i32)
             return DeviceSkeleton(torch.zeros(1, **i32), z, z, z, torch.zeros((0, 3), device=dev), torch.zeros(0, device=dev))
-        nb = res.n_branches[:C].long()
-        tree_off = torch.zeros(C + 1, dtype=torch.int64, device=dev)
-        tree_off[1:] = torch.cumsum(nb, 0)
-        B = int(tree_off[-1].item())
-        comp_of_branch = torch.repeat_interleave(torch.arange(C, device=dev), nb, output_size=B)
-        base = comps.comp_off[:C].long()[comp_of_branch]
-        slot = base + torch.arange(B, device=dev) - tree_off[:-1][comp_of_branch]
-        lens = res.branch_len[slot].long()
-        src0 = base + res.branch_off[slot].long()
-        start = torch.cumsum(lens + 1, 0) - (lens + 1)
-        P = int((lens + 1).sum().item()) if B else 0
-        seg = torch.repeat_interleave(torch.arange(B, device=dev), lens + 1, output_size=P)
-        k = torch.arange(P, device=dev) - start[seg]  # 0 = reserved slot
-        src = src0[seg] + (k - 1).clamp(min=0)
-        ids = comps.vert_order.long()[res.path_verts[src].long() + base[seg]]
-        return DeviceSkeleton(tree_off.int(), res.branch_parent[slot].contiguous(), start.int(), lens.int(),
-                              medial[ids].contiguous(), radius[ids].contiguous())
+        L = _lib.lib()
+        m = comps.vert_order.shape[0]
+        cap_b, cap_p = max(m, 1), max(2 * m, 1)  # every branch has >= 2 vertices; slots = path vertices + branches
+        tree_off = torch.empty(C + 1, **i32)
+        parent, start, length = torch.empty(cap_b, **i32), torch.empty(cap_b, **i32), torch.empty(cap_b, **i32)
+        xyz = torch.empty((cap_p, 3), dtype=torch.float32, device=dev)
+        rad = torch.empty(cap_p, dtype=torch.float32, device=dev)
+        ws = _lib.workspace(L.st_assemble_workspace_bytes(cap_b), dev)
+        counts = (ctypes.c_int64 * 2)()
+        _lib.check(L.st_assemble_branches(
+            C, _lib.ptr(comps.comp_off.contiguous()), _lib.ptr(res.n_branches), _lib.ptr(res.branch_parent), _lib.ptr(res.branch_off),
+            _lib.ptr(res.branch_len), _lib.ptr(res.path_verts), _lib.ptr(comps.vert_order.contiguous()),
+            _lib.ptr(medial.contiguous().float()), _lib.ptr(radius.contiguous().float()), _lib.ptr(tree_off), _lib.ptr(parent),
+            _lib.ptr(start), _lib.ptr(length), _lib.ptr(xyz), _lib.ptr(rad), cap_b, cap_p, counts, _lib.ptr(ws), ws.numel(),
+            _lib.stream(dev)))
+        B, P = counts[0], counts[1]
+        return DeviceSkeleton(tree_off, parent[:B], start[:B], length[:B], xyz[:P], rad[:P])
 
     # -- deferred post-processing ---------------------------------------------------------------
     def _can_defer(self, op: str) -> bool:
