@@ -492,7 +492,7 @@ __device__ __forceinline__ unsigned wave_incl_scan_u(unsigned v, int lane) {
 #define SK_WSLOTS 16   // = SK_MAX_WAVES
 #define SK_WENT 32     // window entries looked at per round (those predicted to be swallowed get no slot)
 #define SK_WPATH 64    // a speculative walk is ONE row of the ancestor table
-#define SK_WROWS 128   // (x, y) cell rows around a speculative path: two per lane
+#define SK_WROWS 256   // (x, y) cell rows around a speculative path: up to four per lane
 #define SK_WAVE_WORK (1 << 20)  // candidate points x path vertices per speculative branch
 #define SK_WAVE_CAND 16384
 #define SK_ROUND_ITEMS 32       // candidates per thread and round
@@ -503,8 +503,8 @@ struct SkSelOne {
     uint32_t row_off[1025], row_first[1024];
 };
 struct SkSelSlot {
-    int path[SK_WPATH];  // root side first
-    float x[SK_WPATH], y[SK_WPATH], z[SK_WPATH], r[SK_WPATH];
+    int path[SK_WPATH];   // root side first
+    float4 p[SK_WPATH];   // position, radius
     uint32_t row_off[SK_WROWS + 1], row_first[SK_WROWS];
     int lo[3], hi[3];  // cell bounding box of the path (LDS min / max)
     unsigned rk;       // ordered bits of the largest radius
@@ -535,7 +535,8 @@ __device__ __forceinline__ int sk_find_row(const uint32_t* row_off, int nrows, u
 // is handed to the chip-wide k_sk_claim and finished at the head of the next launch.
 __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
     long long t_last = A.ticks ? wall_clock64() : 0;
-    long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    __shared__ long long tk[8];  // phase timers (developer aid), touched by thread 0 only
+    if (A.ticks && threadIdx.x == 0) for (int i_ = 0; i_ < 8; i_++) tk[i_] = 0;
     __shared__ unsigned long long s_red[SK_MAX_WAVES];
     __shared__ SkSelLds L;
     __shared__ unsigned cl_list[SK_CL_KEEP][1024];  // claimed points of this round, SK_CL_KEEP private entries per thread
@@ -684,7 +685,7 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
                     const float r = A.rad[base + node];
                     const float* pv = A.pts + 3 * (int64_t)(base + node);
                     const float x = pv[0], y = pv[1], z = pv[2];
-                    S.path[qi] = node; S.x[qi] = x; S.y[qi] = y; S.z[qi] = z; S.r[qi] = r;
+                    S.path[qi] = node; S.p[qi] = make_float4(x, y, z, r);
                     const int cx = (int)floorf((x - g->lo[0]) / g->cell), cy = (int)floorf((y - g->lo[1]) / g->cell),
                               cz = (int)floorf((z - g->lo[2]) / g->cell);
                     atomicMax(&S.rk, st_f2ord(r));  // path.py:31
@@ -702,24 +703,27 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
                 nrows = (nx > 0 && ny > 0 && z0 <= z1) ? nx * ny : 0;
                 big = nrows > SK_WROWS;
                 if (!big) {
-                    uint32_t cnt0 = 0, first0 = 0, cnt1 = 0, first1 = 0;
-                    if (lane < nrows) {
-                        const int64_t row = ((int64_t)(x0 + lane / ny) * g->dim[1] + (y0 + lane % ny)) * g->dim[2];
-                        first0 = A.cell_start[row + z0];
-                        cnt0 = A.cell_start[row + z1 + 1] - first0;
+                    uint32_t cnt[SK_WROWS / 64], first[SK_WROWS / 64];
+#pragma unroll
+                    for (int ch = 0; ch < SK_WROWS / 64; ch++) {  // all loads first, then the scans
+                        const int rr = ch * 64 + lane;
+                        cnt[ch] = 0u; first[ch] = 0u;
+                        if (rr < nrows) {
+                            const int64_t row = ((int64_t)(x0 + rr / ny) * g->dim[1] + (y0 + rr % ny)) * g->dim[2];
+                            first[ch] = A.cell_start[row + z0];
+                            cnt[ch] = A.cell_start[row + z1 + 1] - first[ch];
+                        }
                     }
-                    if (lane + 64 < nrows) {
-                        const int r1 = lane + 64;
-                        const int64_t row = ((int64_t)(x0 + r1 / ny) * g->dim[1] + (y0 + r1 % ny)) * g->dim[2];
-                        first1 = A.cell_start[row + z0];
-                        cnt1 = A.cell_start[row + z1 + 1] - first1;
+                    uint32_t run = 0u;
+#pragma unroll
+                    for (int ch = 0; ch < SK_WROWS / 64; ch++) {
+                        if (ch * 64 >= nrows) break;  // wave-uniform
+                        const uint32_t inc = wave_incl_scan_u(cnt[ch], lane);
+                        const int rr = ch * 64 + lane;
+                        if (rr < nrows) { S.row_off[rr] = run + inc - cnt[ch]; S.row_first[rr] = first[ch]; }
+                        run += __shfl(inc, 63);
                     }
-                    const uint32_t in0 = wave_incl_scan_u(cnt0, lane), tot0 = __shfl(in0, 63);
-                    uint32_t in1 = 0u, tot1 = 0u;
-                    if (nrows > 64) { in1 = wave_incl_scan_u(cnt1, lane); tot1 = __shfl(in1, 63); }
-                    if (lane < nrows) { S.row_off[lane] = in0 - cnt0; S.row_first[lane] = first0; }
-                    if (lane + 64 < nrows) { S.row_off[lane + 64] = tot0 + in1 - cnt1; S.row_first[lane + 64] = first1; }
-                    ncand = (int)(tot0 + tot1);
+                    ncand = (int)run;
                     if (lane == 0) S.row_off[nrows] = (uint32_t)ncand;
                     big = ncand > SK_WAVE_CAND || ncand > SK_ROUND_ITEMS * W || (int64_t)ncand * len > A.wave_work;
                 }
@@ -789,7 +793,8 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
                     float bd2 = __uint_as_float(0x7f800000u);
                     int bq = 0;
                     for (int qi = 0; qi < len; qi++) {  // ascending: ties keep the first path vertex
-                        const float dx = r4[u].x - S.x[qi], dy = r4[u].y - S.y[qi], dz = r4[u].z - S.z[qi];
+                        const float4 q = S.p[qi];
+                        const float dx = r4[u].x - q.x, dy = r4[u].y - q.y, dz = r4[u].z - q.z;
                         float d2 = dx * dx;
                         float tt = dy * dy;
                         d2 = d2 + tt;
@@ -797,7 +802,7 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
                         d2 = d2 + tt;
                         if (d2 < bd2) { bd2 = d2; bq = qi; }
                     }
-                    if (bd2 < rp * rp && sqrtf(bd2) < S.r[bq]) {  // path.py:35-40
+                    if (bd2 < rp * rp && sqrtf(bd2) < S.p[bq].w) {  // path.py:35-40
                         atomicOr(&cmask[p], 1u << ss[u]);
                         if (cl_n < SK_CL_KEEP) cl_list[cl_n][tid] = (unsigned)p | ((unsigned)ss[u] << 28);
                         else cl_bits |= 1u << (k0 + u);

@@ -24,6 +24,9 @@ from .graph import ComponentSet, medial_points, nn_graph
 STAGE_SSSP, STAGE_TREE_DISTANCE, STAGE_SAMPLE = 1, 2, 4
 
 
+GRID_DIV = 4.0  # claim grid: cell = largest radius / GRID_DIV
+
+
 @dataclass
 class ComponentResult:
     """Device arrays in the renumbered vertex space of a ComponentSet (slices per component)."""
@@ -67,7 +70,7 @@ def run_components(comps: ComponentSet, medial_pts: torch.Tensor, radius: torch.
     with profiling.stage("skeleton_kernels"):
         _lib.check(L.st_skeleton_components(
             C, _lib.ptr(comps.comp_off.contiguous()), sizes.ctypes.data, m, _lib.ptr(pts), _lib.ptr(rad), _lib.ptr(ys),
-            _lib.ptr(comps.row_off), _lib.ptr(comps.col), _lib.ptr(comps.wgt), float(max(r_max / 4.0, 1e-4)), int(stages),
+            _lib.ptr(comps.row_off), _lib.ptr(comps.col), _lib.ptr(comps.wgt), float(max(r_max / GRID_DIV, 1e-4)), int(stages),
             int(block_threads), _lib.ptr(res.dist), _lib.ptr(res.pred), _lib.ptr(res.root_local), _lib.ptr(res.tree_dist),
             _lib.ptr(res.branch_parent), _lib.ptr(res.branch_off), _lib.ptr(res.branch_len), _lib.ptr(res.n_branches),
             _lib.ptr(res.path_verts), _lib.ptr(res.branch_of), stats, _lib.ptr(ws), ws.numel(), _lib.stream(dev)))

@@ -11,7 +11,7 @@ from smart_tree_amd.skeleton.filter import outlier_removal
 from smart_tree_amd.skeleton.skeletonize import run_components
 dev = torch.device("cuda:0")
 pipe = bench.build_pipeline(dev)
-c = sample_tree_cloud(1_000_000, seed=0)
+c = sample_tree_cloud(1_000_000, seed=int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 cloud = Cloud(xyz=torch.from_numpy(c["xyz"]).to(dev), rgb=torch.from_numpy(c["rgb"]).to(dev))
 cloud = pipe.preprocessing(cloud)
 lc = pipe.model_inference.forward(cloud)
@@ -34,11 +34,6 @@ def timed(**kw):
         res = run_components(comps, medial, radius, bc.xyz[:,1].contiguous(), **kw)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
     return dt * 1e3, res
-for rep in range(2):
-  for hops, batch, lanes in [(1, 32, 64), (1, 32, 16), (2, 32, 64), (2, 32, 16), (4, 16, 64), (4, 16, 16), (4, 16, 32), (8, 16, 64), (8, 16, 16), (16, 8, 16)]:
-    L.st_debug_set_skeleton_param(6, hops); L.st_debug_set_skeleton_param(7, batch); L.st_debug_set_skeleton_param(8, lanes)
-    ms, res = timed(stages=STAGE_SSSP)
-    print(f"sssp+preds hops {hops} batch {batch} lanes {lanes}: {ms:.2f} ms  rounds {res.stats['sssp_rounds']}")
 L.st_debug_set_skeleton_param(-1, 0)
 base_ms, _ = timed(stages=STAGE_SSSP)
 def phases(tag):
@@ -51,11 +46,15 @@ def phases(tag):
 DEF = {0: 1000, 1: 1 << 18, 2: 32, 3: 16, 4: 0, 5: 1 << 20}
 def setp(kw={}):
     for k, v in {**DEF, **kw}.items(): L.st_debug_set_skeleton_param(int(k), int(v))
-for name, kw in [("default", {})]:
-    setp(kw)
+import smart_tree_amd.skeleton.skeletonize as SKM
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+for div in (4.0, 6.0, 8.0):
+    SKM.GRID_DIV = div
+    setp({})
     ms, res = timed()
-    print(f"{name}: total {ms:.2f} ms  (select part {ms - base_ms:.2f}); stats {res.stats}; branches {int(res.n_branches[0])}")
-    phases(name)
+    print(f"grid div {div}: total {ms:.2f} ms  (select part {ms - base_ms:.2f}); stats {res.stats}; branches {int(res.n_branches[0])}")
+    phases(f"div {div}")
+SKM.GRID_DIV = 4.0
 setp()
 for bt in (256, 512):
     ms, res = timed(block_threads=bt)
