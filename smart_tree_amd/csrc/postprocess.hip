@@ -76,7 +76,8 @@ __global__ void __launch_bounds__(PP_BLOCK) k_post_process(PpArgs A) {
                     seg = sqrtf(pp_dot(d, d));
                 }
                 const int cnt = (n - 1 - i0) < 64 ? (n - 1 - i0) : 64;
-                for (int j = 0; j < cnt; j++) length = length + __shfl(seg, j);
+                for (int j = 0; j < cnt; j++)  // j is wave-uniform: v_readlane, not a cross-lane permute through LDS
+                    length = length + __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(seg), j));
             }
             if (ln == 0) {
                 const float r0 = A.rad_in[s], r1 = A.rad_in[s + n - 1];

@@ -127,6 +127,20 @@ class Skeletonizer:
 
 
 
+class _PackedBranch(BranchSkeleton):
+    """A BranchSkeleton whose `xyz` / `radii` are cut out of the skeleton's packed host arrays when first read
+    (a few hundred tensor views per cloud are not built unless somebody looks at them)."""
+
+    def __getattr__(self, name):  # only reached while `xyz` / `radii` are not in __dict__ yet
+        if name in ("xyz", "radii"):
+            xyz_h, rad_h, a, b, smoothed = self.__dict__["_pack"]
+            self.__dict__["xyz"] = xyz_h[a:b]
+            r = rad_h[a:b]
+            self.__dict__["radii"] = r if smoothed else r.unsqueeze(1)  # smooth flattens radii to 1-D (tree.py:130-134)
+            return self.__dict__[name]
+        raise AttributeError(name)
+
+
 class DeviceSkeleton(DisjointTreeSkeleton):
     """A DisjointTreeSkeleton whose branches still live on the GPU as flat arrays.
 
@@ -222,31 +236,21 @@ class DeviceSkeleton(DisjointTreeSkeleton):
                                      _lib.ptr(depth), int(pr is not None), pr[0] if pr else 0.0, pr[1] if pr else 0.0,
                                      int("repair" in self._ops), int("smooth" in self._ops), self._ops.get("smooth", 0),
                                      _lib.stream(dev)))
-        # two copies (geometry, branch table); torch.split then builds every per-branch view in one C++ call
+        # two copies (geometry, branch table).  Branch k's geometry is the slot range [a_k, b_k) of the packed host arrays;
+        # the BranchSkeleton objects are created here, their tensors are views cut on first access (_PackedBranch).
         xyz_h, rad_h = xyz.cpu(), rad_out.cpu()
         rows = torch.stack((parent, start, length, keep.int(), repaired.int(), smoothed.int()), dim=1).cpu().tolist()
         offs = tree_off.cpu().tolist()
-        # slots are laid out back to back: [start_b + 1 - rep_b, start_b + 1 + len_b), plus one unused slot when not repaired
-        sizes = []
-        for _, _, ln, _, rp, _ in rows:
-            if not rp:
-                sizes.append(1)
-            sizes.append(ln + rp)
-        xyz_pieces = iter(xyz_h.split(sizes))
-        rad1 = iter(rad_h.split(sizes))                # smooth flattens radii to 1-D (tree.py:130-134)
-        rad2 = iter(rad_h.unsqueeze(1).split(sizes))   # everything else keeps [n,1]
-        new, fill = BranchSkeleton.__new__, dict.update
+        new, fill = _PackedBranch.__new__, dict.update
         trees = []
         for t in range(T):
             branches = {}
-            for b in range(offs[t], offs[t + 1]):
-                par, _, _, kp, rp, sm = rows[b]
-                if not rp:
-                    next(xyz_pieces), next(rad1), next(rad2)
-                gx, r1, r2 = next(xyz_pieces), next(rad1), next(rad2)
+            o = offs[t]
+            for b in range(o, offs[t + 1]):
+                par, st, ln, kp, rp, sm = rows[b]
                 if kp:
-                    obj = new(BranchSkeleton)
-                    fill(obj.__dict__, _id=b - offs[t], parent_id=par, xyz=gx, radii=r1 if sm else r2, child_id=None)
-                    branches[b - offs[t]] = obj
+                    obj = new(_PackedBranch)
+                    fill(obj.__dict__, _id=b - o, parent_id=par, child_id=None, _pack=(xyz_h, rad_h, st + 1 - rp, st + 1 + ln, sm))
+                    branches[b - o] = obj
             trees.append(TreeSkeleton(t, branches))
         return trees
