@@ -66,7 +66,14 @@ def test_outlier_and_graph_match_oracle(backend):
     np.testing.assert_array_equal(comps.vert_order.cpu().numpy(), ref_verts)
 
 
-def _compare_components(backend, pts, mv, block_threads):
+_PREPARED = {}
+
+
+def _prepare_components(backend, pts, mv, cache_key=None):
+    """Oracle result + the component set / graph the skeleton kernels start from (cached for the strategy sweep)."""
+    key = (cache_key, str(backend))
+    if cache_key is not None and key in _PREPARED:
+        return _PREPARED[key]
     ref = so.skeletonize(pts, mv, K=16, min_connection_length=0.02, minimum_graph_vertices=32)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(backend)
     cloud = Cloud(xyz=t(pts), medial_vector=t(mv))
@@ -78,7 +85,15 @@ def _compare_components(backend, pts, mv, block_threads):
     g = G.nn_graph(medial, radius.clamp(min=0.02), K=16)
     comps = g.connected_cugraph_components(minimum_vertices=32)
     assert comps.n_components == len(ref.components) and comps.n_components > 0
-    res = run_components(comps, medial, radius, cloud.xyz[:, 1].contiguous(),
+    out = (ref, comps, medial, radius, cloud.xyz[:, 1].contiguous())
+    if cache_key is not None:
+        _PREPARED[key] = out
+    return out
+
+
+def _compare_components(backend, pts, mv, block_threads, cache_key=None):
+    ref, comps, medial, radius, ys = _prepare_components(backend, pts, mv, cache_key)
+    res = run_components(comps, medial, radius, ys,
                          stages=STAGE_SSSP | STAGE_TREE_DISTANCE | STAGE_SAMPLE, block_threads=block_threads)
     off = comps.comp_off.cpu().numpy()
     n_branches = 0
@@ -114,7 +129,9 @@ def test_components_match_oracle(backend):
     {5: -1, 1: -1, 4: 1 << 30},  # ... path-centric inside the workgroup
     {5: -1, 1: -1, 4: -1},       # ... handed to the chip-wide claim kernel
     {5: 300, 1: 2000, 4: 200},   # a mix of all of them
-], ids=["noprune", "prune4", "relaunch", "one", "local", "wide", "mixed"])
+    {6: 1, 8: 16},               # SSSP: one level per launch, 16 lanes per vertex
+    {6: 7, 7: 2},                # SSSP: seven levels per launch, read-back every second launch
+], ids=["noprune", "prune4", "relaunch", "one", "local", "wide", "mixed", "sssp-rows", "sssp-hops"])
 def test_sample_tree_strategies_agree(backend, params):
     """Branch selection has four claim strategies picked by size; each one alone must reproduce the oracle."""
     from smart_tree_amd import _lib
@@ -123,7 +140,7 @@ def test_sample_tree_strategies_agree(backend, params):
     try:
         for k, v in params.items():
             hook(int(k), int(v))
-        assert _compare_components(backend, pts, mv, block_threads=256) >= 2
+        assert _compare_components(backend, pts, mv, block_threads=256, cache_key="strategies") >= 2
     finally:
         hook(-1, 0)
 
@@ -199,5 +216,33 @@ def test_shortest_paths_reference_signature(backend):
     verts, preds, d = shortest_paths(root, t(edges), t(w), points=t(pts))
     np.testing.assert_array_equal(verts.cpu().numpy(), np.arange(n))
     reach = np.isfinite(ref_d)
+    np.testing.assert_array_equal(d.cpu().numpy()[reach], ref_d[reach])
+    np.testing.assert_array_equal(preds.cpu().numpy()[reach], ref_p[reach])
+
+
+@pytest.mark.parametrize("symmetric", [False, True], ids=["rows<=16", "rows>16"])
+def test_shortest_paths_row_lengths(backend, symmetric):
+    """SSSP on the directed K = 16 neighbour graph (rows of <= 16 edges) and on its symmetrised version (longer,
+    uneven rows): several levels per launch must give the same least fixed point as the oracle's Dijkstra."""
+    from smart_tree_amd.skeleton.shortest_path import shortest_paths
+
+    rng = np.random.RandomState(5)
+    n = 600
+    pts = (rng.rand(n, 3) * np.array([1.0, 4.0, 1.0])).astype(np.float32)
+    idx, dist = so.knn(pts, pts, 16, 0.6)
+    src = np.repeat(np.arange(n), 16)
+    ok = (idx.reshape(-1) >= 0) & (idx.reshape(-1) != src)
+    edges = np.stack([src[ok], idx.reshape(-1)[ok]], axis=1).astype(np.int64)
+    w = dist.reshape(-1)[ok].astype(np.float32)
+    if symmetric:
+        edges = np.concatenate([edges, edges[:, ::-1]])
+        w = np.concatenate([w, w])
+        assert np.bincount(edges[:, 0]).max() > 16
+    root = 3
+    ref_d, ref_p = so.sssp(n, edges, w, root)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(backend)
+    _, preds, d = shortest_paths(root, t(edges), t(w), points=t(pts))
+    reach = np.isfinite(ref_d)
+    assert reach.sum() > n // 2
     np.testing.assert_array_equal(d.cpu().numpy()[reach], ref_d[reach])
     np.testing.assert_array_equal(preds.cpu().numpy()[reach], ref_p[reach])
