@@ -104,6 +104,7 @@ int st_knn_radius(const float* src, int64_t n1, const float* dst, int64_t n2, in
 int64_t st_make_edges_workspace_bytes(int64_t n);
 int st_make_edges(const int64_t* idx, const float* dist, int64_t n, int K, int64_t* edges, float* w,
                   int64_t* n_edges_host, void* ws, int64_t ws_bytes, void* stream);
+int64_t st_connected_components_workspace_bytes(int64_t n);
 int st_connected_components(const int64_t* edges, int64_t E, int64_t n, int32_t* labels, void* ws, int64_t ws_bytes, void* stream);
 int64_t st_component_layout_workspace_bytes(int64_t n);
 int st_component_layout(const int32_t* labels, int64_t n, int min_vertices, int32_t* comp_size, int32_t* comp_off,

@@ -50,6 +50,7 @@ SIGNATURES = {
     "st_centre_cloud": (c_int, [P, I64, P, P, I64, P]),
     "st_make_edges_workspace_bytes": (I64, [I64]),
     "st_make_edges": (c_int, [P, P, I64, c_int, P, P, ctypes.POINTER(I64), P, I64, P]),
+    "st_connected_components_workspace_bytes": (c_int64, [c_int64]),
     "st_connected_components": (c_int, [P, I64, I64, P, P, I64, P]),
     "st_component_layout_workspace_bytes": (I64, [I64]),
     "st_component_layout": (c_int, [P, I64, c_int, P, P, P, P, ctypes.POINTER(I64), ctypes.POINTER(I64), P, I64, P]),

@@ -142,62 +142,106 @@ extern "C" int st_make_edges(const int64_t* idx, const float* dist, int64_t n, i
 }
 
 // ------------------------------------------------------------------ connected components ---
-__device__ __forceinline__ int cc_find(int* label, int x) {
-    // chase to the root; path halving (label only ever decreases towards the root, so writing a
+// Union-find over the edge list.  A root with the larger KEY is hooked under the one with the smaller key, where
+// key(x) = x * CC_MUL mod 2^32 (a bijection; idx() is its inverse).  With the vertex id itself as key the spatial
+// ordering of the ids makes the hooks form chains thousands of roots long (tree k under k-1 under k-2 ...), and
+// every find walks them with dependent loads; a scrambled order keeps the forest shallow.  label[] holds the
+// parent's key while the forest is built; a last pass rewrites it to the smallest vertex id of the component.
+#define CC_MUL 0x9E3779B1u
+#define CC_INV 0x0E8B2F51u  // CC_MUL * CC_INV == 1 (mod 2^32)
+__device__ __forceinline__ unsigned cc_key(unsigned x) { return x * CC_MUL; }
+__device__ __forceinline__ unsigned cc_idx(unsigned k) { return k * CC_INV; }
+
+__device__ __forceinline__ unsigned cc_find(unsigned* label, unsigned k) {
+    // chase to the root; path halving (a parent's key is always smaller than the child's, so writing a
     // grandparent is always a valid shortcut, whatever other lanes do concurrently)
-    int p = __atomic_load_n(&label[x], __ATOMIC_RELAXED);
-    while (p != x) {
-        const int gp = __atomic_load_n(&label[p], __ATOMIC_RELAXED);
-        if (gp != p) atomicMin(&label[x], gp);
-        x = p;
+    unsigned p = __atomic_load_n(&label[cc_idx(k)], __ATOMIC_RELAXED);
+    while (p != k) {
+        const unsigned gp = __atomic_load_n(&label[cc_idx(p)], __ATOMIC_RELAXED);
+        if (gp != p) atomicMin(&label[cc_idx(k)], gp);
+        k = p;
         p = gp;
     }
-    return x;
+    return k;
 }
-__global__ void __launch_bounds__(GR_BLOCK) k_cc_init(int* label, int64_t n) { GR_LOOP(i, n) label[i] = (int)i; }
-// Hooking (ECL-CC style): the larger root is hooked under the smaller one with a CAS that only succeeds
+__global__ void __launch_bounds__(GR_BLOCK) k_cc_init(unsigned* label, int64_t n) { GR_LOOP(i, n) label[i] = cc_key((unsigned)i); }
+// Hooking (ECL-CC style): the root with the larger key is hooked under the other with a CAS that only succeeds
 // while it is still a root; on failure the walk continues from whatever it was hooked to, so every
 // processed edge ends up with both ends in one tree -- no "until nothing changes" loop, no host sync.
 // Afforest-style schedule: a sampled eighth of the edges is linked first, the forest is flattened, and
 // the full pass then dismisses almost every edge with two loads (both ends already carry the same root:
 // a tree cloud is one giant component) instead of chasing pointers for it.
-__global__ void __launch_bounds__(GR_BLOCK) k_cc_hook(const int64_t* edges, int64_t E, int* label, int sample) {
+__global__ void __launch_bounds__(GR_BLOCK) k_cc_hook(const int64_t* edges, int64_t E, unsigned* label, int sample) {
     GR_LOOP(e, E) {
         if (sample && (e & 7) != 0) continue;
-        int a = (int)edges[2 * e], b = (int)edges[2 * e + 1];
-        if (a == b) continue;
+        const unsigned u = (unsigned)edges[2 * e], v = (unsigned)edges[2 * e + 1];
+        if (u == v) continue;
         if (!sample) {  // labels were flattened by the preceding compress
-            const int la = __atomic_load_n(&label[a], __ATOMIC_RELAXED), lb = __atomic_load_n(&label[b], __ATOMIC_RELAXED);
-            if (la == lb) continue;
+            // plain (cacheable) loads: a stale pair that still compares equal was and stays in one tree; anything else
+            // goes through the coherent walk below
+            if (label[u] == label[v]) continue;
         }
-        a = cc_find(label, a);
-        b = cc_find(label, b);
+        unsigned a = cc_find(label, cc_key(u)), b = cc_find(label, cc_key(v));
         while (a != b) {
-            if (a < b) { const int t = a; a = b; b = t; }  // a = larger id
-            const int seen = atomicCAS(&label[a], a, b);
+            if (a < b) { const unsigned t = a; a = b; b = t; }  // a = larger key
+            const unsigned seen = atomicCAS(&label[cc_idx(a)], a, b);
             if (seen == a) break;  // hooked
             a = seen;              // a had already been hooked: continue from there
         }
     }
 }
-__global__ void __launch_bounds__(GR_BLOCK) k_cc_compress(int* label, int64_t n) {
-    GR_LOOP(i, n) { int r = cc_find(label, (int)i); label[i] = r; }
+__global__ void __launch_bounds__(GR_BLOCK) k_cc_compress(unsigned* label, int64_t n) {
+    GR_LOOP(i, n) { const unsigned r = cc_find(label, cc_key((unsigned)i)); label[i] = r; }
 }
+// canonical labels: smallest member id of every tree (label[] is flat: it holds root keys)
+__global__ void __launch_bounds__(GR_BLOCK) k_cc_minid_init(unsigned* minid, int64_t n) { GR_LOOP(i, n) minid[i] = 0xffffffffu; }
+__global__ void __launch_bounds__(GR_BLOCK) k_cc_minid(const unsigned* label, int64_t n, unsigned* minid) {
+    // lanes of a wave that share a root are represented by their first lane (ids ascend with the lane): a big tree
+    // is one component, and per-lane atomics on its one word would serialise the launch
+    const int lane = threadIdx.x & 63;
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < n; base += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = base + threadIdx.x;
+        const bool valid = i < n;
+        const unsigned r = valid ? cc_idx(label[i]) : 0xffffffffu;
+        unsigned long long todo = __ballot(valid);
+        while (todo) {  // wave-uniform
+            const int leader = __ffsll(todo) - 1;
+            const unsigned lr = __shfl(r, leader);
+            const unsigned long long same = __ballot(valid && r == lr);
+            if (lane == leader) atomicMin(&minid[lr], (unsigned)i);
+            todo &= ~same;
+        }
+    }
+}
+__global__ void __launch_bounds__(GR_BLOCK) k_cc_relabel(unsigned* label, int64_t n, const unsigned* minid) {
+    GR_LOOP(i, n) label[i] = minid[cc_idx(label[i])];
+}
+
+extern "C" int64_t st_connected_components_workspace_bytes(int64_t n) { return (n > 0 ? n : 1) * (int64_t)sizeof(unsigned) + 256; }
 
 // labels [n] int32 out: smallest vertex id of each vertex's component.
 extern "C" int st_connected_components(const int64_t* edges, int64_t E, int64_t n, int32_t* labels, void* ws,
                                        int64_t ws_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    (void)ws; (void)ws_bytes;
     ST_REQUIRE(n < (1ll << 31), "cc: too many vertices");
     if (n <= 0) return ST_OK;
-    hipLaunchKernelGGL(k_cc_init, dim3(gr_grid(n)), dim3(GR_BLOCK), 0, stream, labels, n);
-    if (E > 0) {
-        hipLaunchKernelGGL(k_cc_hook, dim3(gr_grid(E)), dim3(GR_BLOCK), 0, stream, edges, E, labels, 1);
-        hipLaunchKernelGGL(k_cc_compress, dim3(gr_grid(n)), dim3(GR_BLOCK), 0, stream, labels, n);
-        hipLaunchKernelGGL(k_cc_hook, dim3(gr_grid(E)), dim3(GR_BLOCK), 0, stream, edges, E, labels, 0);
+    StArena ar(ws, ws_bytes);
+    unsigned* minid = ar.take<unsigned>(n);
+    if (!ar.ok() || !minid) {
+        st_set_error("cc: workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)ar.used);
+        return ST_ERR_WORKSPACE;
     }
-    hipLaunchKernelGGL(k_cc_compress, dim3(gr_grid(n)), dim3(GR_BLOCK), 0, stream, labels, n);
+    unsigned* label = (unsigned*)labels;
+    hipLaunchKernelGGL(k_cc_init, dim3(gr_grid(n)), dim3(GR_BLOCK), 0, stream, label, n);
+    if (E > 0) {
+        hipLaunchKernelGGL(k_cc_hook, dim3(gr_grid(E)), dim3(GR_BLOCK), 0, stream, edges, E, label, 1);
+        hipLaunchKernelGGL(k_cc_compress, dim3(gr_grid(n)), dim3(GR_BLOCK), 0, stream, label, n);
+        hipLaunchKernelGGL(k_cc_hook, dim3(gr_grid(E)), dim3(GR_BLOCK), 0, stream, edges, E, label, 0);
+    }
+    hipLaunchKernelGGL(k_cc_compress, dim3(gr_grid(n)), dim3(GR_BLOCK), 0, stream, label, n);
+    hipLaunchKernelGGL(k_cc_minid_init, dim3(gr_grid(n)), dim3(GR_BLOCK), 0, stream, minid, n);
+    hipLaunchKernelGGL(k_cc_minid, dim3(gr_grid(n)), dim3(GR_BLOCK), 0, stream, (const unsigned*)label, n, minid);
+    hipLaunchKernelGGL(k_cc_relabel, dim3(gr_grid(n)), dim3(GR_BLOCK), 0, stream, label, n, (const unsigned*)minid);
     ST_CHECK_LAUNCH();
     return ST_OK;
 }

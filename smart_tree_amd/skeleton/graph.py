@@ -125,7 +125,7 @@ def connected_components(graph: Graph, minimum_vertices: int = 0) -> ComponentSe
     E = edges.shape[0]
     i32 = lambda k: torch.empty((max(k, 1),), dtype=torch.int32, device=dev)
     labels = i32(n)
-    ws = _lib.workspace(256, dev)
+    ws = _lib.workspace(L.st_connected_components_workspace_bytes(n), dev)
     _lib.check(L.st_connected_components(_lib.ptr(edges), E, n, _lib.ptr(labels), _lib.ptr(ws), ws.numel(), _lib.stream(dev)))
     comp_size, comp_off, vert_order, new_id = i32(n), i32(n + 1), i32(n), i32(n)
     nc, nk = ctypes.c_int64(0), ctypes.c_int64(0)
