@@ -118,8 +118,10 @@ def roofline(peak_gbs: float, peak_f32_tflops: float = 157.3):
     out = {"kernel": name, "bound": "hbm", "achieved": achieved, "peak": peak_gbs, "unit": "GB/s",
            "frac": achieved / peak_gbs, "traffic": _pmc_traffic(name), "launches": r["launches"], "avg_us": r["avg_us"],
            "algorithmic_bytes_per_launch": r["bytes_per_launch"],
-           "note": "latency-bound branch selection (one workgroup per tree component, ~16 us of dependent L2 round trips per "
-                   "branch); bytes = path*24 + claimed*16 + 8*vertices per tree, divided over its launches" if name == "k_sk_select" else ""}
+           "note": "latency-bound branch selection: one workgroup per tree component runs speculative rounds (each of its 16 "
+                   "wavefronts walks one candidate tip; ~25 us of dependent accesses and barriers per round, 3-4 branches "
+                   "accepted per round); bytes = path*24 + claimed*16 + 8*vertices per tree, divided over its launches"
+                   if name == "k_sk_select" else ""}
     convs = {k: v for k, v in rows.items() if k.startswith("k_sparse_conv")}
     if convs:
         cname = max(convs, key=lambda k: convs[k]["total_ms"])

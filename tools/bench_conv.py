@@ -1,4 +1,7 @@
-"""Dev script: per-layer timing of the sparse conv kernels (VALU vs MFMA) on the 1M-point bench cloud."""
+"""Dev script: per-layer timing of the sparse conv kernels (VALU vs MFMA) on a bench cloud's rulebooks.
+
+    python tools/bench_conv.py [points=1000000] [voxel=0.02] [foliage_fraction=0]   # config 4: 5000000 0.01 0.6
+"""
 import sys, time
 from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]; sys.path.insert(0, str(ROOT))
@@ -10,9 +13,12 @@ from smart_tree_amd.dataset.dataset import voxelize_blocks
 from smart_tree_amd.model import sparse_ops as ops
 dev = torch.device("cuda:0")
 pipe = bench.build_pipeline(dev)
-c = sample_tree_cloud(1_000_000, seed=0)
+NPTS = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+VOX = float(sys.argv[2]) if len(sys.argv) > 2 else 0.02
+FOL = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
+c = sample_tree_cloud(NPTS, seed=3 if FOL else 0, **({"foliage_fraction": FOL} if FOL else {}))
 cloud = pipe.preprocessing(Cloud(xyz=torch.from_numpy(c["xyz"]).to(dev), rgb=torch.from_numpy(c["rgb"]).to(dev)))
-vb = voxelize_blocks(cloud.xyz, cloud.rgb, 0.02)
+vb = voxelize_blocks(cloud.xyz, cloud.rgb, VOX)
 pyr = ops.build_pyramid(vb.coords, 3)
 N = [x.shape[0] for x in pyr.coords]
 print("levels", N)
@@ -35,18 +41,18 @@ for lvl in range(4):
         bytes_ = pairs * (cin * 4 + 4) + nout * cout * 4
         flops = 2 * pairs * cin * cout
         t_valu = timeit(lambda: ops.sparse_conv(x, w, tbl, nout))
-        line = f"L{lvl} {name:5s} {cin:3d}->{cout:3d} N={nout:7d} P={pairs:8d}: VALU {t_valu:7.1f} us ({bytes_/t_valu/1e3:7.1f} GB/s, {flops/t_valu/1e6:6.2f} TF)"
+        line = f"L{lvl} {name:5s} {cin:3d}->{cout:3d} N={nout:7d} P={pairs:8d}: VALU {t_valu:7.1f} us ({bytes_/t_valu/1e3:7.1f} GB/s = {bytes_/t_valu/1e3/80:4.1f} %, {flops/t_valu/1e6:6.2f} TF)"
         if cin % 16 == 0 and cout % 16 == 0:
             wp = ops.mfma_weight(w)
             import ctypes
             from smart_tree_amd import _lib
             L = _lib.lib(); L.st_debug_set_mfma_variant.argtypes = [ctypes.c_int]
             ya = ops.sparse_conv(x, w, tbl, nout)
-            for var, tag in ((1, "rt1"), (2, "rt2"), (17, "rt1+lds"), (18, "rt2+lds")):
+            for var, tag in ((1, "rt1"),):
                 L.st_debug_set_mfma_variant(var)
                 t_m = timeit(lambda: ops.sparse_conv(x, w, tbl, nout, wp=wp))
                 yb = ops.sparse_conv(x, w, tbl, nout, wp=wp)
                 err = (ya - yb).abs().max().item() / (ya.abs().max().item() + 1e-30)
-                line += f" | {tag} {t_m:6.1f} us {flops/t_m/1e6:5.1f} TF e={err:.0e}"
+                line += f" | mfma {t_m:6.1f} us ({bytes_/t_m/1e3:7.1f} GB/s = {bytes_/t_m/1e3/80:4.1f} % of 8 TB/s) {flops/t_m/1e6:5.1f} TF e={err:.0e}"
             L.st_debug_set_mfma_variant(0)
         print(line)
