@@ -5,7 +5,10 @@
 
 A step = one pass of the hot path (CentreCloud -> blocks/voxelise -> UNet -> class filter ->
 kNN graph -> components -> SSSP -> sample_tree -> prune/repair/smooth) over one 1M-point synthetic
-tree per rank, inputs resident in HBM when the timed region starts.  Prints ONE JSON line
+tree, inputs resident in HBM when the timed region starts.  Clouds are independent, and a third of a
+cloud's GPU time is spent in kernels that occupy ONE compute unit (the greedy branch selection) or wait for
+the host to read a count back -- so every rank keeps `--streams` clouds in flight, each on its own host
+thread and HIP stream; exactly K steps (clouds) are processed in the timed region.  Prints ONE JSON line
 (rank 0) with the throughput, the roofline of the dominant kernel measured live with HIP events,
 and -- at N = 1 -- the CPU baseline (the oracle, i.e. a port of the reference algorithm: the
 reference itself is CUDA-only) timed on this host's cores on one full cloud.
@@ -84,6 +87,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--points", type=int, default=N_POINTS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=4, help="clouds in flight per GPU (one host thread + HIP stream each)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -104,34 +108,87 @@ def main():
     from smart_tree_amd.sharding import gather_skeletons, pack_skeleton
     from smart_tree_amd.synthetic import sample_tree_cloud
 
-    pipe = build_pipeline(device)
+    import threading
+
+    S = max(1, args.streams)
+    pipes = [build_pipeline(device) for _ in range(S)]
+    streams = [torch.cuda.Stream(device=device) for _ in range(S)]
     # two distinct clouds per rank, cycled; different seeds on every rank (independent trees)
     clouds = []
     for j in range(2):
         c = sample_tree_cloud(args.points, seed=rank * 2 + j)
         clouds.append(Cloud(xyz=torch.from_numpy(c["xyz"]).to(device), rgb=torch.from_numpy(c["rgb"]).to(device)))
 
-    def step(i, collect=None):
-        sk = pipe.process_cloud(cloud=clouds[i % len(clouds)])
+    finished = []  # packed skeletons of this rank, gathered to rank 0 once per timed region (no per-step rendezvous:
+    #                 clouds differ in cost, a collective per step would make every step as slow as its slowest rank)
+    last = {}
+
+    def run_steps(total):
+        """`total` steps, dealt to the S workers from a shared counter."""
+        state = {"next": 0, "error": None}
+        lock = threading.Lock()
+
+        def worker(w):
+            try:
+                with torch.cuda.stream(streams[w]):
+                    while True:
+                        with lock:
+                            i = state["next"]
+                            state["next"] += 1
+                        if i >= total:
+                            break
+                        sk = pipes[w].process_cloud(cloud=clouds[i % len(clouds)])
+                        last["sk"] = sk
+                        if world > 1:
+                            finished.append(pack_skeleton(sk, cloud_id=rank * 1_000_000 + i))
+                    streams[w].synchronize()
+            except BaseException as e:  # noqa: BLE001 -- re-raised on the main thread
+                state["error"] = e
+
+        if S == 1:
+            worker(0)
+        else:
+            threads = [threading.Thread(target=worker, args=(w,)) for w in range(S)]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+        if state["error"] is not None:
+            raise state["error"]
+
+    def gather():
         if world > 1:
-            gather_skeletons([pack_skeleton(sk, cloud_id=rank)], device=device)
-        return sk
+            gather_skeletons(finished, device=device)
+            finished.clear()
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
+    fence()  # inputs and weights are resident before any worker stream touches them
+    warm = max(args.warmup, S) if args.warmup > 0 else 0  # every worker runs at least once before the clock starts
+    run_steps(warm)
+    gather()
+    fence()
+    # for the record (untimed): one cloud at a time on one stream = the latency of a single process_cloud call
+    serial_ms = None
+    if warm > 0:
+        with torch.cuda.stream(streams[0]):
+            t1 = time.perf_counter()
+            for i in range(len(clouds)):
+                pipes[0].process_cloud(cloud=clouds[i])
+            streams[0].synchronize()
+            serial_ms = 1e3 * (time.perf_counter() - t1) / len(clouds)
     fence()
     profiling.enable(True)
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        sk = step(i)
+    run_steps(args.steps)
+    gather()  # inside the timed region: the skeletons of all ranks end up on rank 0
     fence()
     dt = time.perf_counter() - t0
     profiling.enable(False)
+    sk = last["sk"]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -146,7 +203,9 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"configs[1]: one {args.points}-point synthetic tree per rank per step, 2 cm voxels, "
                                    "noble-elevator-58 weights, full Pipeline.process_cloud with prune/repair/smooth",
-                       "clouds_per_rank": len(clouds), "parallelism": f"cloud-sharded x{world}"},
+                       "clouds_per_rank": len(clouds), "parallelism": f"cloud-sharded x{world}",
+                       "clouds_in_flight_per_gpu": S, "warmup_steps_run": warm,
+                       "single_stream_ms_per_cloud": None if serial_ms is None else round(serial_ms, 3)},
             "roofline": profiling.roofline(HBM_PEAK_GBS),
             "stage_ms": profiling.stage_ms(args.steps),
             "last_result": {"trees": len(sk.skeletons), "branches": int(sum(len(t.branches) for t in sk.skeletons))},

@@ -120,3 +120,49 @@ def test_config1_ground_truth_medial_many_components():
                 g = tree.branches[b.branch_id]
                 assert g.parent_id == b.parent_id
                 np.testing.assert_array_equal(g.xyz.numpy(), medial[rc.vertex_ids[b.verts]])
+
+
+def test_clouds_in_flight_on_separate_streams_match_serial_results():
+    """bench.py keeps several clouds in flight per GPU (one host thread + HIP stream each): the library keeps all of its
+    state in caller-provided workspaces, so concurrent calls must produce exactly the serial results."""
+    import threading
+
+    dev = torch.device("cuda:0")
+    clouds = []
+    for seed in (5, 6):
+        c = sample_tree_cloud(200_000, seed=seed)
+        clouds.append(Cloud(xyz=torch.from_numpy(c["xyz"]).to(dev), rgb=torch.from_numpy(c["rgb"]).to(dev)))
+
+    def signature(sk):
+        out = []
+        for tree in sk.skeletons:
+            for b in tree.branches.values():
+                out.append((b._id, b.parent_id, b.xyz.numpy().tobytes(), b.radii.numpy().tobytes()))
+        return out
+
+    serial = [signature(_pipeline(dev, 0.02).process_cloud(cloud=c)) for c in clouds]
+    assert all(len(s) > 10 for s in serial)
+    torch.cuda.synchronize()
+    S, rounds = 3, 4
+    pipes = [_pipeline(dev, 0.02) for _ in range(S)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+    got, errors = {}, []
+
+    def worker(w):
+        try:
+            with torch.cuda.stream(streams[w]):
+                for r in range(rounds):
+                    i = (w + r) % len(clouds)
+                    got[(w, r)] = (i, signature(pipes[w].process_cloud(cloud=clouds[i])))
+        except BaseException as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(w,)) for w in range(S)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert len(got) == S * rounds
+    for (w, r), (i, sig) in got.items():
+        assert sig == serial[i], f"worker {w} round {r} differs from the serial result of cloud {i}"
