@@ -78,6 +78,13 @@ int st_sparse_conv_fwd(const float* x0, int c0, const float* x1, int cin, const 
 int st_sparse_conv_mfma_fwd(const float* x0, int c0, const float* x1, int cin, const int32_t* nbr, int K, int64_t n_out,
                             const float* wp, int cout, const float* scale, const float* shift, const float* residual,
                             int relu, float* y, void* stream);
+/* Half-precision storage (BASELINE.json configs[4]; an extension -- the reference's inference, model/model_inference.py:49-100,
+ * is float32): in_half && out_half -> x0 / x1 / residual / y are IEEE half, w is the MFMA order as half, Cin, Cout and the
+ * concat split multiples of 16, v_mfma_f32_16x16x16_f16 with float32 accumulation; exactly one of them -> the float32
+ * kernel with a converting load or store (w [K][cin][cout] float32, no residual, no concat). */
+int st_sparse_conv_f16_fwd(const void* x0, int c0, const void* x1, int cin, const int32_t* nbr, int K, int64_t n_out,
+                           const void* w, int cout, const float* scale, const float* shift, const void* residual, int relu,
+                           void* y, int in_half, int out_half, void* stream);
 int st_head_param_floats(void);
 int st_pointwise_mlp_heads(const float* x, int64_t n, const float* params, float* radius, float* direction,
                            float* class_l, float* medial_vector /*nullable*/, int64_t* class_idx /*nullable*/, void* stream);

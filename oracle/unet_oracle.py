@@ -142,9 +142,18 @@ def sparse_conv(x: torch.Tensor, nbr: np.ndarray, w: torch.Tensor, n_out: int) -
 
 
 class OracleNet:
-    def __init__(self, weights: Dict[str, np.ndarray], dtype=torch.float32, bn_eps: float = 1e-4):
+    def __init__(self, weights: Dict[str, np.ndarray], dtype=torch.float32, bn_eps: float = 1e-4, fp16: bool = False):
+        """fp16 = True restates the half-precision storage mode (BASELINE.json configs[4]; NOT a reference feature -- the
+        reference's inference is float32): convolutions whose channel counts are both multiples of 16 use weights
+        rounded to half, and every activation tensor with a multiple of 16 channels is rounded to half where the HIP
+        path stores it; the arithmetic in between stays in `dtype`."""
         self.w = {k: torch.as_tensor(np.asarray(v)).to(dtype) for k, v in weights.items()
                   if not k.endswith("num_batches_tracked")}
+        self.fp16 = fp16
+        if fp16:
+            for k, v in self.w.items():
+                if k.endswith(".weight") and v.ndim == 5 and v.shape[0] % 16 == 0 and v.shape[-1] % 16 == 0 and "_head." not in k:
+                    self.w[k] = v.half().to(dtype)
         self.dtype = dtype
         self.eps = bn_eps
         self.depth = 0
@@ -153,6 +162,10 @@ class OracleNet:
         self.trace: Dict[str, torch.Tensor] = {}
 
     # -- layers --------------------------------------------------------------------------
+    def q(self, x):
+        """Storage rounding of the half-precision mode (levels with a multiple of 16 channels)."""
+        return x.half().to(self.dtype) if self.fp16 and x.shape[1] % 16 == 0 else x
+
     def bn(self, x, prefix):
         w = self.w
         inv = 1.0 / torch.sqrt(w[prefix + ".running_var"] + self.eps)
@@ -165,11 +178,11 @@ class OracleNet:
     def res_block(self, x, nbr, prefix, has_identity_conv):
         n = x.shape[0]
         y = sparse_conv(x, nbr, self.w[prefix + ".sequence.0.weight"], n)
-        y = torch.relu(self.bn(y, prefix + ".sequence.1"))
+        y = self.q(torch.relu(self.bn(y, prefix + ".sequence.1")))
         y = sparse_conv(y, nbr, self.w[prefix + ".sequence.3.weight"], n)
         y = self.bn(y, prefix + ".sequence.4")
-        ident = self.pointwise(x, prefix + ".identity.0.weight") if has_identity_conv else x
-        return torch.relu(y + ident)
+        ident = self.q(self.pointwise(x, prefix + ".identity.0.weight")) if has_identity_conv else x
+        return self.q(torch.relu(y + ident))
 
     def ublock(self, x, coords, prefix, level):
         nbr = subm_rulebook(coords)
@@ -184,13 +197,13 @@ class OracleNet:
         dn = down_rulebook(coarse, coords)
         self.rulebooks[f"down{level}"] = dn
         z = sparse_conv(x, dn, self.w[prefix + ".Encode.sequence.0.weight"], len(coarse))
-        z = torch.relu(self.bn(z, prefix + ".Encode.sequence.1"))
+        z = self.q(torch.relu(self.bn(z, prefix + ".Encode.sequence.1")))
         self.trace[f"enc{level}"] = z
         z = self.ublock(z, coarse, prefix + ".U", level + 1)
         up = up_rulebook(coords, coarse)
         self.rulebooks[f"up{level}"] = up
         d = sparse_conv(z, up, self.w[prefix + ".Decode.sequence.0.weight"], len(coords))
-        d = torch.relu(self.bn(d, prefix + ".Decode.sequence.1"))
+        d = self.q(torch.relu(self.bn(d, prefix + ".Decode.sequence.1")))
         self.trace[f"dec{level}"] = d
         x = torch.cat((skip, d), dim=1)
         x = self.res_block(x, nbr, prefix + ".Tail", True)

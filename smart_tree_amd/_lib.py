@@ -42,6 +42,7 @@ SIGNATURES = {
     "st_build_strided_rulebook": (c_int, [P, I64, P, P, I64, P, I64, P, P, I64, ctypes.POINTER(ctypes.c_int32), P, P, P]),
     "st_sparse_conv_fwd": (c_int, [P, c_int, P, c_int, P, c_int, I64, P, c_int, P, P, P, c_int, P, P]),
     "st_sparse_conv_mfma_fwd": (c_int, [P, c_int, P, c_int, P, c_int, I64, P, c_int, P, P, P, c_int, P, P]),
+    "st_sparse_conv_f16_fwd": (c_int, [P, c_int, P, c_int, P, c_int, I64, P, c_int, P, P, P, c_int, P, c_int, c_int, P]),
     "st_head_param_floats": (c_int, []),
     "st_pointwise_mlp_heads": (c_int, [P, I64, P, P, P, P, P, P, P]),
     "st_knn_workspace_bytes": (I64, [I64]),

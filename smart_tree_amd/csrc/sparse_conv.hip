@@ -17,13 +17,27 @@
 
 #define CONV_BLOCK 256
 
-template <int CIN, int COT>
-__global__ void __launch_bounds__(CONV_BLOCK) k_sparse_conv(const float* __restrict__ x0, int c0,
-                                                            const float* __restrict__ x1, const int32_t* __restrict__ nbr,
+// fp16 storage (config 5: levels whose channel count is a multiple of 16 keep their features in half precision):
+// TIN / TOUT = float or st_h; the arithmetic is always float32.
+typedef _Float16 st_h;
+typedef _Float16 st_v4h __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 conv_load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 conv_load4(const st_h* p) {
+    const st_v4h v = *reinterpret_cast<const st_v4h*>(p);
+    return make_float4((float)v.x, (float)v.y, (float)v.z, (float)v.w);
+}
+__device__ __forceinline__ void conv_store4(float* p, float a, float b, float c, float d) { *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d); }
+__device__ __forceinline__ void conv_store4(st_h* p, float a, float b, float c, float d) {
+    *reinterpret_cast<st_v4h*>(p) = st_v4h{(st_h)a, (st_h)b, (st_h)c, (st_h)d};  // round to nearest even
+}
+
+template <int CIN, int COT, class TIN = float, class TOUT = float>
+__global__ void __launch_bounds__(CONV_BLOCK) k_sparse_conv(const TIN* __restrict__ x0, int c0,
+                                                            const TIN* __restrict__ x1, const int32_t* __restrict__ nbr,
                                                             int K, int64_t n_out, const float* __restrict__ w, int cout,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
                                                             const float* __restrict__ residual, int relu,
-                                                            float* __restrict__ y) {
+                                                            TOUT* __restrict__ y) {
     const int co_tiles = cout / COT;
     const int co0 = (int)(blockIdx.x % co_tiles) * COT;
     const int64_t o = (int64_t)(blockIdx.x / co_tiles) * CONV_BLOCK + threadIdx.x;
@@ -41,8 +55,8 @@ __global__ void __launch_bounds__(CONV_BLOCK) k_sparse_conv(const float* __restr
         if (CIN % 4 == 0) {
 #pragma unroll 2
             for (int ci = 0; ci < CIN; ci += 4) {
-                const float* row = ci < c0 ? x0 + (int64_t)idx * c0 + ci : x1 + (int64_t)idx * c1 + (ci - c0);
-                const float4 v = *reinterpret_cast<const float4*>(row);
+                const TIN* row = ci < c0 ? x0 + (int64_t)idx * c0 + ci : x1 + (int64_t)idx * c1 + (ci - c0);
+                const float4 v = conv_load4(row);
                 const float xs[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (int j = 0; j < 4; j++)
@@ -51,7 +65,7 @@ __global__ void __launch_bounds__(CONV_BLOCK) k_sparse_conv(const float* __restr
             }
         } else {
             for (int ci = 0; ci < CIN; ci++) {
-                const float xv = x0[(int64_t)idx * CIN + ci];
+                const float xv = (float)x0[(int64_t)idx * CIN + ci];
 #pragma unroll
                 for (int c = 0; c < COT; c++) acc[c] = fmaf(xv, wk[ci * cout + c], acc[c]);
             }
@@ -66,23 +80,22 @@ __global__ void __launch_bounds__(CONV_BLOCK) k_sparse_conv(const float* __restr
         if (relu) v = v > 0.0f ? v : 0.0f;
         acc[c] = v;
     }
-    float* out = y + o * cout + co0;
+    TOUT* out = y + o * cout + co0;
     if (COT % 4 == 0) {
 #pragma unroll
-        for (int c = 0; c < COT; c += 4)
-            *reinterpret_cast<float4*>(out + c) = make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]);
+        for (int c = 0; c < COT; c += 4) conv_store4(out + c, acc[c], acc[c + 1], acc[c + 2], acc[c + 3]);
     } else {
 #pragma unroll
-        for (int c = 0; c < COT; c++) out[c] = acc[c];
+        for (int c = 0; c < COT; c++) out[c] = (TOUT)acc[c];
     }
 }
 
-template <int CIN, int COT>
-static int conv_launch(const float* x0, int c0, const float* x1, const int32_t* nbr, int K, int64_t n_out, const float* w,
-                       int cout, const float* scale, const float* shift, const float* residual, int relu, float* y,
+template <int CIN, int COT, class TIN = float, class TOUT = float>
+static int conv_launch(const TIN* x0, int c0, const TIN* x1, const int32_t* nbr, int K, int64_t n_out, const float* w,
+                       int cout, const float* scale, const float* shift, const float* residual, int relu, TOUT* y,
                        hipStream_t stream) {
     int64_t blocks = st_div_up(n_out, CONV_BLOCK) * (cout / COT);
-    hipLaunchKernelGGL((k_sparse_conv<CIN, COT>), dim3((unsigned)blocks), dim3(CONV_BLOCK), 0, stream, x0, c0, x1, nbr, K,
+    hipLaunchKernelGGL((k_sparse_conv<CIN, COT, TIN, TOUT>), dim3((unsigned)blocks), dim3(CONV_BLOCK), 0, stream, x0, c0, x1, nbr, K,
                        n_out, w, cout, scale, shift, residual, relu, y);
     ST_CHECK_LAUNCH();
     return ST_OK;
@@ -213,6 +226,115 @@ static int conv_launch_mfma(const float* x0, int c0, const float* x1, const int3
 #undef MFMA_V
     ST_CHECK_LAUNCH();
     return ST_OK;
+}
+
+// fp16 rule-GEMM (config 5): features and weights in half precision, v_mfma_f32_16x16x16_f16 with float32
+// accumulation.  The operand layout is the f32 kernel's with four channels per lane and ONE instruction per
+// 16-channel chunk: lane (i = l & 15, kg = l >> 4) feeds channels 16c + 4kg .. +3 of row i (A, an 8-byte load) and of
+// output column i (B: the same host permutation wp[k][c][kg][co][s], stored as half).  Half the gather bytes, a
+// quarter of the matrix instructions.  BatchNorm affine / residual / ReLU in float32, one rounding on the store.
+template <int CIN, int COUT>
+__global__ void __launch_bounds__(MF_BLOCK) k_sparse_conv_mfma_f16(const st_h* __restrict__ x0, int c0, const st_h* __restrict__ x1,
+                                                                   const int32_t* __restrict__ nbr, int K, int64_t n_out,
+                                                                   const st_h* __restrict__ wp, const float* __restrict__ scale,
+                                                                   const float* __restrict__ shift, const st_h* __restrict__ residual,
+                                                                   int relu, st_h* __restrict__ y) {
+    constexpr int CT = COUT / 16, NC = CIN / 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i16 = lane & 15, kg = lane >> 4;
+    const int64_t obase = ((int64_t)blockIdx.x * (MF_BLOCK / 64) + wave) * 16;
+    const int c1 = CIN - c0;
+    st_v4f acc[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++) acc[ct] = st_v4f{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int k = 0; k < K; k++) {
+        const st_v4h* wsrc = reinterpret_cast<const st_v4h*>(wp + (int64_t)k * CIN * COUT);
+        const int64_t o = obase + i16;
+        const int idx = o < n_out ? (nbr ? nbr[(int64_t)k * n_out + o] : (int)o) : -1;
+        if (__ballot(idx >= 0) == 0ull) continue;  // no voxel of this wave has a neighbour at offset k (wave-uniform)
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const int ci = 16 * c + 4 * kg;
+            st_v4h av = st_v4h{(st_h)0.0f, (st_h)0.0f, (st_h)0.0f, (st_h)0.0f};
+            if (idx >= 0) {
+                const st_h* row = ci < c0 ? x0 + (int64_t)idx * c0 + ci : x1 + (int64_t)idx * c1 + (ci - c0);
+                av = *reinterpret_cast<const st_v4h*>(row);
+            }
+#pragma unroll
+            for (int ct = 0; ct < CT; ct++) {
+                const st_v4h bv = wsrc[(c * 4 + kg) * COUT + ct * 16 + i16];
+                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(av, bv, acc[ct], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++) {
+        const int ch = ct * 16 + i16;
+        const float sc = scale ? scale[ch] : 1.0f, sh = scale ? shift[ch] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int64_t o = obase + kg * 4 + r;
+            if (o >= n_out) continue;
+            float v = acc[ct][r];
+            if (scale) v = fmaf(v, sc, sh);
+            if (residual) v += (float)residual[o * COUT + ch];
+            if (relu) v = v > 0.0f ? v : 0.0f;
+            y[o * COUT + ch] = (st_h)v;
+        }
+    }
+}
+
+// Half-precision storage variants of the two calls above (config 5).  in_half / out_half say which side is fp16:
+//   both      -> the f16 matrix-core kernel; weights = the MFMA order as half, residual half, channels % 16 == 0
+//   exactly one -> the float32 kernel with a converting load or store (the 8 -> 16 "down" and 16 -> 8 "up" convs
+//                between the float32 level 0 and the half-precision levels below); weights [K][cin][cout] float32,
+//                no residual
+extern "C" int st_sparse_conv_f16_fwd(const void* x0, int c0, const void* x1, int cin, const int32_t* nbr, int K, int64_t n_out,
+                                      const void* w, int cout, const float* scale, const float* shift, const void* residual,
+                                      int relu, void* y, int in_half, int out_half, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    ST_REQUIRE(K >= 1 && (nbr != nullptr || K == 1), "conv: a NULL neighbour table means pointwise (K = 1)");
+    ST_REQUIRE(c0 > 0 && c0 <= cin && (c0 == cin || x1 != nullptr), "conv: bad concat split");
+    ST_REQUIRE((scale == nullptr) == (shift == nullptr), "conv: scale and shift go together");
+    ST_REQUIRE(in_half || out_half, "conv(f16): neither side is half precision -- use st_sparse_conv_fwd");
+    if (n_out <= 0) return ST_OK;
+    if (in_half && out_half) {
+        ST_REQUIRE(cin % 16 == 0 && cout % 16 == 0 && c0 % 16 == 0, "conv(f16): channels and concat split must be multiples of 16");
+        const int64_t blocks = st_div_up(n_out, (MF_BLOCK / 64) * 16);
+#define F16_CASE(CI, CO)                                                                                                        \
+    if (cin == CI && cout == CO) {                                                                                              \
+        hipLaunchKernelGGL((k_sparse_conv_mfma_f16<CI, CO>), dim3((unsigned)blocks), dim3(MF_BLOCK), 0, stream, (const st_h*)x0, c0, \
+                           (const st_h*)x1, nbr, K, n_out, (const st_h*)w, scale, shift, (const st_h*)residual, relu, (st_h*)y);    \
+        ST_CHECK_LAUNCH();                                                                                                      \
+        return ST_OK;                                                                                                           \
+    }
+        F16_CASE(16, 16)
+        F16_CASE(16, 32)
+        F16_CASE(32, 16)
+        F16_CASE(32, 32)
+        F16_CASE(32, 64)
+        F16_CASE(64, 32)
+        F16_CASE(64, 64)
+#undef F16_CASE
+        st_set_error("conv(f16): no kernel instance for cin=%d cout=%d", cin, cout);
+        return ST_ERR_INVALID;
+    }
+    ST_REQUIRE(residual == nullptr && c0 == cin, "conv(f16): the converting kernels take no residual and no concat");
+    ST_REQUIRE(cin % 4 == 0 && cout % 4 == 0, "conv(f16): channels must be multiples of 4");
+#define CAST_CASE(CI, CO, COT_)                                                                                                 \
+    if (cin == CI && cout == CO) {                                                                                              \
+        if (in_half) return conv_launch<CI, COT_, st_h, float>((const st_h*)x0, c0, (const st_h*)x1, nbr, K, n_out, (const float*)w, \
+                                                               cout, scale, shift, nullptr, relu, (float*)y, stream);           \
+        return conv_launch<CI, COT_, float, st_h>((const float*)x0, c0, (const float*)x1, nbr, K, n_out, (const float*)w, cout,   \
+                                                  scale, shift, nullptr, relu, (st_h*)y, stream);                                \
+    }
+    CAST_CASE(8, 16, 16)
+    CAST_CASE(16, 8, 8)
+    CAST_CASE(16, 32, 16)
+    CAST_CASE(32, 16, 16)
+#undef CAST_CASE
+    st_set_error("conv(f16): no converting kernel instance for cin=%d cout=%d", cin, cout);
+    return ST_ERR_INVALID;
 }
 
 // Same contract as st_sparse_conv_fwd, weights in the MFMA order wp[K][Cin/16][4][Cout][4] (see above).

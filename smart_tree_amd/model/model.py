@@ -39,7 +39,10 @@ class _Affine:
 
 
 class Smart_Tree:
-    def __init__(self, state_dict: Mapping[str, torch.Tensor], device=torch.device("cuda:0")):
+    def __init__(self, state_dict: Mapping[str, torch.Tensor], device=torch.device("cuda:0"), fp16: bool = False):
+        """fp16 (extension, BASELINE.json configs[4]; the reference's inference is float32): the levels whose channel
+        count is a multiple of 16 keep their features AND weights in half precision (f16 matrix-core kernel, float32
+        accumulation); level 0 (8 channels), the BatchNorm affines and the heads stay float32."""
         sd = {k: torch.as_tensor(np.asarray(v)) if not torch.is_tensor(v) else v.detach().cpu()
               for k, v in state_dict.items()}
         self._state = sd
@@ -52,12 +55,16 @@ class Smart_Tree:
         self.wp: Dict[str, torch.Tensor] = {}  # MFMA operand order for the Cin, Cout % 16 == 0 convolutions
         self.bn: Dict[str, _Affine] = {}
         self.use_mfma = True
+        self.fp16 = bool(fp16)
+        self.wp16: Dict[str, torch.Tensor] = {}
         for key, t in sd.items():
             if key.endswith(".weight") and t.ndim == 5 and "_head." not in key:
                 name = key[: -len(".weight")]
                 self.w[name] = _conv_weight(t).to(self.device)
                 if self.w[name].shape[1] % 16 == 0 and self.w[name].shape[2] % 16 == 0:
                     self.wp[name] = ops.mfma_weight(self.w[name])
+                    if self.fp16:
+                        self.wp16[name] = self.wp[name].half()
             elif key.endswith(".running_mean") and "_head." not in key:
                 p = key[: -len(".running_mean")]
                 self.bn[p] = _Affine(sd, p, self.device)
@@ -68,7 +75,7 @@ class Smart_Tree:
         return self
 
     def to(self, device):
-        return self if torch.device(device) == self.device else Smart_Tree(self._state, device)
+        return self if torch.device(device) == self.device else Smart_Tree(self._state, device, self.fp16)
 
     @staticmethod
     def _pack_heads(sd) -> torch.Tensor:
@@ -95,9 +102,11 @@ class Smart_Tree:
     # -- building blocks ---------------------------------------------------------------------
     def _conv(self, name, x, nbr, n_out, x1=None, bn=None, residual=None, relu=False):
         a = self.bn[bn] if bn else None
+        out_half = self.fp16 and self.w[name].shape[2] % 16 == 0  # half storage on the levels with >= 16 channels
         return ops.sparse_conv(x, self.w[name], nbr, n_out, x1=x1, scale=a.scale if a else None,
                                shift=a.shift if a else None, residual=residual, relu=relu,
-                               wp=self.wp.get(name) if self.use_mfma else None)
+                               wp=self.wp.get(name) if self.use_mfma else None, out_half=out_half,
+                               wp16=self.wp16.get(name))
 
     def _res_block(self, prefix, x, nbr, x1=None):
         """ResBlock.forward (model_blocks.py:149-156); x1 != None is the Tail on cat(skip, decoded)."""

@@ -37,15 +37,15 @@ def _load_state_dict(weights_path):
     return torch.load(str(p), map_location="cpu", weights_only=True)
 
 
-def load_model(model_path, weights_path, device=torch.device("cuda:0")):
+def load_model(model_path, weights_path, device=torch.device("cuda:0"), fp16: bool = False):
     """Reference signature (model_inference.py:11-16).  `model_path` (full pickled nn.Module) is ignored:
-    the graph is rebuilt from the state_dict's keys."""
-    return Smart_Tree(_load_state_dict(weights_path), device=device).eval()
+    the graph is rebuilt from the state_dict's keys.  fp16: see Smart_Tree (additive keyword)."""
+    return Smart_Tree(_load_state_dict(weights_path), device=device, fp16=fp16).eval()
 
 
 class ModelInference:
     def __init__(self, model_path, weights_path, voxel_size: float, block_size: float, buffer_size: float,
-                 num_workers=8, batch_size=4, device=torch.device("cuda:0"), verbose=False):
+                 num_workers=8, batch_size=4, device=torch.device("cuda:0"), verbose=False, fp16: bool = False):
         self.device = torch.device(device)
         self.verbose = verbose
         self.voxel_size = voxel_size
@@ -53,7 +53,7 @@ class ModelInference:
         self.buffer_size = buffer_size
         self.num_workers = num_workers
         self.batch_size = batch_size
-        self.model = load_model(model_path, weights_path, self.device)
+        self.model = load_model(model_path, weights_path, self.device, fp16=fp16)
         if self.verbose:
             print("Model Loaded Succesfully")
 

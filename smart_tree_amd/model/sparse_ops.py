@@ -113,12 +113,31 @@ def mfma_eligible(cin: int, cout: int, c0: int) -> bool:
 def sparse_conv(x0: torch.Tensor, w: torch.Tensor, nbr: Optional[torch.Tensor], n_out: int,
                 x1: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None,
                 shift: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
-                relu: bool = False, wp: Optional[torch.Tensor] = None) -> torch.Tensor:
+                relu: bool = False, wp: Optional[torch.Tensor] = None, out_half: bool = False,
+                wp16: Optional[torch.Tensor] = None) -> torch.Tensor:
     """y = act(bn(sum_k W_k . cat(x0, x1)[nbr[k]]) + residual); w is [K, Cin, Cout].
-    wp (optional): the same weights in MFMA order -> the matrix-core kernel is used."""
+    wp (optional): the same weights in MFMA order -> the matrix-core kernel is used.
+    Half-precision storage mode: a float16 x0 and / or out_half select st_sparse_conv_f16_fwd (wp16 = wp as half)."""
     L = _lib.lib()
     K, cin, cout = w.shape
     c0 = x0.shape[1]
+    in_half = x0.dtype == torch.float16
+    if in_half or out_half:
+        both = in_half and out_half
+        if both and wp16 is None:
+            raise ValueError("half -> half convolution needs the half-precision MFMA weights (wp16)")
+        y = torch.empty((n_out, cout), dtype=torch.float16 if out_half else torch.float32, device=x0.device)
+        esz_in, esz_out = (2 if in_half else 4), (2 if out_half else 4)
+        nbytes = (lambda: (_pair_count(nbr) if nbr is not None else n_out) * (cin * esz_in + (4 if nbr is not None else 0))
+                  + n_out * cout * esz_out) if profiling.enabled() else 0
+        nflops = (lambda: 2.0 * (_pair_count(nbr) if nbr is not None else n_out) * cin * cout) if profiling.enabled() else 0
+        name = f"k_sparse_conv_mfma_f16<{cin},{cout}>" if both else f"k_sparse_conv<{cin},{cout}> {'h->f' if in_half else 'f->h'}"
+        with profiling.kernel(name + ("" if nbr is not None else " k1"), nbytes, nflops):
+            _lib.check(L.st_sparse_conv_f16_fwd(_lib.ptr(x0), c0, _lib.ptr(x1), cin, _lib.ptr(nbr), K, n_out,
+                                                _lib.ptr(wp16 if both else w), cout, _lib.ptr(scale), _lib.ptr(shift),
+                                                _lib.ptr(residual), int(relu), _lib.ptr(y), int(in_half), int(out_half),
+                                                _lib.stream(x0.device)))
+        return y
     if wp is not None and mfma_eligible(cin, cout, c0):
         y = torch.empty((n_out, cout), dtype=torch.float32, device=x0.device)
         nbytes = (lambda: (_pair_count(nbr) if nbr is not None else n_out) * (cin * 4 + (4 if nbr is not None else 0))

@@ -328,6 +328,32 @@ inline hipemu_v4f __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, hipemu_
     return c;
 }
 
+// v_mfma_f32_16x16x16_f16: A[i][k] = element k%4 of lane (k/4)*16 + i, B[k][j] = element k%4 of lane (k/4)*16 + j, D as above.
+// Products of two halves are exact in float32; the hardware's summation order is not documented, this emulation adds in
+// k order -- tests of the fp16 path compare against a float64 oracle with a tolerance, never bit for bit.
+typedef _Float16 hipemu_v4h __attribute__((ext_vector_type(4)));
+inline hipemu_v4f __builtin_amdgcn_mfma_f32_16x16x16f16(hipemu_v4h a, hipemu_v4h b, hipemu_v4f c, int, int, int) {
+    uint64_t ab, bb;
+    memcpy(&ab, &a, 8);
+    memcpy(&bb, &b, 8);
+    auto v = hipemu::wave_exchange(ab, bb);
+    auto half_at = [](uint64_t word, unsigned e) {
+        uint16_t h = (uint16_t)(word >> (16 * e));
+        _Float16 f;
+        memcpy(&f, &h, 2);
+        return (float)f;
+    };
+    unsigned col = v.lane & 15;
+    for (int reg = 0; reg < 4; reg++) {
+        unsigned row = (v.lane >> 4) * 4 + reg;
+        float acc = c[reg];
+        for (unsigned k = 0; k < 16; k++)
+            acc = fmaf(half_at(v.lo((k / 4) * 16 + row), k % 4), half_at(v.hi((k / 4) * 16 + col), k % 4), acc);
+        c[reg] = acc;
+    }
+    return c;
+}
+
 // ---- bit / math helpers ----------------------------------------------------------------
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __popc(unsigned x) { return __builtin_popcount(x); }

@@ -166,3 +166,33 @@ def test_clouds_in_flight_on_separate_streams_match_serial_results():
     assert len(got) == S * rounds
     for (w, r), (i, sig) in got.items():
         assert sig == serial[i], f"worker {w} round {r} differs from the serial result of cloud {i}"
+
+
+def test_config5_half_precision_network_on_the_million_point_tree():
+    """BASELINE.json configs[4]: peach-forest-65 with half-precision storage on the >= 16-channel levels.  There is no
+    reference behaviour to match (its inference is float32), so the check is against our float32 network on the same
+    cloud: medial vectors within 2 mm (a tenth of a voxel), classes equal on > 99.9 % of the voxels, and the whole
+    pipeline still produces a forest."""
+    dev = torch.device("cuda:0")
+    peach = WEIGHTS.parent / "peach-forest-65.npz"
+    c = sample_tree_cloud(1_000_000, seed=0)
+    cloud = Cloud(xyz=torch.from_numpy(c["xyz"]).to(dev), rgb=torch.from_numpy(c["rgb"]).to(dev))
+    cloud = AugmentationPipeline([CentreCloud()])(cloud)
+    out = {}
+    for fp16 in (False, True):
+        mi = ModelInference("unused", peach, voxel_size=0.02, block_size=4, buffer_size=0.4, device=dev, fp16=fp16)
+        assert mi.model.fp16 == fp16
+        out[fp16] = mi.forward(cloud)
+    a, b = out[False], out[True]
+    assert len(a) == len(b) > 100_000
+    assert torch.isfinite(b.medial_vector).all()
+    assert float((a.medial_vector - b.medial_vector).abs().max()) < 2e-3
+    assert float((a.class_l == b.class_l).float().mean()) > 0.999
+    mi = ModelInference("unused", peach, voxel_size=0.02, block_size=4, buffer_size=0.4, device=dev, fp16=True)
+    sk = Skeletonizer(K=16, min_connection_length=0.02, minimum_graph_vertices=32, device=dev)
+    pipe = Pipeline(AugmentationPipeline([CentreCloud()]), mi, sk, repair_skeletons=True, smooth_skeletons=True,
+                    smooth_kernel_size=11, prune_skeletons=True, min_skeleton_radius=0.01, min_skeleton_length=0.02, device=dev)
+    skel = pipe.process_cloud(cloud=Cloud(xyz=torch.from_numpy(c["xyz"]).to(dev), rgb=torch.from_numpy(c["rgb"]).to(dev)))
+    for tree in skel.skeletons:
+        for br in tree.branches.values():
+            assert br.parent_id < br._id and torch.isfinite(br.xyz).all()

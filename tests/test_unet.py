@@ -110,3 +110,33 @@ def test_unet_random_weights_every_layer(backend):
     out = net.forward(sp)
     for k in out:
         np.testing.assert_allclose(out[k].cpu().numpy(), ref[k], rtol=1e-4, atol=1e-4 * np.abs(ref[k]).max())
+
+
+def test_unet_half_precision_storage_mode(backend):
+    """BASELINE.json configs[4] (an extension: the reference's inference is float32): levels with >= 16 channels keep
+    features and weights in IEEE half, f16 matrix-core kernel with float32 accumulation.  Checked against the float64
+    oracle that rounds weights and activations at the same places; tolerance = a few half-precision ulps of the
+    tensor's scale (one rounding flip per layer can propagate), written here: 1e-3 of max|ref| on the UNet features,
+    5e-3 on the head outputs (the direction head is normalised: small vectors amplify the deviation)."""
+    vx = _small_batch(n=5000, seed=9)
+    w = random_state_dict(uo.load_weights(WEIGHTS / "peach-forest-65.npz"), seed=2)
+    oracle16 = uo.OracleNet(w, dtype=torch.float64, fp16=True)
+    ref16 = oracle16.forward(vx["feats"][:, :3], vx["coords"])
+    tail16 = oracle16.trace["tail0"].numpy()
+    oracle32 = uo.OracleNet(w, dtype=torch.float64)
+    oracle32.forward(vx["feats"][:, :3], vx["coords"])
+    tail32 = oracle32.trace["tail0"].numpy()
+    net = Smart_Tree(w, device=backend, fp16=True)
+    sp = sparse_from_batch(torch.from_numpy(vx["feats"][:, :3]), torch.from_numpy(vx["coords"]), backend)
+    feats = net.features(sp)
+    assert feats.dtype == torch.float32  # level 0 stays float32
+    feats = feats.cpu().numpy()
+    assert (tail16 > 0).mean() > 0.2, "test input does not exercise the network"
+    scale = np.abs(tail16).max()
+    err16 = np.abs(feats - tail16).max() / scale
+    err32 = np.abs(feats - tail32).max() / scale
+    assert err16 <= 1e-3, err16
+    assert err32 > err16, (err16, err32)  # the half-precision restatement is closer than the float32 network
+    out = net.forward(sp)
+    for k in out:
+        np.testing.assert_allclose(out[k].cpu().numpy(), ref16[k], rtol=0, atol=5e-3 * np.abs(ref16[k]).max())  # heads: F.normalize amplifies

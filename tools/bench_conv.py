@@ -55,4 +55,11 @@ for lvl in range(4):
                 err = (ya - yb).abs().max().item() / (ya.abs().max().item() + 1e-30)
                 line += f" | mfma {t_m:6.1f} us ({bytes_/t_m/1e3:7.1f} GB/s = {bytes_/t_m/1e3/80:4.1f} % of 8 TB/s) {flops/t_m/1e6:5.1f} TF e={err:.0e}"
             L.st_debug_set_mfma_variant(0)
+            # half-precision storage (config 5): f16 matrix-core kernel, half the gather bytes
+            xh, wph = x.half(), wp.half()
+            bytes_h = pairs * (cin * 2 + 4) + nout * cout * 2
+            t_h = timeit(lambda: ops.sparse_conv(xh, w, tbl, nout, out_half=True, wp16=wph))
+            yh = ops.sparse_conv(xh, w, tbl, nout, out_half=True, wp16=wph).float()
+            errh = (ya - yh).abs().max().item() / (ya.abs().max().item() + 1e-30)
+            line += f" | f16 {t_h:6.1f} us ({bytes_h/t_h/1e3:7.1f} GB/s = {bytes_h/t_h/1e3/80:4.1f} %) {flops/t_h/1e6:5.1f} TF e={errh:.0e}"
         print(line)
