@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(RB_BLOCK) k_rb_down_pass(const int32_t* coords
                         if (!st_hash_insert_min(keys, vals, cap, key, cand)) atomicOr(&st->fail, 1u);
                     } else {
                         // find the slot: the winner is the candidate whose id is stored there
-                        unsigned long long slot = st_hash64(key) & (cap - 1);
+                        unsigned long long slot = st_hash_slot(key, cap);
                         while (keys[slot] != key) slot = (slot + 1) & (cap - 1);
                         if (PASS == 1) {
                             if (vals[slot] == cand) mine++;
@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(RB_BLOCK) k_rb_relabel(const int32_t* out_coor
                                                          unsigned* vals, unsigned long long cap) {
     for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < m; o += (int64_t)gridDim.x * blockDim.x) {
         unsigned long long key = st_pack_key(out_coords[4 * o], out_coords[4 * o + 1], out_coords[4 * o + 2], out_coords[4 * o + 3]);
-        unsigned long long slot = st_hash64(key) & (cap - 1);
+        unsigned long long slot = st_hash_slot(key, cap);
         while (keys[slot] != key) slot = (slot + 1) & (cap - 1);
         vals[slot] = (unsigned)o;
     }
