@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(RB_BLOCK) k_rb_down_pass(const int32_t* coords
                     } else {
                         // find the slot: the winner is the candidate whose id is stored there
                         unsigned long long slot = st_hash_slot(key, cap);
-                        while (keys[slot] != key) slot = (slot + 1) & (cap - 1);
+                        while (keys[slot] != key) slot = st_hash_next(slot, key, cap);
                         if (PASS == 1) {
                             if (vals[slot] == cand) mine++;
                         } else if (vals[slot] == cand) {
@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(RB_BLOCK) k_rb_relabel(const int32_t* out_coor
     for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < m; o += (int64_t)gridDim.x * blockDim.x) {
         unsigned long long key = st_pack_key(out_coords[4 * o], out_coords[4 * o + 1], out_coords[4 * o + 2], out_coords[4 * o + 3]);
         unsigned long long slot = st_hash_slot(key, cap);
-        while (keys[slot] != key) slot = (slot + 1) & (cap - 1);
+        while (keys[slot] != key) slot = st_hash_next(slot, key, cap);
         vals[slot] = (unsigned)o;
     }
 }
@@ -170,7 +170,7 @@ __global__ void __launch_bounds__(RB_BLOCK) k_rb_up_nbr(const int32_t* coords, i
     }
 }
 
-extern "C" int64_t st_hash_capacity(int64_t n) { return st_next_pow2(2 * (n > 0 ? n : 1)); }
+extern "C" int64_t st_hash_capacity(int64_t n) { return st_next_pow2(2 * (n > 8 ? n : 8)); }
 
 extern "C" int st_build_coord_hash(const int32_t* coords, int64_t n, unsigned long long* keys, unsigned* vals, int64_t cap,
                                    void* stream_) {

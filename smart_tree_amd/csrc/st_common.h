@@ -101,7 +101,16 @@ __device__ __forceinline__ unsigned long long st_hash64(unsigned long long k) {
 // slots (= one 64-byte line of keys[]): a 3x3x3 neighbourhood probe touches 9-12 lines instead of 27 scattered
 // ones.  Collisions still resolve by linear probing.
 __device__ __forceinline__ unsigned long long st_hash_slot(unsigned long long key, unsigned long long cap) {
-    return ((st_hash64(key >> 3) << 3) | (key & 7ull)) & (cap - 1);
+    const unsigned long long hg = st_hash64(key >> 3);
+    // the lane inside the group is x & 7 permuted by three hash bits: a wall of constant x must not load one lane only
+    return ((hg << 3) | ((key ^ (hg >> 40)) & 7ull)) & (cap - 1);
+}
+// Next slot of the probe sequence: the key stays in its lane and jumps whole groups by a key-dependent odd
+// stride (double hashing) -- with +1 steps a displaced x-run would pile onto its neighbours' groups (primary
+// clustering: twice the probe length at 50 % load).  cap must be a power of two >= 16.
+__device__ __forceinline__ unsigned long long st_hash_next(unsigned long long slot, unsigned long long key, unsigned long long cap) {
+    const unsigned long long stride = ((st_hash64(key >> 3) >> 29) | 8ull) & ~7ull;  // odd number of groups
+    return (slot + stride) & (cap - 1);
 }
 
 // Open-addressing table: keys[cap] (u64), vals[cap] (u32).  cap is a power of two (>= 8).
@@ -115,7 +124,7 @@ __device__ __forceinline__ bool st_hash_insert_min(unsigned long long* keys, uns
             atomicMin(&vals[slot], val);
             return true;
         }
-        slot = (slot + 1) & (cap - 1);
+        slot = st_hash_next(slot, key, cap);
     }
     return false;
 }
@@ -126,7 +135,7 @@ __device__ __forceinline__ int st_hash_find(const unsigned long long* keys, cons
         unsigned long long k = keys[slot];
         if (k == key) return (int)vals[slot];
         if (k == ST_EMPTY_KEY) return -1;
-        slot = (slot + 1) & (cap - 1);
+        slot = st_hash_next(slot, key, cap);
     }
     return -1;
 }

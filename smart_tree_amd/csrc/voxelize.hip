@@ -264,7 +264,7 @@ static int64_t vx_layout(StArena& a, int64_t n, int max_blocks, int64_t max_voxe
                          unsigned** blk_lo, unsigned** blk_hi, unsigned long long** keys, unsigned** vals, uint32_t** cnt,
                          uint32_t** rec_b, uint32_t** rec_pt, uint32_t** order, char** sub, int64_t* sub_bytes,
                          int64_t* cap) {
-    *cap = st_next_pow2(2 * (max_voxels > 0 ? max_voxels : 1));
+    *cap = st_next_pow2(2 * (max_voxels > 8 ? max_voxels : 8));
     *st = a.take<VxState>(1);
     *table = a.take<int>(VX_TABLE_CAP);
     *blk_lo = a.take<unsigned>(3 * (int64_t)max_blocks);
