@@ -260,6 +260,12 @@ static inline unsigned vx_grid(int64_t n) {
     return (unsigned)(g < 4096 ? g : 4096);
 }
 
+// reductions flush a few words per workgroup with global atomics: fewer, longer-running workgroups
+static inline unsigned vx_grid_reduce(int64_t n) {
+    const unsigned g = vx_grid(n);
+    return g < 512 ? g : 512;
+}
+
 static int64_t vx_layout(StArena& a, int64_t n, int max_blocks, int64_t max_voxels, VxState** st, int** table,
                          unsigned** blk_lo, unsigned** blk_hi, unsigned long long** keys, unsigned** vals, uint32_t** cnt,
                          uint32_t** rec_b, uint32_t** rec_pt, uint32_t** order, char** sub, int64_t* sub_bytes,
@@ -326,8 +332,8 @@ extern "C" int st_voxelize_blocks(const float* xyz, const float* rgb, int64_t n,
     (void)hipMemsetAsync(table, 0, VX_TABLE_CAP * sizeof(int), stream);
     (void)hipMemsetAsync(keys, 0xff, cap * sizeof(unsigned long long), stream);
     (void)hipMemsetAsync(vals, 0xff, cap * sizeof(unsigned), stream);
-    hipLaunchKernelGGL(k_vx_bbox, dim3(g), dim3(VX_BLOCK), 0, stream, xyz, n, p.bs, st);
-    hipLaunchKernelGGL(k_vx_hist, dim3(g), dim3(VX_BLOCK), 0, stream, xyz, n, p.bs, st, table);
+    hipLaunchKernelGGL(k_vx_bbox, dim3(vx_grid_reduce(n)), dim3(VX_BLOCK), 0, stream, xyz, n, p.bs, st);
+    hipLaunchKernelGGL(k_vx_hist, dim3(vx_grid_reduce(n)), dim3(VX_BLOCK), 0, stream, xyz, n, p.bs, st, table);
     hipLaunchKernelGGL(k_vx_blocks, dim3(1), dim3(VX_BLOCK), 0, stream, st, table, p, block_centres, blk_lo, blk_hi);
     hipLaunchKernelGGL(k_vx_minmax, dim3(g), dim3(VX_BLOCK), 0, stream, xyz, n, (const VxState*)st, (const int*)table,
                        (const float*)block_centres, p, blk_lo, blk_hi);
