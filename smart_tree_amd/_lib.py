@@ -106,8 +106,19 @@ def ptr(t):
     return t.data_ptr()
 
 
+_HAS_GPU = None
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream(device=None):
-    if torch.cuda.is_available() and not _ALLOW_HOST_POINTERS:
+    """Raw handle of torch's current HIP stream on `device` (the calling thread's: streams are per thread)."""
+    global _HAS_GPU
+    if _HAS_GPU is None:
+        _HAS_GPU = torch.cuda.is_available()
+    if _HAS_GPU and not _ALLOW_HOST_POINTERS:
+        if _RAW_STREAM is not None:  # one C call instead of building a torch.cuda.Stream object per kernel launch
+            idx = device.index if isinstance(device, torch.device) and device.index is not None else torch.cuda.current_device()
+            return _RAW_STREAM(idx)
         return torch.cuda.current_stream(device).cuda_stream
     return None
 
