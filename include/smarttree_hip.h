@@ -147,6 +147,11 @@ int st_post_process(int n_trees, const int32_t* tree_off, const int32_t* parent,
                     int32_t* depth_scratch, int do_prune, float min_radius, float min_length, int do_repair, int do_smooth, int kernel_size,
                     void* stream);
 
+/* st_points_to_nearest_tube replaces: pts_to_nearest_tube_gpu (util/queries.py:107-133) and the chunk loop of
+ * skeleton_to_points (util/queries.py:139-166): per point the tube minimising |distance - interpolated radius|. */
+int st_points_to_nearest_tube(const float* pts, int64_t n, const float* a, const float* b, const float* r1, const float* r2,
+                              int64_t m, float* vec, int64_t* idx, float* rad, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

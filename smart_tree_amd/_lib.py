@@ -59,6 +59,7 @@ SIGNATURES = {
     "st_component_csr": (c_int, [P, P, I64, P, I64, P, P, P, P, I64, P]),
     "st_assemble_workspace_bytes": (c_int64, [c_int64]),
     "st_assemble_branches": (c_int, [c_int, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, c_int64, c_int64, P, P, c_int64, P]),
+    "st_points_to_nearest_tube": (c_int, [P, c_int64, P, P, P, P, c_int64, P, P, P, P]),
     "st_post_process": (c_int, [c_int, P, P, P, P, P, P, P, P, P, P, P, c_int, c_float, c_float, c_int, c_int, c_int, P]),
     "st_skeleton_workspace_bytes": (I64, [I64, I64]),
     "st_skeleton_components": (c_int, [c_int, P, P, I64, P, P, P, P, P, P, c_float, c_int, c_int, P, P, P, P, P, P, P, P,

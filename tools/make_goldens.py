@@ -186,6 +186,35 @@ def blocking_case():
     print("blocking_50k blocks", len(ds.clouds), out["block_sizes"].tolist())
 
 
+def nearest_tube_case():
+    """Reference pts_to_nearest_tube_gpu (util/queries.py:107-133) on the CPU: 400 points x 120 tubes."""
+    r_queries = reference("smart_tree.util.queries")
+    r_tube = reference("smart_tree.data_types.tube")
+    cpu = torch.device("cpu")
+    r_queries.pts_to_nearest_tube_gpu.__defaults__ = (cpu,)
+    r_tube.CollatedTube.to_gpu.__defaults__ = (cpu,)
+    rng = np.random.RandomState(42)
+    m, n = 120, 400
+    a = (rng.rand(m, 3) * 2).astype(np.float32)
+    b = (a + rng.normal(0, 0.2, (m, 3))).astype(np.float32)
+    r1 = (0.01 + 0.08 * rng.rand(m)).astype(np.float32)
+    r2 = (r1 * (0.6 + 0.4 * rng.rand(m))).astype(np.float32)
+    pts = (rng.rand(n, 3) * 2).astype(np.float32)
+    t = torch.from_numpy
+    tubes = [r_tube.Tube(t(a[i]), t(b[i]), t(r1[i:i + 1]), t(r2[i:i + 1])) for i in range(m)]
+    vectors, idx, radii = r_queries.pts_to_nearest_tube_gpu(t(pts), tubes)
+    # gap between the best two scores (float64), so the test knows where a different summation order may flip the index
+    ab = (b - a).astype(np.float64)
+    ap = pts[:, None, :].astype(np.float64) - a[None]
+    tt = np.clip((ap * ab[None]).sum(2) / (ab * ab).sum(1)[None], 0, 1)
+    proj = a[None] + tt[..., None] * ab[None]
+    score = np.abs(np.linalg.norm(proj - pts[:, None, :], axis=2) - ((1 - tt) * r1[None] + tt * r2[None]))
+    part = np.partition(score, 1, axis=1)
+    np.savez_compressed(OUT / "nearest_tube.npz", pts=pts, a=a, b=b, r1=r1, r2=r2, vectors=vectors.numpy(),
+                        idx=idx.numpy().astype(np.int64), radii=radii.numpy(), gap=(part[:, 1] - part[:, 0]))
+    print("nearest_tube", n, "points", m, "tubes")
+
+
 def y_tree(seed=0):
     """A small trunk + two limbs with exact medial vectors and a little noise."""
     rng = np.random.RandomState(seed)
@@ -219,6 +248,7 @@ def main():
     m = vx["mask"]
     skeleton_case("skeleton_small_tree", vx["feats"][m, :3], c["medial_vector"][vx["point"][m]])
     blocking_case()
+    nearest_tube_case()
 
 
 if __name__ == "__main__":
