@@ -95,13 +95,22 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    # ST_BENCH_DRYRUN=1 (developer aid): exercise the multi-rank control flow on a box with ONE GPU -- every rank uses
+    # cuda:0 and the result gather runs over gloo with host tensors.  Never set by the driver.
+    dryrun = os.environ.get("ST_BENCH_DRYRUN") == "1"
+    if dryrun:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist
 
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if dryrun:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    coll_device = torch.device("cpu") if dryrun else device
 
     from smart_tree_amd import profiling
     from smart_tree_amd.data_types.cloud import Cloud
@@ -158,7 +167,7 @@ def main():
 
     def gather():
         if world > 1:
-            gather_skeletons(finished, device=device)
+            gather_skeletons(finished, device=coll_device)
             finished.clear()
 
     def fence():
@@ -190,7 +199,7 @@ def main():
     profiling.enable(False)
     sk = last["sk"]
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
