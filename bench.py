@@ -59,6 +59,15 @@ def usable_cores() -> int:
     return cores
 
 
+def auto_streams(steps: int, world: int) -> int:
+    """Clouds in flight per rank.  Throughput saturates at 8 (the chip-filling kernels of 8 clouds hide each other's
+    single-workgroup stages and host read-backs); every worker waits on its own stream with the runtime's
+    spin-then-block policy, so leave two host cores per worker, and keep >= 3 clouds per worker so that the timed
+    region does not end in a ragged tail."""
+    by_cores = usable_cores() // (2 * max(world, 1))
+    return max(1, min(8, steps // 3, by_cores))
+
+
 def cpu_baseline(n_points: int):
     """The oracle pipeline on the host cores, one full cloud (bounded: ~30 s)."""
     from oracle import pipeline_oracle as po
@@ -87,7 +96,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--points", type=int, default=N_POINTS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=4, help="clouds in flight per GPU (one host thread + HIP stream each)")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="clouds in flight per GPU (one host thread + HIP stream each); 0 = auto: 8, fewer when the run is "
+                         "short (a worker should see >= 3 clouds) or the host has fewer than 2 cores per worker and rank")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -119,7 +130,7 @@ def main():
 
     import threading
 
-    S = max(1, args.streams)
+    S = args.streams if args.streams > 0 else auto_streams(args.steps, world)
     pipes = [build_pipeline(device) for _ in range(S)]
     streams = [torch.cuda.Stream(device=device) for _ in range(S)]
     # two distinct clouds per rank, cycled; different seeds on every rank (independent trees)

@@ -361,27 +361,57 @@ extern "C" int st_component_layout(const int32_t* labels, int64_t n, int min_ver
 }
 
 // ---------------------------------------------------------------------------- component CSR ---
+// make_edges emits the edge list grouped by source vertex (up to K consecutive edges share `u`): a plain atomicAdd per
+// edge end would serialise ~16 lanes on one counter.  Consecutive lanes with the same key elect their first lane, which
+// adds the run length once; the others take their offset inside the run.  key < 0: lane takes no part.
+// Must be reached by all 64 lanes.  Returns the lane's slot (leader's old counter value + rank in the run).
+__device__ __forceinline__ uint32_t gr_run_add(uint32_t* ctr, int key) {
+    const int lane = threadIdx.x & 63;
+    const int prev = __shfl_up(key, 1);
+    const bool head = key >= 0 && (lane == 0 || prev != key);
+    const unsigned long long heads = __ballot(head), active = __ballot(key >= 0);
+    const unsigned long long upto = heads & (~0ull >> (63 - lane));     // heads at or below this lane
+    const int h = 63 - __clzll((long long)(upto | 1ull));                // my run's first lane (lane 0 if none: inactive)
+    const unsigned long long stop = (heads | ~active) & ~(~0ull >> (63 - h));  // first lane above h that is not in the run
+    const int end = stop ? __ffsll((long long)stop) - 1 : 64;
+    uint32_t base = 0;
+    if (head) base = atomicAdd(&ctr[key], (uint32_t)(end - lane));
+    base = __shfl(base, h);
+    return base + (uint32_t)(lane - h);
+}
+
+// the two ends of edge e in the renumbered vertex space, -1/-1 when the edge is dropped
+__device__ __forceinline__ void csr_edge_ends(const int64_t* edges, int64_t E, const int* new_id, int64_t e, int* a, int* b) {
+    *a = -1; *b = -1;
+    if (e >= E) return;
+    const int64_t u = edges[2 * e], v = edges[2 * e + 1];
+    if (u == v) return;  // self loops (every vertex but 0 has one) never matter for paths
+    const int x = new_id[u], y = new_id[v];
+    if (x < 0 || y < 0) return;
+    *a = x; *b = y;
+}
+
 __global__ void __launch_bounds__(GR_BLOCK) k_csr_count(const int64_t* edges, int64_t E, const int* new_id, uint32_t* deg) {
-    GR_LOOP(e, E) {
-        int64_t u = edges[2 * e], v = edges[2 * e + 1];
-        if (u == v) continue;  // self loops (every vertex but 0 has one) never matter for paths
-        int a = new_id[u], b = new_id[v];
-        if (a < 0 || b < 0) continue;
-        atomicAdd(&deg[a], 1u);
-        atomicAdd(&deg[b], 1u);
+    const int lane = threadIdx.x & 63;
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x - lane); base < E; base += (int64_t)gridDim.x * blockDim.x) {
+        int a, b;
+        csr_edge_ends(edges, E, new_id, base + lane, &a, &b);
+        gr_run_add(deg, a);
+        if (b >= 0) atomicAdd(&deg[b], 1u);  // targets are scattered: no runs to aggregate
     }
 }
 __global__ void __launch_bounds__(GR_BLOCK) k_csr_fill(const int64_t* edges, const float* w, int64_t E, const int* new_id,
                                                        uint32_t* cursor, uint32_t* col, float* wgt) {
-    GR_LOOP(e, E) {
-        int64_t u = edges[2 * e], v = edges[2 * e + 1];
-        if (u == v) continue;
-        int a = new_id[u], b = new_id[v];
-        if (a < 0 || b < 0) continue;
-        uint32_t pa = atomicAdd(&cursor[a], 1u);
-        col[pa] = (uint32_t)b; wgt[pa] = w[e];
-        uint32_t pb = atomicAdd(&cursor[b], 1u);
-        col[pb] = (uint32_t)a; wgt[pb] = w[e];
+    const int lane = threadIdx.x & 63;
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x - lane); base < E; base += (int64_t)gridDim.x * blockDim.x) {
+        int a, b;
+        csr_edge_ends(edges, E, new_id, base + lane, &a, &b);
+        const uint32_t pa = gr_run_add(cursor, a);
+        if (a < 0) continue;
+        const float we = w[base + lane];
+        col[pa] = (uint32_t)b; wgt[pa] = we;
+        const uint32_t pb = atomicAdd(&cursor[b], 1u);
+        col[pb] = (uint32_t)a; wgt[pb] = we;
     }
 }
 

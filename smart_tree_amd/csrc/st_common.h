@@ -128,6 +128,23 @@ __device__ __forceinline__ bool st_hash_insert_min(unsigned long long* keys, uns
     }
     return false;
 }
+// Same contract for a stream with MANY duplicates per key (voxelisation: ~9 points per voxel): look before
+// touching the slot with atomics.  A key never changes once written and a value only decreases, so a stale read
+// can only send us down the atomic path needlessly, never skip a needed update.
+__device__ __forceinline__ bool st_hash_insert_min_dup(unsigned long long* keys, unsigned* vals, unsigned long long cap,
+                                                       unsigned long long key, unsigned val) {
+    unsigned long long slot = st_hash_slot(key, cap);
+    for (unsigned long long probe = 0; probe < cap; probe++) {
+        unsigned long long prev = keys[slot];
+        if (prev == ST_EMPTY_KEY) prev = atomicCAS(&keys[slot], (unsigned long long)ST_EMPTY_KEY, key);
+        if (prev == ST_EMPTY_KEY || prev == key) {
+            if (vals[slot] > val) atomicMin(&vals[slot], val);
+            return true;
+        }
+        slot = st_hash_next(slot, key, cap);
+    }
+    return false;
+}
 __device__ __forceinline__ int st_hash_find(const unsigned long long* keys, const unsigned* vals, unsigned long long cap,
                                             unsigned long long key) {
     unsigned long long slot = st_hash_slot(key, cap);

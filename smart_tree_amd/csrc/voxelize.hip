@@ -118,29 +118,34 @@ __global__ void __launch_bounds__(VX_BLOCK) k_vx_blocks(VxState* st, int* table,
     }
 }
 
-// Calls fn(b) for every kept block whose halo cube [c - half_outer, c + half_outer) holds p.
+// Calls fn(b) for every kept block whose halo cube [c - half_outer, c + half_outer) holds p, in (x, y, z) block order.
+// The test is separable: per axis, which of the three neighbouring block columns hold the coordinate (the centre is
+// recomputed with the expression k_vx_blocks stores, so the decision is bit-identical to testing `centres`); only the
+// surviving combinations -- one for an interior point, up to eight near a block corner -- touch the block table.
 template <class F>
 __device__ __forceinline__ void vx_for_each_block(const float* pt, const VxState* st, const int* d, const int* table,
-                                                  const float* centres, const VxParams& p, F fn) {
+                                                  const VxParams& p, F fn) {
     int q[3];
-    for (int a = 0; a < 3; a++) q[a] = vx_block_id(pt[a], p.bs) - st->lo[a];
+    unsigned ok[3];
+    for (int a = 0; a < 3; a++) {
+        q[a] = vx_block_id(pt[a], p.bs) - st->lo[a];
+        ok[a] = 0;
+        for (int o = -1; o <= 1; o++) {
+            const int c = q[a] + o;
+            if (c < 0 || c >= d[a]) continue;
+            const float ctr = (float)(c + st->lo[a]) * p.bs + p.bs_half;
+            if (pt[a] >= ctr - p.half_outer && pt[a] < ctr + p.half_outer) ok[a] |= 1u << (o + 1);
+        }
+    }
+    if (!(ok[0] && ok[1] && ok[2])) return;
     for (int dx = -1; dx <= 1; dx++) {
-        int cx = q[0] + dx;
-        if (cx < 0 || cx >= d[0]) continue;
+        if (!((ok[0] >> (dx + 1)) & 1u)) continue;
         for (int dy = -1; dy <= 1; dy++) {
-            int cy = q[1] + dy;
-            if (cy < 0 || cy >= d[1]) continue;
+            if (!((ok[1] >> (dy + 1)) & 1u)) continue;
             for (int dz = -1; dz <= 1; dz++) {
-                int cz = q[2] + dz;
-                if (cz < 0 || cz >= d[2]) continue;
-                int b = table[(cx * d[1] + cy) * d[2] + cz];
-                if (b < 0) continue;
-                bool in = true;
-                for (int a = 0; a < 3; a++) {
-                    float c = centres[3 * b + a];
-                    in = in && pt[a] >= c - p.half_outer && pt[a] < c + p.half_outer;
-                }
-                if (in) fn(b);
+                if (!((ok[2] >> (dz + 1)) & 1u)) continue;
+                const int b = table[((q[0] + dx) * d[1] + (q[1] + dy)) * d[2] + (q[2] + dz)];
+                if (b >= 0) fn(b);
             }
         }
     }
@@ -159,7 +164,7 @@ __global__ void __launch_bounds__(VX_BLOCK) k_vx_minmax(const float* xyz, int64_
     __syncthreads();
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         float pt[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
-        vx_for_each_block(pt, st, d, table, centres, p, [&](int b) {
+        vx_for_each_block(pt, st, d, table, p, [&](int b) {
             for (int a = 0; a < 3; a++) {
                 unsigned o = st_f2ord(pt[a]);
                 if (use_lds) {
@@ -193,34 +198,45 @@ __device__ __forceinline__ bool vx_coord(const float* pt, int b, const unsigned*
     return ok;
 }
 
-// pass 0: insert (key -> min point index); pass 1: count winners per point; pass 2: emit winners
+// pass 0: insert (key -> min point index); pass 1: count the voxels a point won and remember WHICH of its blocks
+// (bit j of win[i] = the j-th block vx_for_each_block visits; at most 27); pass 2: emit winners from that mask -- no
+// second round of hash look-ups.
 template <int PASS>
 __global__ void __launch_bounds__(VX_BLOCK) k_vx_pass(const float* xyz, int64_t n, VxState* st, const int* table,
-                                                      const float* centres, VxParams p, const unsigned* blk_lo,
-                                                      const unsigned* blk_hi, unsigned long long* keys, unsigned* vals,
-                                                      unsigned long long cap, uint32_t* cnt_or_off, uint32_t* rec_b,
+                                                      VxParams p, const unsigned* blk_lo, const unsigned* blk_hi,
+                                                      unsigned long long* keys, unsigned* vals, unsigned long long cap,
+                                                      uint32_t* cnt_or_off, uint32_t* win, uint32_t* rec_b,
                                                       uint32_t* rec_pt, int64_t max_voxels) {
     int d[3];
     if (!vx_dims(st, d)) return;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t mine = 0, won = PASS == 2 ? win[i] : 0u;
+        if (PASS == 2 && won == 0u) continue;
         float pt[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
-        uint32_t mine = 0;
         uint32_t off = PASS == 2 ? cnt_or_off[i] : 0u;
-        vx_for_each_block(pt, st, d, table, centres, p, [&](int b) {
-            int c[3];
-            if (!vx_coord(pt, b, blk_lo, blk_hi, p.vs, c)) return;
-            unsigned long long key = st_pack_key(b, c[2], c[1], c[0]);
-            if (PASS == 0) {
-                if (!st_hash_insert_min(keys, vals, cap, key, (unsigned)i)) atomicOr(&st->overflow, 4u);
-            } else if (st_hash_find(keys, vals, cap, key) == (int)i) {
-                if (PASS == 2 && (int64_t)(off + mine) < max_voxels) {
+        int j = 0;
+        vx_for_each_block(pt, st, d, table, p, [&](int b) {
+            const uint32_t bit = 1u << j++;
+            if (PASS == 2) {
+                if (!(won & bit)) return;
+                if ((int64_t)(off + mine) < max_voxels) {
                     rec_b[off + mine] = (uint32_t)b;
                     rec_pt[off + mine] = (uint32_t)i;
                 }
                 mine++;
+                return;
+            }
+            int c[3];
+            if (!vx_coord(pt, b, blk_lo, blk_hi, p.vs, c)) return;
+            unsigned long long key = st_pack_key(b, c[2], c[1], c[0]);
+            if (PASS == 0) {
+                if (!st_hash_insert_min_dup(keys, vals, cap, key, (unsigned)i)) atomicOr(&st->overflow, 4u);
+            } else if (st_hash_find(keys, vals, cap, key) == (int)i) {
+                won |= bit;
+                mine++;
             }
         });
-        if (PASS == 1) cnt_or_off[i] = mine;
+        if (PASS == 1) { cnt_or_off[i] = mine; win[i] = won; }
     }
 }
 
@@ -267,7 +283,7 @@ static inline unsigned vx_grid_reduce(int64_t n) {
 }
 
 static int64_t vx_layout(StArena& a, int64_t n, int max_blocks, int64_t max_voxels, VxState** st, int** table,
-                         unsigned** blk_lo, unsigned** blk_hi, unsigned long long** keys, unsigned** vals, uint32_t** cnt,
+                         unsigned** blk_lo, unsigned** blk_hi, unsigned long long** keys, unsigned** vals, uint32_t** cnt, uint32_t** win,
                          uint32_t** rec_b, uint32_t** rec_pt, uint32_t** order, char** sub, int64_t* sub_bytes,
                          int64_t* cap) {
     *cap = st_next_pow2(2 * (max_voxels > 8 ? max_voxels : 8));
@@ -278,6 +294,7 @@ static int64_t vx_layout(StArena& a, int64_t n, int max_blocks, int64_t max_voxe
     *keys = a.take<unsigned long long>(*cap);
     *vals = a.take<unsigned>(*cap);
     *cnt = a.take<uint32_t>(n);
+    *win = a.take<uint32_t>(n);
     *rec_b = a.take<uint32_t>(max_voxels);
     *rec_pt = a.take<uint32_t>(max_voxels);
     *order = a.take<uint32_t>(max_voxels);
@@ -290,8 +307,8 @@ static int64_t vx_layout(StArena& a, int64_t n, int max_blocks, int64_t max_voxe
 extern "C" int64_t st_voxelize_workspace_bytes(int64_t n_points, int max_blocks, int64_t max_voxels) {
     StArena a(nullptr, 0);
     VxState* st; int* table; unsigned *lo, *hi; unsigned long long* keys; unsigned* vals;
-    uint32_t *cnt, *rb, *rp, *ord; char* sub; int64_t sb, cap;
-    return vx_layout(a, n_points, max_blocks, max_voxels, &st, &table, &lo, &hi, &keys, &vals, &cnt, &rb, &rp, &ord, &sub,
+    uint32_t *cnt, *win, *rb, *rp, *ord; char* sub; int64_t sb, cap;
+    return vx_layout(a, n_points, max_blocks, max_voxels, &st, &table, &lo, &hi, &keys, &vals, &cnt, &win, &rb, &rp, &ord, &sub,
                      &sb, &cap);
 }
 
@@ -311,8 +328,8 @@ extern "C" int st_voxelize_blocks(const float* xyz, const float* rgb, int64_t n,
 
     StArena a(ws, ws_bytes);
     VxState* st; int* table; unsigned *blk_lo, *blk_hi; unsigned long long* keys; unsigned* vals;
-    uint32_t *cnt, *rec_b, *rec_pt, *order; char* sub; int64_t sub_bytes, cap;
-    vx_layout(a, n, max_blocks, max_voxels, &st, &table, &blk_lo, &blk_hi, &keys, &vals, &cnt, &rec_b, &rec_pt, &order, &sub,
+    uint32_t *cnt, *win, *rec_b, *rec_pt, *order; char* sub; int64_t sub_bytes, cap;
+    vx_layout(a, n, max_blocks, max_voxels, &st, &table, &blk_lo, &blk_hi, &keys, &vals, &cnt, &win, &rec_b, &rec_pt, &order, &sub,
               &sub_bytes, &cap);
     if (!a.ok() || !sub) {
         st_set_error("voxelize: workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)a.used);
@@ -337,16 +354,16 @@ extern "C" int st_voxelize_blocks(const float* xyz, const float* rgb, int64_t n,
     hipLaunchKernelGGL(k_vx_blocks, dim3(1), dim3(VX_BLOCK), 0, stream, st, table, p, block_centres, blk_lo, blk_hi);
     hipLaunchKernelGGL(k_vx_minmax, dim3(g), dim3(VX_BLOCK), 0, stream, xyz, n, (const VxState*)st, (const int*)table,
                        (const float*)block_centres, p, blk_lo, blk_hi);
-    hipLaunchKernelGGL((k_vx_pass<0>), dim3(g), dim3(VX_BLOCK), 0, stream, xyz, n, st, (const int*)table,
-                       (const float*)block_centres, p, (const unsigned*)blk_lo, (const unsigned*)blk_hi, keys, vals,
-                       (unsigned long long)cap, cnt, rec_b, rec_pt, max_voxels);
-    hipLaunchKernelGGL((k_vx_pass<1>), dim3(g), dim3(VX_BLOCK), 0, stream, xyz, n, st, (const int*)table,
-                       (const float*)block_centres, p, (const unsigned*)blk_lo, (const unsigned*)blk_hi, keys, vals,
-                       (unsigned long long)cap, cnt, rec_b, rec_pt, max_voxels);
+    hipLaunchKernelGGL((k_vx_pass<0>), dim3(g), dim3(VX_BLOCK), 0, stream, xyz, n, st, (const int*)table, p,
+                       (const unsigned*)blk_lo, (const unsigned*)blk_hi, keys, vals, (unsigned long long)cap, cnt, win, rec_b,
+                       rec_pt, max_voxels);
+    hipLaunchKernelGGL((k_vx_pass<1>), dim3(g), dim3(VX_BLOCK), 0, stream, xyz, n, st, (const int*)table, p,
+                       (const unsigned*)blk_lo, (const unsigned*)blk_hi, keys, vals, (unsigned long long)cap, cnt, win, rec_b,
+                       rec_pt, max_voxels);
     ST_TRY(st_exclusive_scan_u32(cnt, cnt, n, &st->n_vox, sub, sub_bytes, stream));
-    hipLaunchKernelGGL((k_vx_pass<2>), dim3(g), dim3(VX_BLOCK), 0, stream, xyz, n, st, (const int*)table,
-                       (const float*)block_centres, p, (const unsigned*)blk_lo, (const unsigned*)blk_hi, keys, vals,
-                       (unsigned long long)cap, cnt, rec_b, rec_pt, max_voxels);
+    hipLaunchKernelGGL((k_vx_pass<2>), dim3(g), dim3(VX_BLOCK), 0, stream, xyz, n, st, (const int*)table, p,
+                       (const unsigned*)blk_lo, (const unsigned*)blk_hi, keys, vals, (unsigned long long)cap, cnt, win, rec_b,
+                       rec_pt, max_voxels);
     ST_CHECK_LAUNCH();
 
     VxState h;
