@@ -112,6 +112,12 @@ def main():
     if dryrun:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    _sched = os.environ.get("ST_BENCH_SCHED")  # developer knob: how host threads wait for the GPU (spin | yield | block)
+    if _sched:
+        import ctypes
+        _hip = ctypes.CDLL("libamdhip64.so")
+        _rc = _hip.hipSetDeviceFlags({"spin": 1, "yield": 2, "block": 4}[_sched])
+        print(f"hipSetDeviceFlags({_sched}) -> {_rc}", file=sys.stderr)
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist
 

@@ -72,26 +72,43 @@ __global__ void __launch_bounds__(RB_BLOCK) k_rb_extent(const int32_t* coords, i
 }
 
 // candidate outputs of input voxel i: o = (c + 1 - k) / 2 per axis when even and inside out_shape
-// PASS 0: insert(o -> min candidate id i*27+k); PASS 1: count candidates that won; PASS 2: emit rows
+// PASS 0: insert(o -> min candidate id i*27+k); PASS 1: count the candidates that won and remember which (bit k of
+// win[i]); PASS 2: emit rows from that mask (no hash access).  Passes 1 and 2 do nothing once pass 0 has flagged a full
+// table (the host sees the flag after pass 2 and retries with a larger capacity).
 template <int PASS>
 __global__ void __launch_bounds__(RB_BLOCK) k_rb_down_pass(const int32_t* coords, int64_t n, RbState* st,
                                                            unsigned long long* keys, unsigned* vals, unsigned long long cap,
-                                                           uint32_t* cnt_or_off, int32_t* out_coords, int64_t max_out) {
+                                                           uint32_t* cnt_or_off, uint32_t* win, int32_t* out_coords,
+                                                           int64_t max_out) {
+    if (PASS != 0 && st->fail) return;
     int oshape[3];
     for (int a = 0; a < 3; a++) oshape[a] = st->ext[a] / 2 + 1;  // ((ext+1) - 1)/2 + 1
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t mine = 0, won = PASS == 2 ? win[i] : 0u;
+        if (PASS == 2 && won == 0u) continue;
         int b = coords[4 * i], c[3] = {coords[4 * i + 1], coords[4 * i + 2], coords[4 * i + 3]};
-        uint32_t mine = 0;
         uint32_t off = PASS == 2 ? cnt_or_off[i] : 0u;
         int k = 0;
         for (int kz = 0; kz < 3; kz++)
             for (int ky = 0; ky < 3; ky++)
                 for (int kx = 0; kx < 3; kx++, k++) {
+                    if (PASS == 2 && !((won >> k) & 1u)) continue;
                     int nz = c[0] + 1 - kz, ny = c[1] + 1 - ky, nx = c[2] + 1 - kx;
                     if ((nz | ny | nx) & 1) continue;
                     if (nz < 0 || ny < 0 || nx < 0) continue;
                     int oz = nz >> 1, oy = ny >> 1, ox = nx >> 1;
                     if (oz >= oshape[0] || oy >= oshape[1] || ox >= oshape[2]) continue;
+                    if (PASS == 2) {
+                        uint32_t row = off + mine;
+                        if ((int64_t)row < max_out) {
+                            out_coords[4 * row] = b;
+                            out_coords[4 * row + 1] = oz;
+                            out_coords[4 * row + 2] = oy;
+                            out_coords[4 * row + 3] = ox;
+                        }
+                        mine++;
+                        continue;
+                    }
                     unsigned long long key = st_pack_key(b, oz, oy, ox);
                     unsigned cand = (unsigned)(i * 27 + k);
                     if (PASS == 0) {
@@ -100,21 +117,10 @@ __global__ void __launch_bounds__(RB_BLOCK) k_rb_down_pass(const int32_t* coords
                         // find the slot: the winner is the candidate whose id is stored there
                         unsigned long long slot = st_hash_slot(key, cap);
                         while (keys[slot] != key) slot = st_hash_next(slot, key, cap);
-                        if (PASS == 1) {
-                            if (vals[slot] == cand) mine++;
-                        } else if (vals[slot] == cand) {
-                            uint32_t row = off + mine;
-                            if ((int64_t)row < max_out) {
-                                out_coords[4 * row] = b;
-                                out_coords[4 * row + 1] = oz;
-                                out_coords[4 * row + 2] = oy;
-                                out_coords[4 * row + 3] = ox;
-                            }
-                            mine++;
-                        }
+                        if (vals[slot] == cand) { mine++; won |= 1u << k; }
                     }
                 }
-        if (PASS == 1) cnt_or_off[i] = mine;
+        if (PASS == 1) { cnt_or_off[i] = mine; win[i] = won; }
     }
 }
 
@@ -129,28 +135,14 @@ __global__ void __launch_bounds__(RB_BLOCK) k_rb_relabel(const int32_t* out_coor
     }
 }
 
-__global__ void __launch_bounds__(RB_BLOCK) k_rb_down_nbr(const int32_t* out_coords, int64_t m, const unsigned long long* fkeys,
-                                                          const unsigned* fvals, unsigned long long fcap, int32_t* nbr) {
-    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < m; o += (int64_t)gridDim.x * blockDim.x) {
-        int b = out_coords[4 * o], z = out_coords[4 * o + 1], y = out_coords[4 * o + 2], x = out_coords[4 * o + 3];
-        int k = 0;
-        for (int kz = 0; kz < 3; kz++)
-            for (int ky = 0; ky < 3; ky++)
-                for (int kx = 0; kx < 3; kx++, k++) {
-                    int zz = 2 * z - 1 + kz, yy = 2 * y - 1 + ky, xx = 2 * x - 1 + kx;
-                    int r = -1;
-                    if (zz >= 0 && yy >= 0 && xx >= 0 && zz < 65535 && yy < 65535 && xx < 65535)
-                        r = st_hash_find(fkeys, fvals, fcap, st_pack_key(b, zz, yy, xx));
-                    nbr[(int64_t)k * m + o] = r;
-                }
-    }
-}
-
 struct RbShape { int v[3]; };
 
+// Both tables of the strided pair set from ONE round of look-ups: fine voxel i reaches coarse row r through offset k
+// (nbr_up[k][i] = r), and that same pair read from the coarse side is nbr_down[k][r] = i -- (k, r) determines the fine
+// coordinate 2*o - 1 + k, so every entry of nbr_down has exactly one writer; the rest keeps the -1 it was filled with.
 __global__ void __launch_bounds__(RB_BLOCK) k_rb_up_nbr(const int32_t* coords, int64_t n, RbShape osh,
                                                         const unsigned long long* ckeys, const unsigned* cvals,
-                                                        unsigned long long ccap, int32_t* nbr) {
+                                                        unsigned long long ccap, int32_t* nbr, int32_t* nbr_down, int64_t m) {
     int oshape[3] = {osh.v[0], osh.v[1], osh.v[2]};
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         int b = coords[4 * i], c[3] = {coords[4 * i + 1], coords[4 * i + 2], coords[4 * i + 3]};
@@ -166,6 +158,7 @@ __global__ void __launch_bounds__(RB_BLOCK) k_rb_up_nbr(const int32_t* coords, i
                             r = st_hash_find(ckeys, cvals, ccap, st_pack_key(b, oz, oy, ox));
                     }
                     nbr[(int64_t)k * n + i] = r;
+                    if (r >= 0 && r < m) nbr_down[(int64_t)k * m + r] = (int32_t)i;
                 }
     }
 }
@@ -201,6 +194,7 @@ extern "C" int64_t st_strided_workspace_bytes(int64_t n_fine) {
     StArena a(nullptr, 0);
     a.take<RbState>(1);
     a.take<uint32_t>(n_fine);
+    a.take<uint32_t>(n_fine);
     a.take<char>(st_scan_ws_bytes(n_fine));
     return a.used;
 }
@@ -218,9 +212,10 @@ extern "C" int st_build_strided_outputs(const int32_t* coords, int64_t n, int64_
     StArena a(ws, ws_bytes);
     RbState* st = a.take<RbState>(1);
     uint32_t* cnt = a.take<uint32_t>(n);
+    uint32_t* win = a.take<uint32_t>(n);
     int64_t scan_bytes = st_scan_ws_bytes(n);
     char* scan_ws = a.take<char>(scan_bytes);
-    if (!st || !cnt || !scan_ws) {
+    if (!st || !cnt || !win || !scan_ws) {
         st_set_error("strided: workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)a.used);
         return ST_ERR_WORKSPACE;
     }
@@ -231,19 +226,17 @@ extern "C" int st_build_strided_outputs(const int32_t* coords, int64_t n, int64_
     const unsigned g = rb_grid(n);
     hipLaunchKernelGGL(k_rb_extent, dim3(g), dim3(RB_BLOCK), 0, stream, coords, n, st);
     hipLaunchKernelGGL((k_rb_down_pass<0>), dim3(g), dim3(RB_BLOCK), 0, stream, coords, n, st, ckeys, cvals,
-                       (unsigned long long)ccap, cnt, out_coords, max_out);
-    RbState h;
-    (void)hipMemcpyAsync(&h, st, sizeof(RbState), hipMemcpyDeviceToHost, stream);
-    (void)hipStreamSynchronize(stream);
-    ST_REQUIRE(!h.fail, "strided: more than max_out=%lld output voxels", (long long)max_out);
+                       (unsigned long long)ccap, cnt, win, out_coords, max_out);
     hipLaunchKernelGGL((k_rb_down_pass<1>), dim3(g), dim3(RB_BLOCK), 0, stream, coords, n, st, ckeys, cvals,
-                       (unsigned long long)ccap, cnt, out_coords, max_out);
+                       (unsigned long long)ccap, cnt, win, out_coords, max_out);
     ST_TRY(st_exclusive_scan_u32(cnt, cnt, n, &st->n_out, scan_ws, scan_bytes, stream));
     hipLaunchKernelGGL((k_rb_down_pass<2>), dim3(g), dim3(RB_BLOCK), 0, stream, coords, n, st, ckeys, cvals,
-                       (unsigned long long)ccap, cnt, out_coords, max_out);
+                       (unsigned long long)ccap, cnt, win, out_coords, max_out);
+    RbState h;
     (void)hipMemcpyAsync(&h, st, sizeof(RbState), hipMemcpyDeviceToHost, stream);
-    (void)hipStreamSynchronize(stream);
+    (void)hipStreamSynchronize(stream);  // the ONE read-back of this stage: n_out sizes everything downstream
     ST_CHECK_LAUNCH();
+    ST_REQUIRE(!h.fail, "strided: more than max_out=%lld output voxels", (long long)max_out);
     ST_REQUIRE((int64_t)h.n_out <= max_out, "strided: %u output voxels exceed max_out=%lld", h.n_out, (long long)max_out);
     *n_out_host = h.n_out;
     for (int a = 0; a < 3; a++) extent_host[a] = h.ext[a];
@@ -263,11 +256,10 @@ extern "C" int st_build_strided_rulebook(const int32_t* coords, int64_t n, const
     if (n == 0) return ST_OK;
     RbShape osh;
     for (int a = 0; a < 3; a++) osh.v[a] = extent_host[a] / 2 + 1;
-    if (n_out)
-        hipLaunchKernelGGL(k_rb_down_nbr, dim3(rb_grid(n_out)), dim3(RB_BLOCK), 0, stream, out_coords, n_out, fkeys, fvals,
-                           (unsigned long long)fcap, nbr_down);
+    (void)fkeys; (void)fvals; (void)fcap;  // the fine hash is no longer consulted (kept in the signature)
+    if (n_out) (void)hipMemsetAsync(nbr_down, 0xff, 27 * n_out * sizeof(int32_t), stream);
     hipLaunchKernelGGL(k_rb_up_nbr, dim3(rb_grid(n)), dim3(RB_BLOCK), 0, stream, coords, n, osh, ckeys, cvals,
-                       (unsigned long long)ccap, nbr_up);
+                       (unsigned long long)ccap, nbr_up, nbr_down, n_out);
     ST_CHECK_LAUNCH();
     return ST_OK;
 }

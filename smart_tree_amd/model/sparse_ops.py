@@ -55,7 +55,7 @@ def build_strided_rulebook(coords: torch.Tensor, h: CoordHash) -> StridedRuleboo
     n_out = ctypes.c_int64(0)
     extent = (ctypes.c_int32 * 3)()
     rc = -1
-    for max_out in (2 * n + 1024, 8 * n + 1024):  # k3 s2 p1: an input reaches <= 8 outputs
+    for max_out in (n + 1024, 8 * n + 1024):  # k3 s2 p1: an input reaches <= 8 outputs; dense data halves the set
         out_coords = torch.empty((max_out, 4), dtype=torch.int32, device=dev)
         ccap = L.st_hash_capacity(max_out)
         ckeys = torch.empty(ccap, dtype=torch.int64, device=dev)

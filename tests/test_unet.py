@@ -37,6 +37,21 @@ def test_rulebooks_bit_exact(backend):
         level_coords = coarse
 
 
+def test_strided_rulebook_isolated_odd_voxels_take_the_retry_path(backend):
+    """An isolated voxel with odd coordinates reaches up to 8 coarse outputs: n_out ~ 6.4 n overflows the first
+    capacity guess (n + 1024), the build must notice (device-side flag, read after the last pass) and retry."""
+    g = np.arange(7, dtype=np.int32) * 10 + 5
+    z, y, x = np.meshgrid(g, g, g, indexing="ij")
+    coords = np.stack([np.zeros(z.size, np.int32), z.ravel(), y.ravel(), x.ravel()], axis=1).astype(np.int32)
+    h = ops.build_coord_hash(torch.from_numpy(coords).to(backend))
+    rb = ops.build_strided_rulebook(torch.from_numpy(coords).to(backend), h)
+    coarse = uo.strided_out_coords(coords)
+    assert coarse.shape[0] > coords.shape[0] + 1024  # (2*7 - 1)^3: the max-face voxels lose the outputs beyond the extent
+    np.testing.assert_array_equal(rb.out_coords.cpu().numpy(), coarse)
+    np.testing.assert_array_equal(rb.nbr_down.cpu().numpy(), uo.down_rulebook(coarse, coords))
+    np.testing.assert_array_equal(rb.nbr_up.cpu().numpy(), uo.up_rulebook(coords, coarse))
+
+
 def test_rulebook_empty(backend):
     coords = torch.zeros((0, 4), dtype=torch.int32, device=backend)
     pyr = ops.build_pyramid(coords, depth=3)
