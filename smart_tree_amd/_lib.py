@@ -67,12 +67,37 @@ SIGNATURES = {
 }
 
 
-def declare(cdll):
+# Entry points that only ENQUEUE work (or compute a size) and return in microseconds.  ctypes drops the GIL around
+# every CDLL call; with several clouds in flight (one host thread each, bench.py --streams) re-acquiring it after a
+# 5 us launch means queueing behind the other threads -- a convoy that costs more than the launch.  These are bound
+# through PyDLL (GIL kept); everything that waits for the GPU inside the call (a count read back) stays on CDLL.
+ENQUEUE_ONLY = frozenset({
+    "st_version", "st_last_error", "st_scan_workspace_bytes", "st_sort_workspace_bytes", "st_voxelize_workspace_bytes",
+    "st_hash_capacity", "st_strided_workspace_bytes", "st_head_param_floats", "st_knn_workspace_bytes",
+    "st_make_edges_workspace_bytes", "st_connected_components_workspace_bytes", "st_component_layout_workspace_bytes",
+    "st_component_csr_workspace_bytes", "st_assemble_workspace_bytes", "st_skeleton_workspace_bytes",
+    "st_build_coord_hash", "st_build_subm_rulebook", "st_build_strided_rulebook", "st_sparse_conv_fwd",
+    "st_sparse_conv_mfma_fwd", "st_sparse_conv_f16_fwd", "st_pointwise_mlp_heads", "st_medial_points", "st_centre_cloud",
+    "st_connected_components", "st_component_csr", "st_post_process",
+})
+
+
+class _Bound:
+    """The declared entry points as attributes (one ctypes function object each)."""
+
+
+def declare(cdll, pydll=None):
+    """Set the C signatures on `cdll`; returns the object whose attributes are the callable entry points.  With
+    `pydll` (a second handle of the SAME library that keeps the GIL) the ENQUEUE_ONLY functions are taken from it."""
+    out = _Bound() if pydll is not None else cdll
     for name, (res, args) in SIGNATURES.items():
-        fn = getattr(cdll, name)
-        fn.restype = res
-        fn.argtypes = args
-    return cdll
+        for handle in ((cdll, pydll) if pydll is not None else (cdll,)):
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        if pydll is not None:
+            setattr(out, name, getattr(pydll if name in ENQUEUE_ONLY else cdll, name))
+    return out
 
 
 def lib():
@@ -83,7 +108,11 @@ def lib():
                 f"{LIB_PATH} is missing: the HIP extension has not been built. "
                 "Run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
                 "smart_tree_amd has no CPU fallback.")
-        _LIB = declare(ctypes.CDLL(str(LIB_PATH)))
+        import os
+        if os.environ.get("ST_CDLL_ONLY") == "1":  # developer knob for A/B timing of the GIL policy
+            _LIB = declare(ctypes.CDLL(str(LIB_PATH)))
+        else:
+            _LIB = declare(ctypes.CDLL(str(LIB_PATH)), ctypes.PyDLL(str(LIB_PATH)))
     return _LIB
 
 
