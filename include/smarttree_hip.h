@@ -63,7 +63,9 @@ int st_build_strided_outputs(const int32_t* coords, int64_t n, int64_t max_out, 
 int st_build_strided_rulebook(const int32_t* coords, int64_t n, const unsigned long long* fkeys, const unsigned* fvals,
                               int64_t fcap, const int32_t* out_coords, int64_t n_out, const unsigned long long* ckeys,
                               const unsigned* cvals, int64_t ccap, const int32_t* extent_host,
-                              int32_t* nbr_down /*[27,n_out]*/, int32_t* nbr_up /*[27,n]*/, void* stream);
+                              int32_t* nbr_down /*[27,n_out]*/, int32_t* nbr_up /*[27,n]*/,
+                              int32_t* up_order /*[n+16] or NULL: fine rows grouped by coordinate parity, entry = row | (8 + class) << 28 (tail = scratch)*/,
+                              void* stream);
 
 /* ---- network --------------------------------------------------------------------------------------
  * replaces: spconv's gather-GEMM-scatter conv kernels + torch BatchNorm1d/ReLU/add/cat around them
@@ -72,19 +74,21 @@ int st_build_strided_rulebook(const int32_t* coords, int64_t n, const unsigned l
  * st_sparse_conv_fwd: y = act(bn(sum_k W_k . cat(x0,x1)[nbr[k]]) + residual); w is [K][cin][cout]. */
 int st_sparse_conv_fwd(const float* x0, int c0, const float* x1, int cin, const int32_t* nbr, int K, int64_t n_out,
                        const float* w, int cout, const float* scale, const float* shift, const float* residual,
-                       int relu, float* y, void* stream);
+                       int relu, float* y, const int32_t* row_order /*[n_out] or NULL: launch order of the output rows (bits 0-27 row, top 4 bits 0 or the parity tag of st_build_strided_rulebook)*/,
+                       void* stream);
 /* same contract; weights pre-permuted to wp[K][cin/16][4][cout][4] = W[k][16c+4kg+s][co]; cin, cout, c0 % 16 == 0.
  * The per-offset [16 x cin].[cin x cout] contraction runs on v_mfma_f32_16x16x4_f32 (exact fp32). */
 int st_sparse_conv_mfma_fwd(const float* x0, int c0, const float* x1, int cin, const int32_t* nbr, int K, int64_t n_out,
                             const float* wp, int cout, const float* scale, const float* shift, const float* residual,
-                            int relu, float* y, void* stream);
+                            int relu, float* y, const int32_t* row_order /*[n_out] or NULL: launch order of the output rows (bits 0-27 row, top 4 bits 0 or the parity tag of st_build_strided_rulebook)*/,
+                       void* stream);
 /* Half-precision storage (BASELINE.json configs[4]; an extension -- the reference's inference, model/model_inference.py:49-100,
  * is float32): in_half && out_half -> x0 / x1 / residual / y are IEEE half, w is the MFMA order as half, Cin, Cout and the
  * concat split multiples of 16, v_mfma_f32_16x16x16_f16 with float32 accumulation; exactly one of them -> the float32
  * kernel with a converting load or store (w [K][cin][cout] float32, no residual, no concat). */
 int st_sparse_conv_f16_fwd(const void* x0, int c0, const void* x1, int cin, const int32_t* nbr, int K, int64_t n_out,
                            const void* w, int cout, const float* scale, const float* shift, const void* residual, int relu,
-                           void* y, int in_half, int out_half, void* stream);
+                           void* y, int in_half, int out_half, const int32_t* row_order, void* stream);
 int st_head_param_floats(void);
 int st_pointwise_mlp_heads(const float* x, int64_t n, const float* params, float* radius, float* direction,
                            float* class_l, float* medial_vector /*nullable*/, int64_t* class_idx /*nullable*/, void* stream);

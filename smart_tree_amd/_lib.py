@@ -39,10 +39,10 @@ SIGNATURES = {
     "st_strided_workspace_bytes": (I64, [I64]),
     "st_build_strided_outputs": (c_int, [P, I64, I64, P, P, P, I64, ctypes.POINTER(I64), ctypes.POINTER(ctypes.c_int32),
                                          P, I64, P]),
-    "st_build_strided_rulebook": (c_int, [P, I64, P, P, I64, P, I64, P, P, I64, ctypes.POINTER(ctypes.c_int32), P, P, P]),
-    "st_sparse_conv_fwd": (c_int, [P, c_int, P, c_int, P, c_int, I64, P, c_int, P, P, P, c_int, P, P]),
-    "st_sparse_conv_mfma_fwd": (c_int, [P, c_int, P, c_int, P, c_int, I64, P, c_int, P, P, P, c_int, P, P]),
-    "st_sparse_conv_f16_fwd": (c_int, [P, c_int, P, c_int, P, c_int, I64, P, c_int, P, P, P, c_int, P, c_int, c_int, P]),
+    "st_build_strided_rulebook": (c_int, [P, I64, P, P, I64, P, I64, P, P, I64, ctypes.POINTER(ctypes.c_int32), P, P, P, P]),
+    "st_sparse_conv_fwd": (c_int, [P, c_int, P, c_int, P, c_int, I64, P, c_int, P, P, P, c_int, P, P, P]),
+    "st_sparse_conv_mfma_fwd": (c_int, [P, c_int, P, c_int, P, c_int, I64, P, c_int, P, P, P, c_int, P, P, P]),
+    "st_sparse_conv_f16_fwd": (c_int, [P, c_int, P, c_int, P, c_int, I64, P, c_int, P, P, P, c_int, P, c_int, c_int, P, P]),
     "st_head_param_floats": (c_int, []),
     "st_pointwise_mlp_heads": (c_int, [P, I64, P, P, P, P, P, P, P]),
     "st_knn_workspace_bytes": (I64, [I64]),
@@ -83,13 +83,20 @@ ENQUEUE_ONLY = frozenset({
 
 
 class _Bound:
-    """The declared entry points as attributes (one ctypes function object each)."""
+    """The declared entry points as attributes (one ctypes function object each); any other exported symbol
+    (the st_debug_* developer knobs) resolves through the GIL-dropping handle."""
+
+    def __init__(self, cdll):
+        self._cdll = cdll
+
+    def __getattr__(self, name):  # only reached for names that were not bound by declare()
+        return getattr(self._cdll, name)
 
 
 def declare(cdll, pydll=None):
     """Set the C signatures on `cdll`; returns the object whose attributes are the callable entry points.  With
     `pydll` (a second handle of the SAME library that keeps the GIL) the ENQUEUE_ONLY functions are taken from it."""
-    out = _Bound() if pydll is not None else cdll
+    out = _Bound(cdll) if pydll is not None else cdll
     for name, (res, args) in SIGNATURES.items():
         for handle in ((cdll, pydll) if pydll is not None else (cdll,)):
             fn = getattr(handle, name)

@@ -137,15 +137,24 @@ __global__ void __launch_bounds__(RB_BLOCK) k_rb_relabel(const int32_t* out_coor
 
 struct RbShape { int v[3]; };
 
+// parity class of a fine voxel: which of the 27 offsets of the strided pair set can have a partner depends only on it
+// (per axis an even coordinate pairs through k = 1, an odd one through k = 0 and k = 2): 1, 2, 4 or 8 live offsets.
+__device__ __forceinline__ int rb_parity_class(const int* c) { return ((c[0] & 1) << 2) | ((c[1] & 1) << 1) | (c[2] & 1); }
+
 // Both tables of the strided pair set from ONE round of look-ups: fine voxel i reaches coarse row r through offset k
 // (nbr_up[k][i] = r), and that same pair read from the coarse side is nbr_down[k][r] = i -- (k, r) determines the fine
 // coordinate 2*o - 1 + k, so every entry of nbr_down has exactly one writer; the rest keeps the -1 it was filled with.
 __global__ void __launch_bounds__(RB_BLOCK) k_rb_up_nbr(const int32_t* coords, int64_t n, RbShape osh,
                                                         const unsigned long long* ckeys, const unsigned* cvals,
-                                                        unsigned long long ccap, int32_t* nbr, int32_t* nbr_down, int64_t m) {
+                                                        unsigned long long ccap, int32_t* nbr, int32_t* nbr_down, int64_t m,
+                                                        uint32_t* parity_count) {
+    __shared__ uint32_t hist[8];
+    if (threadIdx.x < 8) hist[threadIdx.x] = 0;
+    __syncthreads();
     int oshape[3] = {osh.v[0], osh.v[1], osh.v[2]};
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         int b = coords[4 * i], c[3] = {coords[4 * i + 1], coords[4 * i + 2], coords[4 * i + 3]};
+        if (parity_count) atomicAdd(&hist[rb_parity_class(c)], 1u);
         int k = 0;
         for (int kz = 0; kz < 3; kz++)
             for (int ky = 0; ky < 3; ky++)
@@ -160,6 +169,56 @@ __global__ void __launch_bounds__(RB_BLOCK) k_rb_up_nbr(const int32_t* coords, i
                     nbr[(int64_t)k * n + i] = r;
                     if (r >= 0 && r < m) nbr_down[(int64_t)k * m + r] = (int32_t)i;
                 }
+    }
+    __syncthreads();
+    if (parity_count && threadIdx.x < 8 && hist[threadIdx.x]) atomicAdd(&parity_count[threadIdx.x], hist[threadIdx.x]);
+}
+
+// order[p] = fine row | (8 + class) << 28, rows grouped by parity class (class-major; inside a class in whatever order the
+// workgroups reach the cursors -- the convolution's result does not depend on it, see st_sparse_conv_fwd; the tag in
+// the top four bits tells the conv kernel which offsets can be live for the row).  count[8] from k_rb_up_nbr, cursor[8]
+// zeroed.  A workgroup owns a contiguous chunk of rows: it counts its chunk, reserves one range per class with ONE global
+// atomic each (a few thousand atomics on eight words instead of one per wavefront and class), then deals the rows out
+// through cursors in LDS.
+#define RB_ORDER_BLOCKS 512
+__global__ void __launch_bounds__(RB_BLOCK) k_rb_parity_order(const int32_t* coords, int64_t n, const uint32_t* count,
+                                                              uint32_t* cursor, int32_t* order) {
+    __shared__ uint32_t hist[8], gbase[8], lcur[8];
+    const int lane = threadIdx.x & 63;
+    const int64_t per = (n + gridDim.x - 1) / gridDim.x, chunk = (per + RB_BLOCK - 1) / RB_BLOCK * RB_BLOCK;
+    const int64_t lo = (int64_t)blockIdx.x * chunk, hi = lo + chunk < n ? lo + chunk : n;
+    if (threadIdx.x < 8) { hist[threadIdx.x] = 0; lcur[threadIdx.x] = 0; }
+    __syncthreads();
+    for (int64_t i0 = lo + (threadIdx.x - lane); i0 < hi; i0 += RB_BLOCK) {
+        const int64_t i = i0 + lane;
+        int cls = -1;
+        if (i < hi) { const int c[3] = {coords[4 * i + 1], coords[4 * i + 2], coords[4 * i + 3]}; cls = rb_parity_class(c); }
+        for (int q = 0; q < 8; q++) {
+            const unsigned long long mask = __ballot(cls == q);
+            if (mask != 0ull && lane == __ffsll((long long)mask) - 1) atomicAdd(&hist[q], (uint32_t)__popcll(mask));
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        uint32_t base = 0;
+        for (int q = 0; q < (int)threadIdx.x; q++) base += count[q];
+        gbase[threadIdx.x] = base + (hist[threadIdx.x] ? atomicAdd(&cursor[threadIdx.x], hist[threadIdx.x]) : 0u);
+    }
+    __syncthreads();
+    for (int64_t i0 = lo + (threadIdx.x - lane); i0 < hi; i0 += RB_BLOCK) {
+        const int64_t i = i0 + lane;
+        int cls = -1;
+        if (i < hi) { const int c[3] = {coords[4 * i + 1], coords[4 * i + 2], coords[4 * i + 3]}; cls = rb_parity_class(c); }
+        for (int q = 0; q < 8; q++) {
+            const unsigned long long mask = __ballot(cls == q);
+            if (mask == 0ull) continue;
+            const int leader = __ffsll((long long)mask) - 1;
+            uint32_t at = 0;
+            if (lane == leader) at = atomicAdd(&lcur[q], (uint32_t)__popcll(mask));
+            at = __shfl(at, leader);
+            if (cls == q)
+                order[gbase[q] + at + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (int32_t)((uint32_t)i | ((8u + (uint32_t)q) << 28));
+        }
     }
 }
 
@@ -247,19 +306,28 @@ extern "C" int st_build_strided_outputs(const int32_t* coords, int64_t n, int64_
     return ST_OK;
 }
 
-// Phase 2: the two neighbour tables of the pair set: nbr_down [27][n_out] (fine rows), nbr_up [27][n] (coarse rows)
+// Phase 2: the two neighbour tables of the pair set: nbr_down [27][n_out] (fine rows), nbr_up [27][n] (coarse rows);
+// up_order (optional, n + 16 words: the tail is scratch): the fine rows grouped by coordinate parity and tagged with
+// their class, the row order the inverse convolution should be launched with (st_sparse_conv_fwd's row_order).
 extern "C" int st_build_strided_rulebook(const int32_t* coords, int64_t n, const unsigned long long* fkeys,
                                          const unsigned* fvals, int64_t fcap, const int32_t* out_coords, int64_t n_out,
                                          const unsigned long long* ckeys, const unsigned* cvals, int64_t ccap,
-                                         const int32_t* extent_host, int32_t* nbr_down, int32_t* nbr_up, void* stream_) {
+                                         const int32_t* extent_host, int32_t* nbr_down, int32_t* nbr_up,
+                                         int32_t* up_order /*[n + 16] or NULL*/, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n == 0) return ST_OK;
+    ST_REQUIRE(up_order == nullptr || n < (1ll << 28), "strided: the tagged row order holds at most 2^28 rows");
     RbShape osh;
     for (int a = 0; a < 3; a++) osh.v[a] = extent_host[a] / 2 + 1;
     (void)fkeys; (void)fvals; (void)fcap;  // the fine hash is no longer consulted (kept in the signature)
     if (n_out) (void)hipMemsetAsync(nbr_down, 0xff, 27 * n_out * sizeof(int32_t), stream);
+    uint32_t* pc = up_order ? reinterpret_cast<uint32_t*>(up_order + n) : nullptr;  // 8 class counts + 8 cursors
+    if (pc) (void)hipMemsetAsync(pc, 0, 16 * sizeof(uint32_t), stream);
     hipLaunchKernelGGL(k_rb_up_nbr, dim3(rb_grid(n)), dim3(RB_BLOCK), 0, stream, coords, n, osh, ckeys, cvals,
-                       (unsigned long long)ccap, nbr_up, nbr_down, n_out);
+                       (unsigned long long)ccap, nbr_up, nbr_down, n_out, pc);
+    if (pc)
+        hipLaunchKernelGGL(k_rb_parity_order, dim3(rb_grid(n) < RB_ORDER_BLOCKS ? rb_grid(n) : RB_ORDER_BLOCKS), dim3(RB_BLOCK), 0, stream, coords,
+                           n, (const uint32_t*)pc, pc + 8, up_order);
     ST_CHECK_LAUNCH();
     return ST_OK;
 }

@@ -31,17 +31,37 @@ __device__ __forceinline__ void conv_store4(st_h* p, float a, float b, float c, 
     *reinterpret_cast<st_v4h*>(p) = st_v4h{(st_h)a, (st_h)b, (st_h)c, (st_h)d};  // round to nearest even
 }
 
+// row_order entries: bits 0-27 = output row.  Top four bits 0 = nothing known; 8 + c = the row belongs to coordinate
+// parity class c = (z&1)<<2 | (y&1)<<1 | (x&1) of an inverse k3-s2-p1 convolution: per axis an even coordinate pairs
+// through k = 1 only, an odd one through k = 0 and 2, so at most 8 of the 27 table entries can be >= 0 and the rest
+// need not be read.  Returns the 27-bit mask of offsets worth reading.
+__device__ __forceinline__ uint32_t conv_live_offsets(int32_t entry, int K) {
+    const uint32_t tag = (uint32_t)entry >> 28;
+    if (!(tag & 8u) || K != 27) return 0xffffffffu;
+    const uint32_t ax[3] = {(tag & 4u) ? 5u : 2u, (tag & 2u) ? 5u : 2u, (tag & 1u) ? 5u : 2u};  // z, y, x: {0,2} or {1}
+    uint32_t live = 0;
+#pragma unroll
+    for (int k = 0; k < 27; k++)
+        if (((ax[0] >> (k / 9)) & (ax[1] >> ((k / 3) % 3)) & (ax[2] >> (k % 3))) & 1u) live |= 1u << k;
+    return live;
+}
+#define CONV_ROW_MASK 0x0fffffff
+
 template <int CIN, int COT, class TIN = float, class TOUT = float>
 __global__ void __launch_bounds__(CONV_BLOCK) k_sparse_conv(const TIN* __restrict__ x0, int c0,
                                                             const TIN* __restrict__ x1, const int32_t* __restrict__ nbr,
                                                             int K, int64_t n_out, const float* __restrict__ w, int cout,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
                                                             const float* __restrict__ residual, int relu,
-                                                            TOUT* __restrict__ y) {
+                                                            TOUT* __restrict__ y, const int32_t* __restrict__ row_order) {
     const int co_tiles = cout / COT;
     const int co0 = (int)(blockIdx.x % co_tiles) * COT;
-    const int64_t o = (int64_t)(blockIdx.x / co_tiles) * CONV_BLOCK + threadIdx.x;
-    const bool active = o < n_out;
+    const int64_t pos = (int64_t)(blockIdx.x / co_tiles) * CONV_BLOCK + threadIdx.x;
+    const bool active = pos < n_out;
+    // row_order (optional): the output rows in an order that makes the live offsets wave-uniform (see st_sparse_conv_fwd)
+    const int32_t entry = active && row_order ? row_order[pos] : 0;
+    const int64_t o = active && row_order ? (int64_t)(entry & CONV_ROW_MASK) : pos;
+    const uint32_t live = conv_live_offsets(entry, K);
     const int c1 = CIN - c0;
     float acc[COT];
 #pragma unroll
@@ -49,7 +69,7 @@ __global__ void __launch_bounds__(CONV_BLOCK) k_sparse_conv(const TIN* __restric
 
     for (int k = 0; k < K; k++) {
         int idx = -1;
-        if (active) idx = nbr ? nbr[(int64_t)k * n_out + o] : (int)o;
+        if (active && ((live >> k) & 1u)) idx = nbr ? nbr[(int64_t)k * n_out + o] : (int)o;
         if (idx < 0) continue;
         const float* __restrict__ wk = w + (int64_t)k * CIN * cout + co0;
         if (CIN % 4 == 0) {
@@ -93,10 +113,10 @@ __global__ void __launch_bounds__(CONV_BLOCK) k_sparse_conv(const TIN* __restric
 template <int CIN, int COT, class TIN = float, class TOUT = float>
 static int conv_launch(const TIN* x0, int c0, const TIN* x1, const int32_t* nbr, int K, int64_t n_out, const float* w,
                        int cout, const float* scale, const float* shift, const float* residual, int relu, TOUT* y,
-                       hipStream_t stream) {
+                       hipStream_t stream, const int32_t* row_order = nullptr) {
     int64_t blocks = st_div_up(n_out, CONV_BLOCK) * (cout / COT);
     hipLaunchKernelGGL((k_sparse_conv<CIN, COT, TIN, TOUT>), dim3((unsigned)blocks), dim3(CONV_BLOCK), 0, stream, x0, c0, x1, nbr, K,
-                       n_out, w, cout, scale, shift, residual, relu, y);
+                       n_out, w, cout, scale, shift, residual, relu, y, row_order);
     ST_CHECK_LAUNCH();
     return ST_OK;
 }
@@ -124,7 +144,7 @@ __global__ void __launch_bounds__(MF_BLOCK) k_sparse_conv_mfma(const float* __re
                                                                const int32_t* __restrict__ nbr, int K, int64_t n_out,
                                                                const float* __restrict__ wp, const float* __restrict__ scale,
                                                                const float* __restrict__ shift, const float* __restrict__ residual,
-                                                               int relu, float* __restrict__ y) {
+                                                               int relu, float* __restrict__ y, const int32_t* __restrict__ row_order) {
     constexpr int CT = COUT / 16, NC = CIN / 16;
     __shared__ float4 wl[LDSW ? CIN * COUT / 4 : 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -137,6 +157,15 @@ __global__ void __launch_bounds__(MF_BLOCK) k_sparse_conv_mfma(const float* __re
 #pragma unroll
         for (int ct = 0; ct < CT; ct++) acc[t][ct] = st_v4f{0.0f, 0.0f, 0.0f, 0.0f};
 
+    int64_t orow[RT];  // output row of tile position i16 (identity unless row_order is given)
+    uint32_t live[RT];
+#pragma unroll
+    for (int t = 0; t < RT; t++) {
+        const int64_t pos = obase + t * 16 + i16;
+        const int32_t entry = pos < n_out && row_order ? row_order[pos] : 0;
+        orow[t] = pos < n_out ? (row_order ? (int64_t)(entry & CONV_ROW_MASK) : pos) : -1;
+        live[t] = conv_live_offsets(entry, K);
+    }
     for (int k = 0; k < K; k++) {
         const float4* wsrc = reinterpret_cast<const float4*>(wp + (int64_t)k * CIN * COUT);
         if (LDSW) {
@@ -147,8 +176,7 @@ __global__ void __launch_bounds__(MF_BLOCK) k_sparse_conv_mfma(const float* __re
         bool any = false;
 #pragma unroll
         for (int t = 0; t < RT; t++) {
-            const int64_t o = obase + t * 16 + i16;
-            idx[t] = o < n_out ? (nbr ? nbr[(int64_t)k * n_out + o] : (int)o) : -1;
+            idx[t] = orow[t] >= 0 && ((live[t] >> k) & 1u) ? (nbr ? nbr[(int64_t)k * n_out + orow[t]] : (int)orow[t]) : -1;
             any = any || idx[t] >= 0;
         }
         if (LDSW) __syncthreads();
@@ -187,8 +215,9 @@ __global__ void __launch_bounds__(MF_BLOCK) k_sparse_conv_mfma(const float* __re
         for (int t = 0; t < RT; t++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const int64_t o = obase + t * 16 + kg * 4 + r;
-                if (o >= n_out) continue;
+                const int64_t pos = obase + t * 16 + kg * 4 + r;
+                if (pos >= n_out) continue;
+                const int64_t o = row_order ? (int64_t)(row_order[pos] & CONV_ROW_MASK) : pos;
                 float v = acc[t][ct][r];
                 if (scale) v = fmaf(v, sc, sh);
                 if (residual) v += residual[o * COUT + ch];
@@ -204,19 +233,19 @@ extern "C" void st_debug_set_mfma_variant(int v) { g_mfma_variant = v; }
 template <int CIN, int COUT, int RT, bool LDSW>
 static void conv_launch_mfma_v(const float* x0, int c0, const float* x1, const int32_t* nbr, int K, int64_t n_out, const float* wp,
                                const float* scale, const float* shift, const float* residual, int relu, float* y,
-                               hipStream_t stream) {
+                               hipStream_t stream, const int32_t* row_order) {
     const int64_t blocks = st_div_up(n_out, (MF_BLOCK / 64) * 16 * RT);
     hipLaunchKernelGGL((k_sparse_conv_mfma<CIN, COUT, RT, LDSW>), dim3((unsigned)blocks), dim3(MF_BLOCK), 0, stream, x0, c0, x1,
-                       nbr, K, n_out, wp, scale, shift, residual, relu, y);
+                       nbr, K, n_out, wp, scale, shift, residual, relu, y, row_order);
 }
 
 template <int CIN, int COUT>
 static int conv_launch_mfma(const float* x0, int c0, const float* x1, const int32_t* nbr, int K, int64_t n_out, const float* wp,
                             const float* scale, const float* shift, const float* residual, int relu, float* y,
-                            hipStream_t stream) {
+                            hipStream_t stream, const int32_t* row_order) {
     int v = g_mfma_variant;
     if (v == 0) v = 1;  // measured on MI355X (tools/bench_conv.py): RT = 1 with direct weight loads wins at every level
-#define MFMA_V(RT_, L_) conv_launch_mfma_v<CIN, COUT, RT_, L_>(x0, c0, x1, nbr, K, n_out, wp, scale, shift, residual, relu, y, stream)
+#define MFMA_V(RT_, L_) conv_launch_mfma_v<CIN, COUT, RT_, L_>(x0, c0, x1, nbr, K, n_out, wp, scale, shift, residual, relu, y, stream, row_order)
     switch (v) {
         case 1: MFMA_V(1, false); break;
         case 2: MFMA_V(2, false); break;
@@ -238,7 +267,7 @@ __global__ void __launch_bounds__(MF_BLOCK) k_sparse_conv_mfma_f16(const st_h* _
                                                                    const int32_t* __restrict__ nbr, int K, int64_t n_out,
                                                                    const st_h* __restrict__ wp, const float* __restrict__ scale,
                                                                    const float* __restrict__ shift, const st_h* __restrict__ residual,
-                                                                   int relu, st_h* __restrict__ y) {
+                                                                   int relu, st_h* __restrict__ y, const int32_t* __restrict__ row_order) {
     constexpr int CT = COUT / 16, NC = CIN / 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i16 = lane & 15, kg = lane >> 4;
@@ -247,10 +276,12 @@ __global__ void __launch_bounds__(MF_BLOCK) k_sparse_conv_mfma_f16(const st_h* _
     st_v4f acc[CT];
 #pragma unroll
     for (int ct = 0; ct < CT; ct++) acc[ct] = st_v4f{0.0f, 0.0f, 0.0f, 0.0f};
+    const int32_t entry = obase + i16 < n_out && row_order ? row_order[obase + i16] : 0;
+    const int64_t orow = obase + i16 < n_out ? (row_order ? (int64_t)(entry & CONV_ROW_MASK) : obase + i16) : -1;
+    const uint32_t live = conv_live_offsets(entry, K);
     for (int k = 0; k < K; k++) {
         const st_v4h* wsrc = reinterpret_cast<const st_v4h*>(wp + (int64_t)k * CIN * COUT);
-        const int64_t o = obase + i16;
-        const int idx = o < n_out ? (nbr ? nbr[(int64_t)k * n_out + o] : (int)o) : -1;
+        const int idx = orow >= 0 && ((live >> k) & 1u) ? (nbr ? nbr[(int64_t)k * n_out + orow] : (int)orow) : -1;
         if (__ballot(idx >= 0) == 0ull) continue;  // no voxel of this wave has a neighbour at offset k (wave-uniform)
 #pragma unroll
         for (int c = 0; c < NC; c++) {
@@ -273,8 +304,9 @@ __global__ void __launch_bounds__(MF_BLOCK) k_sparse_conv_mfma_f16(const st_h* _
         const float sc = scale ? scale[ch] : 1.0f, sh = scale ? shift[ch] : 0.0f;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            const int64_t o = obase + kg * 4 + r;
-            if (o >= n_out) continue;
+            const int64_t pos = obase + kg * 4 + r;
+            if (pos >= n_out) continue;
+            const int64_t o = row_order ? (int64_t)(row_order[pos] & CONV_ROW_MASK) : pos;
             float v = acc[ct][r];
             if (scale) v = fmaf(v, sc, sh);
             if (residual) v += (float)residual[o * COUT + ch];
@@ -291,7 +323,7 @@ __global__ void __launch_bounds__(MF_BLOCK) k_sparse_conv_mfma_f16(const st_h* _
 //                no residual
 extern "C" int st_sparse_conv_f16_fwd(const void* x0, int c0, const void* x1, int cin, const int32_t* nbr, int K, int64_t n_out,
                                       const void* w, int cout, const float* scale, const float* shift, const void* residual,
-                                      int relu, void* y, int in_half, int out_half, void* stream_) {
+                                      int relu, void* y, int in_half, int out_half, const int32_t* row_order, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     ST_REQUIRE(K >= 1 && (nbr != nullptr || K == 1), "conv: a NULL neighbour table means pointwise (K = 1)");
     ST_REQUIRE(c0 > 0 && c0 <= cin && (c0 == cin || x1 != nullptr), "conv: bad concat split");
@@ -304,7 +336,7 @@ extern "C" int st_sparse_conv_f16_fwd(const void* x0, int c0, const void* x1, in
 #define F16_CASE(CI, CO)                                                                                                        \
     if (cin == CI && cout == CO) {                                                                                              \
         hipLaunchKernelGGL((k_sparse_conv_mfma_f16<CI, CO>), dim3((unsigned)blocks), dim3(MF_BLOCK), 0, stream, (const st_h*)x0, c0, \
-                           (const st_h*)x1, nbr, K, n_out, (const st_h*)w, scale, shift, (const st_h*)residual, relu, (st_h*)y);    \
+                           (const st_h*)x1, nbr, K, n_out, (const st_h*)w, scale, shift, (const st_h*)residual, relu, (st_h*)y, row_order); \
         ST_CHECK_LAUNCH();                                                                                                      \
         return ST_OK;                                                                                                           \
     }
@@ -324,9 +356,9 @@ extern "C" int st_sparse_conv_f16_fwd(const void* x0, int c0, const void* x1, in
 #define CAST_CASE(CI, CO, COT_)                                                                                                 \
     if (cin == CI && cout == CO) {                                                                                              \
         if (in_half) return conv_launch<CI, COT_, st_h, float>((const st_h*)x0, c0, (const st_h*)x1, nbr, K, n_out, (const float*)w, \
-                                                               cout, scale, shift, nullptr, relu, (float*)y, stream);           \
+                                                               cout, scale, shift, nullptr, relu, (float*)y, stream, row_order); \
         return conv_launch<CI, COT_, float, st_h>((const float*)x0, c0, (const float*)x1, nbr, K, n_out, (const float*)w, cout,   \
-                                                  scale, shift, nullptr, relu, (st_h*)y, stream);                                \
+                                                  scale, shift, nullptr, relu, (st_h*)y, stream, row_order);                     \
     }
     CAST_CASE(8, 16, 16)
     CAST_CASE(16, 8, 8)
@@ -341,7 +373,7 @@ extern "C" int st_sparse_conv_f16_fwd(const void* x0, int c0, const void* x1, in
 // Needs Cin, Cout multiples of 16 and a concat split that is a multiple of 16 (or no concat).
 extern "C" int st_sparse_conv_mfma_fwd(const float* x0, int c0, const float* x1, int cin, const int32_t* nbr, int K,
                                        int64_t n_out, const float* wp, int cout, const float* scale, const float* shift,
-                                       const float* residual, int relu, float* y, void* stream_) {
+                                       const float* residual, int relu, float* y, const int32_t* row_order, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     ST_REQUIRE(K >= 1 && (nbr != nullptr || K == 1), "conv: a NULL neighbour table means pointwise (K = 1)");
     ST_REQUIRE(c0 > 0 && c0 <= cin && (c0 == cin || x1 != nullptr), "conv: bad concat split");
@@ -349,7 +381,7 @@ extern "C" int st_sparse_conv_mfma_fwd(const float* x0, int c0, const float* x1,
     ST_REQUIRE(cin % 16 == 0 && cout % 16 == 0 && c0 % 16 == 0, "conv(mfma): channels and concat split must be multiples of 16");
     if (n_out <= 0) return ST_OK;
 #define MFMA_CASE(CI, CO) \
-    if (cin == CI && cout == CO) return conv_launch_mfma<CI, CO>(x0, c0, x1, nbr, K, n_out, wp, scale, shift, residual, relu, y, stream);
+    if (cin == CI && cout == CO) return conv_launch_mfma<CI, CO>(x0, c0, x1, nbr, K, n_out, wp, scale, shift, residual, relu, y, stream, row_order);
     MFMA_CASE(16, 16)
     MFMA_CASE(16, 32)
     MFMA_CASE(32, 16)
@@ -364,9 +396,15 @@ extern "C" int st_sparse_conv_mfma_fwd(const float* x0, int c0, const float* x1,
 
 // x = cat(x0[:, :c0], x1[:, :cin-c0]) (x1 may be NULL when c0 == cin); w [K][cin][cout];
 // nbr [K][n_out] or NULL (K must be 1: pointwise); scale/shift/residual may be NULL.
+// row_order (may be NULL): a permutation of the output rows (bits 0-27; the top four bits may carry the parity tag
+// described at conv_live_offsets, 0 = none); wave / tile position p works on output row_order[p].
+// Every row is still computed by one lane (or one MFMA tile row) with the same k-ordered arithmetic, so the result
+// does not depend on it -- it only decides which rows share a wavefront.  The inverse ("up") convs pass the fine
+// rows grouped by coordinate parity (st_build_strided_rulebook): inside a parity class only 1, 2, 4 or 8 of the 27
+// offsets can have a partner, and the wave-uniform "nobody has offset k" skip then drops the other 19-26.
 extern "C" int st_sparse_conv_fwd(const float* x0, int c0, const float* x1, int cin, const int32_t* nbr, int K,
                                   int64_t n_out, const float* w, int cout, const float* scale, const float* shift,
-                                  const float* residual, int relu, float* y, void* stream_) {
+                                  const float* residual, int relu, float* y, const int32_t* row_order, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     ST_REQUIRE(K >= 1 && (nbr != nullptr || K == 1), "conv: a NULL neighbour table means pointwise (K = 1)");
     ST_REQUIRE(c0 > 0 && c0 <= cin && (c0 == cin || x1 != nullptr), "conv: bad concat split");
@@ -376,7 +414,7 @@ extern "C" int st_sparse_conv_fwd(const float* x0, int c0, const float* x1, int 
     if (n_out <= 0) return ST_OK;
 #define CONV_CASE(CI, CO, COT_)                                                                                  \
     if (cin == CI && cout == CO)                                                                                 \
-        return conv_launch<CI, COT_>(x0, c0, x1, nbr, K, n_out, w, cout, scale, shift, residual, relu, y, stream);
+        return conv_launch<CI, COT_>(x0, c0, x1, nbr, K, n_out, w, cout, scale, shift, residual, relu, y, stream, row_order);
     CONV_CASE(3, 8, 8)
     CONV_CASE(8, 8, 8)
     CONV_CASE(8, 16, 16)

@@ -100,13 +100,13 @@ class Smart_Tree:
         return torch.cat(blocks).float().contiguous()
 
     # -- building blocks ---------------------------------------------------------------------
-    def _conv(self, name, x, nbr, n_out, x1=None, bn=None, residual=None, relu=False):
+    def _conv(self, name, x, nbr, n_out, x1=None, bn=None, residual=None, relu=False, row_order=None):
         a = self.bn[bn] if bn else None
         out_half = self.fp16 and self.w[name].shape[2] % 16 == 0  # half storage on the levels with >= 16 channels
         return ops.sparse_conv(x, self.w[name], nbr, n_out, x1=x1, scale=a.scale if a else None,
                                shift=a.shift if a else None, residual=residual, relu=relu,
                                wp=self.wp.get(name) if self.use_mfma else None, out_half=out_half,
-                               wp16=self.wp16.get(name))
+                               wp16=self.wp16.get(name), row_order=row_order)
 
     def _res_block(self, prefix, x, nbr, x1=None):
         """ResBlock.forward (model_blocks.py:149-156); x1 != None is the Tail on cat(skip, decoded)."""
@@ -125,7 +125,7 @@ class Smart_Tree:
                        relu=True)
         z = self._ublock(prefix + ".U", z, pyr, level + 1)
         d = self._conv(prefix + ".Decode.sequence.0", z, pyr.up[level], n_fine, bn=prefix + ".Decode.sequence.1",
-                       relu=True)
+                       relu=True, row_order=pyr.up_order[level] if pyr.up_order else None)
         return self._res_block(prefix + ".Tail", x, pyr.subm[level], x1=d)
 
     def features(self, sparse_input):

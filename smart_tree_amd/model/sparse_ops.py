@@ -45,6 +45,7 @@ class StridedRulebook:
     out_hash: CoordHash
     nbr_down: torch.Tensor  # [27, M] fine rows
     nbr_up: torch.Tensor  # [27, N] coarse rows
+    up_order: torch.Tensor = None  # [N] fine rows grouped by coordinate parity: the inverse conv's launch order
 
 
 def build_strided_rulebook(coords: torch.Tensor, h: CoordHash) -> StridedRulebook:
@@ -70,10 +71,11 @@ def build_strided_rulebook(coords: torch.Tensor, h: CoordHash) -> StridedRuleboo
     out_coords = out_coords[:m].contiguous()
     nbr_down = torch.empty((27, m), dtype=torch.int32, device=dev)
     nbr_up = torch.empty((27, n), dtype=torch.int32, device=dev)
+    up_order = torch.empty(n + 16, dtype=torch.int32, device=dev)  # the 16-word tail is the kernel's scratch
     _lib.check(L.st_build_strided_rulebook(_lib.ptr(coords), n, _lib.ptr(h.keys), _lib.ptr(h.vals), h.cap,
                                            _lib.ptr(out_coords), m, _lib.ptr(ckeys), _lib.ptr(cvals), ccap, extent,
-                                           _lib.ptr(nbr_down), _lib.ptr(nbr_up), _lib.stream(dev)))
-    return StridedRulebook(out_coords, CoordHash(ckeys, cvals, ccap), nbr_down, nbr_up)
+                                           _lib.ptr(nbr_down), _lib.ptr(nbr_up), _lib.ptr(up_order), _lib.stream(dev)))
+    return StridedRulebook(out_coords, CoordHash(ckeys, cvals, ccap), nbr_down, nbr_up, up_order[:n])
 
 
 @dataclass
@@ -83,6 +85,7 @@ class RulebookPyramid:
     subm: List[torch.Tensor] = field(default_factory=list)
     down: List[torch.Tensor] = field(default_factory=list)  # down[l]: level l -> l+1
     up: List[torch.Tensor] = field(default_factory=list)  # up[l]:   level l+1 -> l
+    up_order: List[torch.Tensor] = field(default_factory=list)  # up_order[l]: launch order of level l's rows for up[l]
 
 
 def build_pyramid(coords: torch.Tensor, depth: int) -> RulebookPyramid:
@@ -96,6 +99,7 @@ def build_pyramid(coords: torch.Tensor, depth: int) -> RulebookPyramid:
         s = build_strided_rulebook(coords, h)
         pyr.down.append(s.nbr_down)
         pyr.up.append(s.nbr_up)
+        pyr.up_order.append(s.up_order)
         coords, h = s.out_coords, s.out_hash
     return pyr
 
@@ -114,9 +118,10 @@ def sparse_conv(x0: torch.Tensor, w: torch.Tensor, nbr: Optional[torch.Tensor], 
                 x1: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None,
                 shift: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
                 relu: bool = False, wp: Optional[torch.Tensor] = None, out_half: bool = False,
-                wp16: Optional[torch.Tensor] = None) -> torch.Tensor:
+                wp16: Optional[torch.Tensor] = None, row_order: Optional[torch.Tensor] = None) -> torch.Tensor:
     """y = act(bn(sum_k W_k . cat(x0, x1)[nbr[k]]) + residual); w is [K, Cin, Cout].
     wp (optional): the same weights in MFMA order -> the matrix-core kernel is used.
+    row_order (optional, [n_out] int32): launch order of the output rows (never changes the result).
     Half-precision storage mode: a float16 x0 and / or out_half select st_sparse_conv_f16_fwd (wp16 = wp as half)."""
     L = _lib.lib()
     K, cin, cout = w.shape
@@ -136,7 +141,7 @@ def sparse_conv(x0: torch.Tensor, w: torch.Tensor, nbr: Optional[torch.Tensor], 
             _lib.check(L.st_sparse_conv_f16_fwd(_lib.ptr(x0), c0, _lib.ptr(x1), cin, _lib.ptr(nbr), K, n_out,
                                                 _lib.ptr(wp16 if both else w), cout, _lib.ptr(scale), _lib.ptr(shift),
                                                 _lib.ptr(residual), int(relu), _lib.ptr(y), int(in_half), int(out_half),
-                                                _lib.stream(x0.device)))
+                                                _lib.ptr(row_order), _lib.stream(x0.device)))
         return y
     if wp is not None and mfma_eligible(cin, cout, c0):
         y = torch.empty((n_out, cout), dtype=torch.float32, device=x0.device)
@@ -146,7 +151,7 @@ def sparse_conv(x0: torch.Tensor, w: torch.Tensor, nbr: Optional[torch.Tensor], 
         with profiling.kernel(f"k_sparse_conv_mfma<{cin},{cout}>" + ("" if nbr is not None else " k1"), nbytes, nflops):
             _lib.check(L.st_sparse_conv_mfma_fwd(_lib.ptr(x0), c0, _lib.ptr(x1), cin, _lib.ptr(nbr), K, n_out, _lib.ptr(wp), cout,
                                                  _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(residual), int(relu), _lib.ptr(y),
-                                                 _lib.stream(x0.device)))
+                                                 _lib.ptr(row_order), _lib.stream(x0.device)))
         return y
     y = torch.empty((n_out, cout), dtype=torch.float32, device=x0.device)
     # algorithmic bytes: P*(Cin*4 + 4) + N*Cout*4 (pointwise: N*(Cin+Cout)*4); the pair count
@@ -157,7 +162,7 @@ def sparse_conv(x0: torch.Tensor, w: torch.Tensor, nbr: Optional[torch.Tensor], 
     with profiling.kernel(f"k_sparse_conv<{cin},{cout}>" + ("" if nbr is not None else " k1"), nbytes, nflops):
       _lib.check(L.st_sparse_conv_fwd(_lib.ptr(x0), c0, _lib.ptr(x1), cin, _lib.ptr(nbr), K, n_out, _lib.ptr(w), cout,
                                     _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(residual), int(relu), _lib.ptr(y),
-                                    _lib.stream(x0.device)))
+                                    _lib.ptr(row_order), _lib.stream(x0.device)))
     return y
 
 

@@ -52,6 +52,36 @@ def test_strided_rulebook_isolated_odd_voxels_take_the_retry_path(backend):
     np.testing.assert_array_equal(rb.nbr_up.cpu().numpy(), uo.up_rulebook(coords, coarse))
 
 
+def test_up_order_groups_rows_by_parity_and_leaves_the_conv_unchanged(backend):
+    """up_order: a permutation of the fine rows, grouped by coordinate parity class (z, y, x bits); launching the
+    inverse conv in that order must give bit-identical features (every row is computed on its own)."""
+    vx = _small_batch()
+    coords = torch.from_numpy(vx["coords"]).to(backend)
+    pyr = ops.build_pyramid(coords, depth=2)
+    g = torch.Generator().manual_seed(3)
+    for level, (cin, cout) in enumerate([(16, 8), (32, 16)]):
+        fine = pyr.coords[level].cpu().numpy()
+        tagged = pyr.up_order[level].cpu().numpy()
+        order = tagged & 0x0FFFFFFF  # top four bits: 8 + parity class (lets the kernel skip the 19-26 dead offsets)
+        assert sorted(order.tolist()) == list(range(fine.shape[0]))
+        cls = ((fine[order, 1] & 1) << 2) | ((fine[order, 2] & 1) << 1) | (fine[order, 3] & 1)
+        assert (np.diff(cls) >= 0).all()
+        np.testing.assert_array_equal((tagged >> 28) & 0xF, 8 + cls)
+        live = (pyr.up[level].cpu().numpy() >= 0)  # [27, n]: pairs exist only at the offsets the class allows
+        for k in range(27):
+            ok = np.ones(fine.shape[0], bool)
+            for a, ka in enumerate((k // 9, (k // 3) % 3, k % 3)):
+                ok &= ((fine[:, 1 + a] & 1) == 1) == (ka != 1)
+            assert not (live[k] & ~ok).any()
+        n_fine, n_coarse = fine.shape[0], pyr.coords[level + 1].shape[0]
+        z = torch.randn((n_coarse, cin), generator=g).to(backend)
+        w = (torch.randn((27, cin, cout), generator=g) * 0.1).to(backend)
+        wp = ops.mfma_weight(w) if ops.mfma_eligible(cin, cout, cin) else None
+        a = ops.sparse_conv(z, w, pyr.up[level], n_fine, relu=True, wp=wp)
+        b = ops.sparse_conv(z, w, pyr.up[level], n_fine, relu=True, wp=wp, row_order=pyr.up_order[level])
+        assert torch.equal(a, b)
+
+
 def test_rulebook_empty(backend):
     coords = torch.zeros((0, 4), dtype=torch.int32, device=backend)
     pyr = ops.build_pyramid(coords, depth=3)

@@ -35,31 +35,32 @@ for lvl in range(4):
     for (cin, cout, tbl, nout, name) in [(C, C, pyr.subm[lvl], N[lvl], "subm")] + \
             ([(2 * C, C, pyr.subm[lvl], N[lvl], "tail"), (C, 2 * C, pyr.down[lvl], N[lvl + 1], "down"), (2 * C, C, pyr.up[lvl], N[lvl], "up")] if lvl < 3 else []):
         nin = N[lvl + 1] if name == "up" else N[lvl]
+        ro = pyr.up_order[lvl] if name == "up" else None  # the inverse convs run in parity order (as in model.py)
         x = torch.randn(nin, cin, device=dev)
         w = torch.randn(27, cin, cout, device=dev) * 0.05
         pairs = int((tbl >= 0).sum())
         bytes_ = pairs * (cin * 4 + 4) + nout * cout * 4
         flops = 2 * pairs * cin * cout
-        t_valu = timeit(lambda: ops.sparse_conv(x, w, tbl, nout))
+        t_valu = timeit(lambda: ops.sparse_conv(x, w, tbl, nout, row_order=ro))
         line = f"L{lvl} {name:5s} {cin:3d}->{cout:3d} N={nout:7d} P={pairs:8d}: VALU {t_valu:7.1f} us ({bytes_/t_valu/1e3:7.1f} GB/s = {bytes_/t_valu/1e3/80:4.1f} %, {flops/t_valu/1e6:6.2f} TF)"
         if cin % 16 == 0 and cout % 16 == 0:
             wp = ops.mfma_weight(w)
             import ctypes
             from smart_tree_amd import _lib
             L = _lib.lib(); L.st_debug_set_mfma_variant.argtypes = [ctypes.c_int]
-            ya = ops.sparse_conv(x, w, tbl, nout)
+            ya = ops.sparse_conv(x, w, tbl, nout, row_order=ro)
             for var, tag in ((1, "rt1"),):
                 L.st_debug_set_mfma_variant(var)
-                t_m = timeit(lambda: ops.sparse_conv(x, w, tbl, nout, wp=wp))
-                yb = ops.sparse_conv(x, w, tbl, nout, wp=wp)
+                t_m = timeit(lambda: ops.sparse_conv(x, w, tbl, nout, wp=wp, row_order=ro))
+                yb = ops.sparse_conv(x, w, tbl, nout, wp=wp, row_order=ro)
                 err = (ya - yb).abs().max().item() / (ya.abs().max().item() + 1e-30)
                 line += f" | mfma {t_m:6.1f} us ({bytes_/t_m/1e3:7.1f} GB/s = {bytes_/t_m/1e3/80:4.1f} % of 8 TB/s) {flops/t_m/1e6:5.1f} TF e={err:.0e}"
             L.st_debug_set_mfma_variant(0)
             # half-precision storage (config 5): f16 matrix-core kernel, half the gather bytes
             xh, wph = x.half(), wp.half()
             bytes_h = pairs * (cin * 2 + 4) + nout * cout * 2
-            t_h = timeit(lambda: ops.sparse_conv(xh, w, tbl, nout, out_half=True, wp16=wph))
-            yh = ops.sparse_conv(xh, w, tbl, nout, out_half=True, wp16=wph).float()
+            t_h = timeit(lambda: ops.sparse_conv(xh, w, tbl, nout, out_half=True, wp16=wph, row_order=ro))
+            yh = ops.sparse_conv(xh, w, tbl, nout, out_half=True, wp16=wph, row_order=ro).float()
             errh = (ya - yh).abs().max().item() / (ya.abs().max().item() + 1e-30)
             line += f" | f16 {t_h:6.1f} us ({bytes_h/t_h/1e3:7.1f} GB/s = {bytes_h/t_h/1e3/80:4.1f} %) {flops/t_h/1e6:5.1f} TF e={errh:.0e}"
         print(line)
