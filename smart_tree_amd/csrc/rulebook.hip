@@ -33,18 +33,22 @@ __global__ void __launch_bounds__(RB_BLOCK) k_rb_insert(const int32_t* coords, i
 __global__ void __launch_bounds__(RB_BLOCK) k_rb_subm(const int32_t* coords, int64_t n, const unsigned long long* keys,
                                                       const unsigned* vals, unsigned long long cap, int32_t* nbr) {
     for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < n; o += (int64_t)gridDim.x * blockDim.x) {
-        int b = coords[4 * o], z = coords[4 * o + 1], y = coords[4 * o + 2], x = coords[4 * o + 3];
-        int k = 0;
-        for (int dz = -1; dz <= 1; dz++)
-            for (int dy = -1; dy <= 1; dy++)
-                for (int dx = -1; dx <= 1; dx++, k++) {
-                    int zz = z + dz, yy = y + dy, xx = x + dx;
-                    int r = -1;
-                    if (k == 13) r = (int)o;
-                    else if (zz >= 0 && yy >= 0 && xx >= 0 && zz < 65535 && yy < 65535 && xx < 65535)
-                        r = st_hash_find(keys, vals, cap, st_pack_key(b, zz, yy, xx));
-                    nbr[(int64_t)k * n + o] = r;
-                }
+        const int b = coords[4 * o], z = coords[4 * o + 1], y = coords[4 * o + 2], x = coords[4 * o + 3];
+#pragma unroll
+        for (int dz = -1; dz <= 1; dz++) {  // one z-plane of nine neighbours per batch of overlapped look-ups (all 27 at
+            unsigned long long key[9];      // once was measured and is slower: register pressure)
+            bool valid[9];
+            int r[9];
+#pragma unroll
+            for (int j = 0; j < 9; j++) {
+                const int zz = z + dz, yy = y + j / 3 - 1, xx = x + j % 3 - 1;
+                valid[j] = !(dz == 0 && j == 4) && zz >= 0 && yy >= 0 && xx >= 0 && zz < 65535 && yy < 65535 && xx < 65535;
+                key[j] = st_pack_key(b, zz, yy, xx);
+            }
+            st_hash_find_batch<9>(keys, vals, cap, key, valid, r);
+#pragma unroll
+            for (int j = 0; j < 9; j++) nbr[(int64_t)((dz + 1) * 9 + j) * n + o] = (dz == 0 && j == 4) ? (int)o : r[j];
+        }
     }
 }
 
@@ -88,6 +92,28 @@ __global__ void __launch_bounds__(RB_BLOCK) k_rb_down_pass(const int32_t* coords
         if (PASS == 2 && won == 0u) continue;
         int b = coords[4 * i], c[3] = {coords[4 * i + 1], coords[4 * i + 2], coords[4 * i + 3]};
         uint32_t off = PASS == 2 ? cnt_or_off[i] : 0u;
+        if (PASS == 1) {  // which of my candidates is the stored winner: nine overlapped look-ups per z-plane
+#pragma unroll
+            for (int kz = 0; kz < 3; kz++) {
+                unsigned long long key[9];
+                bool valid[9];
+                int r[9];
+#pragma unroll
+                for (int j = 0; j < 9; j++) {
+                    const int nz = c[0] + 1 - kz, ny = c[1] + 1 - j / 3, nx = c[2] + 1 - j % 3;
+                    const int oz = nz >> 1, oy = ny >> 1, ox = nx >> 1;
+                    valid[j] = !((nz | ny | nx) & 1) && nz >= 0 && ny >= 0 && nx >= 0 && oz < oshape[0] && oy < oshape[1] && ox < oshape[2];
+                    key[j] = st_pack_key(b, oz, oy, ox);
+                }
+                st_hash_find_batch<9>(keys, vals, cap, key, valid, r);
+#pragma unroll
+                for (int j = 0; j < 9; j++)
+                    if (valid[j] && (unsigned)r[j] == (unsigned)(i * 27 + kz * 9 + j)) { mine++; won |= 1u << (kz * 9 + j); }
+            }
+            cnt_or_off[i] = mine;
+            win[i] = won;
+            continue;
+        }
         int k = 0;
         for (int kz = 0; kz < 3; kz++)
             for (int ky = 0; ky < 3; ky++)
@@ -111,16 +137,8 @@ __global__ void __launch_bounds__(RB_BLOCK) k_rb_down_pass(const int32_t* coords
                     }
                     unsigned long long key = st_pack_key(b, oz, oy, ox);
                     unsigned cand = (unsigned)(i * 27 + k);
-                    if (PASS == 0) {
-                        if (!st_hash_insert_min(keys, vals, cap, key, cand)) atomicOr(&st->fail, 1u);
-                    } else {
-                        // find the slot: the winner is the candidate whose id is stored there
-                        unsigned long long slot = st_hash_slot(key, cap);
-                        while (keys[slot] != key) slot = st_hash_next(slot, key, cap);
-                        if (vals[slot] == cand) { mine++; won |= 1u << k; }
-                    }
+                    if (!st_hash_insert_min(keys, vals, cap, key, cand)) atomicOr(&st->fail, 1u);
                 }
-        if (PASS == 1) { cnt_or_off[i] = mine; win[i] = won; }
     }
 }
 
@@ -155,20 +173,26 @@ __global__ void __launch_bounds__(RB_BLOCK) k_rb_up_nbr(const int32_t* coords, i
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         int b = coords[4 * i], c[3] = {coords[4 * i + 1], coords[4 * i + 2], coords[4 * i + 3]};
         if (parity_count) atomicAdd(&hist[rb_parity_class(c)], 1u);
-        int k = 0;
-        for (int kz = 0; kz < 3; kz++)
-            for (int ky = 0; ky < 3; ky++)
-                for (int kx = 0; kx < 3; kx++, k++) {
-                    int nz = c[0] + 1 - kz, ny = c[1] + 1 - ky, nx = c[2] + 1 - kx;
-                    int r = -1;
-                    if (!((nz | ny | nx) & 1) && nz >= 0 && ny >= 0 && nx >= 0) {
-                        int oz = nz >> 1, oy = ny >> 1, ox = nx >> 1;
-                        if (oz < oshape[0] && oy < oshape[1] && ox < oshape[2])
-                            r = st_hash_find(ckeys, cvals, ccap, st_pack_key(b, oz, oy, ox));
-                    }
-                    nbr[(int64_t)k * n + i] = r;
-                    if (r >= 0 && r < m) nbr_down[(int64_t)k * m + r] = (int32_t)i;
-                }
+#pragma unroll
+        for (int kz = 0; kz < 3; kz++) {  // nine offsets per batch of overlapped look-ups (at most four of them live)
+            unsigned long long key[9];
+            bool valid[9];
+            int r[9];
+#pragma unroll
+            for (int j = 0; j < 9; j++) {
+                const int nz = c[0] + 1 - kz, ny = c[1] + 1 - j / 3, nx = c[2] + 1 - j % 3;
+                const int oz = nz >> 1, oy = ny >> 1, ox = nx >> 1;
+                valid[j] = !((nz | ny | nx) & 1) && nz >= 0 && ny >= 0 && nx >= 0 && oz < oshape[0] && oy < oshape[1] && ox < oshape[2];
+                key[j] = st_pack_key(b, oz, oy, ox);
+            }
+            st_hash_find_batch<9>(ckeys, cvals, ccap, key, valid, r);
+#pragma unroll
+            for (int j = 0; j < 9; j++) {
+                const int k = kz * 9 + j;
+                nbr[(int64_t)k * n + i] = r[j];
+                if (r[j] >= 0 && r[j] < m) nbr_down[(int64_t)k * m + r[j]] = (int32_t)i;
+            }
+        }
     }
     __syncthreads();
     if (parity_count && threadIdx.x < 8 && hist[threadIdx.x]) atomicAdd(&parity_count[threadIdx.x], hist[threadIdx.x]);

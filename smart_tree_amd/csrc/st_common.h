@@ -157,6 +157,34 @@ __device__ __forceinline__ int st_hash_find(const unsigned long long* keys, cons
     return -1;
 }
 
+// N look-ups whose memory round trips overlap: all home-slot keys are requested before the first is inspected, then
+// all values of the hits (a thread that walks 26 neighbours one st_hash_find after the other waits for ~50 dependent
+// loads; this way it waits for two).  Keys displaced from their home slot (rare below 50 % load) take the ordinary
+// probe loop.  out[j] = value or -1; valid[j] == false -> -1 without touching memory.
+template <int N>
+__device__ __forceinline__ void st_hash_find_batch(const unsigned long long* keys, const unsigned* vals, unsigned long long cap,
+                                                   const unsigned long long (&key)[N], const bool (&valid)[N], int (&out)[N]) {
+    unsigned long long slot[N], got[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) slot[j] = st_hash_slot(key[j], cap);
+#pragma unroll
+    for (int j = 0; j < N; j++) got[j] = valid[j] ? keys[slot[j]] : (unsigned long long)ST_EMPTY_KEY;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        if (got[j] != key[j] && got[j] != ST_EMPTY_KEY) {  // displaced: follow the probe sequence
+            unsigned long long s = slot[j], g = got[j];
+            for (unsigned long long probe = 1; probe < cap && g != key[j] && g != ST_EMPTY_KEY; probe++) {
+                s = st_hash_next(s, key[j], cap);
+                g = keys[s];
+            }
+            slot[j] = s;
+            got[j] = g;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < N; j++) out[j] = (valid[j] && got[j] == key[j]) ? (int)vals[slot[j]] : -1;
+}
+
 // exclusive scan of one value per thread across the workgroup; *total = workgroup sum.
 // lds needs blockDim.x/64 + 1 words.  Must be reached by every thread of the workgroup.
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* lds, uint32_t* total) {
