@@ -34,23 +34,16 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_reduce(const uint32_t* in, 
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
 
-__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_sums(uint32_t* block_sums, int64_t nb, uint32_t* total_out) {
-    __shared__ uint32_t lds[SCAN_BLOCK / 64 + 1];
-    uint32_t carry = 0;
-    for (int64_t base = 0; base < nb; base += SCAN_BLOCK) {
-        int64_t i = base + threadIdx.x;
-        uint32_t v = i < nb ? block_sums[i] : 0u;
-        uint32_t total;
-        uint32_t ex = block_exclusive_scan(v, lds, &total);
-        if (i < nb) block_sums[i] = ex + carry;
-        carry += total;
-    }
-    if (threadIdx.x == 0 && total_out) *total_out = carry;
-}
-
+// Second (last) pass: every workgroup sums the tile totals in front of its own tile itself (at most a few hundred
+// words, L2 resident) instead of waiting for a third, single-workgroup kernel to scan them -- one launch less per scan,
+// and a pipeline pass runs ~20 scans.  The last workgroup also reports the grand total.
 __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_apply(const uint32_t* in, uint32_t* out, const uint32_t* block_sums,
-                                                           int64_t n) {
+                                                           int64_t n, uint32_t* total_out) {
     __shared__ uint32_t lds[SCAN_BLOCK / 64 + 1];
+    uint32_t pre = 0;
+    for (int64_t j = threadIdx.x; j < (int64_t)blockIdx.x; j += SCAN_BLOCK) pre += block_sums[j];
+    uint32_t carry;
+    block_exclusive_scan(pre, lds, &carry);
     int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
     uint32_t v[SCAN_ITEMS];
     uint32_t s = 0;
@@ -59,11 +52,12 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_apply(const uint32_t* in, u
         s += v[i];
     }
     uint32_t total;
-    uint32_t ex = block_exclusive_scan(s, lds, &total) + block_sums[blockIdx.x];
+    uint32_t ex = block_exclusive_scan(s, lds, &total) + carry;
     for (int i = 0; i < SCAN_ITEMS; i++) {
         if (base + i < n) out[base + i] = ex;
         ex += v[i];
     }
+    if (total_out && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total_out = carry + total;
 }
 
 int64_t st_scan_ws_bytes(int64_t n) {
@@ -86,8 +80,7 @@ int st_exclusive_scan_u32(const uint32_t* in, uint32_t* out, int64_t n, uint32_t
         return ST_ERR_WORKSPACE;
     }
     hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, stream, in, sums, n);
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_BLOCK), 0, stream, sums, nb, total);
-    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, stream, in, out, (const uint32_t*)sums, n);
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, stream, in, out, (const uint32_t*)sums, n, total);
     ST_CHECK_LAUNCH();
     return ST_OK;
 }

@@ -67,6 +67,45 @@ __global__ void __launch_bounds__(CONV_BLOCK) k_sparse_conv(const TIN* __restric
 #pragma unroll
     for (int c = 0; c < COT; c++) acc[c] = 0.0f;
 
+    if (CIN % 4 == 0 && CIN <= 16) {
+        // Offsets in groups of G: all neighbour indices of the group first, then all row gathers, then the FMAs (still in
+        // ascending k, ci order -- bit-identical sums).  A lane that walks 27 offsets one by one waits for 27 dependent
+        // index -> row round trips; at the finest level there are only 2-3 wavefronts per SIMD to hide them.
+        constexpr int G = CIN <= 8 ? 9 : 3, Q = CIN / 4;
+        for (int k0 = 0; k0 < K; k0 += G) {
+            int idx[G];
+            float4 v[G][Q];
+#pragma unroll
+            for (int j = 0; j < G; j++) {
+                const int k = k0 + j;
+                idx[j] = -1;
+                if (k < K && active && ((live >> k) & 1u)) idx[j] = nbr ? nbr[(int64_t)k * n_out + o] : (int)o;
+            }
+#pragma unroll
+            for (int j = 0; j < G; j++)
+                if (idx[j] >= 0) {
+#pragma unroll
+                    for (int q = 0; q < Q; q++) {
+                        const int ci = 4 * q;
+                        const TIN* row = ci < c0 ? x0 + (int64_t)idx[j] * c0 + ci : x1 + (int64_t)idx[j] * c1 + (ci - c0);
+                        v[j][q] = conv_load4(row);
+                    }
+                }
+#pragma unroll
+            for (int j = 0; j < G; j++) {
+                if (idx[j] < 0) continue;
+                const float* __restrict__ wk = w + (int64_t)(k0 + j) * CIN * cout + co0;
+#pragma unroll
+                for (int q = 0; q < Q; q++) {
+                    const float xs[4] = {v[j][q].x, v[j][q].y, v[j][q].z, v[j][q].w};
+#pragma unroll
+                    for (int jj = 0; jj < 4; jj++)
+#pragma unroll
+                        for (int c = 0; c < COT; c++) acc[c] = fmaf(xs[jj], wk[(4 * q + jj) * cout + c], acc[c]);
+                }
+            }
+        }
+    } else
     for (int k = 0; k < K; k++) {
         int idx = -1;
         if (active && ((live >> k) & 1u)) idx = nbr ? nbr[(int64_t)k * n_out + o] : (int)o;
