@@ -112,6 +112,8 @@ def main():
     if dryrun:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    if os.environ.get("ST_BENCH_SWITCH"):  # developer knob: the interpreter's GIL switch interval in seconds
+        sys.setswitchinterval(float(os.environ["ST_BENCH_SWITCH"]))
     _sched = os.environ.get("ST_BENCH_SCHED")  # developer knob: how host threads wait for the GPU (spin | yield | block)
     if _sched:
         import ctypes

@@ -25,6 +25,9 @@ def shard_indices(n_items: int, rank: int, world_size: int) -> List[int]:
 
 def pack_skeleton(sk: DisjointTreeSkeleton, cloud_id: int = 0):
     """-> (table int64 [B,6] = (cloud, tree, branch, parent, offset, length), geom float32 [P,4] = (xyz, radius))."""
+    fast = sk.pack(cloud_id) if hasattr(sk, "pack") else None  # DeviceSkeleton: straight from its packed host arrays
+    if fast is not None:
+        return fast
     rows, geom, off = [], [], 0
     for tree in sk.skeletons:
         for b in tree.branches.values():

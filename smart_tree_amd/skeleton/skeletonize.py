@@ -154,6 +154,7 @@ class DeviceSkeleton(DisjointTreeSkeleton):
         self._dev = (tree_off, parent, start, length, xyz, rad)  # device tensors (flat branch layout)
         self._ops = {}
         self._trees = None
+        self._host = None  # packed host arrays of the materialised skeleton (valid while nobody has touched the objects)
 
     # -- construction ---------------------------------------------------------------------------
     @staticmethod
@@ -193,18 +194,24 @@ class DeviceSkeleton(DisjointTreeSkeleton):
         if self._can_defer("prune"):
             self._ops["prune"] = (float(min_radius), float(min_length))
         else:
+            _ = self.skeletons
+            self._host = None
             super().prune(min_radius, min_length)
 
     def repair(self) -> None:
         if self._can_defer("repair"):
             self._ops["repair"] = True
         else:
+            _ = self.skeletons
+            self._host = None
             super().repair()
 
     def smooth(self, kernel_size: int = 7) -> None:
         if self._can_defer("smooth") and kernel_size > 0:
             self._ops["smooth"] = int(kernel_size)
         else:
+            _ = self.skeletons
+            self._host = None
             super().smooth(kernel_size)
 
     # -- materialisation ------------------------------------------------------------------------
@@ -217,6 +224,7 @@ class DeviceSkeleton(DisjointTreeSkeleton):
     @skeletons.setter
     def skeletons(self, value):
         self._trees = value
+        self._host = None
 
     def _materialise(self) -> List[TreeSkeleton]:
         tree_off, parent, start, length, xyz, rad = self._dev
@@ -237,20 +245,63 @@ class DeviceSkeleton(DisjointTreeSkeleton):
                                      int("repair" in self._ops), int("smooth" in self._ops), self._ops.get("smooth", 0),
                                      _lib.stream(dev)))
         # two copies (geometry, branch table).  Branch k's geometry is the slot range [a_k, b_k) of the packed host arrays;
-        # the BranchSkeleton objects are created here, their tensors are views cut on first access (_PackedBranch).
+        # the TreeSkeleton / BranchSkeleton objects are only built when somebody reads `.branches` (_PackedTree), their
+        # tensors are views cut on first access (_PackedBranch): a few hundred Python objects per cloud are pure
+        # interpreter time, and the interpreter is what the clouds in flight share.
         xyz_h, rad_h = xyz.cpu(), rad_out.cpu()
-        rows = torch.stack((parent, start, length, keep.int(), repaired.int(), smoothed.int()), dim=1).cpu().tolist()
+        rows = torch.stack((parent, start, length, keep.int(), repaired.int(), smoothed.int()), dim=1).cpu()
         offs = tree_off.cpu().tolist()
-        new, fill = _PackedBranch.__new__, dict.update
+        self._host = (xyz_h, rad_h, rows, offs)
         trees = []
         for t in range(T):
-            branches = {}
-            o = offs[t]
-            for b in range(o, offs[t + 1]):
-                par, st, ln, kp, rp, sm = rows[b]
+            tree = _PackedTree.__new__(_PackedTree)
+            tree._id = t
+            tree._lazy = (xyz_h, rad_h, rows, offs[t], offs[t + 1])
+            trees.append(tree)
+        return trees
+
+    def pack(self, cloud_id: int = 0):
+        """What sharding.pack_skeleton builds branch by branch -- (table int64 [B,6], geom float32 [P,4]) -- cut out of
+        the packed host arrays with a dozen tensor operations instead of five per branch."""
+        trees = self.skeletons
+        if self._host is None or any("_branches" in t.__dict__ for t in trees):
+            return None  # host-side edits may have happened: the caller walks the objects instead
+        xyz_h, rad_h, rows, offs = self._host
+        B = rows.shape[0]
+        if B == 0:
+            return torch.zeros((0, 6), dtype=torch.int64), torch.zeros((0, 4), dtype=torch.float32)
+        rows = rows.long()
+        kept = rows[:, 3] != 0
+        ids = torch.arange(B)
+        tree_of = torch.bucketize(ids, torch.tensor(offs[1:], dtype=torch.int64), right=True)
+        first = torch.tensor(offs, dtype=torch.int64)[tree_of]
+        a = (rows[:, 1] + 1 - rows[:, 4])[kept]
+        n = (rows[:, 2] + rows[:, 4])[kept]
+        off = torch.cumsum(n, 0) - n
+        table = torch.stack((torch.full_like(n, cloud_id), tree_of[kept], (ids - first)[kept], rows[kept, 0], off, n), dim=1)
+        idx = torch.arange(int(n.sum())) + torch.repeat_interleave(a - off, n)
+        geom = torch.cat((xyz_h[idx].float(), rad_h[idx].reshape(-1, 1).float()), dim=1)
+        return table, geom
+
+
+class _PackedTree(TreeSkeleton):
+    """A TreeSkeleton whose `branches` dict is built from the packed host arrays on first access."""
+
+    @property
+    def branches(self):
+        d = self.__dict__.get("_branches")
+        if d is None:
+            xyz_h, rad_h, rows, o, e = self._lazy
+            new, fill = _PackedBranch.__new__, dict.update
+            d = {}
+            for j, (par, st, ln, kp, rp, sm) in enumerate(rows[o:e].tolist()):
                 if kp:
                     obj = new(_PackedBranch)
-                    fill(obj.__dict__, _id=b - o, parent_id=par, child_id=None, _pack=(xyz_h, rad_h, st + 1 - rp, st + 1 + ln, sm))
-                    branches[b - o] = obj
-            trees.append(TreeSkeleton(t, branches))
-        return trees
+                    fill(obj.__dict__, _id=j, parent_id=par, child_id=None, _pack=(xyz_h, rad_h, st + 1 - rp, st + 1 + ln, sm))
+                    d[j] = obj
+            self.__dict__["_branches"] = d
+        return d
+
+    @branches.setter
+    def branches(self, value):
+        self.__dict__["_branches"] = value

@@ -44,6 +44,15 @@ def test_process_cloud_stagewise_parity(backend):
     skeleton = pipe.process_cloud(cloud=cloud)
     lc = pipe.last_labelled_cloud
 
+    # the result gather's fast path (packed host arrays -> table / geometry) against the branch-by-branch walk
+    from smart_tree_amd import sharding
+    from smart_tree_amd.data_types.tree import DisjointTreeSkeleton
+    fast = skeleton.pack(cloud_id=5)
+    assert fast is not None
+    slow = sharding.pack_skeleton(DisjointTreeSkeleton(list(skeleton.skeletons)), cloud_id=5)  # plain container: the walk
+    assert torch.equal(fast[0], slow[0]) and torch.equal(fast[1], slow[1])
+    assert skeleton.pack(cloud_id=5) is None  # the objects have been handed out: no shortcut any more
+
     # stage 1: labelled cloud vs the oracle network (fp32 tolerance; coordinates exact)
     w = uo.load_weights(WEIGHTS)
     ref = po.labelled_cloud(c["xyz"], c["rgb"], w, 0.03, dtype=torch.float64)
