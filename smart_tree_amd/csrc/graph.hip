@@ -135,7 +135,7 @@ extern "C" int st_make_edges(const int64_t* idx, const float* dist, int64_t n, i
     hipLaunchKernelGGL(k_edge_emit, dim3(gr_grid(n)), dim3(GR_BLOCK), 0, stream, idx, dist, n, K, (const uint32_t*)cnt, edges, w);
     uint32_t total = 0;
     (void)hipMemcpyAsync(&total, cnt + n, sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
-    (void)hipStreamSynchronize(stream);
+    st_stream_wait(stream);
     ST_CHECK_LAUNCH();
     *n_edges_host = total;
     return ST_OK;
@@ -329,7 +329,7 @@ extern "C" int st_component_layout(const int32_t* labels, int64_t n, int min_ver
     ST_TRY(st_exclusive_scan_u32(flag, flag, n, flag + n, sw, sb, stream));
     uint32_t C = 0;
     (void)hipMemcpyAsync(&C, flag + n, sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
-    (void)hipStreamSynchronize(stream);
+    st_stream_wait(stream);
     ST_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_fill_i32, dim3(g), dim3(GR_BLOCK), 0, stream, new_id, n, -1);
     if (C == 0) { ST_CHECK_LAUNCH(); return ST_OK; }
@@ -346,7 +346,7 @@ extern "C" int st_component_layout(const int32_t* labels, int64_t n, int min_ver
     ST_TRY(st_exclusive_scan_u32(flag, flag, n, flag + n, sw, sb, stream));
     uint32_t m = 0;
     (void)hipMemcpyAsync(&m, flag + n, sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
-    (void)hipStreamSynchronize(stream);
+    st_stream_wait(stream);
     hipLaunchKernelGGL(k_cl_vlist, dim3(g), dim3(GR_BLOCK), 0, stream, (const uint32_t*)flag, labels, (const int*)rank_of_root, n,
                        key, val);
     int bits = 1;

@@ -101,7 +101,7 @@ int st_grid_build(const float* pts, int64_t n, float cell, int64_t max_cells, St
     // one small read-back sizes the histogram/scan to the cells actually used instead of the capacity
     StGrid h;
     (void)hipMemcpyAsync(&h, g, sizeof(StGrid), hipMemcpyDeviceToHost, stream);
-    (void)hipStreamSynchronize(stream);
+    st_stream_wait(stream);
     ST_CHECK_LAUNCH();
     const int64_t ncell = h.ncell;
     ST_REQUIRE(ncell >= 1 && ncell <= max_cells, "grid: bad cell count %lld", (long long)ncell);

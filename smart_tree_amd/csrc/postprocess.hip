@@ -343,7 +343,7 @@ extern "C" int st_assemble_branches(int n_comp, const int32_t* comp_off, const i
     ST_TRY(st_exclusive_scan_u32(A.len1, (uint32_t*)start, cap_b, nullptr, scan_ws, scan_bytes, stream));
     hipLaunchKernelGGL(k_asm_geometry, dim3(gp), dim3(256), 0, stream, A);
     (void)hipMemcpyAsync(counts_host, A.counts, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, stream);
-    (void)hipStreamSynchronize(stream);
+    st_stream_wait(stream);
     ST_CHECK_LAUNCH();
     ST_REQUIRE(counts_host[0] <= cap_b && counts_host[1] <= cap_p, "assemble: capacity exceeded (%lld branches, %lld slots)",
                (long long)counts_host[0], (long long)counts_host[1]);

@@ -317,7 +317,7 @@ extern "C" int st_build_strided_outputs(const int32_t* coords, int64_t n, int64_
                        (unsigned long long)ccap, cnt, win, out_coords, max_out);
     RbState h;
     (void)hipMemcpyAsync(&h, st, sizeof(RbState), hipMemcpyDeviceToHost, stream);
-    (void)hipStreamSynchronize(stream);  // the ONE read-back of this stage: n_out sizes everything downstream
+    st_stream_wait(stream);  // the ONE read-back of this stage: n_out sizes everything downstream
     ST_CHECK_LAUNCH();
     ST_REQUIRE(!h.fail, "strided: more than max_out=%lld output voxels", (long long)max_out);
     ST_REQUIRE((int64_t)h.n_out <= max_out, "strided: %u output voxels exceed max_out=%lld", h.n_out, (long long)max_out);

@@ -1164,7 +1164,7 @@ static inline unsigned sk_vgrid(int64_t m) {
 
 static int sk_read(void* dst, const void* src, size_t bytes, hipStream_t stream) {
     (void)hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream);
-    (void)hipStreamSynchronize(stream);
+    st_stream_wait(stream);
     ST_CHECK_LAUNCH();
     return ST_OK;
 }

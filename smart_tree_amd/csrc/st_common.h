@@ -18,6 +18,8 @@ enum StStatus : int {
 };
 
 void st_set_error(const char* fmt, ...);
+// Wait until everything enqueued on `stream` has finished (every count read-back of the library goes through this).
+void st_stream_wait(hipStream_t stream);
 
 #define ST_REQUIRE(cond, ...)            \
     do {                                 \

@@ -368,7 +368,7 @@ extern "C" int st_voxelize_blocks(const float* xyz, const float* rgb, int64_t n,
 
     VxState h;
     (void)hipMemcpyAsync(&h, st, sizeof(VxState), hipMemcpyDeviceToHost, stream);
-    (void)hipStreamSynchronize(stream);
+    st_stream_wait(stream);
     ST_CHECK_LAUNCH();
     ST_REQUIRE(!(h.overflow & 1u), "voxelize: cloud spans more than %d blocks", VX_TABLE_CAP);
     ST_REQUIRE(!(h.overflow & 2u), "voxelize: %u blocks exceed max_blocks=%d", h.n_blocks, max_blocks);

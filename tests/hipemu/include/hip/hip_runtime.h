@@ -12,6 +12,7 @@
 // Limits (kernels are written to respect them): 1-D grids/blocks, static __shared__ only, no
 // inter-workgroup communication inside a launch, wave collectives only in wave-convergent code.
 #pragma once
+#define ST_HIPEMU 1  // lets a source file skip host-only runtime calls the shim does not model
 
 #include <ucontext.h>
 
