@@ -89,6 +89,113 @@ def cpu_baseline(n_points: int):
             "branches": int(sum(len(t.branches) for t in trees))}
 
 
+class CloudWorker:
+    """S pipelines on S HIP streams of one process, two resident 1M-point clouds, steps dealt from a shared counter."""
+
+    def __init__(self, device, n_streams, n_points, rank):
+        from smart_tree_amd.data_types.cloud import Cloud
+        from smart_tree_amd.synthetic import sample_tree_cloud
+
+        self.device, self.S, self.rank = device, n_streams, rank
+        self.pipes = [build_pipeline(device) for _ in range(n_streams)]
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(n_streams)]
+        # two distinct clouds per rank, cycled; different seeds on every rank (independent trees)
+        self.clouds = []
+        for j in range(2):
+            c = sample_tree_cloud(n_points, seed=rank * 2 + j)
+            self.clouds.append(Cloud(xyz=torch.from_numpy(c["xyz"]).to(device), rgb=torch.from_numpy(c["rgb"]).to(device)))
+        self.last = None
+        self.id_base = 0
+
+    def run(self, total, collect):
+        """`total` steps, dealt to the S worker threads from a shared counter; returns the packed skeletons (if asked
+        for) once every stream has drained."""
+        import threading
+
+        from smart_tree_amd.sharding import pack_skeleton
+
+        state = {"next": 0, "error": None}
+        lock = threading.Lock()
+        finished = []
+
+        def work(w):
+            try:
+                with torch.cuda.stream(self.streams[w]):
+                    while True:
+                        with lock:
+                            i = state["next"]
+                            state["next"] += 1
+                        if i >= total:
+                            break
+                        sk = self.pipes[w].process_cloud(cloud=self.clouds[i % len(self.clouds)])
+                        self.last = sk
+                        if collect:
+                            finished.append(pack_skeleton(sk, cloud_id=self.rank * 1_000_000 + self.id_base + i))
+                    self.streams[w].synchronize()
+            except BaseException as e:  # noqa: BLE001 -- re-raised on the calling thread
+                state["error"] = e
+
+        if self.S == 1:
+            work(0)
+        else:
+            threads = [threading.Thread(target=work, args=(w,)) for w in range(self.S)]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+        if state["error"] is not None:
+            raise state["error"]
+        return finished
+
+    def serial_ms(self):
+        """Untimed, for the record: one cloud at a time on one stream = the latency of a single process_cloud call."""
+        with torch.cuda.stream(self.streams[0]):
+            t1 = time.perf_counter()
+            for cloud in self.clouds:
+                self.pipes[0].process_cloud(cloud=cloud)
+            self.streams[0].synchronize()
+            return 1e3 * (time.perf_counter() - t1) / len(self.clouds)
+
+    def report(self, steps):
+        from smart_tree_amd import profiling
+
+        sk = self.last
+        return {"roofline": profiling.roofline(HBM_PEAK_GBS), "stage_ms": profiling.stage_ms(steps),
+                "last_result": {"trees": len(sk.skeletons), "branches": int(sum(len(t.branches) for t in sk.skeletons))}}
+
+
+def _proc_worker(conn, local_rank, n_streams, n_points, rank, widx):
+    """--procs helper: owns its own HIP context, pipelines and clouds; obeys run / serial / report / exit."""
+    from smart_tree_amd import profiling
+
+    torch.cuda.set_device(local_rank)
+    w = CloudWorker(torch.device("cuda", local_rank), n_streams, n_points, rank)
+    w.id_base = (widx + 1) * 10_000
+    torch.cuda.synchronize()
+    conn.send(("ready", None))
+    while True:
+        msg = conn.recv()
+        if msg[0] == "run":
+            profiling.enable(bool(msg[3]))
+            out = w.run(msg[1], msg[2])
+            torch.cuda.synchronize()
+            conn.send(("done", [(t.numpy(), g.numpy()) for t, g in out]))
+        elif msg[0] == "serial":
+            conn.send(("serial", w.serial_ms()))
+        elif msg[0] == "report":
+            conn.send(("report", w.report(msg[1])))
+        else:
+            break
+
+
+def _expect(conn, tag, timeout_s):
+    if not conn.poll(timeout_s):
+        raise RuntimeError(f"bench helper process did not answer '{tag}' within {timeout_s} s")
+    got = conn.recv()
+    assert got[0] == tag, got
+    return got[1]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -96,6 +203,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--points", type=int, default=N_POINTS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--procs", type=int, default=1,
+                    help="helper processes per GPU, --streams clouds in flight each (opt-in; the default keeps the one "
+                         "process per GPU of the launch contract)")
     ap.add_argument("--streams", type=int, default=0,
                     help="clouds in flight per GPU (one host thread + HIP stream each); 0 = auto: 8, fewer when the run is "
                          "short (a worker should see >= 3 clouds) or the host has fewer than 2 cores per worker and rank")
@@ -132,57 +242,38 @@ def main():
     coll_device = torch.device("cpu") if dryrun else device
 
     from smart_tree_amd import profiling
-    from smart_tree_amd.data_types.cloud import Cloud
-    from smart_tree_amd.sharding import gather_skeletons, pack_skeleton
-    from smart_tree_amd.synthetic import sample_tree_cloud
+    from smart_tree_amd.sharding import gather_skeletons
 
-    import threading
-
-    S = args.streams if args.streams > 0 else auto_streams(args.steps, world)
-    pipes = [build_pipeline(device) for _ in range(S)]
-    streams = [torch.cuda.Stream(device=device) for _ in range(S)]
-    # two distinct clouds per rank, cycled; different seeds on every rank (independent trees)
-    clouds = []
-    for j in range(2):
-        c = sample_tree_cloud(args.points, seed=rank * 2 + j)
-        clouds.append(Cloud(xyz=torch.from_numpy(c["xyz"]).to(device), rgb=torch.from_numpy(c["rgb"]).to(device)))
-
+    P = max(1, args.procs)
+    S = args.streams if args.streams > 0 else auto_streams(args.steps // P, world * P)
     finished = []  # packed skeletons of this rank, gathered to rank 0 once per timed region (no per-step rendezvous:
     #                 clouds differ in cost, a collective per step would make every step as slow as its slowest rank)
-    last = {}
+    if P == 1:
+        worker = CloudWorker(device, S, args.points, rank)
+        children = []
 
-    def run_steps(total):
-        """`total` steps, dealt to the S workers from a shared counter."""
-        state = {"next": 0, "error": None}
-        lock = threading.Lock()
+        def run_steps(total):
+            finished.extend(worker.run(total, collect=world > 1))
+    else:
+        # --procs P (opt-in): P helper processes drive this rank's GPU, S streams each; this process
+        # keeps the rank's place in the process group, hands out the steps and does the result gather
+        import multiprocessing as mp
+        ctx = mp.get_context("spawn")
+        children = []
+        for w in range(P):
+            here, there = ctx.Pipe()
+            proc = ctx.Process(target=_proc_worker, args=(there, local_rank, S, args.points, rank, w), daemon=True)
+            proc.start()
+            children.append((proc, here))
+        for _, conn in children:
+            _expect(conn, "ready", 600)
+        worker = None
 
-        def worker(w):
-            try:
-                with torch.cuda.stream(streams[w]):
-                    while True:
-                        with lock:
-                            i = state["next"]
-                            state["next"] += 1
-                        if i >= total:
-                            break
-                        sk = pipes[w].process_cloud(cloud=clouds[i % len(clouds)])
-                        last["sk"] = sk
-                        if world > 1:
-                            finished.append(pack_skeleton(sk, cloud_id=rank * 1_000_000 + i))
-                    streams[w].synchronize()
-            except BaseException as e:  # noqa: BLE001 -- re-raised on the main thread
-                state["error"] = e
-
-        if S == 1:
-            worker(0)
-        else:
-            threads = [threading.Thread(target=worker, args=(w,)) for w in range(S)]
-            for t in threads:
-                t.start()
-            for t in threads:
-                t.join()
-        if state["error"] is not None:
-            raise state["error"]
+        def run_steps(total):
+            for w, (_, conn) in enumerate(children):
+                conn.send(("run", total // P + (1 if w < total % P else 0), world > 1, profiling.enabled()))
+            for _, conn in children:
+                finished.extend((torch.from_numpy(t), torch.from_numpy(g)) for t, g in _expect(conn, "done", 600))
 
     def gather():
         if world > 1:
@@ -195,28 +286,35 @@ def main():
         torch.cuda.synchronize()
 
     fence()  # inputs and weights are resident before any worker stream touches them
-    warm = max(args.warmup, S) if args.warmup > 0 else 0  # every worker runs at least once before the clock starts
+    warm = max(args.warmup, S * P) if args.warmup > 0 else 0  # every worker runs at least once before the clock starts
     run_steps(warm)
     gather()
     fence()
     # for the record (untimed): one cloud at a time on one stream = the latency of a single process_cloud call
     serial_ms = None
     if warm > 0:
-        with torch.cuda.stream(streams[0]):
-            t1 = time.perf_counter()
-            for i in range(len(clouds)):
-                pipes[0].process_cloud(cloud=clouds[i])
-            streams[0].synchronize()
-            serial_ms = 1e3 * (time.perf_counter() - t1) / len(clouds)
+        if worker is not None:
+            serial_ms = worker.serial_ms()
+        else:
+            children[0][1].send(("serial",))
+            serial_ms = _expect(children[0][1], "serial", 600)
     fence()
     profiling.enable(True)
     t0 = time.perf_counter()
-    run_steps(args.steps)
+    run_steps(args.steps)  # returns when every worker has synchronised its streams
     gather()  # inside the timed region: the skeletons of all ranks end up on rank 0
     fence()
     dt = time.perf_counter() - t0
     profiling.enable(False)
-    sk = last["sk"]
+    if worker is not None:
+        report = worker.report(args.steps)
+    else:  # the roofline / stage times of helper 0 (each helper measures its own launches with HIP events)
+        children[0][1].send(("report", args.steps // P + (1 if args.steps % P else 0)))
+        report = _expect(children[0][1], "report", 600)
+        for proc, conn in children:
+            conn.send(("exit",))
+        for proc, _ in children:
+            proc.join(30)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -231,12 +329,12 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"configs[1]: one {args.points}-point synthetic tree per rank per step, 2 cm voxels, "
                                    "noble-elevator-58 weights, full Pipeline.process_cloud with prune/repair/smooth",
-                       "clouds_per_rank": len(clouds), "parallelism": f"cloud-sharded x{world}",
-                       "clouds_in_flight_per_gpu": S, "warmup_steps_run": warm,
+                       "clouds_per_rank": 2, "parallelism": f"cloud-sharded x{world}",
+                       "clouds_in_flight_per_gpu": S * P, "worker_processes_per_gpu": P, "warmup_steps_run": warm,
                        "single_stream_ms_per_cloud": None if serial_ms is None else round(serial_ms, 3)},
-            "roofline": profiling.roofline(HBM_PEAK_GBS),
-            "stage_ms": profiling.stage_ms(args.steps),
-            "last_result": {"trees": len(sk.skeletons), "branches": int(sum(len(t.branches) for t in sk.skeletons))},
+            "roofline": report["roofline"],
+            "stage_ms": report["stage_ms"],
+            "last_result": report["last_result"],
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.points)
