@@ -62,8 +62,9 @@ def run_components(comps: ComponentSet, medial_pts: torch.Tensor, radius: torch.
     res = ComponentResult(f32(m), i32(m), i32(C), f32(m), i32(m), i32(m), i32(m), i32(C), i32(m), i32(m))
     if C == 0:
         return res
-    r_max = rad.max().item()
-    sizes = comps.comp_size.cpu().numpy().astype("int32")  # host copy: sizes the claim grid
+    # one read-back for both host-side facts: component sizes (they size the claim grid) and the largest radius
+    both = torch.cat((comps.comp_size.to(torch.float64), rad.max().to(torch.float64).view(1))).cpu().numpy()
+    sizes, r_max = both[:-1].astype("int32"), float(both[-1])
     stats = (ctypes.c_int64 * 8)()
     stats[7] = 1 if profiling.enabled() else 0  # bracket every k_sk_select launch with HIP events
     ws = _lib.workspace(L.st_skeleton_workspace_bytes(m, C), dev)
@@ -248,9 +249,14 @@ class DeviceSkeleton(DisjointTreeSkeleton):
         # the TreeSkeleton / BranchSkeleton objects are only built when somebody reads `.branches` (_PackedTree), their
         # tensors are views cut on first access (_PackedBranch): a few hundred Python objects per cloud are pure
         # interpreter time, and the interpreter is what the clouds in flight share.
-        xyz_h, rad_h = xyz.cpu(), rad_out.cpu()
-        rows = torch.stack((parent, start, length, keep.int(), repaired.int(), smoothed.int()), dim=1).cpu()
-        offs = tree_off.cpu().tolist()
+        # ONE device-to-host copy (a blocking round trip costs ~1 ms beside other clouds' kernels):
+        # geometry, radii, branch table and tree offsets travel as one float32 buffer (the integers bit-cast)
+        P = xyz.shape[0]
+        table = torch.stack((parent, start, length, keep.int(), repaired.int(), smoothed.int()), dim=1)
+        blob = torch.cat((xyz.reshape(-1), rad_out, table.reshape(-1).view(torch.float32), tree_off.view(torch.float32))).cpu()
+        xyz_h, rad_h = blob[: 3 * P].view(P, 3), blob[3 * P: 4 * P]
+        rows = blob[4 * P: 4 * P + 6 * B].view(torch.int32).view(B, 6)
+        offs = blob[4 * P + 6 * B:].view(torch.int32).tolist()
         self._host = (xyz_h, rad_h, rows, offs)
         trees = []
         for t in range(T):
