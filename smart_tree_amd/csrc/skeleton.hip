@@ -1227,8 +1227,10 @@ extern "C" int st_skeleton_components(int n_comp, const int32_t* comp_off, const
     if (stages & 1) {
         hipLaunchKernelGGL(k_sk_init, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A);
         hipLaunchKernelGGL(k_sk_roots, dim3((unsigned)n_comp), dim3((unsigned)block_threads), 0, stream, A);
-        for (int r = 0;;) {  // frontier rounds in batches of 32 launches, one counter read-back per batch
-            for (int b = 0; b < g_sssp_batch; b++, r++)
+        for (int r = 0;;) {  // frontier rounds in batches, one counter read-back per batch.  The first batch is twice as long:
+            // a tree of a million points needs 65-96 launches, an empty round costs ~4 us, a read-back beside other clouds ~1 ms
+            const int batch = r == 0 ? 2 * g_sssp_batch : g_sssp_batch;
+            for (int b = 0; b < batch; b++, r++)
                 hipLaunchKernelGGL(k_sk_sssp_round, dim3(fg), dim3(SK_WIDE_BLOCK), 0, stream, A, r, g_sssp_hops, g_sssp_lanes);
             ST_TRY(sk_read(h, s.cnt, sizeof(unsigned) * 8, stream));
             sssp_rounds = r;
