@@ -78,7 +78,7 @@ ENQUEUE_ONLY = frozenset({
     "st_component_csr_workspace_bytes", "st_assemble_workspace_bytes", "st_skeleton_workspace_bytes",
     "st_build_coord_hash", "st_build_subm_rulebook", "st_build_strided_rulebook", "st_sparse_conv_fwd",
     "st_sparse_conv_mfma_fwd", "st_sparse_conv_f16_fwd", "st_pointwise_mlp_heads", "st_medial_points", "st_centre_cloud",
-    "st_connected_components", "st_component_csr", "st_post_process",
+    "st_connected_components", "st_component_csr", "st_post_process", "st_knn_radius",
 })
 
 

@@ -7,4 +7,4 @@ timeout 400 python tools/bench_conv.py 5000000 0.01 0.6 > gpurun_out/conv_5m.txt
 timeout 300 python tools/time_fp16.py > gpurun_out/fp16_1m.txt 2>&1
 timeout 400 python tools/time_fp16.py 5000000 0.01 0.6 > gpurun_out/fp16_5m.txt 2>&1
 bash tools/prof_solo.sh
-tail -3 gpurun_out/fp16_1m.txt gpurun_out/fp16_5m.txt
+tail -n 3 gpurun_out/fp16_1m.txt; tail -n 3 gpurun_out/fp16_5m.txt
