@@ -80,3 +80,17 @@ def test_gather_world_size_2_gloo():
     for i in range(n_clouds):
         t, g = (torch.from_numpy(a) for a in got[i])
         _same(unpack_skeletons(t, g)[i], _fake_skeleton(i))
+
+
+def test_bench_auto_streams_bounds(monkeypatch):
+    """bench.py's default clouds-in-flight: at most 8, at least 1, >= 3 clouds per worker, two host cores per worker and rank."""
+    import importlib.util
+    from pathlib import Path
+    spec = importlib.util.spec_from_file_location("bench_mod", Path(__file__).resolve().parents[1] / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.setattr(bench, "usable_cores", lambda: 128)
+    assert bench.auto_streams(24, 1) == 8 and bench.auto_streams(24, 8) == 8
+    assert bench.auto_streams(10, 1) == 3 and bench.auto_streams(1, 1) == 1 and bench.auto_streams(0, 1) == 1
+    monkeypatch.setattr(bench, "usable_cores", lambda: 16)
+    assert bench.auto_streams(24, 1) == 8 and bench.auto_streams(24, 8) == 1 and bench.auto_streams(24, 2) == 4
