@@ -23,7 +23,23 @@
 __global__ void k_grid_init(StGrid* g) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         for (int a = 0; a < 3; a++) { g->lo_ord[a] = 0xffffffffu; g->hi_ord[a] = 0u; }
+        g->rmax_ord = 0u;
+        g->r = 0.0f;
     }
+}
+
+__global__ void __launch_bounds__(KNN_BLOCK) k_bound_max(const float* bound, int64_t n, StGrid* g) {
+    __shared__ unsigned m;
+    if (threadIdx.x == 0) m = 0u;
+    __syncthreads();
+    unsigned mine = 0u;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned o = st_f2ord(bound[i]);
+        if (o > mine) mine = o;
+    }
+    if (mine > m) atomicMax(&m, mine);
+    __syncthreads();
+    if (threadIdx.x == 0 && m) atomicMax(&g->rmax_ord, m);
 }
 
 __global__ void __launch_bounds__(KNN_BLOCK) k_grid_bbox(const float* pts, int64_t n, StGrid* g) {
@@ -40,10 +56,13 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_grid_bbox(const float* pts, int64
     if (threadIdx.x < 3) { atomicMin(&g->lo_ord[threadIdx.x], lo[threadIdx.x]); atomicMax(&g->hi_ord[threadIdx.x], hi[threadIdx.x]); }
 }
 
-__global__ void k_grid_dims(StGrid* g, float cell, int64_t max_cells) {
+__global__ void k_grid_dims(StGrid* g, float cell, int64_t max_cells, float r) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     float lo[3], hi[3];
     for (int a = 0; a < 3; a++) { lo[a] = st_ord2f(g->lo_ord[a]); hi[a] = st_ord2f(g->hi_ord[a]); g->lo[a] = lo[a]; }
+    if (r < 0.0f) r = st_ord2f(g->rmax_ord);  // the largest per-query bound, reduced by k_bound_max
+    g->r = r;
+    if (cell < 0.0f) cell = fmaxf(r / -cell, 1e-4f);
     if (!(cell > 0.0f)) cell = 1.0f;
     for (;;) {
         double total = 1.0;
@@ -85,7 +104,7 @@ int64_t st_grid_ws_bytes(int64_t n, int64_t max_cells) {
 
 // Builds grid over pts[n]; g (device struct), cell_start[max_cells+1], recs[n] are caller arrays.
 int st_grid_build(const float* pts, int64_t n, float cell, int64_t max_cells, StGrid* g, uint32_t* cell_start, float4* recs,
-                  void* ws, int64_t ws_bytes, hipStream_t stream) {
+                  void* ws, int64_t ws_bytes, hipStream_t stream, float r, const float* bound, int64_t n_bound) {
     StArena a(ws, ws_bytes);
     uint32_t* cursor = a.take<uint32_t>(max_cells + 1);
     int64_t scan_bytes = st_scan_ws_bytes(max_cells + 1);
@@ -102,7 +121,10 @@ int st_grid_build(const float* pts, int64_t n, float cell, int64_t max_cells, St
     // copy run over that bound; cells past the real count stay empty.  A cloud that would need more gets a coarser grid
     // (k_grid_dims doubles the cell), which changes the speed of a search, never its result.
     const int64_t ncell = st_min64(max_cells, 128 * n + 65536);
-    hipLaunchKernelGGL(k_grid_dims, dim3(1), dim3(64), 0, stream, g, cell, ncell);
+    if (r < 0.0f && bound && n_bound > 0)
+        hipLaunchKernelGGL(k_bound_max, dim3((unsigned)st_min64(st_div_up(n_bound, KNN_BLOCK), 1024)), dim3(KNN_BLOCK), 0, stream,
+                           bound, n_bound, g);
+    hipLaunchKernelGGL(k_grid_dims, dim3(1), dim3(64), 0, stream, g, cell, ncell, r);
     if (getenv("ST_GRID_DEBUG")) {
         StGrid h;
         (void)hipMemcpyAsync(&h, g, sizeof(StGrid), hipMemcpyDeviceToHost, stream);
@@ -181,6 +203,7 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn(const float* __restrict__ src
     uint32_t* rfirst = s_rfirst[wave];
     unsigned long long* keys = s_keys[wave];
     const float px = src[3 * i], py = src[3 * i + 1], pz = src[3 * i + 2];
+    if (r < 0.0f) r = g->r;  // radius reduced on the device (st_knn_radius with r < 0)
     const float r2 = r * r;
     float reach_r = r;
     float bnd = 0.0f;
@@ -299,13 +322,17 @@ extern "C" int64_t st_knn_workspace_bytes(int64_t n_dst) {
 }
 
 // idx [n1,K] int64 (-1 pad), dist [n1,K] float32 = sqrtf(d2) (NaN pad).  bound/bound_mode: see above.
-// cell_hint: preferred grid cell size (<= 0: use r).
+// cell_hint: preferred grid cell size (0: use r).  r < 0 (needs `bound`): the search radius is max(bound) -- what the
+// callers used to read back to the host just to pass it in again; the reduction stays on the device.  cell_hint < 0
+// (with r < 0): cell = max(r / -cell_hint, 1e-4).
 extern "C" int st_knn_radius(const float* src, int64_t n1, const float* dst, int64_t n2, int K, float r, const float* bound,
                              int bound_mode, float cell_hint, int64_t* idx, float* dist, void* ws, int64_t ws_bytes,
                              void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     ST_REQUIRE(K == 1 || K == 8 || K == 16, "knn: K must be 1, 8 or 16 (got %d)", K);
     ST_REQUIRE(bound_mode == 0 || bound != nullptr, "knn: bound_mode needs a bound array");
+    ST_REQUIRE(r >= 0.0f || bound != nullptr, "knn: r < 0 (radius = max(bound)) needs a bound array");
+    ST_REQUIRE(cell_hint >= 0.0f || r < 0.0f, "knn: a relative cell size (cell_hint < 0) goes with r < 0");
     ST_REQUIRE(n2 < (1ll << 31), "knn: too many points");
     if (n1 <= 0) return ST_OK;
     StArena a(ws, ws_bytes);
@@ -315,7 +342,8 @@ extern "C" int st_knn_radius(const float* src, int64_t n1, const float* dst, int
         st_set_error("knn: workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)a.used);
         return ST_ERR_WORKSPACE;
     }
-    ST_TRY(st_grid_build(dst, n2, cell_hint > 0.0f ? cell_hint : r, KNN_MAX_CELLS, g, cell_start, recs, sub, sub_bytes, stream));
+    const float cell_arg = cell_hint != 0.0f ? cell_hint : (r >= 0.0f ? r : -1.0f);
+    ST_TRY(st_grid_build(dst, n2, cell_arg, KNN_MAX_CELLS, g, cell_start, recs, sub, sub_bytes, stream, r, bound, n1));
     dim3 grid((unsigned)st_div_up(n1, KNN_WAVES)), block(KNN_BLOCK);
     if (K == 1)
         hipLaunchKernelGGL((k_knn<1>), grid, block, 0, stream, src, n1, (const StGrid*)g, (const uint32_t*)cell_start,

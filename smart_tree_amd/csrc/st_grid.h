@@ -9,6 +9,8 @@ struct StGrid {
     float cell;
     int dim[3];
     int64_t ncell;
+    unsigned rmax_ord;  // largest per-query bound (order-preserving bits), when the search radius is taken from the device
+    float r;            // search radius the kNN kernels use
 };
 
 static inline int64_t st_min64(int64_t a, int64_t b) { return a < b ? a : b; }
@@ -24,5 +26,8 @@ __device__ __forceinline__ int64_t st_grid_cell(const StGrid* g, float x, float 
 }
 
 int64_t st_grid_ws_bytes(int64_t n, int64_t max_cells);
+// r < 0: the search radius is max(bound[0 .. n_bound)), reduced on the device (no host round trip); cell < 0: the
+// cell size is max(r / -cell, 1e-4).
 int st_grid_build(const float* pts, int64_t n, float cell, int64_t max_cells, StGrid* g, uint32_t* cell_start, float4* recs,
-                  void* ws, int64_t ws_bytes, hipStream_t stream);
+                  void* ws, int64_t ws_bytes, hipStream_t stream, float r = 0.0f, const float* bound = nullptr,
+                  int64_t n_bound = 0);

@@ -3,7 +3,7 @@ from __future__ import annotations
 
 import torch
 
-from .graph import BOUND_LT, _search_cell, knn
+from .graph import BOUND_LT, SEARCH_CELL_DIV, knn
 
 
 def outlier_removal(points: torch.Tensor, radii: torch.Tensor, nb_points: int = 4) -> torch.Tensor:
@@ -12,7 +12,7 @@ def outlier_removal(points: torch.Tensor, radii: torch.Tensor, nb_points: int = 
     The strict per-point bound runs inside the search, so "all nb_points slots filled" is the test."""
     if points.shape[0] == 0:
         return torch.zeros((0,), dtype=torch.bool, device=points.device)
-    r_max = torch.max(radii).item()
     bound = radii.reshape(-1)
-    idxs, _, _ = knn(points, points, K=nb_points, r=r_max, bound=bound, bound_mode=BOUND_LT, cell=_search_cell(bound, r_max))
+    # r = -1: the search radius max(radii) is reduced on the device (one host round trip less); cell = r / 8
+    idxs, _, _ = knn(points, points, K=nb_points, r=-1.0, bound=bound, bound_mode=BOUND_LT, cell=-SEARCH_CELL_DIV)
     return idxs[:, nb_points - 1] != -1

@@ -62,6 +62,9 @@ def nn(src, dest, r=1.0, grid=None):
     return idx.squeeze(1), dist.squeeze(1), grid
 
 
+SEARCH_CELL_DIV = 8.0  # knn(..., r=-1, cell=-SEARCH_CELL_DIV): the same cell, with r_max left on the device
+
+
 def _search_cell(radii: torch.Tensor, r_max: float) -> float:
     """Grid cell for per-query bounded searches: fine enough for thin twigs, coarse enough that
     the thickest branch scans a bounded number of cells."""
@@ -88,8 +91,7 @@ def nn_graph(points: torch.Tensor, radii: torch.Tensor, K: int = 40) -> Graph:
     if points.shape[0] == 0:
         return Graph(points, torch.zeros((0, 2), dtype=torch.int64, device=points.device),
                      torch.zeros((0,), dtype=torch.float32, device=points.device))
-    r_max = radii.max().item()
-    idxs, dists, _ = knn(points, points, K=K, r=r_max, bound=radii, bound_mode=BOUND_LE, cell=_search_cell(radii, r_max))
+    idxs, dists, _ = knn(points, points, K=K, r=-1.0, bound=radii, bound_mode=BOUND_LE, cell=-SEARCH_CELL_DIV)
     edges, edge_weights = make_edges(dists, idxs)
     return Graph(points, edges, edge_weights)
 
