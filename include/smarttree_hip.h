@@ -127,6 +127,8 @@ int64_t st_component_csr_workspace_bytes(int64_t m);
 int st_component_csr(const int64_t* edges, const float* w, int64_t E, const int32_t* new_id, int64_t m, uint32_t* row_off,
                      uint32_t* col, float* wgt, void* ws, int64_t ws_bytes, void* stream);
 int64_t st_skeleton_workspace_bytes(int64_t m, int64_t n_comp);
+/* comp_size_host is unused and may be NULL (the claim grid is laid out on the device from comp_off); grid_cell < 0:
+ * cell = max(max(rad) / -grid_cell, 1e-4) with the maximum reduced on the device -- neither costs the caller a read-back */
 int st_skeleton_components(int n_comp, const int32_t* comp_off, const int32_t* comp_size_host, int64_t m, const float* pts,
                            const float* rad, const float* ysurf, const uint32_t* row_off, const uint32_t* col,
                            const float* wgt, float grid_cell, int stages, int block_threads, float* dist, int32_t* pred,

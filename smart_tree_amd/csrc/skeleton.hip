@@ -1064,15 +1064,46 @@ __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_claim(SkArgs A) {
     __shared__ unsigned lq[SK_LQ_CLAIM];
     __shared__ unsigned lq_n, lq_base;
     const int c = A.blk_comp[blockIdx.x];
-    if (A.s_done[c] || !A.s_wide[c]) return;
+    if (c < 0 || A.s_done[c] || !A.s_wide[c]) return;  // c < 0: padding of the bound-sized grid
     const int base = A.comp_off[c], n = A.comp_off[c + 1] - base;
     sk_claim_items(A, c, base, n, A.s_len[c], A.s_rp[c], A.path_verts + base + A.s_cur_off[c], false,
                    blockIdx.x - A.blk_first[c], A.blk_count[c], lq, &lq_n, &lq_base, false);
 }
 
+#define SK_MAX_CLAIM_BLOCKS 256
+// Claim grid laid out on the device (one workgroup): component c gets clamp(ceil(size / 1024), 1, SK_MAX_CLAIM_BLOCKS)
+// consecutive workgroups from blk_first[c]; the host launches the bound n_comp + ceil(m / 1024) and the rest is padding
+// (-1).  The component sizes therefore never travel to the host.
+__global__ void __launch_bounds__(1024) k_sk_blk_tables(SkArgs A, int* blk_comp, int* blk_first, int* blk_count, int nblk_bound) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x, per = (A.C + 1023) / 1024, c0 = tid * per, c1 = min(A.C, c0 + per);
+    int mine = 0;
+    for (int c = c0; c < c1; c++) {
+        const int k = (A.comp_off[c + 1] - A.comp_off[c] + 1023) / 1024;
+        mine += k < 1 ? 1 : (k > SK_MAX_CLAIM_BLOCKS ? SK_MAX_CLAIM_BLOCKS : k);
+    }
+    part[tid] = mine;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {  // inclusive scan of the per-lane totals
+        const int o = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += o;
+        __syncthreads();
+    }
+    int at = part[tid] - mine;
+    const int total = part[1023];
+    for (int c = c0; c < c1; c++) {
+        int k = (A.comp_off[c + 1] - A.comp_off[c] + 1023) / 1024;
+        k = k < 1 ? 1 : (k > SK_MAX_CLAIM_BLOCKS ? SK_MAX_CLAIM_BLOCKS : k);
+        blk_first[c] = at;
+        blk_count[c] = k;
+        for (int j = 0; j < k; j++) blk_comp[at++] = c;
+    }
+    for (int b = total + tid; b < nblk_bound; b += 1024) blk_comp[b] = -1;
+}
+
 // ------------------------------------------------------------------------------- host side ---
 #define SK_GRID_CELLS (1ll << 24)
-#define SK_MAX_CLAIM_BLOCKS 256
 
 struct SkLayout {
     unsigned *dist_ord, *stamp, *q0, *q1, *term, *touched, *cnt, *s_ntouched, *sort_keys, *order;
@@ -1169,13 +1200,9 @@ static int sk_read(void* dst, const void* src, size_t bytes, hipStream_t stream)
     return ST_OK;
 }
 
-static inline int sk_claim_blocks(int64_t comp_size) {
-    int64_t k = st_div_up(comp_size, 1024);
-    return (int)(k < 1 ? 1 : (k > SK_MAX_CLAIM_BLOCKS ? SK_MAX_CLAIM_BLOCKS : k));
-}
-
 // All components of one cloud.  Vertex arrays are in the renumbered space of st_component_layout;
-// comp_size_host [n_comp] = component sizes (host copy, sizes the claim grid).
+// comp_size_host: unused (may be NULL) -- the claim grid is laid out on the device from comp_off.
+// grid_cell > 0: cell size of the claim grid; < 0: max(rad) / -grid_cell, reduced on the device.
 // stages: 1 = roots + SSSP + predecessors, 2 = literal second SSSP into tree_dist, 4 = sample_tree
 // (on tree_dist if stage 2 ran, else on dist -- the two are bit-identical).
 // block_threads: lanes of the per-component select workgroup (0 = 1024).
@@ -1224,6 +1251,20 @@ extern "C" int st_skeleton_components(int n_comp, const int32_t* comp_off, const
     const unsigned fg = (unsigned)st_min64(st_div_up(m, SK_WIDE_BLOCK), SK_SSSP_BLOCKS);
     unsigned h[8];
     int64_t sssp_rounds = 0;
+    const bool defer_plateaus = (stages & 1) && (stages & 4) && !(stages & 2);
+    auto resolve_plateaus = [&](unsigned unresolved) -> int {
+        unsigned round = 2;
+        while (unresolved > 0) {
+            (void)hipMemsetAsync(&s.cnt[4], 0, sizeof(unsigned), stream);
+            hipLaunchKernelGGL(k_sk_preds_plateau, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A, round);
+            ST_TRY(sk_read(h, s.cnt, sizeof(unsigned) * 8, stream));
+            if (h[4] == 0) break;  // unreachable leftovers (cannot happen inside a component)
+            unresolved -= h[4];
+            round++;
+        }
+        if (stats_host) stats_host[1] = round - 2;
+        return ST_OK;
+    };
     if (stages & 1) {
         hipLaunchKernelGGL(k_sk_init, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A);
         hipLaunchKernelGGL(k_sk_roots, dim3((unsigned)n_comp), dim3((unsigned)block_threads), 0, stream, A);
@@ -1239,17 +1280,14 @@ extern "C" int st_skeleton_components(int n_comp, const int32_t* comp_off, const
         }
         hipLaunchKernelGGL(k_sk_dist_out, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A);
         hipLaunchKernelGGL(k_sk_preds, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A);
-        ST_TRY(sk_read(h, s.cnt, sizeof(unsigned) * 8, stream));
-        unsigned unresolved = h[3], round = 2;
-        while (unresolved > 0) {
-            (void)hipMemsetAsync(&s.cnt[4], 0, sizeof(unsigned), stream);
-            hipLaunchKernelGGL(k_sk_preds_plateau, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A, round);
+        // Vertices whose tight in-neighbours all sit on their own distance plateau (cnt[3]) are rare; with sample_tree
+        // next, their count is not read back here (a blocking round trip costs ~1 ms beside other clouds' kernels,
+        // DESIGN.md section 5) but arrives with the first progress read-back of the select loop, which is then redone.
+        if (!defer_plateaus) {
             ST_TRY(sk_read(h, s.cnt, sizeof(unsigned) * 8, stream));
-            if (h[4] == 0) break;  // unreachable leftovers (cannot happen inside a component)
-            unresolved -= h[4];
-            round++;
+            ST_TRY(resolve_plateaus(h[3]));
         }
-        if (stats_host) { stats_host[0] = sssp_rounds; stats_host[1] = round - 2; }
+        if (stats_host) stats_host[0] = sssp_rounds;
     }
     if (!(stages & 1)) hipLaunchKernelGGL(k_sk_fill_comp_of, dim3((unsigned)n_comp), dim3((unsigned)block_threads), 0, stream, A);
     if (stages & 2) {
@@ -1264,59 +1302,64 @@ extern "C" int st_skeleton_components(int n_comp, const int32_t* comp_off, const
         }
     }
     if (stages & 4) {
-        // claim / finalize grid: workgroups per component proportional to its size
-        int nblk = 0;
-        for (int c = 0; c < n_comp; c++) nblk += sk_claim_blocks(comp_size_host[c]);
-        int* hb = (int*)malloc(sizeof(int) * ((size_t)nblk + 2 * (size_t)n_comp));
-        int *bc = hb, *bf = hb + nblk, *bn = bf + n_comp;
-        for (int c = 0, at = 0; c < n_comp; c++) {
-            const int k = sk_claim_blocks(comp_size_host[c]);
-            bf[c] = at;
-            bn[c] = k;
-            for (int j = 0; j < k; j++) bc[at++] = c;
-        }
-        (void)hipMemcpyAsync(s.blk_comp, bc, sizeof(int) * (size_t)nblk, hipMemcpyHostToDevice, stream);
-        (void)hipMemcpyAsync(s.blk_first, bf, sizeof(int) * (size_t)n_comp, hipMemcpyHostToDevice, stream);
-        (void)hipMemcpyAsync(s.blk_count, bn, sizeof(int) * (size_t)n_comp, hipMemcpyHostToDevice, stream);
-        int rc = st_grid_build(pts, m, grid_cell, SK_GRID_CELLS, s.g, s.cell_start, s.recs, s.gws, s.gws_bytes, stream);  // syncs
-        free(hb);
-        ST_TRY(rc);
-        (void)hipMemsetAsync(&s.cnt[5], 0, sizeof(unsigned), stream);
-        hipLaunchKernelGGL(k_sk_lift_init, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A,
-                           (const float*)((stages & 2) ? tree_dist : dist));
-        for (int span = 1; span < SK_ANC; span *= 2)  // direct ancestor table by doubling
-            hipLaunchKernelGGL(k_sk_anc_pass, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A, span);
-        // order the vertices of every component by distance, once: the per-branch argmax becomes a cursor
-        hipLaunchKernelGGL(k_sk_sort_keys, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A, s.sort_keys, s.order, 0);
-        ST_TRY(st_radix_sort_pairs_u32(s.sort_keys, s.order, m, 32, s.sort_ws, s.sort_bytes, stream));
-        if (n_comp > 1) {
-            int bits = 1;
-            while ((1ll << bits) < n_comp) bits++;
-            hipLaunchKernelGGL(k_sk_sort_keys, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A, s.sort_keys, s.order, 1);
-            ST_TRY(st_radix_sort_pairs_u32(s.sort_keys, s.order, m, bits, s.sort_ws, s.sort_bytes, stream));
-        }
-        hipLaunchKernelGGL(k_sk_order_init, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A, s.order_init, s.pos);
+        // claim / finalize grid: workgroups per component proportional to its size, laid out by k_sk_blk_tables
+        const int nblk = (int)st_min64((int64_t)n_comp + st_div_up(m, 1024), (int64_t)n_comp * SK_MAX_CLAIM_BLOCKS);
+        hipLaunchKernelGGL(k_sk_blk_tables, dim3(1), dim3(1024), 0, stream, A, s.blk_comp, s.blk_first, s.blk_count, nblk);
+        // grid_cell < 0: cell = max(rad) / -grid_cell with the maximum reduced on the device (no host round trip)
+        ST_TRY(st_grid_build(pts, m, grid_cell, SK_GRID_CELLS, s.g, s.cell_start, s.recs, s.gws, s.gws_bytes, stream,
+                             grid_cell < 0.0f ? -1.0f : 0.0f, grid_cell < 0.0f ? rad : nullptr, grid_cell < 0.0f ? m : 0));
         int64_t iters = 0;
         hipEvent_t ev[32];
         if (time_select) for (int i = 0; i < 32; i++) (void)hipEventCreate(&ev[i]);
         double select_ms = 0.0;
-        for (int batch = g_launch_batch;; batch = batch > 4 ? 4 : batch) {  // launch pairs per counter read-back: a long first
-            // batch, short ones for the stragglers (a finished launch pair still costs its ~10 us of launch latency)
-            for (int b = 0; b < batch; b++, iters++) {
-                if (time_select) (void)hipEventRecord(ev[2 * b], stream);
-                hipLaunchKernelGGL(k_sk_select, dim3((unsigned)n_comp), dim3((unsigned)block_threads), 0, stream, A);
-                if (time_select) (void)hipEventRecord(ev[2 * b + 1], stream);
-                hipLaunchKernelGGL(k_sk_claim, dim3((unsigned)nblk), dim3(SK_WIDE_BLOCK), 0, stream, A);
+        bool plateaus_pending = defer_plateaus;
+        for (;;) {  // second pass only if the deferred check found plateau vertices: predecessors completed, selection redone
+            (void)hipMemsetAsync(&s.cnt[5], 0, sizeof(unsigned), stream);
+            hipLaunchKernelGGL(k_sk_lift_init, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A,
+                               (const float*)((stages & 2) ? tree_dist : dist));
+            for (int span = 1; span < SK_ANC; span *= 2)  // direct ancestor table by doubling
+                hipLaunchKernelGGL(k_sk_anc_pass, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A, span);
+            // order the vertices of every component by distance, once: the per-branch argmax becomes a cursor
+            hipLaunchKernelGGL(k_sk_sort_keys, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A, s.sort_keys, s.order, 0);
+            ST_TRY(st_radix_sort_pairs_u32(s.sort_keys, s.order, m, 32, s.sort_ws, s.sort_bytes, stream));
+            if (n_comp > 1) {
+                int bits = 1;
+                while ((1ll << bits) < n_comp) bits++;
+                hipLaunchKernelGGL(k_sk_sort_keys, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A, s.sort_keys, s.order, 1);
+                ST_TRY(st_radix_sort_pairs_u32(s.sort_keys, s.order, m, bits, s.sort_ws, s.sort_bytes, stream));
             }
-            ST_TRY(sk_read(h, s.cnt, sizeof(unsigned) * 8, stream));
-            if (time_select)
-                for (int b = 0; b < batch; b++) {
-                    float ms = 0.0f;
-                    (void)hipEventElapsedTime(&ms, ev[2 * b], ev[2 * b + 1]);
-                    select_ms += ms;
+            hipLaunchKernelGGL(k_sk_order_init, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A, s.order_init, s.pos);
+            iters = 0;
+            select_ms = 0.0;
+            bool redo = false;
+            for (int batch = g_launch_batch;; batch = batch > 4 ? 4 : batch) {  // launch pairs per counter read-back: a long first
+                // batch, short ones for the stragglers (a finished launch pair still costs its ~10 us of launch latency)
+                for (int b = 0; b < batch; b++, iters++) {
+                    if (time_select) (void)hipEventRecord(ev[2 * b], stream);
+                    hipLaunchKernelGGL(k_sk_select, dim3((unsigned)n_comp), dim3((unsigned)block_threads), 0, stream, A);
+                    if (time_select) (void)hipEventRecord(ev[2 * b + 1], stream);
+                    hipLaunchKernelGGL(k_sk_claim, dim3((unsigned)nblk), dim3(SK_WIDE_BLOCK), 0, stream, A);
                 }
-            if (h[5] >= (unsigned)n_comp) break;
-            ST_REQUIRE(iters <= m + 64 && iters < (1 << 26), "skeleton: sample_tree did not terminate");
+                ST_TRY(sk_read(h, s.cnt, sizeof(unsigned) * 8, stream));
+                if (time_select)
+                    for (int b = 0; b < batch; b++) {
+                        float ms = 0.0f;
+                        (void)hipEventElapsedTime(&ms, ev[2 * b], ev[2 * b + 1]);
+                        select_ms += ms;
+                    }
+                if (plateaus_pending) {  // first read-back after the deferred predecessor check
+                    plateaus_pending = false;
+                    if (h[3] > 0) { redo = true; break; }
+                }
+                if (h[5] >= (unsigned)n_comp) break;
+                ST_REQUIRE(iters <= m + 64 && iters < (1 << 26), "skeleton: sample_tree did not terminate");
+            }
+            if (!redo) break;
+            // the selection overwrote stamp[] (its speculation marks): recompute the resolved / unresolved marks first
+            (void)hipMemsetAsync(&s.cnt[3], 0, sizeof(unsigned), stream);
+            hipLaunchKernelGGL(k_sk_preds, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A);
+            ST_TRY(sk_read(h, s.cnt, sizeof(unsigned) * 8, stream));
+            ST_TRY(resolve_plateaus(h[3]));
         }
         if (time_select) {
             for (int i = 0; i < 32; i++) (void)hipEventDestroy(ev[i]);

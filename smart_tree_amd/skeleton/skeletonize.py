@@ -62,16 +62,15 @@ def run_components(comps: ComponentSet, medial_pts: torch.Tensor, radius: torch.
     res = ComponentResult(f32(m), i32(m), i32(C), f32(m), i32(m), i32(m), i32(m), i32(C), i32(m), i32(m))
     if C == 0:
         return res
-    # one read-back for both host-side facts: component sizes (they size the claim grid) and the largest radius
-    both = torch.cat((comps.comp_size.to(torch.float64), rad.max().to(torch.float64).view(1))).cpu().numpy()
-    sizes, r_max = both[:-1].astype("int32"), float(both[-1])
+    # no host-side facts needed: the library lays out the claim grid from comp_off and takes the grid cell as
+    # max(rad) / GRID_DIV reduced on the device (grid_cell < 0), so this stage starts without a read-back
     stats = (ctypes.c_int64 * 8)()
     stats[7] = 1 if profiling.enabled() else 0  # bracket every k_sk_select launch with HIP events
     ws = _lib.workspace(L.st_skeleton_workspace_bytes(m, C), dev)
     with profiling.stage("skeleton_kernels"):
         _lib.check(L.st_skeleton_components(
-            C, _lib.ptr(comps.comp_off.contiguous()), sizes.ctypes.data, m, _lib.ptr(pts), _lib.ptr(rad), _lib.ptr(ys),
-            _lib.ptr(comps.row_off), _lib.ptr(comps.col), _lib.ptr(comps.wgt), float(max(r_max / GRID_DIV, 1e-4)), int(stages),
+            C, _lib.ptr(comps.comp_off.contiguous()), None, m, _lib.ptr(pts), _lib.ptr(rad), _lib.ptr(ys),
+            _lib.ptr(comps.row_off), _lib.ptr(comps.col), _lib.ptr(comps.wgt), -float(GRID_DIV), int(stages),
             int(block_threads), _lib.ptr(res.dist), _lib.ptr(res.pred), _lib.ptr(res.root_local), _lib.ptr(res.tree_dist),
             _lib.ptr(res.branch_parent), _lib.ptr(res.branch_off), _lib.ptr(res.branch_len), _lib.ptr(res.n_branches),
             _lib.ptr(res.path_verts), _lib.ptr(res.branch_of), stats, _lib.ptr(ws), ws.numel(), _lib.stream(dev)))
