@@ -266,8 +266,12 @@ __global__ void __launch_bounds__(GR_BLOCK) k_cl_sizes(const int* label, int64_t
     }
 }
 __global__ void __launch_bounds__(GR_BLOCK) k_cl_rootflag(const int* label, const uint32_t* size, int64_t n, uint32_t minv,
-                                                          uint32_t* flag) {
-    GR_LOOP(i, n) flag[i] = (label[i] == (int)i && size[i] >= minv) ? 1u : 0u;
+                                                          uint32_t* flag, uint32_t* kept) {
+    GR_LOOP(i, n) {
+        const bool root = label[i] == (int)i && size[i] >= minv;
+        flag[i] = root ? 1u : 0u;
+        if (root) atomicAdd(kept, size[i]);  // vertices in kept components: known together with their number
+    }
 }
 __global__ void __launch_bounds__(GR_BLOCK) k_cl_rootlist(const uint32_t* flag_off, const int* label, const uint32_t* size,
                                                           int64_t n, uint32_t minv, uint32_t* key, uint32_t* root) {
@@ -294,7 +298,7 @@ __global__ void __launch_bounds__(GR_BLOCK) k_fill_i32(int* p, int64_t n, int v)
 
 extern "C" int64_t st_component_layout_workspace_bytes(int64_t n) {
     StArena a(nullptr, 0);
-    a.take<uint32_t>(n);      // size
+    a.take<uint32_t>(n + 1);  // size (+ kept-vertex counter)
     a.take<uint32_t>(n + 1);  // flag / offsets
     a.take<uint32_t>(n);      // key
     a.take<uint32_t>(n);      // val
@@ -313,7 +317,7 @@ extern "C" int st_component_layout(const int32_t* labels, int64_t n, int min_ver
     *n_kept_host = 0;
     if (n <= 0) return ST_OK;
     StArena a(ws, ws_bytes);
-    uint32_t* size = a.take<uint32_t>(n);
+    uint32_t* size = a.take<uint32_t>(n + 1);  // size[n] = number of vertices in kept components
     uint32_t* flag = a.take<uint32_t>(n + 1);
     uint32_t* key = a.take<uint32_t>(n);
     uint32_t* val = a.take<uint32_t>(n);
@@ -323,12 +327,13 @@ extern "C" int st_component_layout(const int32_t* labels, int64_t n, int min_ver
     if (!a.ok() || !sw) { st_set_error("component_layout: workspace too small"); return ST_ERR_WORKSPACE; }
     const unsigned g = gr_grid(n);
     uint32_t minv = min_vertices > 0 ? (uint32_t)min_vertices : 0u;
-    (void)hipMemsetAsync(size, 0, n * sizeof(uint32_t), stream);
+    (void)hipMemsetAsync(size, 0, (n + 1) * sizeof(uint32_t), stream);
     hipLaunchKernelGGL(k_cl_sizes, dim3(g), dim3(GR_BLOCK), 0, stream, labels, n, size);
-    hipLaunchKernelGGL(k_cl_rootflag, dim3(g), dim3(GR_BLOCK), 0, stream, labels, (const uint32_t*)size, n, minv, flag);
+    hipLaunchKernelGGL(k_cl_rootflag, dim3(g), dim3(GR_BLOCK), 0, stream, labels, (const uint32_t*)size, n, minv, flag, size + n);
     ST_TRY(st_exclusive_scan_u32(flag, flag, n, flag + n, sw, sb, stream));
-    uint32_t C = 0;
+    uint32_t C = 0, m = 0;  // ONE round trip for both counts (a blocking read-back costs ~1 ms beside other clouds' kernels)
     (void)hipMemcpyAsync(&C, flag + n, sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+    (void)hipMemcpyAsync(&m, size + n, sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
     st_stream_wait(stream);
     ST_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_fill_i32, dim3(g), dim3(GR_BLOCK), 0, stream, new_id, n, -1);
@@ -344,9 +349,6 @@ extern "C" int st_component_layout(const int32_t* labels, int64_t n, int min_ver
     // vertices of kept components, ascending id, then stable sort by component rank
     hipLaunchKernelGGL(k_cl_vflag, dim3(g), dim3(GR_BLOCK), 0, stream, labels, (const int*)rank_of_root, n, flag);
     ST_TRY(st_exclusive_scan_u32(flag, flag, n, flag + n, sw, sb, stream));
-    uint32_t m = 0;
-    (void)hipMemcpyAsync(&m, flag + n, sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
-    st_stream_wait(stream);
     hipLaunchKernelGGL(k_cl_vlist, dim3(g), dim3(GR_BLOCK), 0, stream, (const uint32_t*)flag, labels, (const int*)rank_of_root, n,
                        key, val);
     int bits = 1;
