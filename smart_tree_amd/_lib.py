@@ -120,6 +120,9 @@ def lib():
             _LIB = declare(ctypes.CDLL(str(LIB_PATH)))
         else:
             _LIB = declare(ctypes.CDLL(str(LIB_PATH)), ctypes.PyDLL(str(LIB_PATH)))
+        for kv in filter(None, os.environ.get("ST_SKELETON_PARAMS", "").split(",")):  # developer knob, e.g. "3=24,9=3"
+            which, value = kv.split("=")
+            _LIB.st_debug_set_skeleton_param(int(which), int(value))
     return _LIB
 
 

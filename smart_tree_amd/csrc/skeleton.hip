@@ -1160,24 +1160,26 @@ static void sk_layout(StArena& a, int64_t m, int64_t C, SkLayout* s) {
 
 static long long* g_debug_ticks = nullptr;
 static float g_prune_factor = 1.0f;
-static int g_sssp_hops = 4, g_sssp_batch = 32, g_sssp_lanes = 64;
-static int g_small_work = SK_SMALL_WORK, g_iters_per_launch = SK_ITERS_PER_LAUNCH, g_launch_batch = 16, g_local_items = 0, g_wave_work = SK_WAVE_WORK;
+static int g_sssp_hops = 4, g_sssp_batch = 32, g_sssp_lanes = 64, g_sssp_first = 2;
+#define SK_MAX_LAUNCH_BATCH 32
+static int g_small_work = SK_SMALL_WORK, g_iters_per_launch = SK_ITERS_PER_LAUNCH, g_launch_batch = 24, g_local_items = 0, g_wave_work = SK_WAVE_WORK;
 // developer aid / test hook (forces every claim strategy): 0 prune factor (x1000), 1 small_work, 2 rounds per launch,
-// 3 launches per host read-back, 4 local_items, 5 wave_work, 6 SSSP levels per launch, 7 SSSP launches per read-back; a negative `which` restores the defaults
+// 3 launches per host read-back, 4 local_items, 5 wave_work, 6 SSSP levels per launch, 7 SSSP launches per read-back, 9 length of the first SSSP batch (in batches); a negative `which` restores the defaults
 extern "C" void st_debug_set_skeleton_param(int which, int value) {
     if (which < 0) {
-        g_prune_factor = 1.0f; g_small_work = SK_SMALL_WORK; g_iters_per_launch = SK_ITERS_PER_LAUNCH; g_launch_batch = 16;
-        g_local_items = 0; g_wave_work = SK_WAVE_WORK; g_sssp_hops = 4; g_sssp_batch = 32; g_sssp_lanes = 64;
+        g_prune_factor = 1.0f; g_small_work = SK_SMALL_WORK; g_iters_per_launch = SK_ITERS_PER_LAUNCH; g_launch_batch = 24;
+        g_local_items = 0; g_wave_work = SK_WAVE_WORK; g_sssp_hops = 4; g_sssp_batch = 32; g_sssp_lanes = 64; g_sssp_first = 2;
     }
     if (which == 0) g_prune_factor = value / 1000.0f;
     if (which == 1) g_small_work = value;
     if (which == 2) g_iters_per_launch = value;
-    if (which == 3) g_launch_batch = value < 1 ? 1 : (value > 16 ? 16 : value);
+    if (which == 3) g_launch_batch = value < 1 ? 1 : (value > SK_MAX_LAUNCH_BATCH ? SK_MAX_LAUNCH_BATCH : value);
     if (which == 4) g_local_items = value;
     if (which == 5) g_wave_work = value;
     if (which == 6) g_sssp_hops = value < 1 ? 1 : value;
     if (which == 8) g_sssp_lanes = value == 64 ? 64 : (value == 32 ? 32 : 16);
     if (which == 7) g_sssp_batch = value < 1 ? 1 : (value > 64 ? 64 : value);
+    if (which == 9) g_sssp_first = value < 1 ? 1 : (value > 8 ? 8 : value);
 }
 extern "C" void st_debug_set_ticks(long long* device_ptr) { g_debug_ticks = device_ptr; }
 
@@ -1270,7 +1272,7 @@ extern "C" int st_skeleton_components(int n_comp, const int32_t* comp_off, const
         hipLaunchKernelGGL(k_sk_roots, dim3((unsigned)n_comp), dim3((unsigned)block_threads), 0, stream, A);
         for (int r = 0;;) {  // frontier rounds in batches, one counter read-back per batch.  The first batch is twice as long:
             // a tree of a million points needs 65-96 launches, an empty round costs ~4 us, a read-back beside other clouds ~1 ms
-            const int batch = r == 0 ? 2 * g_sssp_batch : g_sssp_batch;
+            const int batch = r == 0 ? g_sssp_first * g_sssp_batch : g_sssp_batch;
             for (int b = 0; b < batch; b++, r++)
                 hipLaunchKernelGGL(k_sk_sssp_round, dim3(fg), dim3(SK_WIDE_BLOCK), 0, stream, A, r, g_sssp_hops, g_sssp_lanes);
             ST_TRY(sk_read(h, s.cnt, sizeof(unsigned) * 8, stream));
@@ -1309,8 +1311,8 @@ extern "C" int st_skeleton_components(int n_comp, const int32_t* comp_off, const
         ST_TRY(st_grid_build(pts, m, grid_cell, SK_GRID_CELLS, s.g, s.cell_start, s.recs, s.gws, s.gws_bytes, stream,
                              grid_cell < 0.0f ? -1.0f : 0.0f, grid_cell < 0.0f ? rad : nullptr, grid_cell < 0.0f ? m : 0));
         int64_t iters = 0;
-        hipEvent_t ev[32];
-        if (time_select) for (int i = 0; i < 32; i++) (void)hipEventCreate(&ev[i]);
+        hipEvent_t ev[2 * SK_MAX_LAUNCH_BATCH];
+        if (time_select) for (int i = 0; i < 2 * SK_MAX_LAUNCH_BATCH; i++) (void)hipEventCreate(&ev[i]);
         double select_ms = 0.0;
         bool plateaus_pending = defer_plateaus;
         for (;;) {  // second pass only if the deferred check found plateau vertices: predecessors completed, selection redone
@@ -1332,6 +1334,8 @@ extern "C" int st_skeleton_components(int n_comp, const int32_t* comp_off, const
             iters = 0;
             select_ms = 0.0;
             bool redo = false;
+            // the 1M-point synthetic trees need 10-21 launch pairs (tools/round_counts.py): a first batch of 24 ends them with ONE
+            // progress read-back; A/B on one box, 8 clouds in flight: 5.08 ms per cloud against 5.66 with 16 (tools/sweep_batches.sh)
             for (int batch = g_launch_batch;; batch = batch > 4 ? 4 : batch) {  // launch pairs per counter read-back: a long first
                 // batch, short ones for the stragglers (a finished launch pair still costs its ~10 us of launch latency)
                 for (int b = 0; b < batch; b++, iters++) {
@@ -1362,7 +1366,7 @@ extern "C" int st_skeleton_components(int n_comp, const int32_t* comp_off, const
             ST_TRY(resolve_plateaus(h[3]));
         }
         if (time_select) {
-            for (int i = 0; i < 32; i++) (void)hipEventDestroy(ev[i]);
+            for (int i = 0; i < 2 * SK_MAX_LAUNCH_BATCH; i++) (void)hipEventDestroy(ev[i]);
             stats_host[4] = (int64_t)(select_ms * 1e6);
             stats_host[5] = iters;
         }
