@@ -115,6 +115,8 @@ int64_t st_knn_workspace_bytes(int64_t n_dst);
 int st_knn_radius(const float* src, int64_t n1, const float* dst, int64_t n2, int K, float r, const float* bound,
                   int bound_mode, float cell_hint, int64_t* idx, float* dist, void* ws, int64_t ws_bytes, void* stream);
 int64_t st_make_edges_workspace_bytes(int64_t n);
+/* n_edges_host may be NULL: the edge count stays on the device and the tail of edges / w [n*K] is padded with (0, 0)
+ * self loops of weight 0, which the component entry points below ignore (real edges have dst > 0) */
 int st_make_edges(const int64_t* idx, const float* dist, int64_t n, int K, int64_t* edges, float* w,
                   int64_t* n_edges_host, void* ws, int64_t ws_bytes, void* stream);
 int64_t st_connected_components_workspace_bytes(int64_t n);

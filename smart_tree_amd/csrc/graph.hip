@@ -120,10 +120,13 @@ extern "C" int64_t st_make_edges_workspace_bytes(int64_t n) {
 }
 
 // idx/dist [n,K] from st_knn_radius (after the caller's radius filter); edges [n*K,2] int64, w [n*K].
+// n_edges_host == NULL: no read-back of the edge count (a blocking round trip costs ~1 ms beside other clouds' kernels);
+// the n*K - E unused entries are (0, 0) self loops of weight 0, which st_connected_components and st_component_csr ignore
+// (a real edge always has dst > 0: the reference's `idx > 0` filter, graph.py:59).
 extern "C" int st_make_edges(const int64_t* idx, const float* dist, int64_t n, int K, int64_t* edges, float* w,
                              int64_t* n_edges_host, void* ws, int64_t ws_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    *n_edges_host = 0;
+    if (n_edges_host) *n_edges_host = 0;
     if (n <= 0) return ST_OK;
     StArena a(ws, ws_bytes);
     uint32_t* cnt = a.take<uint32_t>(n + 1);
@@ -132,7 +135,12 @@ extern "C" int st_make_edges(const int64_t* idx, const float* dist, int64_t n, i
     if (!cnt || !sw) { st_set_error("make_edges: workspace too small"); return ST_ERR_WORKSPACE; }
     hipLaunchKernelGGL(k_edge_count, dim3(gr_grid(n)), dim3(GR_BLOCK), 0, stream, idx, n, K, cnt);
     ST_TRY(st_exclusive_scan_u32(cnt, cnt, n, cnt + n, sw, sb, stream));
+    if (!n_edges_host) {  // no count on the host: the tail of the capacity-sized list is padded with (0, 0) edges of weight 0
+        (void)hipMemsetAsync(edges, 0, (size_t)n * K * 2 * sizeof(int64_t), stream);
+        (void)hipMemsetAsync(w, 0, (size_t)n * K * sizeof(float), stream);
+    }
     hipLaunchKernelGGL(k_edge_emit, dim3(gr_grid(n)), dim3(GR_BLOCK), 0, stream, idx, dist, n, K, (const uint32_t*)cnt, edges, w);
+    if (!n_edges_host) { ST_CHECK_LAUNCH(); return ST_OK; }
     uint32_t total = 0;
     (void)hipMemcpyAsync(&total, cnt + n, sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
     st_stream_wait(stream);

@@ -28,3 +28,39 @@ class Graph:
         return connected_components(self, minimum_vertices)
 
     connected_components = connected_cugraph_components
+
+
+class PaddedGraph(Graph):
+    """What `nn_graph` returns: the edge list at its capacity `[n*K]`, the unused tail padded with (0, 0) self loops of
+    weight 0 (a real edge has dst > 0, reference skeleton/graph.py:59), so that building it needs no read-back of the
+    edge count.  `connected_cugraph_components` consumes the padded arrays as they are (the padding neither joins
+    components nor enters the CSR); `edges` / `edge_weights` -- the reference's `[E,2]` / `[E]` views -- are cut on first
+    access, which is where the count comes to the host."""
+
+    def __init__(self, vertices: torch.Tensor, edges_cap: torch.Tensor, weights_cap: torch.Tensor):
+        self.vertices = vertices
+        self._cap = (edges_cap, weights_cap)
+        self._cut = None
+
+    def _trim(self):
+        if self._cut is None:
+            e, w = self._cap
+            E = int((e[:, 1] > 0).sum().item())  # real edges are a prefix of the list
+            self._cut = (e[:E], w[:E])
+        return self._cut
+
+    @property
+    def padded(self):
+        return self._cap
+
+    @property
+    def edges(self) -> torch.Tensor:
+        return self._trim()[0]
+
+    @property
+    def edge_weights(self) -> torch.Tensor:
+        return self._trim()[1]
+
+    def __repr__(self):
+        return f"PaddedGraph(vertices={tuple(self.vertices.shape)}, capacity={self._cap[0].shape[0]})"
+

@@ -14,7 +14,7 @@ from typing import Optional
 import torch
 
 from .. import _lib
-from ..data_types.graph import Graph
+from ..data_types.graph import Graph, PaddedGraph
 
 BOUND_NONE, BOUND_LE, BOUND_LT = 0, 1, 2
 
@@ -71,9 +71,10 @@ def _search_cell(radii: torch.Tensor, r_max: float) -> float:
     return max(r_max / 8.0, 1e-4)
 
 
-def make_edges(dists: torch.Tensor, idxs: torch.Tensor):
+def make_edges(dists: torch.Tensor, idxs: torch.Tensor, padded: bool = False):
     """graph.py:52-60: edges (i -> idx) for idx > 0 (the reference's filter drops every edge INTO
-    vertex 0 and vertex 0's self loop; kept), in (i, k) order."""
+    vertex 0 and vertex 0's self loop; kept), in (i, k) order.  `padded`: the capacity-sized arrays come back as they
+    are, tail filled with (0, 0) / 0, and the edge count is not read back (data_types.graph.PaddedGraph)."""
     L = _lib.lib()
     dev = dists.device
     n, K = dists.shape
@@ -82,7 +83,9 @@ def make_edges(dists: torch.Tensor, idxs: torch.Tensor):
     ne = ctypes.c_int64(0)
     ws = _lib.workspace(L.st_make_edges_workspace_bytes(n), dev)
     _lib.check(L.st_make_edges(_lib.ptr(idxs.contiguous()), _lib.ptr(dists.contiguous()), n, K, _lib.ptr(edges), _lib.ptr(w),
-                               ctypes.byref(ne), _lib.ptr(ws), ws.numel(), _lib.stream(dev)))
+                               None if padded else ctypes.byref(ne), _lib.ptr(ws), ws.numel(), _lib.stream(dev)))
+    if padded:
+        return edges[: n * K], w[: n * K]
     return edges[: ne.value], w[: ne.value]
 
 
@@ -92,8 +95,8 @@ def nn_graph(points: torch.Tensor, radii: torch.Tensor, K: int = 40) -> Graph:
         return Graph(points, torch.zeros((0, 2), dtype=torch.int64, device=points.device),
                      torch.zeros((0,), dtype=torch.float32, device=points.device))
     idxs, dists, _ = knn(points, points, K=K, r=-1.0, bound=radii, bound_mode=BOUND_LE, cell=-SEARCH_CELL_DIV)
-    edges, edge_weights = make_edges(dists, idxs)
-    return Graph(points, edges, edge_weights)
+    edges, edge_weights = make_edges(dists, idxs, padded=True)
+    return PaddedGraph(points, edges, edge_weights)
 
 
 @dataclass
@@ -122,8 +125,8 @@ def connected_components(graph: Graph, minimum_vertices: int = 0) -> ComponentSe
     L = _lib.lib()
     dev = graph.vertices.device
     n = graph.vertices.shape[0]
-    edges = graph.edges.contiguous()
-    w = graph.edge_weights.contiguous()
+    edges, w = graph.padded if isinstance(graph, PaddedGraph) else (graph.edges, graph.edge_weights)
+    edges, w = edges.contiguous(), w.contiguous()
     E = edges.shape[0]
     i32 = lambda k: torch.empty((max(k, 1),), dtype=torch.int32, device=dev)
     labels = i32(n)
