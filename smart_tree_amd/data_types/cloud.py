@@ -133,3 +133,49 @@ class Cloud:
             elif key == "vector":
                 kw["medial_vector"] = torch.as_tensor(np.asarray(value))
         return Cloud(**kw)
+
+
+def _same_device(a: torch.device, b) -> bool:
+    b = torch.device(b)
+    return a.type == b.type and (b.index is None or a.index is None or a.index == b.index)
+
+
+class MaskedCloud(Cloud):
+    """`base.filter(mask)` (boolean mask) not carried out yet -- what `ModelInference.forward` returns.  Every field reads
+    as the filtered cloud's (the compaction happens on first access), but `filter_by_class`, the next thing the pipeline
+    does (pipeline.py:71), folds the class test into the pending mask: one compaction and one host round trip for the
+    count instead of two (a blocking read-back costs ~1 ms beside other clouds' kernels).  The
+    result is the same cloud: both filters keep the surviving points in input order."""
+
+    def __init__(self, base: Cloud, mask: torch.Tensor):
+        assert mask.dtype == torch.bool and mask.shape[0] == len(base)
+        self.__dict__.update(_base=base, _mask=mask.to(base.xyz.device), _real=None)
+
+    def _cloud(self) -> Cloud:
+        if self.__dict__["_real"] is None:
+            self.__dict__["_real"] = self.__dict__["_base"].filter(self.__dict__["_mask"])
+        return self.__dict__["_real"]
+
+    def filter_by_class(self, classes) -> Cloud:
+        base, mask = self.__dict__["_base"], self.__dict__["_mask"]
+        if self.__dict__["_real"] is not None or base.class_l is None:
+            return self._cloud().filter_by_class(classes)
+        wanted = torch.as_tensor(classes, device=base.class_l.device)
+        return base.filter(mask & torch.isin(base.class_l, wanted).view(-1))
+
+    def _map(self, fn) -> Cloud:
+        return self._cloud()._map(fn)
+
+    def to_device(self, device) -> Cloud:
+        if self.__dict__["_real"] is None and _same_device(self.__dict__["_base"].xyz.device, device):
+            return self
+        return self._cloud().to_device(device)
+
+    def __repr__(self):
+        return f"MaskedCloud({self._cloud()!r})"
+
+
+for _name in [f.name for f in fields(Cloud)]:
+    setattr(MaskedCloud, _name, property(lambda self, _name=_name: getattr(self._cloud(), _name)))
+del _name
+

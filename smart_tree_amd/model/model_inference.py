@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from .. import profiling
-from ..data_types.cloud import Cloud
+from ..data_types.cloud import Cloud, MaskedCloud
 from ..dataset.dataset import load_dataloader
 from .model import Smart_Tree
 from .sparse import sparse_from_batch
@@ -78,7 +78,8 @@ class ModelInference:
         inputs, masks = torch.cat(inputs), torch.cat(masks)
         lc = Cloud(xyz=inputs[:, :3].contiguous(), rgb=inputs[:, 3:6].contiguous(), medial_vector=torch.cat(medial),
                    class_l=torch.cat(classes))
-        return lc.filter(masks) if return_masked else lc
+        # the inner-block filter (reference :97-100) is handed on as a pending mask: Pipeline's filter_by_class folds into it
+        return MaskedCloud(lc, masks) if return_masked else lc
 
     @staticmethod
     def from_cfg(cfg):

@@ -1,0 +1,50 @@
+"""Host-side containers that defer a compaction: MaskedCloud (ModelInference.forward's result) and PaddedGraph
+(nn_graph's result) must read exactly like the eager objects of the reference (cloud.py:72-103, graph.py:15-31)."""
+import torch
+
+from smart_tree_amd.data_types.cloud import Cloud, MaskedCloud
+from smart_tree_amd.data_types.graph import Graph, PaddedGraph
+
+
+def _cloud(n=1000):
+    g = torch.Generator().manual_seed(0)
+    return Cloud(xyz=torch.randn(n, 3, generator=g), rgb=torch.rand(n, 3, generator=g),
+                 medial_vector=torch.randn(n, 3, generator=g), class_l=torch.randint(0, 2, (n, 1), generator=g))
+
+
+def test_masked_cloud_folds_the_class_filter_into_the_pending_mask():
+    base = _cloud()
+    mask = torch.rand(len(base), generator=torch.Generator().manual_seed(1)) > 0.3
+    want = base.filter(mask).filter_by_class([0])
+    lazy = MaskedCloud(base, mask)
+    got = lazy.filter_by_class([0])
+    assert type(got) is Cloud and lazy.__dict__["_real"] is None  # nothing was compacted on the way
+    for name in ("xyz", "rgb", "medial_vector", "class_l"):
+        assert torch.equal(getattr(got, name), getattr(want, name))
+    assert lazy.to_device("cpu") is lazy
+
+
+def test_masked_cloud_reads_like_the_filtered_cloud():
+    base = _cloud()
+    mask = base.xyz[:, 0] > 0
+    eager, lazy = base.filter(mask), MaskedCloud(base, mask)
+    assert isinstance(lazy, Cloud) and len(lazy) == len(eager)
+    for name in ("xyz", "rgb", "medial_vector", "class_l"):
+        assert torch.equal(getattr(lazy, name), getattr(eager, name))
+    assert lazy.branch_ids is None and lazy.filename is None
+    assert torch.equal(lazy.medial_pts, eager.medial_pts) and torch.equal(lazy.radius, eager.radius)
+    assert lazy.root_idx == eager.root_idx
+    assert torch.equal(lazy.filter(torch.arange(5)).xyz, eager.xyz[:5])
+    assert torch.equal(lazy.filter_by_class([1]).xyz, eager.filter_by_class([1]).xyz)  # after materialisation
+    assert torch.equal(lazy.translate(torch.ones(3)).xyz, eager.xyz + 1)
+
+
+def test_padded_graph_cuts_the_reference_views():
+    verts = torch.zeros(4, 3)
+    edges = torch.tensor([[0, 1], [1, 2], [2, 3], [3, 3], [0, 0], [0, 0]])  # real edges have dst > 0, padding is (0, 0)
+    w = torch.tensor([1.0, 2.0, 3.0, 0.5, 0.0, 0.0])
+    g = PaddedGraph(verts, edges, w)
+    assert isinstance(g, Graph) and g.padded[0] is edges
+    assert torch.equal(g.edges, edges[:4]) and torch.equal(g.edge_weights, w[:4])
+    moved = g.to_device("cpu")
+    assert type(moved) is Graph and torch.equal(moved.edges, edges[:4])
