@@ -129,7 +129,8 @@ int64_t st_component_csr_workspace_bytes(int64_t m);
 int st_component_csr(const int64_t* edges, const float* w, int64_t E, const int32_t* new_id, int64_t m, uint32_t* row_off,
                      uint32_t* col, float* wgt, void* ws, int64_t ws_bytes, void* stream);
 int64_t st_skeleton_workspace_bytes(int64_t m, int64_t n_comp);
-/* comp_size_host is unused and may be NULL (the claim grid is laid out on the device from comp_off); grid_cell < 0:
+/* stats_host[6] = branches of the cloud | path vertices << 32 (sample_tree stage).
+ * comp_size_host is unused and may be NULL (the claim grid is laid out on the device from comp_off); grid_cell < 0:
  * cell = max(max(rad) / -grid_cell, 1e-4) with the maximum reduced on the device -- neither costs the caller a read-back */
 int st_skeleton_components(int n_comp, const int32_t* comp_off, const int32_t* comp_size_host, int64_t m, const float* pts,
                            const float* rad, const float* ysurf, const uint32_t* row_off, const uint32_t* col,
@@ -147,6 +148,8 @@ int st_sssp(ST_SKELETON_STAGE_ARGS);
 int st_tree_distance(ST_SKELETON_STAGE_ARGS);
 int st_sample_tree(ST_SKELETON_STAGE_ARGS);
 int64_t st_assemble_workspace_bytes(int64_t cap_b);
+/* counts_host may be NULL: no read-back; the caller takes branches B = stats_host[6] & 0xffffffff and geometry slots
+ * P = (stats_host[6] >> 32) + B from st_skeleton_components (totals carried by its last progress read-back) */
 int st_assemble_branches(int n_comp, const int32_t* comp_off, const int32_t* n_branches, const int32_t* branch_parent,
                          const int32_t* branch_off, const int32_t* branch_len, const int32_t* path_verts,
                          const int32_t* vert_order, const float* medial, const float* radius, int32_t* tree_off,

@@ -314,14 +314,15 @@ extern "C" int64_t st_assemble_workspace_bytes(int64_t cap_b) {
 }
 
 // Outputs are sized by the caller to the capacities cap_b (branches; every component-local branch slot is enough:
-// cap_b = m) and cap_p (geometry slots; path vertices + branches <= 2 m); counts_host receives the numbers used.
+// cap_b = m) and cap_p (geometry slots; path vertices + branches <= 2 m); counts_host receives the numbers used
+// (NULL: no read-back -- branches and path vertices + branches are known from st_skeleton_components' stats_host[6]).
 extern "C" int st_assemble_branches(int n_comp, const int32_t* comp_off, const int32_t* n_branches, const int32_t* branch_parent,
                                     const int32_t* branch_off, const int32_t* branch_len, const int32_t* path_verts,
                                     const int32_t* vert_order, const float* medial, const float* radius, int32_t* tree_off,
                                     int32_t* parent, int32_t* start, int32_t* length, float* xyz, float* rad, int64_t cap_b,
                                     int64_t cap_p, int64_t* counts_host, void* ws, int64_t ws_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    counts_host[0] = counts_host[1] = 0;
+    if (counts_host) counts_host[0] = counts_host[1] = 0;
     if (n_comp <= 0) return ST_OK;
     ST_REQUIRE(cap_b >= 1 && cap_p >= 1, "assemble: empty capacity");
     StArena a(ws, ws_bytes);
@@ -342,6 +343,7 @@ extern "C" int st_assemble_branches(int n_comp, const int32_t* comp_off, const i
     hipLaunchKernelGGL(k_asm_branches, dim3(gb), dim3(256), 0, stream, A);
     ST_TRY(st_exclusive_scan_u32(A.len1, (uint32_t*)start, cap_b, nullptr, scan_ws, scan_bytes, stream));
     hipLaunchKernelGGL(k_asm_geometry, dim3(gp), dim3(256), 0, stream, A);
+    if (!counts_host) { ST_CHECK_LAUNCH(); return ST_OK; }  // the caller has the counts from st_skeleton_components' stats[6]
     (void)hipMemcpyAsync(counts_host, A.counts, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, stream);
     st_stream_wait(stream);
     ST_CHECK_LAUNCH();

@@ -622,6 +622,8 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
         if (exhausted) {  // path.py:94-95 (uniform)
             if (tid == 0) {
                 A.s_done[c] = 1; A.s_len[c] = 0; A.s_wide[c] = 0; A.n_branches[c] = nb; A.s_nb[c] = nb; A.s_total[c] = total;
+                atomicAdd(&A.cnt[6], (unsigned)nb);     // cloud totals: branches and path vertices arrive with the progress
+                atomicAdd(&A.cnt[7], (unsigned)total);  // read-back, so assembling the skeleton needs no count read-back
                 atomicAdd(&A.cnt[5], 1u);
             }
             SK_TICK_FLUSH();
@@ -1210,7 +1212,8 @@ static int sk_read(void* dst, const void* src, size_t bytes, hipStream_t stream)
 // block_threads: lanes of the per-component select workgroup (0 = 1024).
 // stats_host (optional, 8 x int64): [0] SSSP rounds, [1] plateau rounds, [2] select/claim launch pairs, [3] lifting
 // levels; if stats_host[7] != 0 on entry, every k_sk_select launch is bracketed by HIP events on `stream` and
-// [4] = their summed duration in ns, [5] = number of launches (profiling aid for bench.py's roofline block).
+// [4] = their summed duration in ns, [5] = number of launches (profiling aid for bench.py's roofline block);
+// [6] = branches of the cloud | path vertices << 32 (sizes st_assemble_branches' outputs without a read-back of its own).
 extern "C" int st_skeleton_components(int n_comp, const int32_t* comp_off, const int32_t* comp_size_host, int64_t m,
                                       const float* pts, const float* rad, const float* ysurf, const uint32_t* row_off,
                                       const uint32_t* col, const float* wgt, float grid_cell, int stages, int block_threads,
@@ -1316,7 +1319,7 @@ extern "C" int st_skeleton_components(int n_comp, const int32_t* comp_off, const
         double select_ms = 0.0;
         bool plateaus_pending = defer_plateaus;
         for (;;) {  // second pass only if the deferred check found plateau vertices: predecessors completed, selection redone
-            (void)hipMemsetAsync(&s.cnt[5], 0, sizeof(unsigned), stream);
+            (void)hipMemsetAsync(&s.cnt[5], 0, 3 * sizeof(unsigned), stream);  // finished components, branches, path vertices
             hipLaunchKernelGGL(k_sk_lift_init, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A,
                                (const float*)((stages & 2) ? tree_dist : dist));
             for (int span = 1; span < SK_ANC; span *= 2)  // direct ancestor table by doubling
@@ -1370,7 +1373,7 @@ extern "C" int st_skeleton_components(int n_comp, const int32_t* comp_off, const
             stats_host[4] = (int64_t)(select_ms * 1e6);
             stats_host[5] = iters;
         }
-        if (stats_host) { stats_host[2] = iters; stats_host[3] = SK_ANC; }
+        if (stats_host) { stats_host[2] = iters; stats_host[3] = SK_ANC; stats_host[6] = ((int64_t)h[7] << 32) | (int64_t)h[6]; }
     }
     ST_CHECK_LAUNCH();
     return ST_OK;

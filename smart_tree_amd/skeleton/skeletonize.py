@@ -75,6 +75,8 @@ def run_components(comps: ComponentSet, medial_pts: torch.Tensor, radius: torch.
             _lib.ptr(res.branch_parent), _lib.ptr(res.branch_off), _lib.ptr(res.branch_len), _lib.ptr(res.n_branches),
             _lib.ptr(res.path_verts), _lib.ptr(res.branch_of), stats, _lib.ptr(ws), ws.numel(), _lib.stream(dev)))
     res.stats = {"sssp_rounds": stats[0], "plateau_rounds": stats[1], "select_launches": stats[2], "lift_levels": stats[3]}
+    if stages & STAGE_SAMPLE:  # cloud totals from the select loop's last progress read-back
+        res.stats["branches"], res.stats["path_vertices"] = int(stats[6] & 0xFFFFFFFF), int(stats[6] >> 32)
     if stats[7] and stats[5]:
         # algorithmic bytes of the branch selection (SURVEY.md 8d "sample_tree"): each path vertex is written once
         # (24 B: id + xyz lookups), each claimed point raced and stamped once (16 B), plus the sorted-order cursor (8 B/vertex)
@@ -158,7 +160,8 @@ class DeviceSkeleton(DisjointTreeSkeleton):
 
     # -- construction ---------------------------------------------------------------------------
     @staticmethod
-    def from_components(comps: ComponentSet, res: ComponentResult, medial: torch.Tensor, radius: torch.Tensor):
+    def from_components(comps: ComponentSet, res: ComponentResult, medial: torch.Tensor, radius: torch.Tensor,
+                        verify_counts: bool = False):
         """Flat layout: branch k of the cloud owns geometry slots [start[k], start[k] + len[k] + 1); slot
         start[k] is reserved for the connection point `repair` prepends (radius pre-filled, tree.py:92)."""
         dev = medial.device
@@ -175,14 +178,21 @@ class DeviceSkeleton(DisjointTreeSkeleton):
         xyz = torch.empty((cap_p, 3), dtype=torch.float32, device=dev)
         rad = torch.empty(cap_p, dtype=torch.float32, device=dev)
         ws = _lib.workspace(L.st_assemble_workspace_bytes(cap_b), dev)
-        counts = (ctypes.c_int64 * 2)()
+        known = res.stats is not None and "branches" in res.stats and not verify_counts
+        counts = None if known else (ctypes.c_int64 * 2)()
         _lib.check(L.st_assemble_branches(
             C, _lib.ptr(comps.comp_off.contiguous()), _lib.ptr(res.n_branches), _lib.ptr(res.branch_parent), _lib.ptr(res.branch_off),
             _lib.ptr(res.branch_len), _lib.ptr(res.path_verts), _lib.ptr(comps.vert_order.contiguous()),
             _lib.ptr(medial.contiguous().float()), _lib.ptr(radius.contiguous().float()), _lib.ptr(tree_off), _lib.ptr(parent),
             _lib.ptr(start), _lib.ptr(length), _lib.ptr(xyz), _lib.ptr(rad), cap_b, cap_p, counts, _lib.ptr(ws), ws.numel(),
             _lib.stream(dev)))
-        B, P = counts[0], counts[1]
+        if known:  # no count read-back: the skeleton stage reported them
+            B = res.stats["branches"]
+            P = res.stats["path_vertices"] + B
+        else:
+            B, P = counts[0], counts[1]
+            if res.stats is not None and "branches" in res.stats:
+                assert (B, P) == (res.stats["branches"], res.stats["path_vertices"] + res.stats["branches"]), "select totals disagree"
         return DeviceSkeleton(tree_off, parent[:B], start[:B], length[:B], xyz[:P], rad[:P])
 
     # -- deferred post-processing ---------------------------------------------------------------

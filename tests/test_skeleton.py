@@ -9,7 +9,7 @@ from smart_tree_amd.data_types.cloud import Cloud
 from smart_tree_amd.data_types.graph import Graph
 from smart_tree_amd.skeleton import graph as G
 from smart_tree_amd.skeleton.filter import outlier_removal
-from smart_tree_amd.skeleton.skeletonize import (STAGE_SAMPLE, STAGE_SSSP, STAGE_TREE_DISTANCE, Skeletonizer,
+from smart_tree_amd.skeleton.skeletonize import (STAGE_SAMPLE, STAGE_SSSP, STAGE_TREE_DISTANCE, DeviceSkeleton, Skeletonizer,
                                                  run_components)
 from smart_tree_amd.synthetic import sample_tree_cloud
 
@@ -113,6 +113,10 @@ def _compare_components(backend, pts, mv, block_threads, cache_key=None):
             np.testing.assert_array_equal(res.path_verts[s: s + int(res.branch_len[i])].cpu().numpy(), br.verts)
         np.testing.assert_array_equal(res.branch_of[a:b].cpu().numpy(), rc.branch_of_point)
         n_branches += len(rc.branches)
+    # the totals the select loop reports (they size the assembled skeleton without a read-back) against the counted ones
+    assert res.stats["branches"] == n_branches
+    assert res.stats["path_vertices"] == sum(len(br.verts) for rc in ref.components for br in rc.branches)
+    DeviceSkeleton.from_components(comps, res, medial, radius, verify_counts=True)  # asserts equality with its own counts
     return n_branches
 
 
