@@ -82,6 +82,11 @@ ENQUEUE_ONLY = frozenset({
 })
 
 
+# Entry points that wait only when asked for a count on the host: `<name>_nowait` is the GIL-keeping binding for calls
+# that pass NULL for it (st_make_edges: n_edges_host, st_assemble_branches: counts_host).
+NOWAIT_VARIANTS = ("st_make_edges", "st_assemble_branches")
+
+
 class _Bound:
     """The declared entry points as attributes (one ctypes function object each); any other exported symbol
     (the st_debug_* developer knobs) resolves through the GIL-dropping handle."""
@@ -104,6 +109,8 @@ def declare(cdll, pydll=None):
             fn.argtypes = args
         if pydll is not None:
             setattr(out, name, getattr(pydll if name in ENQUEUE_ONLY else cdll, name))
+    for name in NOWAIT_VARIANTS:
+        setattr(out, name + "_nowait", getattr(pydll if pydll is not None else cdll, name))
     return out
 
 

@@ -82,7 +82,7 @@ def make_edges(dists: torch.Tensor, idxs: torch.Tensor, padded: bool = False):
     w = torch.empty((max(n * K, 1),), dtype=torch.float32, device=dev)
     ne = ctypes.c_int64(0)
     ws = _lib.workspace(L.st_make_edges_workspace_bytes(n), dev)
-    _lib.check(L.st_make_edges(_lib.ptr(idxs.contiguous()), _lib.ptr(dists.contiguous()), n, K, _lib.ptr(edges), _lib.ptr(w),
+    _lib.check((L.st_make_edges_nowait if padded else L.st_make_edges)(_lib.ptr(idxs.contiguous()), _lib.ptr(dists.contiguous()), n, K, _lib.ptr(edges), _lib.ptr(w),
                                None if padded else ctypes.byref(ne), _lib.ptr(ws), ws.numel(), _lib.stream(dev)))
     if padded:
         return edges[: n * K], w[: n * K]

@@ -180,7 +180,7 @@ class DeviceSkeleton(DisjointTreeSkeleton):
         ws = _lib.workspace(L.st_assemble_workspace_bytes(cap_b), dev)
         known = res.stats is not None and "branches" in res.stats and not verify_counts
         counts = None if known else (ctypes.c_int64 * 2)()
-        _lib.check(L.st_assemble_branches(
+        _lib.check((L.st_assemble_branches_nowait if known else L.st_assemble_branches)(
             C, _lib.ptr(comps.comp_off.contiguous()), _lib.ptr(res.n_branches), _lib.ptr(res.branch_parent), _lib.ptr(res.branch_off),
             _lib.ptr(res.branch_len), _lib.ptr(res.path_verts), _lib.ptr(comps.vert_order.contiguous()),
             _lib.ptr(medial.contiguous().float()), _lib.ptr(radius.contiguous().float()), _lib.ptr(tree_off), _lib.ptr(parent),
