@@ -119,6 +119,15 @@ extern "C" int64_t st_make_edges_workspace_bytes(int64_t n) {
     return a.used;
 }
 
+// the unused tail of a capacity-sized edge list (a kNN graph fills ~99 % of n*K: only the tail is written)
+__global__ void __launch_bounds__(GR_BLOCK) k_edge_pad(int64_t* edges, float* w, const uint32_t* total, int64_t cap) {
+    for (int64_t e = (int64_t)*total + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < cap; e += (int64_t)gridDim.x * blockDim.x) {
+        edges[2 * e] = 0;
+        edges[2 * e + 1] = 0;
+        w[e] = 0.0f;
+    }
+}
+
 // idx/dist [n,K] from st_knn_radius (after the caller's radius filter); edges [n*K,2] int64, w [n*K].
 // n_edges_host == NULL: no read-back of the edge count (a blocking round trip costs ~1 ms beside other clouds' kernels);
 // the n*K - E unused entries are (0, 0) self loops of weight 0, which st_connected_components and st_component_csr ignore
@@ -135,12 +144,12 @@ extern "C" int st_make_edges(const int64_t* idx, const float* dist, int64_t n, i
     if (!cnt || !sw) { st_set_error("make_edges: workspace too small"); return ST_ERR_WORKSPACE; }
     hipLaunchKernelGGL(k_edge_count, dim3(gr_grid(n)), dim3(GR_BLOCK), 0, stream, idx, n, K, cnt);
     ST_TRY(st_exclusive_scan_u32(cnt, cnt, n, cnt + n, sw, sb, stream));
-    if (!n_edges_host) {  // no count on the host: the tail of the capacity-sized list is padded with (0, 0) edges of weight 0
-        (void)hipMemsetAsync(edges, 0, (size_t)n * K * 2 * sizeof(int64_t), stream);
-        (void)hipMemsetAsync(w, 0, (size_t)n * K * sizeof(float), stream);
-    }
     hipLaunchKernelGGL(k_edge_emit, dim3(gr_grid(n)), dim3(GR_BLOCK), 0, stream, idx, dist, n, K, (const uint32_t*)cnt, edges, w);
-    if (!n_edges_host) { ST_CHECK_LAUNCH(); return ST_OK; }
+    if (!n_edges_host) {  // no count on the host: the tail [E, n*K) of the capacity-sized list becomes (0, 0) edges of weight 0
+        hipLaunchKernelGGL(k_edge_pad, dim3(64), dim3(GR_BLOCK), 0, stream, edges, w, (const uint32_t*)(cnt + n), n * (int64_t)K);
+        ST_CHECK_LAUNCH();
+        return ST_OK;
+    }
     uint32_t total = 0;
     (void)hipMemcpyAsync(&total, cnt + n, sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
     st_stream_wait(stream);
