@@ -98,7 +98,7 @@ def repair(tree: OTree) -> None:
 def smooth(tree: OTree, kernel_size: int) -> None:
     """tree.py:123-134: zero-padded box filter (F.conv1d padding="same"), only when len > kernel; radii become 1-D."""
     w = F32(1) / F32(kernel_size)
-    half = kernel_size // 2
+    half = (kernel_size - 1) // 2  # torch pads left (k-1)//2, right k-1-left (even kernels: the extra sample goes right)
     for b in tree.branches.values():
         n = b.radii.shape[0]
         if n > kernel_size:

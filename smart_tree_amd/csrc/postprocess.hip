@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(PP_BLOCK) k_post_process(PpArgs A) {
     }
     // ---- radii: box filter over the (possibly prepended) radius array
     const float w = A.kernel > 0 ? 1.0f / (float)A.kernel : 0.0f;
-    const int half = A.kernel / 2;
+    const int half = (A.kernel - 1) / 2;  // F.conv1d(padding="same"): left pad (k-1)/2, the extra sample of an even kernel goes right
     for (int b = wave; b < nb; b += PP_WAVES) {  // one wavefront per branch
         const int rep = __hip_atomic_load(&A.repaired[b0 + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int s = A.start[b0 + b] + (rep ? 0 : 1), n = A.len[b0 + b] + rep;

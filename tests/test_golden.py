@@ -64,6 +64,11 @@ def test_oracle_blocking_matches_reference_glue():
         assert member.sum() == g["block_sizes"][i]
         np.testing.assert_array_equal(xyz[member][:64], g[f"block_{i}_first_xyz"])
         assert vo.cube_mask(xyz[member], ctr, 4.0).sum() == g[f"block_{i}_inner_count"]
+    # the whole collated batch the reference's __getitem__ / batch_collate emit (inner mask on the representatives)
+    vx = vo.voxelize_cloud(xyz, c["rgb"], 0.02)
+    np.testing.assert_array_equal(vx["coords"], g["collated_coords"])
+    np.testing.assert_array_equal(vx["mask"], g["collated_mask"])
+    np.testing.assert_array_equal(vx["feats"][:, :3], g["collated_xyz"])
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -99,5 +104,41 @@ def test_hip_blocking_matches_reference_glue(backend):
     xyz = torch.from_numpy(g["centred_xyz"]).to(backend)
     out = voxelize_blocks(xyz, None, 0.02)
     np.testing.assert_array_equal(out.block_centres.cpu().numpy(), g["block_centres"])
-    inner = np.bincount(out.coords[:, 0].cpu().numpy()[out.mask.cpu().numpy()], minlength=len(g["block_centres"]))
-    assert (inner <= np.array([g[f"block_{i}_inner_count"] for i in range(len(inner))])).all()
+    # the reference's own __getitem__ + batch_collate (PointToVoxel stand-in, tools/make_goldens.py): equality
+    np.testing.assert_array_equal(out.coords.cpu().numpy(), g["collated_coords"])
+    np.testing.assert_array_equal(out.mask.cpu().numpy(), g["collated_mask"])
+    np.testing.assert_array_equal(out.feats[:, :3].cpu().numpy(), g["collated_xyz"])
+
+
+@pytest.mark.parametrize("kernel", [4, 6, 7])
+def test_device_smooth_matches_conv1d_same_padding_for_even_kernels(backend, kernel):
+    """tree.py:123-134 smooths with F.conv1d(padding="same"): an even kernel pads (k-1)//2 on the left and the extra
+    sample on the right.  The deferred device box filter, the host fallback (F.conv1d itself) and the oracle agree."""
+    g = np.load(GOLD / "skeleton_y_tree.npz")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(backend)
+    sk = Skeletonizer(K=16, min_connection_length=0.02, minimum_graph_vertices=32, device=backend)
+    sk.block_threads = 128 if backend.type == "cpu" else 0
+    cloud = Cloud(xyz=t(g["raw_xyz"]), medial_vector=t(g["raw_medial_vector"]))
+    dev_out = sk.forward(cloud)
+    dev_out.smooth(kernel)  # deferred: k_post_process
+    host_out = sk.forward(cloud)
+    _ = host_out.skeletons  # materialise first -> TreeSkeleton.smooth = F.conv1d(padding="same")
+    host_out.smooth(kernel)
+    n_smoothed = 0
+    for td, th in zip(dev_out.skeletons, host_out.skeletons):
+        assert list(td.branches) == list(th.branches)
+        for k in td.branches:
+            rd, rh = td.branches[k].radii.numpy(), th.branches[k].radii.numpy()
+            assert rd.shape == rh.shape
+            np.testing.assert_allclose(rd, rh, rtol=1e-5, atol=1e-7)
+            n_smoothed += rd.ndim == 1
+        ot = po.OTree(0, {k: po.OBranch(k, b.parent_id, b.xyz.numpy(), b.radii.numpy()) for k, b in
+                          sk.forward(cloud).skeletons[td._id].branches.items()})
+        po.smooth(ot, kernel)
+        for k in td.branches:
+            np.testing.assert_array_equal(td.branches[k].radii.numpy(), ot.branches[k].radii)
+    assert n_smoothed >= 2
+    # the advisor's example: k = 4 on [1,2,4,8,16,32] -> [7,15,30,60,56,48] / 4
+    ob = po.OTree(0, {0: po.OBranch(0, -1, np.zeros((6, 3), np.float32), np.array([1, 2, 4, 8, 16, 32], np.float32))})
+    po.smooth(ob, 4)
+    np.testing.assert_array_equal(ob.branches[0].radii, np.array([7, 15, 30, 60, 56, 48], np.float32) / 4)

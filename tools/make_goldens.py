@@ -99,6 +99,24 @@ def install_stubs():
 
     _stub("frnn", frnn_grid_points=frnn_grid_points)
 
+    # spconv PointToVoxel stand-in (CPU generator, max_num_points_per_voxel = 1): oracle/voxel_oracle.voxelize_block
+    from oracle import voxel_oracle as vo
+
+    class PointToVoxel:
+        def __init__(self, vsize_xyz, coors_range_xyz, num_point_features, max_num_voxels, max_num_points_per_voxel):
+            assert max_num_points_per_voxel == 1 and len(set(float(v) for v in vsize_xyz)) == 1
+            self.v, self.range = float(vsize_xyz[0]), [float(c) for c in coors_range_xyz]
+
+        def generate_voxel_with_id(self, pc):
+            pts = pc.numpy()
+            assert np.array_equal(pts[:, :3].min(0), np.float32(self.range[:3])) and np.array_equal(pts[:, :3].max(0), np.float32(self.range[3:]))
+            first, czyx = vo.voxelize_block(pts, self.v)
+            vid = np.full(len(pts), -1, np.int64)
+            return (torch.from_numpy(pts[first]).unsqueeze(1), torch.from_numpy(czyx), torch.ones(len(first), dtype=torch.int32),
+                    torch.from_numpy(vid))
+
+    sys.modules["spconv.pytorch.utils"].PointToVoxel = PointToVoxel
+
 
 def reference(module: str):
     if str(REF) not in sys.path:
@@ -182,6 +200,14 @@ def blocking_case():
         out[f"block_{i}_first_xyz"] = b.xyz[:64].numpy()
         inner = reference("smart_tree.util.maths").cube_filter(b.xyz, ds.block_centres[i], 4)
         out[f"block_{i}_inner_count"] = np.int64(int(inner.sum()))
+    # the reference's own __getitem__ (dataset.py:192-226: voxel range = block min/max, inner mask = cube_filter of the
+    # voxel's representative point) and batch_collate (sparse.py:40-61), with spconv's PointToVoxel served by the
+    # stand-in below (canonical semantics of oracle/voxel_oracle.voxelize_block)
+    items = [ds[i] for i in range(len(ds))]
+    feats, coords, mask, _ = reference("smart_tree.model.sparse").batch_collate(items)
+    out["collated_coords"] = coords.numpy().astype(np.int32)
+    out["collated_mask"] = mask.numpy().astype(bool)
+    out["collated_xyz"] = feats[:, :3].numpy()
     np.savez_compressed(OUT / "blocking_50k.npz", **out)
     print("blocking_50k blocks", len(ds.clouds), out["block_sizes"].tolist())
 
