@@ -165,6 +165,56 @@ int st_post_process(int n_trees, const int32_t* tree_off, const int32_t* parent,
 int st_points_to_nearest_tube(const float* pts, int64_t n, const float* a, const float* b, const float* r1, const float* r2,
                               int64_t m, float* vec, int64_t* idx, float* rad, void* stream);
 
+/* ---- batched forms: B independent clouds in ONE launch set -------------------------------------------
+ * replaces: the batch dimension of the reference's data path -- model/sparse.py:40-61 (batch_collate writes the
+ *           sample index into coords[:,0]) and model/model_inference.py:62-78 (one forward per collated batch) --
+ *           extended over the whole of Pipeline.process_cloud (pipeline.py:55-93), which the reference runs one
+ *           cloud at a time.  Cloud s of a batch owns the index range [seg_off[s], seg_off[s+1]) of the batched
+ *           arrays (seg_off: device int32 [nseg+1], nseg <= 64).  Every function returns, for every cloud, exactly
+ *           what its one-cloud form returns for that cloud alone (indices are positions in the batched arrays):
+ *           clouds never share a neighbourhood, a grid slab, a spatial extent or a component. */
+int st_centre_cloud_seg(const float* xyz, int64_t n, const int32_t* seg_off, int nseg, float* out, void* ws,
+                        int64_t ws_bytes /* >= 24 * nseg + 256 */, void* stream);
+int64_t st_voxelize_workspace_bytes_seg(int64_t n_points, int max_blocks, int64_t max_voxels, int nseg);
+int st_voxelize_blocks_seg(const float* xyz, const float* rgb, int64_t n, const int32_t* seg_off, int nseg,
+                           double voxel_size, double block_size, double buffer_size, int min_points, int max_blocks,
+                           int64_t max_voxels, float* feats, int32_t* coords, uint8_t* mask, int64_t* point_index,
+                           float* block_centres, int32_t* blk_seg /*[max_blocks] cloud of every block*/,
+                           int32_t* seg_vox_off /*[nseg+1]*/, int32_t* seg_blk_off /*[nseg+1]*/, int64_t* n_voxels_host,
+                           int64_t* n_blocks_host, void* ws, int64_t ws_bytes, void* stream);
+int st_build_strided_outputs_seg(const int32_t* coords, int64_t n, int64_t max_out, int32_t* out_coords,
+                                 unsigned long long* ckeys, unsigned* cvals, int64_t ccap, int64_t* n_out_host,
+                                 int32_t* extent_host, const int32_t* blk_seg, int nseg, int32_t* ext_dev /*[nseg*3] out*/,
+                                 void* ws, int64_t ws_bytes, void* stream);
+int st_build_strided_rulebook_seg(const int32_t* coords, int64_t n, const unsigned long long* fkeys, const unsigned* fvals,
+                                  int64_t fcap, const int32_t* out_coords, int64_t n_out, const unsigned long long* ckeys,
+                                  const unsigned* cvals, int64_t ccap, const int32_t* extent_host, int32_t* nbr_down,
+                                  int32_t* nbr_up, int32_t* up_order, const int32_t* blk_seg, const int32_t* ext_dev,
+                                  void* stream);
+int64_t st_knn_workspace_bytes_seg(int64_t n_dst, int nseg);
+int st_knn_radius_seg(const float* src, int64_t n1, const float* dst, int64_t n2, int K, float r, const float* bound,
+                      int bound_mode, float cell_hint, int64_t* idx, float* dist, const int32_t* src_seg_off,
+                      const int32_t* dst_seg_off, int nseg, void* ws, int64_t ws_bytes, void* stream);
+int st_make_edges_seg(const int64_t* idx, const float* dist, int64_t n, int K, int64_t* edges, float* w,
+                      int64_t* n_edges_host, const int32_t* seg_off, int nseg, void* ws, int64_t ws_bytes, void* stream);
+int st_component_layout_seg(const int32_t* labels, int64_t n, int min_vertices, const int32_t* seg_off, int nseg,
+                            int32_t* comp_size, int32_t* comp_off, int32_t* vert_order, int32_t* new_id,
+                            int32_t* comp_seg /*[C]*/, int32_t* comp_seg_off /*[nseg+1]*/, int32_t* vert_seg_off /*[nseg+1]*/,
+                            int64_t* n_comp_host, int64_t* n_kept_host, void* ws, int64_t ws_bytes, void* stream);
+int64_t st_skeleton_workspace_bytes_seg(int64_t m, int64_t n_comp, int nseg);
+int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, const int32_t* comp_seg, const int32_t* vert_seg_off,
+                               int nseg, int64_t m, const float* pts, const float* rad, const float* ysurf,
+                               const uint32_t* row_off, const uint32_t* col, const float* wgt, float grid_cell, int stages,
+                               int block_threads, float* dist, int32_t* pred, int32_t* root_local, float* tree_dist,
+                               int32_t* branch_parent, int32_t* branch_off, int32_t* branch_len, int32_t* n_branches,
+                               int32_t* path_verts, int32_t* branch_of, int64_t* stats_host, void* ws, int64_t ws_bytes,
+                               void* stream);
+int st_post_process_seg(int n_trees, const int32_t* tree_off, const int32_t* parent, const int32_t* start, const int32_t* len,
+                        float* xyz, const float* rad_in, float* rad_out, uint8_t* keep, uint8_t* repaired, uint8_t* smoothed,
+                        int32_t* depth_scratch, int do_prune, float min_radius, float min_length, int do_repair,
+                        int do_smooth, int kernel_size, const int32_t* first_tree /*[n_first] first tree of every cloud*/,
+                        int n_first, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

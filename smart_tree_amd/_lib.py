@@ -62,6 +62,22 @@ SIGNATURES = {
     "st_points_to_nearest_tube": (c_int, [P, c_int64, P, P, P, P, c_int64, P, P, P, P]),
     "st_post_process": (c_int, [c_int, P, P, P, P, P, P, P, P, P, P, P, c_int, c_float, c_float, c_int, c_int, c_int, P]),
     "st_skeleton_workspace_bytes": (I64, [I64, I64]),
+    # batched forms (B clouds per launch set)
+    "st_centre_cloud_seg": (c_int, [P, I64, P, c_int, P, P, I64, P]),
+    "st_voxelize_workspace_bytes_seg": (I64, [I64, c_int, I64, c_int]),
+    "st_voxelize_blocks_seg": (c_int, [P, P, I64, P, c_int, c_double, c_double, c_double, c_int, c_int, I64, P, P, P, P, P, P, P, P,
+                                       ctypes.POINTER(I64), ctypes.POINTER(I64), P, I64, P]),
+    "st_build_strided_outputs_seg": (c_int, [P, I64, I64, P, P, P, I64, ctypes.POINTER(I64), ctypes.POINTER(ctypes.c_int32),
+                                             P, c_int, P, P, I64, P]),
+    "st_build_strided_rulebook_seg": (c_int, [P, I64, P, P, I64, P, I64, P, P, I64, ctypes.POINTER(ctypes.c_int32), P, P, P, P, P, P]),
+    "st_knn_workspace_bytes_seg": (I64, [I64, c_int]),
+    "st_knn_radius_seg": (c_int, [P, I64, P, I64, c_int, c_float, P, c_int, c_float, P, P, P, P, c_int, P, I64, P]),
+    "st_make_edges_seg": (c_int, [P, P, I64, c_int, P, P, ctypes.POINTER(I64), P, c_int, P, I64, P]),
+    "st_component_layout_seg": (c_int, [P, I64, c_int, P, c_int, P, P, P, P, P, P, P, ctypes.POINTER(I64), ctypes.POINTER(I64), P, I64, P]),
+    "st_skeleton_workspace_bytes_seg": (I64, [I64, I64, c_int]),
+    "st_skeleton_components_seg": (c_int, [c_int, P, P, P, c_int, I64, P, P, P, P, P, P, c_float, c_int, c_int, P, P, P, P, P, P, P, P,
+                                           P, P, ctypes.POINTER(I64), P, I64, P]),
+    "st_post_process_seg": (c_int, [c_int, P, P, P, P, P, P, P, P, P, P, P, c_int, c_float, c_float, c_int, c_int, c_int, P, c_int, P]),
     "st_skeleton_components": (c_int, [c_int, P, P, I64, P, P, P, P, P, P, c_float, c_int, c_int, P, P, P, P, P, P, P, P,
                                        P, P, ctypes.POINTER(I64), P, I64, P]),
 }
@@ -79,12 +95,14 @@ ENQUEUE_ONLY = frozenset({
     "st_build_coord_hash", "st_build_subm_rulebook", "st_build_strided_rulebook", "st_sparse_conv_fwd",
     "st_sparse_conv_mfma_fwd", "st_sparse_conv_f16_fwd", "st_pointwise_mlp_heads", "st_medial_points", "st_centre_cloud",
     "st_connected_components", "st_component_csr", "st_post_process", "st_knn_radius",
+    "st_centre_cloud_seg", "st_voxelize_workspace_bytes_seg", "st_build_strided_rulebook_seg", "st_knn_workspace_bytes_seg",
+    "st_knn_radius_seg", "st_skeleton_workspace_bytes_seg", "st_post_process_seg",
 })
 
 
 # Entry points that wait only when asked for a count on the host: `<name>_nowait` is the GIL-keeping binding for calls
 # that pass NULL for it (st_make_edges: n_edges_host, st_assemble_branches: counts_host).
-NOWAIT_VARIANTS = ("st_make_edges", "st_assemble_branches")
+NOWAIT_VARIANTS = ("st_make_edges", "st_assemble_branches", "st_make_edges_seg")
 
 
 class _Bound:

@@ -12,6 +12,7 @@
 // then label ascending, vertices inside a component keep ascending original id: the same choices
 // as oracle/skeleton_oracle.py.
 #include "st_common.h"
+#include "st_grid.h"  // st_seg_find, ST_MAX_SEG
 
 #define GR_BLOCK 256
 static inline unsigned gr_grid(int64_t n) {
@@ -51,63 +52,139 @@ extern "C" int st_medial_points(const float* xyz, const float* mv, int64_t n, fl
 // half = (max - min) / 2, centre = min + half, xyz += -centre + (0, half_y, 0) -- same float32 operation
 // order as torch evaluates it, but one bounding-box pass (LDS reduction) + one translate pass instead of
 // four strided torch reductions.
-__global__ void __launch_bounds__(GR_BLOCK) k_bbox(const float* xyz, int64_t n, unsigned* box /*[6] ord lo, ord hi*/) {
+// blockIdx.y = cloud of a batched call (seg_off == nullptr: one cloud of n points); box [nseg][6] = ord lo, ord hi.
+// A cloud is streamed as float4 -- four points per three 16-byte loads -- over the 16-byte aligned body of its range;
+// the <= 3 points before and after it (and everything, if the base pointer is not 16-byte aligned) go one float at a time.
+struct GrRange {
+    int64_t i0, i1;  // the cloud's points
+    int64_t a0, a1;  // aligned body [a0, a1): a0 % 4 == 0, (a1 - a0) % 4 == 0
+    int64_t nq;      // float4s in the body; float4 q starts at axis q % 3: (x y z x) (y z x y) (z x y z)
+};
+__device__ __forceinline__ GrRange gr_range(const void* p0, const void* p1, int64_t n, const int* seg_off, int seg) {
+    GrRange r;
+    r.i0 = seg_off ? seg_off[seg] : 0;
+    r.i1 = seg_off ? seg_off[seg + 1] : n;
+    const bool vec = ((((uintptr_t)p0) | ((uintptr_t)p1)) & 15) == 0;
+    r.a0 = vec ? st_min((r.i0 + 3) & ~(int64_t)3, r.i1) : r.i1;
+    r.a1 = r.a0 + ((r.i1 - r.a0) & ~(int64_t)3);
+    r.nq = (r.a1 - r.a0) / 4 * 3;
+    return r;
+}
+// j-th point outside the aligned body (j < (a0 - i0) + (i1 - a1))
+__device__ __forceinline__ int64_t gr_edge_point(const GrRange& r, int64_t j) { return j < r.a0 - r.i0 ? r.i0 + j : r.a1 + (j - (r.a0 - r.i0)); }
+
+__global__ void __launch_bounds__(GR_BLOCK) k_bbox(const float* xyz, int64_t n, unsigned* box, const int* seg_off) {
     __shared__ unsigned lo[3], hi[3];
     if (threadIdx.x < 3) { lo[threadIdx.x] = 0xffffffffu; hi[threadIdx.x] = 0u; }
     __syncthreads();
-    unsigned l[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, h[3] = {0u, 0u, 0u};
-    GR_LOOP(i, n)
-        for (int a = 0; a < 3; a++) {
-            const unsigned o = st_f2ord(xyz[3 * i + a]);
-            l[a] = o < l[a] ? o : l[a];
-            h[a] = o > h[a] ? o : h[a];
-        }
-    for (int a = 0; a < 3; a++) { atomicMin(&lo[a], l[a]); atomicMax(&hi[a], h[a]); }
+    const int seg = blockIdx.y;
+    const GrRange r = gr_range(xyz, nullptr, n, seg_off, seg);
+    unsigned lx = 0xffffffffu, ly = 0xffffffffu, lz = 0xffffffffu, hx = 0u, hy = 0u, hz = 0u;
+    const float4* v = reinterpret_cast<const float4*>(xyz + 3 * r.a0);
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < r.nq; q += (int64_t)gridDim.x * blockDim.x) {
+        const float4 f = v[q];
+        const int ax = (int)(q % 3);
+        const unsigned o0 = st_f2ord(f.x), o1 = st_f2ord(f.y), o2 = st_f2ord(f.z), o3 = st_f2ord(f.w);
+        const unsigned a = st_min(o0, o3), b = st_max(o0, o3);  // f.x and f.w share an axis
+        lx = st_min(lx, ax == 0 ? a : (ax == 1 ? o2 : o1)); hx = st_max(hx, ax == 0 ? b : (ax == 1 ? o2 : o1));
+        ly = st_min(ly, ax == 0 ? o1 : (ax == 1 ? a : o2)); hy = st_max(hy, ax == 0 ? o1 : (ax == 1 ? b : o2));
+        lz = st_min(lz, ax == 0 ? o2 : (ax == 1 ? o1 : a)); hz = st_max(hz, ax == 0 ? o2 : (ax == 1 ? o1 : b));
+    }
+    const int64_t ne = (r.a0 - r.i0) + (r.i1 - r.a1);
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < ne; j += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = gr_edge_point(r, j);
+        const unsigned ox = st_f2ord(xyz[3 * i]), oy = st_f2ord(xyz[3 * i + 1]), oz = st_f2ord(xyz[3 * i + 2]);
+        lx = st_min(lx, ox); hx = st_max(hx, ox); ly = st_min(ly, oy); hy = st_max(hy, oy); lz = st_min(lz, oz); hz = st_max(hz, oz);
+    }
+    // wavefront reduction first: six LDS atomics per wavefront instead of per lane
+    for (int d = 32; d > 0; d >>= 1) {
+        lx = st_min(lx, (unsigned)__shfl_xor((int)lx, d)); ly = st_min(ly, (unsigned)__shfl_xor((int)ly, d)); lz = st_min(lz, (unsigned)__shfl_xor((int)lz, d));
+        hx = st_max(hx, (unsigned)__shfl_xor((int)hx, d)); hy = st_max(hy, (unsigned)__shfl_xor((int)hy, d)); hz = st_max(hz, (unsigned)__shfl_xor((int)hz, d));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&lo[0], lx); atomicMin(&lo[1], ly); atomicMin(&lo[2], lz);
+        atomicMax(&hi[0], hx); atomicMax(&hi[1], hy); atomicMax(&hi[2], hz);
+    }
     __syncthreads();
-    if (threadIdx.x < 3) { atomicMin(&box[threadIdx.x], lo[threadIdx.x]); atomicMax(&box[3 + threadIdx.x], hi[threadIdx.x]); }
+    if (threadIdx.x < 3 && r.i1 > r.i0) { atomicMin(&box[6 * seg + threadIdx.x], lo[threadIdx.x]); atomicMax(&box[6 * seg + 3 + threadIdx.x], hi[threadIdx.x]); }
 }
-__global__ void __launch_bounds__(GR_BLOCK) k_centre(const float* xyz, int64_t n, const unsigned* box, float* out) {
+__global__ void __launch_bounds__(GR_BLOCK) k_centre(const float* xyz, int64_t n, const unsigned* box, float* out, const int* seg_off) {
+    const int seg = blockIdx.y;
+    const GrRange r = gr_range(xyz, out, n, seg_off, seg);
     float shift[3];
     for (int a = 0; a < 3; a++) {
-        const float mn = st_ord2f(box[a]), mx = st_ord2f(box[3 + a]);
+        const float mn = st_ord2f(box[6 * seg + a]), mx = st_ord2f(box[6 * seg + 3 + a]);
         const float half = (mx - mn) / 2.0f;
         const float centre = mn + half;
         shift[a] = -centre + (a == 1 ? half : 0.0f);
     }
-    GR_LOOP(i, n)
+    const float4* v = reinterpret_cast<const float4*>(xyz + 3 * r.a0);
+    float4* o = reinterpret_cast<float4*>(out + 3 * r.a0);
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < r.nq; q += (int64_t)gridDim.x * blockDim.x) {
+        float4 f = v[q];
+        const int ax = (int)(q % 3);
+        const float s0 = ax == 0 ? shift[0] : (ax == 1 ? shift[1] : shift[2]);
+        const float s1 = ax == 0 ? shift[1] : (ax == 1 ? shift[2] : shift[0]);
+        const float s2 = ax == 0 ? shift[2] : (ax == 1 ? shift[0] : shift[1]);
+        f.x = f.x + s0; f.y = f.y + s1; f.z = f.z + s2; f.w = f.w + s0;
+        o[q] = f;
+    }
+    const int64_t ne = (r.a0 - r.i0) + (r.i1 - r.a1);
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < ne; j += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = gr_edge_point(r, j);
         for (int a = 0; a < 3; a++) out[3 * i + a] = xyz[3 * i + a] + shift[a];
+    }
 }
 
-// out [n,3]; scratch: 6 x uint32
-extern "C" int st_centre_cloud(const float* xyz, int64_t n, float* out, void* ws, int64_t ws_bytes, void* stream_) {
+// Batched form: `nseg` clouds in one array, cloud b = points [seg_off[b], seg_off[b+1]) (device int32 [nseg+1]); every
+// cloud is centred on ITS OWN bounding box, exactly as the one-cloud call does.  out [n,3]; scratch: 6 x uint32 per cloud.
+extern "C" int st_centre_cloud_seg(const float* xyz, int64_t n, const int32_t* seg_off, int nseg, float* out, void* ws,
+                                   int64_t ws_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n <= 0) return ST_OK;
+    ST_REQUIRE(nseg >= 1 && nseg <= ST_MAX_SEG && (nseg == 1 || seg_off), "centre_cloud: 1 <= clouds per batch <= %d", ST_MAX_SEG);
+    if (nseg == 1) seg_off = nullptr;
     StArena a(ws, ws_bytes);
-    unsigned* box = a.take<unsigned>(6);
+    unsigned* box = a.take<unsigned>(6 * (int64_t)nseg);
     if (!box) { st_set_error("centre_cloud: workspace too small"); return ST_ERR_WORKSPACE; }
-    (void)hipMemsetAsync(box, 0xff, 3 * sizeof(unsigned), stream);
-    (void)hipMemsetAsync(box + 3, 0, 3 * sizeof(unsigned), stream);
-    hipLaunchKernelGGL(k_bbox, dim3(gr_grid(n) < 1024 ? gr_grid(n) : 1024), dim3(GR_BLOCK), 0, stream, xyz, n, box);
-    hipLaunchKernelGGL(k_centre, dim3(gr_grid(n)), dim3(GR_BLOCK), 0, stream, xyz, n, (const unsigned*)box, out);
+    for (int s = 0; s < nseg; s++) {
+        (void)hipMemsetAsync(box + 6 * s, 0xff, 3 * sizeof(unsigned), stream);
+        (void)hipMemsetAsync(box + 6 * s + 3, 0, 3 * sizeof(unsigned), stream);
+    }
+    // float4 items per cloud ~ 0.75 n / nseg; a few hundred workgroups per cloud keep the final atomics few
+    const int64_t per = st_div_up(st_div_up(3 * n, 4), nseg);
+    const unsigned gx = (unsigned)st_min64(st_div_up(per > 0 ? per : 1, GR_BLOCK), 2048 / (nseg < 8 ? nseg : 8) + 1);
+    hipLaunchKernelGGL(k_bbox, dim3(gx, (unsigned)nseg), dim3(GR_BLOCK), 0, stream, xyz, n, box, seg_off);
+    hipLaunchKernelGGL(k_centre, dim3((unsigned)st_min64(st_div_up(per > 0 ? per : 1, GR_BLOCK), 8192), (unsigned)nseg), dim3(GR_BLOCK), 0, stream,
+                       xyz, n, (const unsigned*)box, out, seg_off);
     ST_CHECK_LAUNCH();
     return ST_OK;
 }
+extern "C" int st_centre_cloud(const float* xyz, int64_t n, float* out, void* ws, int64_t ws_bytes, void* stream_) {
+    return st_centre_cloud_seg(xyz, n, nullptr, 1, out, ws, ws_bytes, stream_);
+}
 
 // ------------------------------------------------------------------------------ make_edges ---
-__global__ void __launch_bounds__(GR_BLOCK) k_edge_count(const int64_t* idx, int64_t n, int K, uint32_t* cnt) {
+// `idx > 0` (graph.py:59) is a test on the index INSIDE the cloud: in a batched call vertex 0 of cloud b is seg_off[b]
+// (a neighbour always belongs to the query's own cloud, so "local index > 0" reads idx > seg_off[cloud of i]).
+__global__ void __launch_bounds__(GR_BLOCK) k_edge_count(const int64_t* idx, int64_t n, int K, uint32_t* cnt, const int* seg_off,
+                                                         int nseg) {
     GR_LOOP(i, n) {
+        const int64_t first = seg_off ? seg_off[st_seg_find(seg_off, nseg, i)] : 0;
         uint32_t c = 0;
-        for (int k = 0; k < K; k++) c += idx[i * K + k] > 0;
+        for (int k = 0; k < K; k++) c += idx[i * K + k] > first;
         cnt[i] = c;
     }
 }
 __global__ void __launch_bounds__(GR_BLOCK) k_edge_emit(const int64_t* idx, const float* dist, int64_t n, int K,
-                                                        const uint32_t* off, int64_t* edges, float* w) {
+                                                        const uint32_t* off, int64_t* edges, float* w, const int* seg_off,
+                                                        int nseg) {
     GR_LOOP(i, n) {
+        const int64_t first = seg_off ? seg_off[st_seg_find(seg_off, nseg, i)] : 0;
         uint32_t o = off[i];
         for (int k = 0; k < K; k++) {
             int64_t j = idx[i * K + k];
-            if (j > 0) { edges[2 * (int64_t)o] = i; edges[2 * (int64_t)o + 1] = j; w[o] = dist[i * K + k]; o++; }
+            if (j > first) { edges[2 * (int64_t)o] = i; edges[2 * (int64_t)o + 1] = j; w[o] = dist[i * K + k]; o++; }
         }
     }
 }
@@ -132,19 +209,24 @@ __global__ void __launch_bounds__(GR_BLOCK) k_edge_pad(int64_t* edges, float* w,
 // n_edges_host == NULL: no read-back of the edge count (a blocking round trip costs ~1 ms beside other clouds' kernels);
 // the n*K - E unused entries are (0, 0) self loops of weight 0, which st_connected_components and st_component_csr ignore
 // (a real edge always has dst > 0: the reference's `idx > 0` filter, graph.py:59).
-extern "C" int st_make_edges(const int64_t* idx, const float* dist, int64_t n, int K, int64_t* edges, float* w,
-                             int64_t* n_edges_host, void* ws, int64_t ws_bytes, void* stream_) {
+// Batched form: seg_off [nseg + 1] (device) = the clouds' vertex ranges; the padding stays (0, 0).
+extern "C" int st_make_edges_seg(const int64_t* idx, const float* dist, int64_t n, int K, int64_t* edges, float* w,
+                                 int64_t* n_edges_host, const int32_t* seg_off, int nseg, void* ws, int64_t ws_bytes,
+                                 void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n_edges_host) *n_edges_host = 0;
     if (n <= 0) return ST_OK;
+    ST_REQUIRE(nseg >= 1 && nseg <= ST_MAX_SEG && (nseg == 1 || seg_off), "make_edges: 1 <= clouds per batch <= %d", ST_MAX_SEG);
+    if (nseg == 1) seg_off = nullptr;
     StArena a(ws, ws_bytes);
     uint32_t* cnt = a.take<uint32_t>(n + 1);
     int64_t sb = st_scan_ws_bytes(n);
     char* sw = a.take<char>(sb);
     if (!cnt || !sw) { st_set_error("make_edges: workspace too small"); return ST_ERR_WORKSPACE; }
-    hipLaunchKernelGGL(k_edge_count, dim3(gr_grid(n)), dim3(GR_BLOCK), 0, stream, idx, n, K, cnt);
+    hipLaunchKernelGGL(k_edge_count, dim3(gr_grid(n)), dim3(GR_BLOCK), 0, stream, idx, n, K, cnt, seg_off, nseg);
     ST_TRY(st_exclusive_scan_u32(cnt, cnt, n, cnt + n, sw, sb, stream));
-    hipLaunchKernelGGL(k_edge_emit, dim3(gr_grid(n)), dim3(GR_BLOCK), 0, stream, idx, dist, n, K, (const uint32_t*)cnt, edges, w);
+    hipLaunchKernelGGL(k_edge_emit, dim3(gr_grid(n)), dim3(GR_BLOCK), 0, stream, idx, dist, n, K, (const uint32_t*)cnt, edges, w,
+                       seg_off, nseg);
     if (!n_edges_host) {  // no count on the host: the tail [E, n*K) of the capacity-sized list becomes (0, 0) edges of weight 0
         hipLaunchKernelGGL(k_edge_pad, dim3(64), dim3(GR_BLOCK), 0, stream, edges, w, (const uint32_t*)(cnt + n), n * (int64_t)K);
         ST_CHECK_LAUNCH();
@@ -156,6 +238,11 @@ extern "C" int st_make_edges(const int64_t* idx, const float* dist, int64_t n, i
     ST_CHECK_LAUNCH();
     *n_edges_host = total;
     return ST_OK;
+}
+
+extern "C" int st_make_edges(const int64_t* idx, const float* dist, int64_t n, int K, int64_t* edges, float* w,
+                             int64_t* n_edges_host, void* ws, int64_t ws_bytes, void* stream_) {
+    return st_make_edges_seg(idx, dist, n, K, edges, w, n_edges_host, nullptr, 1, ws, ws_bytes, stream_);
 }
 
 // ------------------------------------------------------------------ connected components ---
@@ -294,9 +381,30 @@ __global__ void __launch_bounds__(GR_BLOCK) k_cl_rootlist(const uint32_t* flag_o
                                                           int64_t n, uint32_t minv, uint32_t* key, uint32_t* root) {
     GR_LOOP(i, n) if (label[i] == (int)i && size[i] >= minv) { key[flag_off[i]] = 0xffffffffu - size[i]; root[flag_off[i]] = (uint32_t)i; }
 }
-__global__ void __launch_bounds__(GR_BLOCK) k_cl_rank(const uint32_t* root_sorted, const uint32_t* key_sorted, int64_t C,
+__global__ void __launch_bounds__(GR_BLOCK) k_cl_rank(const uint32_t* root_sorted, const uint32_t* size, int64_t C,
                                                       int* rank_of_root, uint32_t* comp_size) {
-    GR_LOOP(c, C) { rank_of_root[root_sorted[c]] = (int)c; comp_size[c] = 0xffffffffu - key_sorted[c]; }
+    GR_LOOP(c, C) { rank_of_root[root_sorted[c]] = (int)c; comp_size[c] = size[root_sorted[c]]; }
+}
+// batched call: second (stable) sort key = cloud of the component's root; afterwards comp_seg / the per-cloud ranges
+__global__ void __launch_bounds__(GR_BLOCK) k_cl_segkey(const uint32_t* root_sorted, int64_t C, const int* seg_off, int nseg,
+                                                        uint32_t* key) {
+    GR_LOOP(c, C) key[c] = (uint32_t)st_seg_find(seg_off, nseg, root_sorted[c]);
+}
+// comp_seg [C]; comp_seg_off [nseg+1] = component ranges of the clouds; vert_seg_off [nseg+1] = their vertex ranges in the
+// renumbered space.  One workgroup (C is a few hundred).
+__global__ void __launch_bounds__(GR_BLOCK) k_cl_segments(const uint32_t* root_sorted, int C, const int* seg_off, int nseg,
+                                                          const int32_t* comp_off, int32_t* comp_seg, int32_t* comp_seg_off,
+                                                          int32_t* vert_seg_off) {
+    for (int b = threadIdx.x; b <= nseg; b += blockDim.x) comp_seg_off[b] = C;  // clouds after the last component
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const int s = st_seg_find(seg_off, nseg, root_sorted[c]);
+        comp_seg[c] = s;
+        const int prev = c > 0 ? st_seg_find(seg_off, nseg, root_sorted[c - 1]) : -1;
+        for (int b = prev + 1; b <= s; b++) comp_seg_off[b] = c;  // clouds without components share their successor's start
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b <= nseg; b += blockDim.x) vert_seg_off[b] = comp_off[comp_seg_off[b]];
 }
 __global__ void __launch_bounds__(GR_BLOCK) k_cl_vflag(const int* label, const int* rank_of_root, int64_t n, uint32_t* flag) {
     GR_LOOP(i, n) flag[i] = rank_of_root[label[i]] >= 0 ? 1u : 0u;
@@ -326,13 +434,24 @@ extern "C" int64_t st_component_layout_workspace_bytes(int64_t n) {
 
 // Outputs (caller-allocated, capacity n each): comp_size [C], comp_off [C+1], vert_order [m] (original
 // vertex ids grouped by component, ascending inside), new_id [n] (-1 for dropped vertices).
-extern "C" int st_component_layout(const int32_t* labels, int64_t n, int min_vertices, int32_t* comp_size, int32_t* comp_off,
-                                   int32_t* vert_order, int32_t* new_id, int64_t* n_comp_host, int64_t* n_kept_host,
-                                   void* ws, int64_t ws_bytes, void* stream_) {
+//
+// Batched form: seg_off [nseg + 1] (device) = the clouds' vertex ranges.  Components are ordered cloud by cloud (inside a
+// cloud: size descending, smallest member ascending -- the one-cloud order), so every cloud's components, and its
+// vertices in the renumbered space, are contiguous.  Extra outputs (device): comp_seg [C capacity n], comp_seg_off
+// [nseg + 1], vert_seg_off [nseg + 1].
+extern "C" int st_component_layout_seg(const int32_t* labels, int64_t n, int min_vertices, const int32_t* seg_off, int nseg,
+                                       int32_t* comp_size, int32_t* comp_off, int32_t* vert_order, int32_t* new_id,
+                                       int32_t* comp_seg, int32_t* comp_seg_off, int32_t* vert_seg_off,
+                                       int64_t* n_comp_host, int64_t* n_kept_host, void* ws, int64_t ws_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     *n_comp_host = 0;
     *n_kept_host = 0;
-    if (n <= 0) return ST_OK;
+    ST_REQUIRE(nseg >= 1 && nseg <= ST_MAX_SEG, "component_layout: 1 <= clouds per batch <= %d", ST_MAX_SEG);
+    ST_REQUIRE(nseg == 1 || (seg_off && comp_seg && comp_seg_off && vert_seg_off), "component_layout: a batch needs seg_off and the per-cloud outputs");
+    if (n <= 0) {
+        if (nseg > 1) { (void)hipMemsetAsync(comp_seg_off, 0, (nseg + 1) * sizeof(int32_t), stream); (void)hipMemsetAsync(vert_seg_off, 0, (nseg + 1) * sizeof(int32_t), stream); }
+        return ST_OK;
+    }
     StArena a(ws, ws_bytes);
     uint32_t* size = a.take<uint32_t>(n + 1);  // size[n] = number of vertices in kept components
     uint32_t* flag = a.take<uint32_t>(n + 1);
@@ -354,15 +473,28 @@ extern "C" int st_component_layout(const int32_t* labels, int64_t n, int min_ver
     st_stream_wait(stream);
     ST_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_fill_i32, dim3(g), dim3(GR_BLOCK), 0, stream, new_id, n, -1);
-    if (C == 0) { ST_CHECK_LAUNCH(); return ST_OK; }
+    if (C == 0) {
+        if (nseg > 1) { (void)hipMemsetAsync(comp_seg_off, 0, (nseg + 1) * sizeof(int32_t), stream); (void)hipMemsetAsync(vert_seg_off, 0, (nseg + 1) * sizeof(int32_t), stream); }
+        ST_CHECK_LAUNCH();
+        return ST_OK;
+    }
     hipLaunchKernelGGL(k_cl_rootlist, dim3(g), dim3(GR_BLOCK), 0, stream, (const uint32_t*)flag, labels, (const uint32_t*)size, n,
                        minv, key, val);
     ST_TRY(st_radix_sort_pairs_u32(key, val, C, 32, sw, sb, stream));  // size desc; stable => root id asc on ties
+    if (nseg > 1) {  // ... then stably by cloud
+        int sbits = 1;
+        while ((1 << sbits) < nseg) sbits++;
+        hipLaunchKernelGGL(k_cl_segkey, dim3(gr_grid(C)), dim3(GR_BLOCK), 0, stream, (const uint32_t*)val, (int64_t)C, seg_off, nseg, key);
+        ST_TRY(st_radix_sort_pairs_u32(key, val, C, sbits, sw, sb, stream));
+    }
     hipLaunchKernelGGL(k_fill_i32, dim3(g), dim3(GR_BLOCK), 0, stream, rank_of_root, n, -1);
-    hipLaunchKernelGGL(k_cl_rank, dim3(gr_grid(C)), dim3(GR_BLOCK), 0, stream, (const uint32_t*)val, (const uint32_t*)key,
+    hipLaunchKernelGGL(k_cl_rank, dim3(gr_grid(C)), dim3(GR_BLOCK), 0, stream, (const uint32_t*)val, (const uint32_t*)size,
                        (int64_t)C, rank_of_root, (uint32_t*)comp_size);
     // comp_off = exclusive scan of comp_size (+ total at [C])
     ST_TRY(st_exclusive_scan_u32((const uint32_t*)comp_size, (uint32_t*)comp_off, C, (uint32_t*)comp_off + C, sw, sb, stream));
+    if (nseg > 1)
+        hipLaunchKernelGGL(k_cl_segments, dim3(1), dim3(GR_BLOCK), 0, stream, (const uint32_t*)val, (int)C, seg_off, nseg,
+                           (const int32_t*)comp_off, comp_seg, comp_seg_off, vert_seg_off);
     // vertices of kept components, ascending id, then stable sort by component rank
     hipLaunchKernelGGL(k_cl_vflag, dim3(g), dim3(GR_BLOCK), 0, stream, labels, (const int*)rank_of_root, n, flag);
     ST_TRY(st_exclusive_scan_u32(flag, flag, n, flag + n, sw, sb, stream));
@@ -377,6 +509,13 @@ extern "C" int st_component_layout(const int32_t* labels, int64_t n, int min_ver
     *n_comp_host = C;
     *n_kept_host = m;
     return ST_OK;
+}
+
+extern "C" int st_component_layout(const int32_t* labels, int64_t n, int min_vertices, int32_t* comp_size, int32_t* comp_off,
+                                   int32_t* vert_order, int32_t* new_id, int64_t* n_comp_host, int64_t* n_kept_host,
+                                   void* ws, int64_t ws_bytes, void* stream_) {
+    return st_component_layout_seg(labels, n, min_vertices, nullptr, 1, comp_size, comp_off, vert_order, new_id, nullptr, nullptr,
+                                   nullptr, n_comp_host, n_kept_host, ws, ws_bytes, stream_);
 }
 
 // ---------------------------------------------------------------------------- component CSR ---

@@ -26,20 +26,24 @@ __global__ void k_grid_init(StGrid* g) {
         g->rmax_ord = 0u;
         g->r = 0.0f;
     }
+    if (blockIdx.x == 0 && threadIdx.x < ST_MAX_SEG) { g->seg_rmax_ord[threadIdx.x] = 0u; g->seg_r[threadIdx.x] = 0.0f; }
 }
 
-__global__ void __launch_bounds__(KNN_BLOCK) k_bound_max(const float* bound, int64_t n, StGrid* g) {
+// blockIdx.y = cloud (gridDim.y = 1, seg_off == nullptr: the whole array is one cloud)
+__global__ void __launch_bounds__(KNN_BLOCK) k_bound_max(const float* bound, int64_t n, StGrid* g, const int* seg_off) {
     __shared__ unsigned m;
     if (threadIdx.x == 0) m = 0u;
     __syncthreads();
+    const int seg = blockIdx.y;
+    const int64_t i0 = seg_off ? seg_off[seg] : 0, i1 = seg_off ? seg_off[seg + 1] : n;
     unsigned mine = 0u;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t i = i0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < i1; i += (int64_t)gridDim.x * blockDim.x) {
         const unsigned o = st_f2ord(bound[i]);
         if (o > mine) mine = o;
     }
     if (mine > m) atomicMax(&m, mine);
     __syncthreads();
-    if (threadIdx.x == 0 && m) atomicMax(&g->rmax_ord, m);
+    if (threadIdx.x == 0 && m) { atomicMax(&g->rmax_ord, m); atomicMax(&g->seg_rmax_ord[seg], m); }
 }
 
 __global__ void __launch_bounds__(KNN_BLOCK) k_grid_bbox(const float* pts, int64_t n, StGrid* g) {
@@ -56,16 +60,18 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_grid_bbox(const float* pts, int64
     if (threadIdx.x < 3) { atomicMin(&g->lo_ord[threadIdx.x], lo[threadIdx.x]); atomicMax(&g->hi_ord[threadIdx.x], hi[threadIdx.x]); }
 }
 
-__global__ void k_grid_dims(StGrid* g, float cell, int64_t max_cells, float r) {
+__global__ void k_grid_dims(StGrid* g, float cell, int64_t max_cells, float r, int nseg) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     float lo[3], hi[3];
     for (int a = 0; a < 3; a++) { lo[a] = st_ord2f(g->lo_ord[a]); hi[a] = st_ord2f(g->hi_ord[a]); g->lo[a] = lo[a]; }
+    for (int s = 0; s < nseg; s++) g->seg_r[s] = r < 0.0f ? st_ord2f(g->seg_rmax_ord[s]) : r;
     if (r < 0.0f) r = st_ord2f(g->rmax_ord);  // the largest per-query bound, reduced by k_bound_max
     g->r = r;
     if (cell < 0.0f) cell = fmaxf(r / -cell, 1e-4f);
     if (!(cell > 0.0f)) cell = 1.0f;
+    g->nseg = nseg;
     for (;;) {
-        double total = 1.0;
+        double total = (double)nseg;
         for (int a = 0; a < 3; a++) {
             float ext = (hi[a] - lo[a]) / cell;
             int d = ext < 2.0e9f ? (int)floorf(ext) + 1 : 0x7fffffff;
@@ -76,19 +82,22 @@ __global__ void k_grid_dims(StGrid* g, float cell, int64_t max_cells, float r) {
         if (total <= (double)max_cells) break;
         cell *= 2.0f;
     }
+    g->seg_dim0 = g->dim[0];
+    g->dim[0] = g->seg_dim0 * nseg;  // every cloud gets its own slab of cells along x
     g->cell = cell;
     g->ncell = (int64_t)g->dim[0] * g->dim[1] * g->dim[2];
 }
 
-__global__ void __launch_bounds__(KNN_BLOCK) k_grid_count(const float* pts, int64_t n, const StGrid* g, uint32_t* counts) {
+__global__ void __launch_bounds__(KNN_BLOCK) k_grid_count(const float* pts, int64_t n, const StGrid* g, uint32_t* counts,
+                                                          const int* seg_off, int nseg) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        atomicAdd(&counts[st_grid_cell(g, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2])], 1u);
+        atomicAdd(&counts[st_grid_cell(g, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], st_seg_find(seg_off, nseg, i))], 1u);
 }
 
 __global__ void __launch_bounds__(KNN_BLOCK) k_grid_fill(const float* pts, int64_t n, const StGrid* g, uint32_t* cursor,
-                                                         float4* recs) {
+                                                         float4* recs, const int* seg_off, int nseg) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        int64_t c = st_grid_cell(g, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+        int64_t c = st_grid_cell(g, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], st_seg_find(seg_off, nseg, i));
         uint32_t pos = atomicAdd(&cursor[c], 1u);
         recs[pos] = make_float4(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], __uint_as_float((unsigned)i));
     }
@@ -104,7 +113,10 @@ int64_t st_grid_ws_bytes(int64_t n, int64_t max_cells) {
 
 // Builds grid over pts[n]; g (device struct), cell_start[max_cells+1], recs[n] are caller arrays.
 int st_grid_build(const float* pts, int64_t n, float cell, int64_t max_cells, StGrid* g, uint32_t* cell_start, float4* recs,
-                  void* ws, int64_t ws_bytes, hipStream_t stream, float r, const float* bound, int64_t n_bound) {
+                  void* ws, int64_t ws_bytes, hipStream_t stream, float r, const float* bound, int64_t n_bound,
+                  const int* seg_off, int nseg, const int* bound_seg_off) {
+    if (nseg < 1 || nseg > ST_MAX_SEG) { st_set_error("grid: 1 <= clouds per batch <= %d (got %d)", ST_MAX_SEG, nseg); return ST_ERR_INVALID; }
+    if (!seg_off) nseg = 1;
     StArena a(ws, ws_bytes);
     uint32_t* cursor = a.take<uint32_t>(max_cells + 1);
     int64_t scan_bytes = st_scan_ws_bytes(max_cells + 1);
@@ -115,6 +127,7 @@ int st_grid_build(const float* pts, int64_t n, float cell, int64_t max_cells, St
     }
     unsigned gb = (unsigned)st_min64(st_div_up(n > 0 ? n : 1, KNN_BLOCK), 4096);
     hipLaunchKernelGGL(k_grid_init, dim3(1), dim3(64), 0, stream, g);
+    static_assert(ST_MAX_SEG <= 64, "k_grid_init clears the per-cloud radii with one wavefront");
     hipLaunchKernelGGL(k_grid_bbox, dim3(gb), dim3(KNN_BLOCK), 0, stream, pts, n, g);
     // No read-back of the cell count (a blocking round trip costs ~1 ms beside other clouds' kernels):
     // the grid is limited to 128 cells per point -- a 2 cm kNN grid over a tree has ~65 -- and histogram, scan and cursor
@@ -122,9 +135,9 @@ int st_grid_build(const float* pts, int64_t n, float cell, int64_t max_cells, St
     // (k_grid_dims doubles the cell), which changes the speed of a search, never its result.
     const int64_t ncell = st_min64(max_cells, 128 * n + 65536);
     if (r < 0.0f && bound && n_bound > 0)
-        hipLaunchKernelGGL(k_bound_max, dim3((unsigned)st_min64(st_div_up(n_bound, KNN_BLOCK), 1024)), dim3(KNN_BLOCK), 0, stream,
-                           bound, n_bound, g);
-    hipLaunchKernelGGL(k_grid_dims, dim3(1), dim3(64), 0, stream, g, cell, ncell, r);
+        hipLaunchKernelGGL(k_bound_max, dim3((unsigned)st_min64(st_div_up(n_bound, (int64_t)KNN_BLOCK * nseg), 1024), (unsigned)nseg),
+                           dim3(KNN_BLOCK), 0, stream, bound, n_bound, g, nseg > 1 ? (bound_seg_off ? bound_seg_off : seg_off) : (const int*)nullptr);
+    hipLaunchKernelGGL(k_grid_dims, dim3(1), dim3(64), 0, stream, g, cell, ncell, r, nseg);
     if (getenv("ST_GRID_DEBUG")) {
         StGrid h;
         (void)hipMemcpyAsync(&h, g, sizeof(StGrid), hipMemcpyDeviceToHost, stream);
@@ -133,10 +146,10 @@ int st_grid_build(const float* pts, int64_t n, float cell, int64_t max_cells, St
                 (long long)ncell, h.dim[0], h.dim[1], h.dim[2]);
     }
     (void)hipMemsetAsync(cell_start, 0, (ncell + 1) * sizeof(uint32_t), stream);
-    hipLaunchKernelGGL(k_grid_count, dim3(gb), dim3(KNN_BLOCK), 0, stream, pts, n, (const StGrid*)g, cell_start);
+    hipLaunchKernelGGL(k_grid_count, dim3(gb), dim3(KNN_BLOCK), 0, stream, pts, n, (const StGrid*)g, cell_start, seg_off, nseg);
     ST_TRY(st_exclusive_scan_u32(cell_start, cell_start, ncell + 1, nullptr, scan_ws, scan_bytes, stream));
     (void)hipMemcpyAsync(cursor, cell_start, (ncell + 1) * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream);
-    hipLaunchKernelGGL(k_grid_fill, dim3(gb), dim3(KNN_BLOCK), 0, stream, pts, n, (const StGrid*)g, cursor, recs);
+    hipLaunchKernelGGL(k_grid_fill, dim3(gb), dim3(KNN_BLOCK), 0, stream, pts, n, (const StGrid*)g, cursor, recs, seg_off, nseg);
     ST_CHECK_LAUNCH();
     return ST_OK;
 }
@@ -193,7 +206,8 @@ template <int K>
 __global__ void __launch_bounds__(KNN_BLOCK) k_knn(const float* __restrict__ src, int64_t n1, const StGrid* __restrict__ g,
                                                    const uint32_t* __restrict__ cell_start, const float4* __restrict__ recs,
                                                    float r, const float* __restrict__ bound, int mode,
-                                                   int64_t* __restrict__ idx_out, float* __restrict__ dist_out) {
+                                                   int64_t* __restrict__ idx_out, float* __restrict__ dist_out,
+                                                   const int* __restrict__ seg_off, int nseg) {
     __shared__ uint32_t s_roff[KNN_WAVES][65], s_rfirst[KNN_WAVES][64];
     __shared__ unsigned long long s_keys[KNN_WAVES][KNN_CAP];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -203,7 +217,8 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn(const float* __restrict__ src
     uint32_t* rfirst = s_rfirst[wave];
     unsigned long long* keys = s_keys[wave];
     const float px = src[3 * i], py = src[3 * i + 1], pz = src[3 * i + 2];
-    if (r < 0.0f) r = g->r;  // radius reduced on the device (st_knn_radius with r < 0)
+    const int seg = st_seg_find(seg_off, nseg, i);  // wave-uniform: one query per wavefront
+    if (r < 0.0f) r = g->seg_r[seg];  // radius reduced on the device (st_knn_radius with r < 0): max(bound) over the query's cloud
     const float r2 = r * r;
     float reach_r = r;
     float bnd = 0.0f;
@@ -215,7 +230,8 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn(const float* __restrict__ src
     int reach = reach_r > 0.0f ? (int)ceilf(reach_r / cell) : 0;
     if (reach < 1) reach = 1;
     const int cx = (int)floorf((px - g->lo[0]) / cell), cy = (int)floorf((py - g->lo[1]) / cell), cz = (int)floorf((pz - g->lo[2]) / cell);
-    const int x0 = st_max(cx - reach, 0), x1 = st_min(cx + reach, g->dim[0] - 1);
+    const int xoff = seg * g->seg_dim0;  // the cloud's slab of cells
+    const int x0 = st_max(cx - reach, 0), x1 = st_min(cx + reach, g->seg_dim0 - 1);
     const int y0 = st_max(cy - reach, 0), y1 = st_min(cy + reach, g->dim[1] - 1);
     const int z0 = st_max(cz - reach, 0), z1 = st_min(cz + reach, g->dim[2] - 1);
     // rows (x, y) farther than the search radius in the xy-plane are skipped and the z-range of the others
@@ -236,7 +252,7 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn(const float* __restrict__ src
                 const int za = st_max((int)floorf((pz - rz - g->lo[2]) / cell) - 1, z0),
                           zb = st_min((int)floorf((pz + rz - g->lo[2]) / cell) + 1, z1);
                 if (za <= zb) {
-                    const int64_t row = ((int64_t)x * g->dim[1] + y) * g->dim[2];
+                    const int64_t row = ((int64_t)(xoff + x) * g->dim[1] + y) * g->dim[2];
                     first = cell_start[row + za];
                     cnt = cell_start[row + zb + 1] - first;
                 }
@@ -305,55 +321,73 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn(const float* __restrict__ src
 }
 
 #define KNN_MAX_CELLS (1ll << 24)
+// a batch of clouds gets one slab of cells per cloud: the cap grows with the batch (up to 8 x)
+static inline int64_t knn_max_cells(int nseg) { return KNN_MAX_CELLS * (nseg < 1 ? 1 : (nseg > 8 ? 8 : nseg)); }
 
-static void knn_layout(StArena& a, int64_t n2, StGrid** g, uint32_t** cell_start, float4** recs, char** sub, int64_t* sub_bytes) {
+static void knn_layout(StArena& a, int64_t n2, int nseg, StGrid** g, uint32_t** cell_start, float4** recs, char** sub, int64_t* sub_bytes) {
     *g = a.take<StGrid>(1);
-    *cell_start = a.take<uint32_t>(KNN_MAX_CELLS + 1);
+    *cell_start = a.take<uint32_t>(knn_max_cells(nseg) + 1);
     *recs = a.take<float4>(n2);
-    *sub_bytes = st_grid_ws_bytes(n2, KNN_MAX_CELLS);
+    *sub_bytes = st_grid_ws_bytes(n2, knn_max_cells(nseg));
     *sub = a.take<char>(*sub_bytes);
 }
 
-extern "C" int64_t st_knn_workspace_bytes(int64_t n_dst) {
+extern "C" int64_t st_knn_workspace_bytes_seg(int64_t n_dst, int nseg) {
     StArena a(nullptr, 0);
     StGrid* g; uint32_t* cs; float4* recs; char* sub; int64_t sb;
-    knn_layout(a, n_dst, &g, &cs, &recs, &sub, &sb);
+    knn_layout(a, n_dst, nseg, &g, &cs, &recs, &sub, &sb);
     return a.used;
 }
+extern "C" int64_t st_knn_workspace_bytes(int64_t n_dst) { return st_knn_workspace_bytes_seg(n_dst, 1); }
 
 // idx [n1,K] int64 (-1 pad), dist [n1,K] float32 = sqrtf(d2) (NaN pad).  bound/bound_mode: see above.
 // cell_hint: preferred grid cell size (0: use r).  r < 0 (needs `bound`): the search radius is max(bound) -- what the
 // callers used to read back to the host just to pass it in again; the reduction stays on the device.  cell_hint < 0
 // (with r < 0): cell = max(r / -cell_hint, 1e-4).
-extern "C" int st_knn_radius(const float* src, int64_t n1, const float* dst, int64_t n2, int K, float r, const float* bound,
-                             int bound_mode, float cell_hint, int64_t* idx, float* dist, void* ws, int64_t ws_bytes,
-                             void* stream_) {
+// Batched form: src and dst hold `nseg` independent clouds each (cloud b = index ranges [src_seg_off[b], src_seg_off[b+1]) /
+// [dst_seg_off[b], dst_seg_off[b+1]), device int32 arrays of nseg + 1 entries); a query only sees the points of its own
+// cloud, r < 0 means max(bound) over the query's own cloud, and every cloud's rows equal what the one-cloud call returns
+// for it (indices are positions in the batched dst array).
+extern "C" int st_knn_radius_seg(const float* src, int64_t n1, const float* dst, int64_t n2, int K, float r, const float* bound,
+                                 int bound_mode, float cell_hint, int64_t* idx, float* dist, const int32_t* src_seg_off,
+                                 const int32_t* dst_seg_off, int nseg, void* ws, int64_t ws_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     ST_REQUIRE(K == 1 || K == 8 || K == 16, "knn: K must be 1, 8 or 16 (got %d)", K);
     ST_REQUIRE(bound_mode == 0 || bound != nullptr, "knn: bound_mode needs a bound array");
     ST_REQUIRE(r >= 0.0f || bound != nullptr, "knn: r < 0 (radius = max(bound)) needs a bound array");
     ST_REQUIRE(cell_hint >= 0.0f || r < 0.0f, "knn: a relative cell size (cell_hint < 0) goes with r < 0");
     ST_REQUIRE(n2 < (1ll << 31), "knn: too many points");
+    ST_REQUIRE(nseg >= 1 && nseg <= ST_MAX_SEG, "knn: 1 <= clouds per batch <= %d", ST_MAX_SEG);
+    ST_REQUIRE(nseg == 1 || (src_seg_off && dst_seg_off), "knn: a batch needs the cloud offsets of src and dst");
+    if (nseg == 1) { src_seg_off = nullptr; dst_seg_off = nullptr; }
     if (n1 <= 0) return ST_OK;
     StArena a(ws, ws_bytes);
     StGrid* g; uint32_t* cell_start; float4* recs; char* sub; int64_t sub_bytes;
-    knn_layout(a, n2, &g, &cell_start, &recs, &sub, &sub_bytes);
+    knn_layout(a, n2, nseg, &g, &cell_start, &recs, &sub, &sub_bytes);
     if (!a.ok() || !sub) {
         st_set_error("knn: workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)a.used);
         return ST_ERR_WORKSPACE;
     }
     const float cell_arg = cell_hint != 0.0f ? cell_hint : (r >= 0.0f ? r : -1.0f);
-    ST_TRY(st_grid_build(dst, n2, cell_arg, KNN_MAX_CELLS, g, cell_start, recs, sub, sub_bytes, stream, r, bound, n1));
+    ST_TRY(st_grid_build(dst, n2, cell_arg, knn_max_cells(nseg), g, cell_start, recs, sub, sub_bytes, stream, r, bound, n1,
+                         dst_seg_off, nseg, src_seg_off));
     dim3 grid((unsigned)st_div_up(n1, KNN_WAVES)), block(KNN_BLOCK);
     if (K == 1)
         hipLaunchKernelGGL((k_knn<1>), grid, block, 0, stream, src, n1, (const StGrid*)g, (const uint32_t*)cell_start,
-                           (const float4*)recs, r, bound, bound_mode, idx, dist);
+                           (const float4*)recs, r, bound, bound_mode, idx, dist, src_seg_off, nseg);
     else if (K == 8)
         hipLaunchKernelGGL((k_knn<8>), grid, block, 0, stream, src, n1, (const StGrid*)g, (const uint32_t*)cell_start,
-                           (const float4*)recs, r, bound, bound_mode, idx, dist);
+                           (const float4*)recs, r, bound, bound_mode, idx, dist, src_seg_off, nseg);
     else
         hipLaunchKernelGGL((k_knn<16>), grid, block, 0, stream, src, n1, (const StGrid*)g, (const uint32_t*)cell_start,
-                           (const float4*)recs, r, bound, bound_mode, idx, dist);
+                           (const float4*)recs, r, bound, bound_mode, idx, dist, src_seg_off, nseg);
     ST_CHECK_LAUNCH();
     return ST_OK;
+}
+
+extern "C" int st_knn_radius(const float* src, int64_t n1, const float* dst, int64_t n2, int K, float r, const float* bound,
+                             int bound_mode, float cell_hint, int64_t* idx, float* dist, void* ws, int64_t ws_bytes,
+                             void* stream_) {
+    return st_knn_radius_seg(src, n1, dst, n2, K, r, bound, bound_mode, cell_hint, idx, dist, nullptr, nullptr, 1, ws, ws_bytes,
+                             stream_);
 }

@@ -36,6 +36,8 @@ struct PpArgs {
     int* depth;           // [B] scratch: level of each branch in the repair order
     int do_prune, do_repair, do_smooth, kernel;
     float min_radius, min_length;
+    const int* first_tree;  // batched call: [n_first] the first tree of every cloud (the one `prune` works on); nullptr: tree 0
+    int n_first;
 };
 
 // L2 (agent scope) load of a float another wavefront of this workgroup wrote earlier in the launch
@@ -63,7 +65,12 @@ __global__ void __launch_bounds__(PP_BLOCK) k_post_process(PpArgs A) {
     // ---- prune (tree 0 only): length / initial radius per branch in parallel, then the keep chain
     for (int b = tid; b < nb; b += PP_BLOCK) A.keep[b0 + b] = 1;
     __syncthreads();
-    if (A.do_prune && tree == 0 && nb > 0) {
+    bool prune_this = tree == 0;  // tree.py:164-168: only skeleton 0 (of its cloud) is pruned
+    if (A.first_tree) {
+        prune_this = false;
+        for (int k = 0; k < A.n_first; k++) prune_this = prune_this || A.first_tree[k] == tree;  // uniform: n_first <= 64
+    }
+    if (A.do_prune && prune_this && nb > 0) {
         for (int b = tid >> 6; b < nb; b += PP_WAVES) {  // one wavefront per branch
             const int s = A.start[b0 + b] + 1, n = A.len[b0 + b], ln = tid & 63;
             float length = 0.0f;  // lanes evaluate 64 segment norms at a time; they are added in path order (sequential float32 sum)
@@ -211,22 +218,35 @@ __global__ void __launch_bounds__(PP_BLOCK) k_post_process(PpArgs A) {
 
 // tree_off [T+1], parent/start/len [B], xyz [P,3] (in/out), rad_in/rad_out [P], keep/repaired/smoothed [B],
 // depth_scratch [B] int32
-extern "C" int st_post_process(int n_trees, const int32_t* tree_off, const int32_t* parent, const int32_t* start,
+// Batched form: the trees of several clouds in one call; first_tree [n_first] (device) = the first tree of every cloud that
+// has one -- `prune` applies to those (DisjointTreeSkeleton.prune touches skeletons[0] of ITS cloud only).
+extern "C" int st_post_process_seg(int n_trees, const int32_t* tree_off, const int32_t* parent, const int32_t* start,
                                const int32_t* len, float* xyz, const float* rad_in, float* rad_out, uint8_t* keep,
                                uint8_t* repaired, uint8_t* smoothed, int32_t* depth_scratch, int do_prune, float min_radius,
-                               float min_length, int do_repair, int do_smooth, int kernel_size, void* stream_) {
+                               float min_length, int do_repair, int do_smooth, int kernel_size, const int32_t* first_tree,
+                               int n_first, void* stream_) {
     if (n_trees <= 0) return ST_OK;
+    ST_REQUIRE(n_first >= 0 && n_first <= 64, "post_process: at most 64 clouds per batch");
     ST_REQUIRE(!do_smooth || kernel_size > 0, "post_process: smoothing needs kernel_size > 0");
     PpArgs A;
     A.n_trees = n_trees; A.tree_off = tree_off; A.parent = parent; A.start = start; A.len = len; A.xyz = xyz;
     A.rad_in = rad_in; A.rad_out = rad_out; A.keep = keep; A.repaired = repaired; A.smoothed = smoothed; A.depth = depth_scratch;
     A.do_prune = do_prune; A.do_repair = do_repair; A.do_smooth = do_smooth; A.kernel = kernel_size;
     A.min_radius = min_radius; A.min_length = min_length;
+    A.first_tree = first_tree; A.n_first = first_tree ? n_first : 0;
     hipLaunchKernelGGL(k_post_process, dim3((unsigned)n_trees), dim3(PP_BLOCK), 0, (hipStream_t)stream_, A);
     ST_CHECK_LAUNCH();
     return ST_OK;
 }
 
+extern "C" int st_post_process(int n_trees, const int32_t* tree_off, const int32_t* parent, const int32_t* start,
+                               const int32_t* len, float* xyz, const float* rad_in, float* rad_out, uint8_t* keep,
+                               uint8_t* repaired, uint8_t* smoothed, int32_t* depth_scratch, int do_prune, float min_radius,
+                               float min_length, int do_repair, int do_smooth, int kernel_size, void* stream_) {
+    return st_post_process_seg(n_trees, tree_off, parent, start, len, xyz, rad_in, rad_out, keep, repaired, smoothed,
+                               depth_scratch, do_prune, min_radius, min_length, do_repair, do_smooth, kernel_size, nullptr, 0,
+                               stream_);
+}
 
 // ------------------------------------------------------------------ branch assembly ---
 // sample_tree's per-component output (branch table + path vertex lists, skeleton.hip) -> the flat branch

@@ -14,6 +14,7 @@
 // k ascending) via hash insert with atomicMin(candidate id) + ordered compaction -- no sort, no
 // atomics-order dependence, bit-reproducible.
 #include "st_common.h"
+#include "st_grid.h"  // ST_MAX_SEG
 
 #define RB_BLOCK 256
 
@@ -52,27 +53,34 @@ __global__ void __launch_bounds__(RB_BLOCK) k_rb_subm(const int32_t* coords, int
     }
 }
 
+// The spatial extent that clips the strided output set is the extent of the voxel's own CLOUD: a one-cloud call has one
+// extent for the whole batch of blocks (DESIGN.md "canonical choices"); a batched call keeps one per cloud (blk_seg maps
+// the block index coords[:,0] to its cloud), so a cloud's coarse sets do not depend on what else is in the batch.
 struct RbState {
-    int ext[3];       // max coordinate per axis (z,y,x) over the whole batch
+    int ext[ST_MAX_SEG][3];  // max coordinate per axis (z,y,x) over the blocks of each cloud
     uint32_t n_out;
     uint32_t fail;
 };
 
 __global__ void k_rb_state_init(RbState* st) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) { st->ext[0] = st->ext[1] = st->ext[2] = 0; st->n_out = 0; st->fail = 0; }
+    for (int i = threadIdx.x; i < ST_MAX_SEG * 3; i += blockDim.x) (&st->ext[0][0])[i] = 0;
+    if (threadIdx.x == 0 && blockIdx.x == 0) { st->n_out = 0; st->fail = 0; }
 }
 
-__global__ void __launch_bounds__(RB_BLOCK) k_rb_extent(const int32_t* coords, int64_t n, RbState* st) {
-    __shared__ int m[3];
-    if (threadIdx.x < 3) m[threadIdx.x] = 0;
+__global__ void __launch_bounds__(RB_BLOCK) k_rb_extent(const int32_t* coords, int64_t n, RbState* st, const int32_t* blk_seg,
+                                                        int nseg) {
+    __shared__ int m[ST_MAX_SEG * 3];
+    for (int i = threadIdx.x; i < nseg * 3; i += blockDim.x) m[i] = 0;
     __syncthreads();
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int s = blk_seg ? blk_seg[coords[4 * i]] : 0;
         for (int a = 0; a < 3; a++) {
             int c = coords[4 * i + 1 + a];
-            if (c > m[a]) atomicMax(&m[a], c);
+            if (c > m[3 * s + a]) atomicMax(&m[3 * s + a], c);
         }
+    }
     __syncthreads();
-    if (threadIdx.x < 3) atomicMax(&st->ext[threadIdx.x], m[threadIdx.x]);
+    for (int i = threadIdx.x; i < nseg * 3; i += blockDim.x) if (m[i]) atomicMax(&(&st->ext[0][0])[i], m[i]);
 }
 
 // candidate outputs of input voxel i: o = (c + 1 - k) / 2 per axis when even and inside out_shape
@@ -83,14 +91,15 @@ template <int PASS>
 __global__ void __launch_bounds__(RB_BLOCK) k_rb_down_pass(const int32_t* coords, int64_t n, RbState* st,
                                                            unsigned long long* keys, unsigned* vals, unsigned long long cap,
                                                            uint32_t* cnt_or_off, uint32_t* win, int32_t* out_coords,
-                                                           int64_t max_out) {
+                                                           int64_t max_out, const int32_t* blk_seg) {
     if (PASS != 0 && st->fail) return;
     int oshape[3];
-    for (int a = 0; a < 3; a++) oshape[a] = st->ext[a] / 2 + 1;  // ((ext+1) - 1)/2 + 1
+    for (int a = 0; a < 3; a++) oshape[a] = st->ext[0][a] / 2 + 1;  // ((ext+1) - 1)/2 + 1
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         uint32_t mine = 0, won = PASS == 2 ? win[i] : 0u;
         if (PASS == 2 && won == 0u) continue;
         int b = coords[4 * i], c[3] = {coords[4 * i + 1], coords[4 * i + 2], coords[4 * i + 3]};
+        if (blk_seg) { const int* e = st->ext[blk_seg[b]]; for (int a = 0; a < 3; a++) oshape[a] = e[a] / 2 + 1; }
         uint32_t off = PASS == 2 ? cnt_or_off[i] : 0u;
         if (PASS == 1) {  // which of my candidates is the stored winner: nine overlapped look-ups per z-plane
 #pragma unroll
@@ -165,13 +174,14 @@ __device__ __forceinline__ int rb_parity_class(const int* c) { return ((c[0] & 1
 __global__ void __launch_bounds__(RB_BLOCK) k_rb_up_nbr(const int32_t* coords, int64_t n, RbShape osh,
                                                         const unsigned long long* ckeys, const unsigned* cvals,
                                                         unsigned long long ccap, int32_t* nbr, int32_t* nbr_down, int64_t m,
-                                                        uint32_t* parity_count) {
+                                                        uint32_t* parity_count, const int32_t* blk_seg, const int32_t* ext_dev) {
     __shared__ uint32_t hist[8];
     if (threadIdx.x < 8) hist[threadIdx.x] = 0;
     __syncthreads();
     int oshape[3] = {osh.v[0], osh.v[1], osh.v[2]};
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         int b = coords[4 * i], c[3] = {coords[4 * i + 1], coords[4 * i + 2], coords[4 * i + 3]};
+        if (blk_seg) { const int32_t* e = ext_dev + 3 * blk_seg[b]; for (int a = 0; a < 3; a++) oshape[a] = e[a] / 2 + 1; }
         if (parity_count) atomicAdd(&hist[rb_parity_class(c)], 1u);
 #pragma unroll
         for (int kz = 0; kz < 3; kz++) {  // nine offsets per batch of overlapped look-ups (at most four of them live)
@@ -283,13 +293,16 @@ extern "C" int64_t st_strided_workspace_bytes(int64_t n_fine) {
 }
 
 // Phase 1: discover the coarse active set (canonical order), build its hash.  Returns n_out on the host.
-extern "C" int st_build_strided_outputs(const int32_t* coords, int64_t n, int64_t max_out, int32_t* out_coords,
+// Batched form (blk_seg [n_blocks], nseg): one extent per cloud; ext_dev [nseg * 3] (device, out) is what phase 2 reads.
+extern "C" int st_build_strided_outputs_seg(const int32_t* coords, int64_t n, int64_t max_out, int32_t* out_coords,
                                         unsigned long long* ckeys, unsigned* cvals, int64_t ccap, int64_t* n_out_host,
-                                        int32_t* extent_host /*[3] max (z,y,x) coordinate*/, void* ws, int64_t ws_bytes,
-                                        void* stream_) {
+                                        int32_t* extent_host /*[3] max (z,y,x) coordinate (cloud 0)*/, const int32_t* blk_seg,
+                                        int nseg, int32_t* ext_dev, void* ws, int64_t ws_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     *n_out_host = 0;
     extent_host[0] = extent_host[1] = extent_host[2] = 0;
+    ST_REQUIRE(nseg >= 1 && nseg <= ST_MAX_SEG && (nseg == 1 || (blk_seg && ext_dev)), "strided: 1 <= clouds per batch <= %d", ST_MAX_SEG);
+    if (nseg == 1) blk_seg = nullptr;
     ST_REQUIRE(ccap >= 2 * max_out && (ccap & (ccap - 1)) == 0, "strided: coarse hash capacity must be a power of two >= 2*max_out");
     ST_REQUIRE(n < (1ll << 31) / 27, "strided: too many voxels for 32-bit candidate ids");
     StArena a(ws, ws_bytes);
@@ -305,20 +318,29 @@ extern "C" int st_build_strided_outputs(const int32_t* coords, int64_t n, int64_
     (void)hipMemsetAsync(ckeys, 0xff, ccap * sizeof(unsigned long long), stream);
     (void)hipMemsetAsync(cvals, 0xff, ccap * sizeof(unsigned), stream);
     hipLaunchKernelGGL(k_rb_state_init, dim3(1), dim3(64), 0, stream, st);
-    if (n == 0) return ST_OK;
+    if (n == 0) {
+        if (ext_dev) (void)hipMemsetAsync(ext_dev, 0, 3 * nseg * sizeof(int32_t), stream);
+        return ST_OK;
+    }
     const unsigned g = rb_grid(n);
-    hipLaunchKernelGGL(k_rb_extent, dim3(g), dim3(RB_BLOCK), 0, stream, coords, n, st);
+    hipLaunchKernelGGL(k_rb_extent, dim3(g), dim3(RB_BLOCK), 0, stream, coords, n, st, blk_seg, nseg);
     hipLaunchKernelGGL((k_rb_down_pass<0>), dim3(g), dim3(RB_BLOCK), 0, stream, coords, n, st, ckeys, cvals,
-                       (unsigned long long)ccap, cnt, win, out_coords, max_out);
+                       (unsigned long long)ccap, cnt, win, out_coords, max_out, blk_seg);
     hipLaunchKernelGGL((k_rb_down_pass<1>), dim3(g), dim3(RB_BLOCK), 0, stream, coords, n, st, ckeys, cvals,
-                       (unsigned long long)ccap, cnt, win, out_coords, max_out);
+                       (unsigned long long)ccap, cnt, win, out_coords, max_out, blk_seg);
     ST_TRY(st_exclusive_scan_u32(cnt, cnt, n, &st->n_out, scan_ws, scan_bytes, stream));
     hipLaunchKernelGGL((k_rb_down_pass<2>), dim3(g), dim3(RB_BLOCK), 0, stream, coords, n, st, ckeys, cvals,
-                       (unsigned long long)ccap, cnt, win, out_coords, max_out);
-    RbState h;
-    (void)hipMemcpyAsync(&h, st, sizeof(RbState), hipMemcpyDeviceToHost, stream);
+                       (unsigned long long)ccap, cnt, win, out_coords, max_out, blk_seg);
+    if (ext_dev) (void)hipMemcpyAsync(ext_dev, &st->ext[0][0], 3 * nseg * sizeof(int32_t), hipMemcpyDeviceToDevice, stream);
+    struct { uint32_t n_out, fail; } hc;
+    int hext[3];
+    (void)hipMemcpyAsync(hext, &st->ext[0][0], sizeof(hext), hipMemcpyDeviceToHost, stream);
+    (void)hipMemcpyAsync(&hc, &st->n_out, sizeof(hc), hipMemcpyDeviceToHost, stream);
+    struct { int ext[3]; uint32_t n_out, fail; } h;
     st_stream_wait(stream);  // the ONE read-back of this stage: n_out sizes everything downstream
     ST_CHECK_LAUNCH();
+    for (int a = 0; a < 3; a++) h.ext[a] = hext[a];
+    h.n_out = hc.n_out; h.fail = hc.fail;
     ST_REQUIRE(!h.fail, "strided: more than max_out=%lld output voxels", (long long)max_out);
     ST_REQUIRE((int64_t)h.n_out <= max_out, "strided: %u output voxels exceed max_out=%lld", h.n_out, (long long)max_out);
     *n_out_host = h.n_out;
@@ -330,16 +352,27 @@ extern "C" int st_build_strided_outputs(const int32_t* coords, int64_t n, int64_
     return ST_OK;
 }
 
+extern "C" int st_build_strided_outputs(const int32_t* coords, int64_t n, int64_t max_out, int32_t* out_coords,
+                                        unsigned long long* ckeys, unsigned* cvals, int64_t ccap, int64_t* n_out_host,
+                                        int32_t* extent_host /*[3] max (z,y,x) coordinate*/, void* ws, int64_t ws_bytes,
+                                        void* stream_) {
+    return st_build_strided_outputs_seg(coords, n, max_out, out_coords, ckeys, cvals, ccap, n_out_host, extent_host, nullptr, 1,
+                                        nullptr, ws, ws_bytes, stream_);
+}
+
 // Phase 2: the two neighbour tables of the pair set: nbr_down [27][n_out] (fine rows), nbr_up [27][n] (coarse rows);
 // up_order (optional, n + 16 words: the tail is scratch): the fine rows grouped by coordinate parity and tagged with
 // their class, the row order the inverse convolution should be launched with (st_sparse_conv_fwd's row_order).
-extern "C" int st_build_strided_rulebook(const int32_t* coords, int64_t n, const unsigned long long* fkeys,
+// Batched form: blk_seg / ext_dev as given to / filled by st_build_strided_outputs_seg (NULL: one cloud, extent_host).
+extern "C" int st_build_strided_rulebook_seg(const int32_t* coords, int64_t n, const unsigned long long* fkeys,
                                          const unsigned* fvals, int64_t fcap, const int32_t* out_coords, int64_t n_out,
                                          const unsigned long long* ckeys, const unsigned* cvals, int64_t ccap,
                                          const int32_t* extent_host, int32_t* nbr_down, int32_t* nbr_up,
-                                         int32_t* up_order /*[n + 16] or NULL*/, void* stream_) {
+                                         int32_t* up_order /*[n + 16] or NULL*/, const int32_t* blk_seg, const int32_t* ext_dev,
+                                         void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n == 0) return ST_OK;
+    ST_REQUIRE((blk_seg == nullptr) == (ext_dev == nullptr), "strided: blk_seg and ext_dev go together");
     ST_REQUIRE(up_order == nullptr || n < (1ll << 28), "strided: the tagged row order holds at most 2^28 rows");
     RbShape osh;
     for (int a = 0; a < 3; a++) osh.v[a] = extent_host[a] / 2 + 1;
@@ -348,10 +381,19 @@ extern "C" int st_build_strided_rulebook(const int32_t* coords, int64_t n, const
     uint32_t* pc = up_order ? reinterpret_cast<uint32_t*>(up_order + n) : nullptr;  // 8 class counts + 8 cursors
     if (pc) (void)hipMemsetAsync(pc, 0, 16 * sizeof(uint32_t), stream);
     hipLaunchKernelGGL(k_rb_up_nbr, dim3(rb_grid(n)), dim3(RB_BLOCK), 0, stream, coords, n, osh, ckeys, cvals,
-                       (unsigned long long)ccap, nbr_up, nbr_down, n_out, pc);
+                       (unsigned long long)ccap, nbr_up, nbr_down, n_out, pc, blk_seg, ext_dev);
     if (pc)
         hipLaunchKernelGGL(k_rb_parity_order, dim3(rb_grid(n) < RB_ORDER_BLOCKS ? rb_grid(n) : RB_ORDER_BLOCKS), dim3(RB_BLOCK), 0, stream, coords,
                            n, (const uint32_t*)pc, pc + 8, up_order);
     ST_CHECK_LAUNCH();
     return ST_OK;
+}
+
+extern "C" int st_build_strided_rulebook(const int32_t* coords, int64_t n, const unsigned long long* fkeys,
+                                         const unsigned* fvals, int64_t fcap, const int32_t* out_coords, int64_t n_out,
+                                         const unsigned long long* ckeys, const unsigned* cvals, int64_t ccap,
+                                         const int32_t* extent_host, int32_t* nbr_down, int32_t* nbr_up,
+                                         int32_t* up_order /*[n + 16] or NULL*/, void* stream_) {
+    return st_build_strided_rulebook_seg(coords, n, fkeys, fvals, fcap, out_coords, n_out, ckeys, cvals, ccap, extent_host,
+                                         nbr_down, nbr_up, up_order, nullptr, nullptr, stream_);
 }

@@ -40,6 +40,7 @@ struct SkArgs {
     int C;
     int64_t m;
     const int* comp_off;  // [C+1] offsets into the renumbered vertex space
+    const int* comp_seg;  // [C] cloud of each component in a batched call (nullptr: one cloud) -- selects the slab of grid cells
     int* comp_of;         // [m] component of each vertex
     const float* pts;     // [m,3] medial points
     const float* rad;     // [m] raw radius (cloud.radius)
@@ -394,6 +395,7 @@ __device__ __forceinline__ bool sk_claim_items(const SkArgs& A, int c, int base,
                                                bool path_in_lds, int slice, int nslice, unsigned* lq, unsigned* lq_n,
                                                unsigned* lq_base, bool keep_local) {
     const StGrid* g = A.grid;
+    const int xoff = A.comp_seg ? A.comp_seg[c] * g->seg_dim0 : 0;  // this cloud's slab of cells
     const float rp2 = rp * rp;
     int reach = rp > 0.0f ? (int)ceilf(rp / g->cell) : 0;
     if (reach < 1) reach = 1;
@@ -408,11 +410,11 @@ __device__ __forceinline__ bool sk_claim_items(const SkArgs& A, int c, int base,
         const float* pv = A.pts + 3 * (int64_t)(base + (path_in_lds ? path[qi] : ld(&path[qi])));
         const int x = (int)floorf((pv[0] - g->lo[0]) / g->cell) - reach + rr / side;
         const int y = (int)floorf((pv[1] - g->lo[1]) / g->cell) - reach + rr % side;
-        if (x < 0 || x >= g->dim[0] || y < 0 || y >= g->dim[1]) continue;
+        if (x < 0 || x >= g->seg_dim0 || y < 0 || y >= g->dim[1]) continue;
         const int cz = (int)floorf((pv[2] - g->lo[2]) / g->cell);
         const int z0 = st_max(cz - reach, 0), z1 = st_min(cz + reach, g->dim[2] - 1);
         if (z0 > z1) continue;
-        const int64_t row = ((int64_t)x * g->dim[1] + y) * g->dim[2];
+        const int64_t row = ((int64_t)(xoff + x) * g->dim[1] + y) * g->dim[2];
         const uint32_t s = A.cell_start[row + z0], e = A.cell_start[row + z1 + 1];
         for (uint32_t t = s + sub; t < e; t += 16) {
             const float4 r4 = A.recs[t];
@@ -562,6 +564,7 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
     unsigned* cmask = A.stamp + base;  // speculation marks (zeroed by k_sk_lift_init, zero again after every round)
     const float4* __restrict__ recs = A.recs;
     const StGrid* g = A.grid;
+    const int xoff = A.comp_seg ? A.comp_seg[c] * g->seg_dim0 : 0;  // this cloud's slab of grid cells (batched call)
     // a long path left over from the previous launch: k_sk_claim filled `touched`
     {
         const int plen = A.s_len[c];
@@ -698,7 +701,7 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
                 rp = st_ord2f(S.rk);
                 int reach = rp > 0.0f ? (int)ceilf(rp / g->cell) : 0;
                 if (reach < 1) reach = 1;
-                const int x0 = st_max(S.lo[0] - reach, 0), x1 = st_min(S.hi[0] + reach, g->dim[0] - 1);
+                const int x0 = st_max(S.lo[0] - reach, 0), x1 = st_min(S.hi[0] + reach, g->seg_dim0 - 1);
                 const int y0 = st_max(S.lo[1] - reach, 0), y1 = st_min(S.hi[1] + reach, g->dim[1] - 1);
                 const int z0 = st_max(S.lo[2] - reach, 0), z1 = st_min(S.hi[2] + reach, g->dim[2] - 1);
                 const int nx = x1 - x0 + 1, ny = y1 - y0 + 1;
@@ -711,7 +714,7 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
                         const int rr = ch * 64 + lane;
                         cnt[ch] = 0u; first[ch] = 0u;
                         if (rr < nrows) {
-                            const int64_t row = ((int64_t)(x0 + rr / ny) * g->dim[1] + (y0 + rr % ny)) * g->dim[2];
+                            const int64_t row = ((int64_t)(xoff + x0 + rr / ny) * g->dim[1] + (y0 + rr % ny)) * g->dim[2];
                             first[ch] = A.cell_start[row + z0];
                             cnt[ch] = A.cell_start[row + z1 + 1] - first[ch];
                         }
@@ -967,7 +970,7 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
         bool small = fits;
         int nrows_s = 0, ncand = 0;
         if (small) {
-            const int x0 = st_max(s_lo[0] - reach, 0), x1 = st_min(s_hi[0] + reach, g->dim[0] - 1);
+            const int x0 = st_max(s_lo[0] - reach, 0), x1 = st_min(s_hi[0] + reach, g->seg_dim0 - 1);
             const int y0 = st_max(s_lo[1] - reach, 0), y1 = st_min(s_hi[1] + reach, g->dim[1] - 1);
             const int z0 = st_max(s_lo[2] - reach, 0), z1 = st_min(s_hi[2] + reach, g->dim[2] - 1);
             const int nx = x1 - x0 + 1, ny = y1 - y0 + 1;
@@ -975,7 +978,7 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
             small = nrows <= (int)blockDim.x;  // one lane per (x, y) row of cells; z is contiguous in memory
             uint32_t cnt = 0, first = 0;
             if (small && tid < nrows) {
-                const int64_t row = ((int64_t)(x0 + tid / ny) * g->dim[1] + (y0 + tid % ny)) * g->dim[2];
+                const int64_t row = ((int64_t)(xoff + x0 + tid / ny) * g->dim[1] + (y0 + tid % ny)) * g->dim[2];
                 first = A.cell_start[row + z0];
                 cnt = A.cell_start[row + z1 + 1] - first;
             }
@@ -1122,7 +1125,9 @@ struct SkLayout {
     int64_t gws_bytes;
 };
 
-static void sk_layout(StArena& a, int64_t m, int64_t C, SkLayout* s) {
+static inline int64_t sk_grid_cells(int nseg) { return SK_GRID_CELLS * (nseg < 1 ? 1 : (nseg > 8 ? 8 : nseg)); }
+
+static void sk_layout(StArena& a, int64_t m, int64_t C, SkLayout* s, int nseg = 1) {
     s->dist_ord = a.take<unsigned>(m);
     s->stamp = a.take<unsigned>(m);
     s->q0 = a.take<unsigned>(m + C);
@@ -1154,9 +1159,9 @@ static void sk_layout(StArena& a, int64_t m, int64_t C, SkLayout* s) {
     s->blk_count = a.take<int>(C);
     s->blk_comp = a.take<int>(C + st_div_up(m, 1024));
     s->g = a.take<StGrid>(1);
-    s->cell_start = a.take<uint32_t>(SK_GRID_CELLS + 1);
+    s->cell_start = a.take<uint32_t>(sk_grid_cells(nseg) + 1);
     s->recs = a.take<float4>(m);
-    s->gws_bytes = st_grid_ws_bytes(m, SK_GRID_CELLS);
+    s->gws_bytes = st_grid_ws_bytes(m, sk_grid_cells(nseg));
     s->gws = a.take<char>(s->gws_bytes);
 }
 
@@ -1185,12 +1190,13 @@ extern "C" void st_debug_set_skeleton_param(int which, int value) {
 }
 extern "C" void st_debug_set_ticks(long long* device_ptr) { g_debug_ticks = device_ptr; }
 
-extern "C" int64_t st_skeleton_workspace_bytes(int64_t m, int64_t n_comp) {
+extern "C" int64_t st_skeleton_workspace_bytes_seg(int64_t m, int64_t n_comp, int nseg) {
     StArena a(nullptr, 0);
     SkLayout s;
-    sk_layout(a, m > 0 ? m : 1, n_comp > 0 ? n_comp : 1, &s);
+    sk_layout(a, m > 0 ? m : 1, n_comp > 0 ? n_comp : 1, &s, nseg);
     return a.used;
 }
+extern "C" int64_t st_skeleton_workspace_bytes(int64_t m, int64_t n_comp) { return st_skeleton_workspace_bytes_seg(m, n_comp, 1); }
 
 static inline unsigned sk_vgrid(int64_t m) {
     int64_t g = st_div_up(m > 0 ? m : 1, SK_WIDE_BLOCK);
@@ -1214,7 +1220,13 @@ static int sk_read(void* dst, const void* src, size_t bytes, hipStream_t stream)
 // levels; if stats_host[7] != 0 on entry, every k_sk_select launch is bracketed by HIP events on `stream` and
 // [4] = their summed duration in ns, [5] = number of launches (profiling aid for bench.py's roofline block);
 // [6] = branches of the cloud | path vertices << 32 (sizes st_assemble_branches' outputs without a read-back of its own).
-extern "C" int st_skeleton_components(int n_comp, const int32_t* comp_off, const int32_t* comp_size_host, int64_t m,
+//
+// Batched form (st_skeleton_components_seg): the components of `nseg` independent clouds in one call.  comp_seg [C] = cloud
+// of each component, vert_seg_off [nseg + 1] = the clouds' ranges in the renumbered vertex space (both device arrays,
+// from st_component_layout_seg).  Components never interact, so the only thing the batch shares is the claim grid, where
+// every cloud has its own slab of cells: each component's outputs are those of the one-cloud call.
+extern "C" int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, const int32_t* comp_seg,
+                                          const int32_t* vert_seg_off, int nseg, int64_t m,
                                       const float* pts, const float* rad, const float* ysurf, const uint32_t* row_off,
                                       const uint32_t* col, const float* wgt, float grid_cell, int stages, int block_threads,
                                       float* dist, int32_t* pred, int32_t* root_local, float* tree_dist,
@@ -1229,16 +1241,19 @@ extern "C" int st_skeleton_components(int n_comp, const int32_t* comp_off, const
     if (block_threads <= 0) block_threads = 1024;
     ST_REQUIRE(block_threads % 64 == 0 && block_threads <= 1024, "skeleton: block_threads must be a multiple of 64, <= 1024");
     ST_REQUIRE(m < (1ll << 28), "skeleton: at most 2^28 graph vertices");
+    ST_REQUIRE(nseg >= 1 && nseg <= ST_MAX_SEG, "skeleton: 1 <= clouds per batch <= %d", ST_MAX_SEG);
+    ST_REQUIRE(nseg == 1 || (comp_seg && vert_seg_off), "skeleton: a batch needs comp_seg and vert_seg_off");
+    if (nseg == 1) { comp_seg = nullptr; vert_seg_off = nullptr; }
     StArena a(ws, ws_bytes);
     SkLayout s;
-    sk_layout(a, m, n_comp, &s);
+    sk_layout(a, m, n_comp, &s, nseg);
     if (!a.ok() || !s.gws) {
         st_set_error("skeleton: workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)a.used);
         return ST_ERR_WORKSPACE;
     }
     SkArgs A;
     memset(&A, 0, sizeof(A));
-    A.C = n_comp; A.m = m; A.comp_off = comp_off; A.comp_of = s.comp_of; A.pts = pts; A.rad = rad; A.ysurf = ysurf;
+    A.C = n_comp; A.m = m; A.comp_off = comp_off; A.comp_seg = comp_seg; A.comp_of = s.comp_of; A.pts = pts; A.rad = rad; A.ysurf = ysurf;
     A.row_off = row_off; A.col = col; A.wgt = wgt; A.grid = s.g; A.cell_start = s.cell_start; A.recs = s.recs;
     A.dist = dist; A.pred = pred; A.root_local = root_local; A.tree_dist = tree_dist;
     A.branch_parent = branch_parent; A.branch_off = branch_off; A.branch_len = branch_len; A.n_branches = n_branches;
@@ -1311,11 +1326,20 @@ extern "C" int st_skeleton_components(int n_comp, const int32_t* comp_off, const
         const int nblk = (int)st_min64((int64_t)n_comp + st_div_up(m, 1024), (int64_t)n_comp * SK_MAX_CLAIM_BLOCKS);
         hipLaunchKernelGGL(k_sk_blk_tables, dim3(1), dim3(1024), 0, stream, A, s.blk_comp, s.blk_first, s.blk_count, nblk);
         // grid_cell < 0: cell = max(rad) / -grid_cell with the maximum reduced on the device (no host round trip)
-        ST_TRY(st_grid_build(pts, m, grid_cell, SK_GRID_CELLS, s.g, s.cell_start, s.recs, s.gws, s.gws_bytes, stream,
-                             grid_cell < 0.0f ? -1.0f : 0.0f, grid_cell < 0.0f ? rad : nullptr, grid_cell < 0.0f ? m : 0));
+        ST_TRY(st_grid_build(pts, m, grid_cell, sk_grid_cells(nseg), s.g, s.cell_start, s.recs, s.gws, s.gws_bytes, stream,
+                             grid_cell < 0.0f ? -1.0f : 0.0f, grid_cell < 0.0f ? rad : nullptr, grid_cell < 0.0f ? m : 0,
+                             vert_seg_off, nseg, vert_seg_off));
         int64_t iters = 0;
-        hipEvent_t ev[2 * SK_MAX_LAUNCH_BATCH];
-        if (time_select) for (int i = 0; i < 2 * SK_MAX_LAUNCH_BATCH; i++) (void)hipEventCreate(&ev[i]);
+        struct EventSet {  // destroyed on every way out of the select loop (early error returns included)
+            hipEvent_t e[2 * SK_MAX_LAUNCH_BATCH];
+            int n = 0;
+            bool create() { for (; n < 2 * SK_MAX_LAUNCH_BATCH; n++) if (hipEventCreate(&e[n]) != hipSuccess) return false; return true; }
+            ~EventSet() { for (int i = 0; i < n; i++) (void)hipEventDestroy(e[i]); }
+        } evs;
+        hipEvent_t* ev = evs.e;
+        bool timing_ok = true;  // a failed event call must not put garbage into the roofline numbers
+        if (time_select && !evs.create()) { (void)hipGetLastError(); timing_ok = false; }
+        const bool time_sel = time_select && timing_ok;
         double select_ms = 0.0;
         bool plateaus_pending = defer_plateaus;
         for (;;) {  // second pass only if the deferred check found plateau vertices: predecessors completed, selection redone
@@ -1342,17 +1366,17 @@ extern "C" int st_skeleton_components(int n_comp, const int32_t* comp_off, const
             for (int batch = g_launch_batch;; batch = batch > 4 ? 4 : batch) {  // launch pairs per counter read-back: a long first
                 // batch, short ones for the stragglers (a finished launch pair still costs its ~10 us of launch latency)
                 for (int b = 0; b < batch; b++, iters++) {
-                    if (time_select) (void)hipEventRecord(ev[2 * b], stream);
+                    if (time_sel) (void)hipEventRecord(ev[2 * b], stream);
                     hipLaunchKernelGGL(k_sk_select, dim3((unsigned)n_comp), dim3((unsigned)block_threads), 0, stream, A);
-                    if (time_select) (void)hipEventRecord(ev[2 * b + 1], stream);
+                    if (time_sel) (void)hipEventRecord(ev[2 * b + 1], stream);
                     hipLaunchKernelGGL(k_sk_claim, dim3((unsigned)nblk), dim3(SK_WIDE_BLOCK), 0, stream, A);
                 }
                 ST_TRY(sk_read(h, s.cnt, sizeof(unsigned) * 8, stream));
-                if (time_select)
+                if (time_sel)
                     for (int b = 0; b < batch; b++) {
                         float ms = 0.0f;
-                        (void)hipEventElapsedTime(&ms, ev[2 * b], ev[2 * b + 1]);
-                        select_ms += ms;
+                        if (hipEventElapsedTime(&ms, ev[2 * b], ev[2 * b + 1]) == hipSuccess) select_ms += ms;
+                        else { (void)hipGetLastError(); timing_ok = false; }
                     }
                 if (plateaus_pending) {  // first read-back after the deferred predecessor check
                     plateaus_pending = false;
@@ -1368,15 +1392,27 @@ extern "C" int st_skeleton_components(int n_comp, const int32_t* comp_off, const
             ST_TRY(sk_read(h, s.cnt, sizeof(unsigned) * 8, stream));
             ST_TRY(resolve_plateaus(h[3]));
         }
-        if (time_select) {
-            for (int i = 0; i < 2 * SK_MAX_LAUNCH_BATCH; i++) (void)hipEventDestroy(ev[i]);
-            stats_host[4] = (int64_t)(select_ms * 1e6);
-            stats_host[5] = iters;
+        if (time_select) {  // [5] = 0 tells the caller that no (trustworthy) timing was taken
+            stats_host[4] = timing_ok ? (int64_t)(select_ms * 1e6) : 0;
+            stats_host[5] = timing_ok ? iters : 0;
         }
         if (stats_host) { stats_host[2] = iters; stats_host[3] = SK_ANC; stats_host[6] = ((int64_t)h[7] << 32) | (int64_t)h[6]; }
     }
     ST_CHECK_LAUNCH();
     return ST_OK;
+}
+
+extern "C" int st_skeleton_components(int n_comp, const int32_t* comp_off, const int32_t* comp_size_host, int64_t m,
+                                      const float* pts, const float* rad, const float* ysurf, const uint32_t* row_off,
+                                      const uint32_t* col, const float* wgt, float grid_cell, int stages, int block_threads,
+                                      float* dist, int32_t* pred, int32_t* root_local, float* tree_dist,
+                                      int32_t* branch_parent, int32_t* branch_off, int32_t* branch_len, int32_t* n_branches,
+                                      int32_t* path_verts, int32_t* branch_of, int64_t* stats_host, void* ws,
+                                      int64_t ws_bytes, void* stream_) {
+    (void)comp_size_host;
+    return st_skeleton_components_seg(n_comp, comp_off, nullptr, nullptr, 1, m, pts, rad, ysurf, row_off, col, wgt, grid_cell,
+                                      stages, block_threads, dist, pred, root_local, tree_dist, branch_parent, branch_off,
+                                      branch_len, n_branches, path_verts, branch_of, stats_host, ws, ws_bytes, stream_);
 }
 
 // Named single-stage entry points: the same call with one stage selected.

@@ -11,29 +11,65 @@
 // All float arithmetic that decides an integer (block id, membership, voxel coordinate, grid
 // size, inner mask) is float32 in the same operation order as the oracle (oracle/voxel_oracle.py).
 #include "st_common.h"
+#include "st_grid.h"  // ST_MAX_SEG
 
 #define VX_BLOCK 256
-#define VX_TABLE_CAP 32768  // max cells of the block-id bounding box (32^3 blocks of 4 m = 128 m)
+#define VX_TABLE_CAP 32768  // max cells of the block-id bounding box of ONE cloud (32^3 blocks of 4 m = 128 m)
 #define VX_LDS_BLOCKS 128
 
+// Batched calls: `nseg` independent clouds in one point array, cloud s = points [seg_off[s], seg_off[s+1]).  Every
+// streaming kernel runs with blockIdx.y = cloud; blocks are numbered cloud by cloud (inside a cloud in torch.unique
+// order), so the collated batch is the concatenation of the one-cloud batches with the block index shifted.
 struct VxState {
-    int lo[3], hi[3];
+    int lo[3], hi[3];    // block-id bounding box over ALL clouds of the call
     uint32_t n_blocks;
     uint32_t n_vox;
-    uint32_t overflow;  // bit0: block table, bit1: max_blocks, bit2: hash full
+    uint32_t overflow;   // bit0: block table, bit1: max_blocks, bit2: hash full
+    uint32_t seg_blk_off[ST_MAX_SEG + 1];  // first block of every cloud
+    uint32_t seg_vox_off[ST_MAX_SEG + 1];  // first voxel of every cloud (written by the gather pass)
 };
 
 struct VxParams {
     float bs;          // block size
+    float bs_inv;      // 1 / bs when bs is a power of two (then v * bs_inv == v / bs exactly), else 0
     float half_outer;  // (block + 2*buffer)/2 rounded to float
     float half_inner;  // block/2
     float bs_half;     // block/2 (centre offset)
     float vs;          // voxel size
     int min_points;
     int max_blocks;
+    int nseg;
 };
 
-__device__ __forceinline__ int vx_block_id(float v, float bs) { return (int)floorf(v / bs); }
+__device__ __forceinline__ int vx_block_id(float v, const VxParams& p) {
+    return (int)floorf(p.bs_inv != 0.0f ? v * p.bs_inv : v / p.bs);
+}
+
+// Deals the points [i0, i1) of a cloud over the launch, FOUR CONSECUTIVE POINTS PER LANE per step: three 16-byte loads
+// (48 contiguous bytes) instead of twelve dword loads, all issued before the first point is looked at.
+// fn(i, x, y, z) is called for every point of the range.
+template <class F>
+__device__ __forceinline__ void vx_stream_points(const float* __restrict__ xyz, int64_t n_total, int64_t i0, int64_t i1, F fn) {
+    const bool vec = (((uintptr_t)xyz) & 15) == 0;
+    const int64_t step = (int64_t)gridDim.x * blockDim.x * 4;
+    for (int64_t base = (i0 & ~(int64_t)3) + ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; base < i1; base += step) {
+        float c[12];
+        if (vec && base + 4 <= n_total) {
+            const float4* v = reinterpret_cast<const float4*>(xyz + 3 * base);
+            const float4 f0 = v[0], f1 = v[1], f2 = v[2];
+            c[0] = f0.x; c[1] = f0.y; c[2] = f0.z; c[3] = f0.w; c[4] = f1.x; c[5] = f1.y; c[6] = f1.z; c[7] = f1.w;
+            c[8] = f2.x; c[9] = f2.y; c[10] = f2.z; c[11] = f2.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 12; j++) c[j] = base + j / 3 < n_total ? xyz[3 * base + j] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int64_t i = base + j;
+            if (i >= i0 && i < i1) fn(i, c[3 * j], c[3 * j + 1], c[3 * j + 2]);
+        }
+    }
+}
 
 __global__ void k_vx_init(VxState* st) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -42,18 +78,27 @@ __global__ void k_vx_init(VxState* st) {
     }
 }
 
-__global__ void __launch_bounds__(VX_BLOCK) k_vx_bbox(const float* xyz, int64_t n, float bs, VxState* st) {
+__device__ __forceinline__ int vx_wave_min(int v) { for (int d = 32; d > 0; d >>= 1) { const int o = __shfl_xor(v, d); v = o < v ? o : v; } return v; }
+__device__ __forceinline__ int vx_wave_max(int v) { for (int d = 32; d > 0; d >>= 1) { const int o = __shfl_xor(v, d); v = o > v ? o : v; } return v; }
+
+__global__ void __launch_bounds__(VX_BLOCK) k_vx_bbox(const float* xyz, int64_t n, const int* seg_off, VxParams p, VxState* st) {
     __shared__ int lo[3], hi[3];
     if (threadIdx.x < 3) { lo[threadIdx.x] = 0x7fffffff; hi[threadIdx.x] = (int)0x80000000; }
     __syncthreads();
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        for (int a = 0; a < 3; a++) {
-            int q = vx_block_id(xyz[3 * i + a], bs);
-            if (q < lo[a]) atomicMin(&lo[a], q);
-            if (q > hi[a]) atomicMax(&hi[a], q);
-        }
+    const int seg = blockIdx.y;
+    const int64_t i0 = seg_off ? seg_off[seg] : 0, i1 = seg_off ? seg_off[seg + 1] : n;
+    int l[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, h[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
+    vx_stream_points(xyz, n, i0, i1, [&](int64_t, float x, float y, float z) {
+        const int q[3] = {vx_block_id(x, p), vx_block_id(y, p), vx_block_id(z, p)};
+#pragma unroll
+        for (int a = 0; a < 3; a++) { l[a] = q[a] < l[a] ? q[a] : l[a]; h[a] = q[a] > h[a] ? q[a] : h[a]; }
+    });
+#pragma unroll
+    for (int a = 0; a < 3; a++) { l[a] = vx_wave_min(l[a]); h[a] = vx_wave_max(h[a]); }
+    if ((threadIdx.x & 63) == 0)
+        for (int a = 0; a < 3; a++) { atomicMin(&lo[a], l[a]); atomicMax(&hi[a], h[a]); }
     __syncthreads();
-    if (threadIdx.x < 3) { atomicMin(&st->lo[threadIdx.x], lo[threadIdx.x]); atomicMax(&st->hi[threadIdx.x], hi[threadIdx.x]); }
+    if (threadIdx.x < 3 && lo[threadIdx.x] <= hi[threadIdx.x]) { atomicMin(&st->lo[threadIdx.x], lo[threadIdx.x]); atomicMax(&st->hi[threadIdx.x], hi[threadIdx.x]); }
 }
 
 __device__ __forceinline__ bool vx_dims(const VxState* st, int* d) {
@@ -63,42 +108,48 @@ __device__ __forceinline__ bool vx_dims(const VxState* st, int* d) {
 }
 
 #define VX_LDS_CELLS 2048
-__global__ void __launch_bounds__(VX_BLOCK) k_vx_hist(const float* xyz, int64_t n, float bs, VxState* st, int* table) {
+__global__ void __launch_bounds__(VX_BLOCK) k_vx_hist(const float* xyz, int64_t n, const int* seg_off, VxParams p, VxState* st,
+                                                      int* table) {
     __shared__ int h[VX_LDS_CELLS];
     int d[3];
-    if (!vx_dims(st, d)) { if (threadIdx.x == 0 && blockIdx.x == 0) atomicOr(&st->overflow, 1u); return; }
+    if (!vx_dims(st, d)) { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) atomicOr(&st->overflow, 1u); return; }
     // a tree spans a few dozen blocks: count in LDS, flush once per workgroup (global atomics on a
     // handful of words would serialise a million points)
     const int ncell = d[0] * d[1] * d[2];
+    const int seg = blockIdx.y;
+    int* tab = table + (int64_t)seg * ncell;
+    const int64_t i0 = seg_off ? seg_off[seg] : 0, i1 = seg_off ? seg_off[seg + 1] : n;
     const bool use_lds = ncell <= VX_LDS_CELLS;
     if (use_lds) for (int c = threadIdx.x; c < ncell; c += blockDim.x) h[c] = 0;
     __syncthreads();
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        int cx = vx_block_id(xyz[3 * i], bs) - st->lo[0], cy = vx_block_id(xyz[3 * i + 1], bs) - st->lo[1],
-            cz = vx_block_id(xyz[3 * i + 2], bs) - st->lo[2];
-        const int c = (cx * d[1] + cy) * d[2] + cz;
-        if (use_lds) atomicAdd(&h[c], 1); else atomicAdd(&table[c], 1);
-    }
+    const int l0 = st->lo[0], l1 = st->lo[1], l2 = st->lo[2];
+    vx_stream_points(xyz, n, i0, i1, [&](int64_t, float x, float y, float z) {
+        const int c = ((vx_block_id(x, p) - l0) * d[1] + (vx_block_id(y, p) - l1)) * d[2] + (vx_block_id(z, p) - l2);
+        if (use_lds) atomicAdd(&h[c], 1); else atomicAdd(&tab[c], 1);
+    });
     __syncthreads();
-    if (use_lds) for (int c = threadIdx.x; c < ncell; c += blockDim.x) if (h[c]) atomicAdd(&table[c], h[c]);
+    if (use_lds) for (int c = threadIdx.x; c < ncell; c += blockDim.x) if (h[c]) atomicAdd(&tab[c], h[c]);
 }
 
-// single workgroup: counts -> block rank (or -1), centres, bbox init
+// single workgroup: counts -> block rank (or -1), centres, bbox init; cells are walked cloud by cloud
 __global__ void __launch_bounds__(VX_BLOCK) k_vx_blocks(VxState* st, int* table, VxParams p, float* centres, unsigned* blk_lo,
-                                                        unsigned* blk_hi) {
+                                                        unsigned* blk_hi, int32_t* blk_seg) {
     __shared__ uint32_t lds[VX_BLOCK / 64 + 1];
     int d[3];
     if (!vx_dims(st, d)) return;
-    int ncell = d[0] * d[1] * d[2];
+    const int ncell = d[0] * d[1] * d[2];
+    const int64_t total_cells = (int64_t)ncell * p.nseg;
     uint32_t carry = 0;
-    for (int base = 0; base < ncell; base += VX_BLOCK) {
-        int c = base + threadIdx.x;
-        uint32_t keep = (c < ncell && table[c] > p.min_points) ? 1u : 0u;
+    for (int64_t base = 0; base < total_cells; base += VX_BLOCK) {
+        const int64_t g = base + threadIdx.x;
+        const int seg = (int)(g / ncell), c = (int)(g % ncell);
+        uint32_t keep = (g < total_cells && table[g] > p.min_points) ? 1u : 0u;
         uint32_t total;
         uint32_t rank = block_exclusive_scan(keep, lds, &total) + carry;
-        if (c < ncell) {
+        if (g < total_cells) {
+            if (c == 0) st->seg_blk_off[seg] = rank < (uint32_t)p.max_blocks ? rank : (uint32_t)p.max_blocks;
             if (keep && (int)rank < p.max_blocks) {
-                table[c] = (int)rank;
+                table[g] = (int)rank;
                 int cz = c % d[2], cy = (c / d[2]) % d[1], cx = c / (d[2] * d[1]);
                 float id[3] = {(float)(cx + st->lo[0]), (float)(cy + st->lo[1]), (float)(cz + st->lo[2])};
                 for (int a = 0; a < 3; a++) {
@@ -106,14 +157,16 @@ __global__ void __launch_bounds__(VX_BLOCK) k_vx_blocks(VxState* st, int* table,
                     blk_lo[3 * rank + a] = 0xffffffffu;
                     blk_hi[3 * rank + a] = 0u;
                 }
+                if (blk_seg) blk_seg[rank] = seg;
             } else {
-                table[c] = -1;
+                table[g] = -1;
             }
         }
         carry += total;
     }
     if (threadIdx.x == 0) {
         st->n_blocks = carry;
+        st->seg_blk_off[p.nseg] = carry < (uint32_t)p.max_blocks ? carry : (uint32_t)p.max_blocks;
         if ((int)carry > p.max_blocks) atomicOr(&st->overflow, 2u);
     }
 }
@@ -121,14 +174,15 @@ __global__ void __launch_bounds__(VX_BLOCK) k_vx_blocks(VxState* st, int* table,
 // Calls fn(b) for every kept block whose halo cube [c - half_outer, c + half_outer) holds p, in (x, y, z) block order.
 // The test is separable: per axis, which of the three neighbouring block columns hold the coordinate (the centre is
 // recomputed with the expression k_vx_blocks stores, so the decision is bit-identical to testing `centres`); only the
-// surviving combinations -- one for an interior point, up to eight near a block corner -- touch the block table.
+// surviving combinations -- one for an interior point, up to eight near a block corner -- touch the block table
+// (`table` = the slice of the point's own cloud).
 template <class F>
 __device__ __forceinline__ void vx_for_each_block(const float* pt, const VxState* st, const int* d, const int* table,
                                                   const VxParams& p, F fn) {
     int q[3];
     unsigned ok[3];
     for (int a = 0; a < 3; a++) {
-        q[a] = vx_block_id(pt[a], p.bs) - st->lo[a];
+        q[a] = vx_block_id(pt[a], p) - st->lo[a];
         ok[a] = 0;
         for (int o = -1; o <= 1; o++) {
             const int c = q[a] + o;
@@ -151,37 +205,39 @@ __device__ __forceinline__ void vx_for_each_block(const float* pt, const VxState
     }
 }
 
-__global__ void __launch_bounds__(VX_BLOCK) k_vx_minmax(const float* xyz, int64_t n, const VxState* st, const int* table,
-                                                        const float* centres, VxParams p, unsigned* blk_lo,
-                                                        unsigned* blk_hi) {
+__global__ void __launch_bounds__(VX_BLOCK) k_vx_minmax(const float* xyz, int64_t n, const int* seg_off, const VxState* st,
+                                                        const int* table, VxParams p, unsigned* blk_lo, unsigned* blk_hi) {
     __shared__ unsigned slo[VX_LDS_BLOCKS * 3], shi[VX_LDS_BLOCKS * 3];
     int d[3];
     if (!vx_dims(st, d)) return;
-    const int nb = (int)st_min<uint32_t>(st->n_blocks, (uint32_t)p.max_blocks);
+    const int seg = blockIdx.y;
+    const int* tab = table + (int64_t)seg * (d[0] * d[1] * d[2]);
+    const int64_t i0 = seg_off ? seg_off[seg] : 0, i1 = seg_off ? seg_off[seg + 1] : n;
+    const int b0 = (int)st->seg_blk_off[seg], nb = (int)st->seg_blk_off[seg + 1] - b0;  // this cloud's blocks
     const bool use_lds = nb <= VX_LDS_BLOCKS;
     if (use_lds)
         for (int i = threadIdx.x; i < nb * 3; i += blockDim.x) { slo[i] = 0xffffffffu; shi[i] = 0u; }
     __syncthreads();
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        float pt[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
-        vx_for_each_block(pt, st, d, table, p, [&](int b) {
+    vx_stream_points(xyz, n, i0, i1, [&](int64_t, float x, float y, float z) {
+        const float pt[3] = {x, y, z};
+        vx_for_each_block(pt, st, d, tab, p, [&](int b) {
             for (int a = 0; a < 3; a++) {
                 unsigned o = st_f2ord(pt[a]);
                 if (use_lds) {
-                    if (o < slo[3 * b + a]) atomicMin(&slo[3 * b + a], o);
-                    if (o > shi[3 * b + a]) atomicMax(&shi[3 * b + a], o);
+                    if (o < slo[3 * (b - b0) + a]) atomicMin(&slo[3 * (b - b0) + a], o);
+                    if (o > shi[3 * (b - b0) + a]) atomicMax(&shi[3 * (b - b0) + a], o);
                 } else {
                     atomicMin(&blk_lo[3 * b + a], o);
                     atomicMax(&blk_hi[3 * b + a], o);
                 }
             }
         });
-    }
+    });
     __syncthreads();
     if (use_lds)
         for (int i = threadIdx.x; i < nb * 3; i += blockDim.x) {
-            if (slo[i] != 0xffffffffu) atomicMin(&blk_lo[i], slo[i]);
-            if (shi[i] != 0u) atomicMax(&blk_hi[i], shi[i]);
+            if (slo[i] != 0xffffffffu) atomicMin(&blk_lo[3 * b0 + i], slo[i]);
+            if (shi[i] != 0u) atomicMax(&blk_hi[3 * b0 + i], shi[i]);
         }
 }
 
@@ -202,30 +258,42 @@ __device__ __forceinline__ bool vx_coord(const float* pt, int b, const unsigned*
 // (bit j of win[i] = the j-th block vx_for_each_block visits; at most 27); pass 2: emit winners from that mask -- no
 // second round of hash look-ups.
 template <int PASS>
-__global__ void __launch_bounds__(VX_BLOCK) k_vx_pass(const float* xyz, int64_t n, VxState* st, const int* table,
-                                                      VxParams p, const unsigned* blk_lo, const unsigned* blk_hi,
-                                                      unsigned long long* keys, unsigned* vals, unsigned long long cap,
-                                                      uint32_t* cnt_or_off, uint32_t* win, uint32_t* rec_b,
-                                                      uint32_t* rec_pt, int64_t max_voxels) {
+__global__ void __launch_bounds__(VX_BLOCK) k_vx_pass(const float* xyz, int64_t n, const int* seg_off, VxState* st,
+                                                      const int* table, VxParams p, const unsigned* blk_lo,
+                                                      const unsigned* blk_hi, unsigned long long* keys, unsigned* vals,
+                                                      unsigned long long cap, uint32_t* cnt_or_off, uint32_t* win,
+                                                      uint32_t* rec_b, uint32_t* rec_pt, int64_t max_voxels) {
     int d[3];
     if (!vx_dims(st, d)) return;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        uint32_t mine = 0, won = PASS == 2 ? win[i] : 0u;
-        if (PASS == 2 && won == 0u) continue;
-        float pt[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
-        uint32_t off = PASS == 2 ? cnt_or_off[i] : 0u;
-        int j = 0;
-        vx_for_each_block(pt, st, d, table, p, [&](int b) {
-            const uint32_t bit = 1u << j++;
-            if (PASS == 2) {
+    const int seg = blockIdx.y;
+    const int* tab = table + (int64_t)seg * (d[0] * d[1] * d[2]);
+    const int64_t i0 = seg_off ? seg_off[seg] : 0, i1 = seg_off ? seg_off[seg + 1] : n;
+    if (PASS == 2) {  // one lane per point: only the winners (one point in nine) have anything to do
+        for (int64_t i = i0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < i1; i += (int64_t)gridDim.x * blockDim.x) {
+            const uint32_t won = win[i];
+            if (won == 0u) continue;
+            const float pt[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+            const uint32_t off = cnt_or_off[i];
+            uint32_t mine = 0;
+            int j = 0;
+            vx_for_each_block(pt, st, d, tab, p, [&](int b) {
+                const uint32_t bit = 1u << j++;
                 if (!(won & bit)) return;
                 if ((int64_t)(off + mine) < max_voxels) {
                     rec_b[off + mine] = (uint32_t)b;
                     rec_pt[off + mine] = (uint32_t)i;
                 }
                 mine++;
-                return;
-            }
+            });
+        }
+        return;
+    }
+    vx_stream_points(xyz, n, i0, i1, [&](int64_t i, float x, float y, float z) {
+        const float pt[3] = {x, y, z};
+        uint32_t mine = 0, won = 0u;
+        int j = 0;
+        vx_for_each_block(pt, st, d, tab, p, [&](int b) {
+            const uint32_t bit = 1u << j++;
             int c[3];
             if (!vx_coord(pt, b, blk_lo, blk_hi, p.vs, c)) return;
             unsigned long long key = st_pack_key(b, c[2], c[1], c[0]);
@@ -237,7 +305,7 @@ __global__ void __launch_bounds__(VX_BLOCK) k_vx_pass(const float* xyz, int64_t 
             }
         });
         if (PASS == 1) { cnt_or_off[i] = mine; win[i] = won; }
-    }
+    });
 }
 
 __global__ void __launch_bounds__(VX_BLOCK) k_vx_iota(uint32_t* v, int64_t n) {
@@ -245,10 +313,12 @@ __global__ void __launch_bounds__(VX_BLOCK) k_vx_iota(uint32_t* v, int64_t n) {
         v[i] = (uint32_t)i;
 }
 
+// blk_seg (batched calls): cloud of every block -> the first voxel of every cloud lands in st->seg_vox_off
 __global__ void __launch_bounds__(VX_BLOCK) k_vx_gather(const float* xyz, const float* rgb, int64_t m, const uint32_t* sorted_b,
                                                         const uint32_t* order, const uint32_t* rec_pt, const float* centres,
                                                         VxParams p, const unsigned* blk_lo, const unsigned* blk_hi,
-                                                        float* feats, int32_t* coords, uint8_t* mask, int64_t* point_index) {
+                                                        float* feats, int32_t* coords, uint8_t* mask, int64_t* point_index,
+                                                        const int32_t* blk_seg, VxState* st) {
     for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += (int64_t)gridDim.x * blockDim.x) {
         int b = (int)sorted_b[j];
         int64_t i = rec_pt[order[j]];
@@ -268,7 +338,17 @@ __global__ void __launch_bounds__(VX_BLOCK) k_vx_gather(const float* xyz, const 
         coords[4 * j + 3] = c[0];
         mask[j] = inner ? 1 : 0;
         point_index[j] = i;
+        if (blk_seg) {  // cloud boundaries: voxel j opens every cloud after its predecessor's, up to its own
+            const int s = blk_seg[b], prev = j > 0 ? blk_seg[sorted_b[j - 1]] : -1;
+            for (int t = prev + 1; t <= s; t++) st->seg_vox_off[t] = (uint32_t)j;
+        }
     }
+}
+__global__ void k_vx_seg_vox_init(VxState* st, int nseg, const uint32_t* n_vox) {
+    for (int t = threadIdx.x; t <= nseg; t += blockDim.x) st->seg_vox_off[t] = *n_vox;  // clouds after the last voxel (and the end)
+}
+__global__ void k_vx_seg_out(const VxState* st, int nseg, int32_t* seg_vox_off, int32_t* seg_blk_off) {
+    for (int t = threadIdx.x; t <= nseg; t += blockDim.x) { seg_vox_off[t] = (int32_t)st->seg_vox_off[t]; seg_blk_off[t] = (int32_t)st->seg_blk_off[t]; }
 }
 
 static inline unsigned vx_grid(int64_t n) {
@@ -276,19 +356,22 @@ static inline unsigned vx_grid(int64_t n) {
     return (unsigned)(g < 4096 ? g : 4096);
 }
 
-// reductions flush a few words per workgroup with global atomics: fewer, longer-running workgroups
-static inline unsigned vx_grid_reduce(int64_t n) {
-    const unsigned g = vx_grid(n);
-    return g < 512 ? g : 512;
+// streaming kernels: four points per lane and step, blockIdx.y = cloud; `cap` bounds the workgroups per cloud (the
+// reductions flush a few words per workgroup with global atomics: fewer, longer-running workgroups)
+static inline dim3 vx_grid_seg(int64_t n, int nseg, int64_t cap) {
+    int64_t per = st_div_up(n > 0 ? n : 1, nseg);
+    int64_t g = st_div_up(st_div_up(per, 4), VX_BLOCK) + 1;  // + 1: the range of a cloud starts at its offset rounded down to 4
+    if (g > cap) g = cap;
+    return dim3((unsigned)g, (unsigned)nseg);
 }
 
-static int64_t vx_layout(StArena& a, int64_t n, int max_blocks, int64_t max_voxels, VxState** st, int** table,
+static int64_t vx_layout(StArena& a, int64_t n, int max_blocks, int64_t max_voxels, int nseg, VxState** st, int** table,
                          unsigned** blk_lo, unsigned** blk_hi, unsigned long long** keys, unsigned** vals, uint32_t** cnt, uint32_t** win,
                          uint32_t** rec_b, uint32_t** rec_pt, uint32_t** order, char** sub, int64_t* sub_bytes,
                          int64_t* cap) {
     *cap = st_next_pow2(2 * (max_voxels > 8 ? max_voxels : 8));
     *st = a.take<VxState>(1);
-    *table = a.take<int>(VX_TABLE_CAP);
+    *table = a.take<int>((int64_t)VX_TABLE_CAP * nseg);
     *blk_lo = a.take<unsigned>(3 * (int64_t)max_blocks);
     *blk_hi = a.take<unsigned>(3 * (int64_t)max_blocks);
     *keys = a.take<unsigned long long>(*cap);
@@ -304,66 +387,88 @@ static int64_t vx_layout(StArena& a, int64_t n, int max_blocks, int64_t max_voxe
     return a.used;
 }
 
-extern "C" int64_t st_voxelize_workspace_bytes(int64_t n_points, int max_blocks, int64_t max_voxels) {
+extern "C" int64_t st_voxelize_workspace_bytes_seg(int64_t n_points, int max_blocks, int64_t max_voxels, int nseg) {
     StArena a(nullptr, 0);
     VxState* st; int* table; unsigned *lo, *hi; unsigned long long* keys; unsigned* vals;
     uint32_t *cnt, *win, *rb, *rp, *ord; char* sub; int64_t sb, cap;
-    return vx_layout(a, n_points, max_blocks, max_voxels, &st, &table, &lo, &hi, &keys, &vals, &cnt, &win, &rb, &rp, &ord, &sub,
-                     &sb, &cap);
+    return vx_layout(a, n_points, max_blocks, max_voxels, nseg < 1 ? 1 : nseg, &st, &table, &lo, &hi, &keys, &vals, &cnt, &win, &rb,
+                     &rp, &ord, &sub, &sb, &cap);
+}
+extern "C" int64_t st_voxelize_workspace_bytes(int64_t n_points, int max_blocks, int64_t max_voxels) {
+    return st_voxelize_workspace_bytes_seg(n_points, max_blocks, max_voxels, 1);
 }
 
-extern "C" int st_voxelize_blocks(const float* xyz, const float* rgb, int64_t n, double voxel_size, double block_size,
-                                  double buffer_size, int min_points, int max_blocks, int64_t max_voxels, float* feats,
-                                  int32_t* coords, uint8_t* mask, int64_t* point_index, float* block_centres,
-                                  int64_t* n_voxels_out, int64_t* n_blocks_out, void* ws, int64_t ws_bytes,
-                                  void* stream_) {
+// Batched form: `nseg` clouds in one array (seg_off [nseg + 1], device int32).  Blocks are numbered cloud by cloud, the
+// voxels come out cloud by cloud; extra outputs (device, optional for nseg == 1): blk_seg [max_blocks] = cloud of every
+// block, seg_vox_off / seg_blk_off [nseg + 1] = first voxel / block of every cloud.  point_index holds positions in the
+// batched point array.  The part of cloud s equals what the one-cloud call returns for it (block ids shifted).
+extern "C" int st_voxelize_blocks_seg(const float* xyz, const float* rgb, int64_t n, const int32_t* seg_off, int nseg,
+                                      double voxel_size, double block_size, double buffer_size, int min_points, int max_blocks,
+                                      int64_t max_voxels, float* feats, int32_t* coords, uint8_t* mask, int64_t* point_index,
+                                      float* block_centres, int32_t* blk_seg, int32_t* seg_vox_off, int32_t* seg_blk_off,
+                                      int64_t* n_voxels_out, int64_t* n_blocks_out, void* ws, int64_t ws_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     ST_REQUIRE(n >= 0 && n < (1ll << 31), "voxelize: n_points out of range");
     ST_REQUIRE(voxel_size > 0 && block_size > 0 && buffer_size >= 0 && buffer_size < block_size,
                "voxelize: need voxel_size > 0, 0 <= buffer_size < block_size");
     ST_REQUIRE(max_blocks > 0 && max_blocks < 65536 && max_voxels > 0, "voxelize: bad capacities");
+    ST_REQUIRE(nseg >= 1 && nseg <= ST_MAX_SEG, "voxelize: 1 <= clouds per batch <= %d", ST_MAX_SEG);
+    ST_REQUIRE(nseg == 1 || (seg_off && blk_seg && seg_vox_off && seg_blk_off), "voxelize: a batch needs seg_off and the per-cloud outputs");
+    if (nseg == 1) seg_off = nullptr;
     *n_voxels_out = 0;
     *n_blocks_out = 0;
-    if (n == 0) return ST_OK;
+    if (n == 0) {
+        if (seg_vox_off) (void)hipMemsetAsync(seg_vox_off, 0, (nseg + 1) * sizeof(int32_t), stream);
+        if (seg_blk_off) (void)hipMemsetAsync(seg_blk_off, 0, (nseg + 1) * sizeof(int32_t), stream);
+        return ST_OK;
+    }
 
     StArena a(ws, ws_bytes);
     VxState* st; int* table; unsigned *blk_lo, *blk_hi; unsigned long long* keys; unsigned* vals;
     uint32_t *cnt, *win, *rec_b, *rec_pt, *order; char* sub; int64_t sub_bytes, cap;
-    vx_layout(a, n, max_blocks, max_voxels, &st, &table, &blk_lo, &blk_hi, &keys, &vals, &cnt, &win, &rec_b, &rec_pt, &order, &sub,
-              &sub_bytes, &cap);
+    vx_layout(a, n, max_blocks, max_voxels, nseg, &st, &table, &blk_lo, &blk_hi, &keys, &vals, &cnt, &win, &rec_b, &rec_pt, &order,
+              &sub, &sub_bytes, &cap);
     if (!a.ok() || !sub) {
         st_set_error("voxelize: workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)a.used);
         return ST_ERR_WORKSPACE;
     }
     VxParams p;
     p.bs = (float)block_size;
+    {
+        int e = 0;
+        const float mant = frexpf(p.bs, &e);
+        p.bs_inv = mant == 0.5f ? 1.0f / p.bs : 0.0f;  // power of two: multiplying by the reciprocal IS the division
+    }
     p.half_outer = (float)((block_size + buffer_size * 2) / 2);
     p.half_inner = (float)(block_size / 2);
     p.bs_half = (float)(block_size / 2);
     p.vs = (float)voxel_size;
     p.min_points = min_points;
     p.max_blocks = max_blocks;
+    p.nseg = nseg;
 
-    const unsigned g = vx_grid(n);
+    const dim3 gs = vx_grid_seg(n, nseg, 4096), gr = vx_grid_seg(n, nseg, 512 / (nseg < 8 ? nseg : 8) + 8);
+    const dim3 g1((unsigned)st_min64(st_div_up(st_div_up(n, nseg), VX_BLOCK) + 1, 4096), (unsigned)nseg);  // one lane per point
     hipLaunchKernelGGL(k_vx_init, dim3(1), dim3(64), 0, stream, st);
-    (void)hipMemsetAsync(table, 0, VX_TABLE_CAP * sizeof(int), stream);
+    (void)hipMemsetAsync(table, 0, (int64_t)VX_TABLE_CAP * nseg * sizeof(int), stream);
     (void)hipMemsetAsync(keys, 0xff, cap * sizeof(unsigned long long), stream);
     (void)hipMemsetAsync(vals, 0xff, cap * sizeof(unsigned), stream);
-    hipLaunchKernelGGL(k_vx_bbox, dim3(vx_grid_reduce(n)), dim3(VX_BLOCK), 0, stream, xyz, n, p.bs, st);
-    hipLaunchKernelGGL(k_vx_hist, dim3(vx_grid_reduce(n)), dim3(VX_BLOCK), 0, stream, xyz, n, p.bs, st, table);
-    hipLaunchKernelGGL(k_vx_blocks, dim3(1), dim3(VX_BLOCK), 0, stream, st, table, p, block_centres, blk_lo, blk_hi);
-    hipLaunchKernelGGL(k_vx_minmax, dim3(g), dim3(VX_BLOCK), 0, stream, xyz, n, (const VxState*)st, (const int*)table,
-                       (const float*)block_centres, p, blk_lo, blk_hi);
-    hipLaunchKernelGGL((k_vx_pass<0>), dim3(g), dim3(VX_BLOCK), 0, stream, xyz, n, st, (const int*)table, p,
+    hipLaunchKernelGGL(k_vx_bbox, gr, dim3(VX_BLOCK), 0, stream, xyz, n, seg_off, p, st);
+    hipLaunchKernelGGL(k_vx_hist, gr, dim3(VX_BLOCK), 0, stream, xyz, n, seg_off, p, st, table);
+    hipLaunchKernelGGL(k_vx_blocks, dim3(1), dim3(VX_BLOCK), 0, stream, st, table, p, block_centres, blk_lo, blk_hi, blk_seg);
+    hipLaunchKernelGGL(k_vx_minmax, gr, dim3(VX_BLOCK), 0, stream, xyz, n, seg_off, (const VxState*)st, (const int*)table, p, blk_lo,
+                       blk_hi);
+    hipLaunchKernelGGL((k_vx_pass<0>), gs, dim3(VX_BLOCK), 0, stream, xyz, n, seg_off, st, (const int*)table, p,
                        (const unsigned*)blk_lo, (const unsigned*)blk_hi, keys, vals, (unsigned long long)cap, cnt, win, rec_b,
                        rec_pt, max_voxels);
-    hipLaunchKernelGGL((k_vx_pass<1>), dim3(g), dim3(VX_BLOCK), 0, stream, xyz, n, st, (const int*)table, p,
+    hipLaunchKernelGGL((k_vx_pass<1>), gs, dim3(VX_BLOCK), 0, stream, xyz, n, seg_off, st, (const int*)table, p,
                        (const unsigned*)blk_lo, (const unsigned*)blk_hi, keys, vals, (unsigned long long)cap, cnt, win, rec_b,
                        rec_pt, max_voxels);
     ST_TRY(st_exclusive_scan_u32(cnt, cnt, n, &st->n_vox, sub, sub_bytes, stream));
-    hipLaunchKernelGGL((k_vx_pass<2>), dim3(g), dim3(VX_BLOCK), 0, stream, xyz, n, st, (const int*)table, p,
+    hipLaunchKernelGGL((k_vx_pass<2>), g1, dim3(VX_BLOCK), 0, stream, xyz, n, seg_off, st, (const int*)table, p,
                        (const unsigned*)blk_lo, (const unsigned*)blk_hi, keys, vals, (unsigned long long)cap, cnt, win, rec_b,
                        rec_pt, max_voxels);
+    if (nseg > 1) hipLaunchKernelGGL(k_vx_seg_vox_init, dim3(1), dim3(128), 0, stream, st, nseg, (const uint32_t*)&st->n_vox);
     ST_CHECK_LAUNCH();
 
     VxState h;
@@ -377,16 +482,28 @@ extern "C" int st_voxelize_blocks(const float* xyz, const float* rgb, int64_t n,
     const int64_t m = h.n_vox;
     *n_voxels_out = m;
     *n_blocks_out = h.n_blocks;
-    if (m == 0) return ST_OK;
-
-    // stable sort by block id: records are already ascending in point index
-    int bits = 1;
-    while ((1u << bits) < h.n_blocks) bits++;
-    hipLaunchKernelGGL(k_vx_iota, dim3(vx_grid(m)), dim3(VX_BLOCK), 0, stream, order, m);
-    ST_TRY(st_radix_sort_pairs_u32(rec_b, order, m, bits, sub, sub_bytes, stream));
-    hipLaunchKernelGGL(k_vx_gather, dim3(vx_grid(m)), dim3(VX_BLOCK), 0, stream, xyz, rgb, m, (const uint32_t*)rec_b,
-                       (const uint32_t*)order, (const uint32_t*)rec_pt, (const float*)block_centres, p,
-                       (const unsigned*)blk_lo, (const unsigned*)blk_hi, feats, coords, mask, point_index);
+    if (m > 0) {
+        // stable sort by block id: records are already ascending in point index
+        int bits = 1;
+        while ((1u << bits) < h.n_blocks) bits++;
+        hipLaunchKernelGGL(k_vx_iota, dim3(vx_grid(m)), dim3(VX_BLOCK), 0, stream, order, m);
+        ST_TRY(st_radix_sort_pairs_u32(rec_b, order, m, bits, sub, sub_bytes, stream));
+        hipLaunchKernelGGL(k_vx_gather, dim3(vx_grid(m)), dim3(VX_BLOCK), 0, stream, xyz, rgb, m, (const uint32_t*)rec_b,
+                           (const uint32_t*)order, (const uint32_t*)rec_pt, (const float*)block_centres, p,
+                           (const unsigned*)blk_lo, (const unsigned*)blk_hi, feats, coords, mask, point_index,
+                           (const int32_t*)(nseg > 1 ? blk_seg : nullptr), st);
+    }
+    if (nseg > 1) hipLaunchKernelGGL(k_vx_seg_out, dim3(1), dim3(128), 0, stream, (const VxState*)st, nseg, seg_vox_off, seg_blk_off);
     ST_CHECK_LAUNCH();
     return ST_OK;
+}
+
+extern "C" int st_voxelize_blocks(const float* xyz, const float* rgb, int64_t n, double voxel_size, double block_size,
+                                  double buffer_size, int min_points, int max_blocks, int64_t max_voxels, float* feats,
+                                  int32_t* coords, uint8_t* mask, int64_t* point_index, float* block_centres,
+                                  int64_t* n_voxels_out, int64_t* n_blocks_out, void* ws, int64_t ws_bytes,
+                                  void* stream_) {
+    return st_voxelize_blocks_seg(xyz, rgb, n, nullptr, 1, voxel_size, block_size, buffer_size, min_points, max_blocks, max_voxels,
+                                  feats, coords, mask, point_index, block_centres, nullptr, nullptr, nullptr, n_voxels_out,
+                                  n_blocks_out, ws, ws_bytes, stream_);
 }

@@ -27,6 +27,10 @@ class Cloud:
     branch_ids: Optional[torch.Tensor] = None
     class_l: Optional[torch.Tensor] = None
     filename: Optional[Path] = None
+    # Additive: a BATCH of independent clouds in one set of arrays (Cloud.collate): cloud b owns the points
+    # [seg_off[b], seg_off[b+1]) -- the batch index the reference writes into coords[:,0] (model/sparse.py:40-61), carried
+    # from the input clouds to the skeletons so that a whole batch goes through ONE set of kernel launches.
+    seg_off: Optional[torch.Tensor] = None  # [B+1] int32 on the cloud's device; None = a single cloud
 
     def __post_init__(self):
         n = self.xyz.shape[0]
@@ -54,14 +58,49 @@ class Cloud:
         mask = mask.to(self.xyz.device)
         if mask.dtype == torch.bool:  # one compaction (one host sync) for all fields instead of one per field
             mask = mask.nonzero().view(-1)
-        return self._map(lambda t: t.index_select(0, mask))
+        out = self._map(lambda t: t.index_select(0, mask))
+        if self.seg_off is not None:  # batched: the clouds' new ranges (`mask` must keep the points in order)
+            out.seg_off = torch.searchsorted(mask, self.seg_off.to(mask.dtype)).to(torch.int32)
+        return out
+
+    # -- batches of independent clouds -------------------------------------------------------
+    @property
+    def n_seg(self) -> int:
+        return 1 if self.seg_off is None else int(self.seg_off.shape[0]) - 1
+
+    @staticmethod
+    def collate(clouds) -> "Cloud":
+        """B clouds -> one Cloud whose arrays are the concatenation, with `seg_off` marking the clouds."""
+        clouds = list(clouds)
+        dev = clouds[0].xyz.device
+        sizes = [0] + [len(c) for c in clouds]
+        kw = {}
+        for name in _PER_POINT:
+            parts = [getattr(c, name) for c in clouds]
+            if all(p is not None for p in parts):
+                kw[name] = torch.cat(parts)
+        off = torch.tensor(sizes, dtype=torch.int64).cumsum(0).to(torch.int32)
+        return Cloud(seg_off=off.to(dev, non_blocking=True), **kw)
+
+    def split(self):
+        """The clouds of a batch as separate Cloud objects (views; one host read of the offsets)."""
+        if self.seg_off is None:
+            return [self]
+        off = self.seg_off.tolist()
+        out = []
+        for a, b in zip(off[:-1], off[1:]):
+            out.append(Cloud(**{name: getattr(self, name)[a:b] for name in _PER_POINT if getattr(self, name) is not None}))
+        return out
 
     def filter_by_class(self, classes) -> "Cloud":
         wanted = torch.as_tensor(classes, device=self.class_l.device)
         return self.filter(torch.isin(self.class_l, wanted).view(-1))
 
     def to_device(self, device) -> "Cloud":
-        return self._map(lambda t: t.to(device))
+        out = self._map(lambda t: t.to(device))
+        if self.seg_off is not None:
+            out.seg_off = self.seg_off.to(device)
+        return out
 
     def cpu(self) -> "Cloud":
         return self.to_device(torch.device("cpu"))

@@ -25,14 +25,18 @@ class CentreCloud(Augmentation):
 
     def __call__(self, cloud: Cloud) -> Cloud:
         if cloud.xyz.is_cuda or _lib._ALLOW_HOST_POINTERS:
-            # one bounding-box pass + one translate pass (csrc/graph.hip st_centre_cloud), same float32 arithmetic
+            # one bounding-box pass + one translate pass (csrc/graph.hip st_centre_cloud), same float32 arithmetic; a batch
+            # (Cloud.collate) centres every cloud on its own box in the same two launches
             L = _lib.lib()
             xyz = cloud.xyz.contiguous().float()
             out = torch.empty_like(xyz)
-            ws = _lib.workspace(256, xyz.device)
-            _lib.check(L.st_centre_cloud(_lib.ptr(xyz), xyz.shape[0], _lib.ptr(out), _lib.ptr(ws), ws.numel(),
-                                         _lib.stream(xyz.device)))
-            return Cloud(out, cloud.rgb)
+            nseg = cloud.n_seg
+            ws = _lib.workspace(256 + 24 * nseg, xyz.device)
+            _lib.check(L.st_centre_cloud_seg(_lib.ptr(xyz), xyz.shape[0], _lib.ptr(cloud.seg_off), nseg, _lib.ptr(out), _lib.ptr(ws),
+                                             ws.numel(), _lib.stream(xyz.device)))
+            return Cloud(out, cloud.rgb, seg_off=cloud.seg_off)
+        if cloud.seg_off is not None:
+            raise _lib.StError("batched clouds are centred on the GPU only")
         centre, half = cloud.bbox  # host tensors (e.g. before upload): plain torch, as the reference writes it
         lift = torch.zeros(3, device=centre.device, dtype=centre.dtype)
         lift[1] = half[1]

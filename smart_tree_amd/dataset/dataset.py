@@ -28,32 +28,46 @@ class VoxelBatch:
     mask: torch.Tensor  # [M] bool: representative point inside the un-buffered block
     point_index: torch.Tensor  # [M] int64 index of the representative point in the input cloud
     block_centres: torch.Tensor  # [B,3] float32
+    # batched call (xyz holds several clouds, Cloud.collate): cloud of every block, first voxel / block of every cloud
+    blk_seg: Optional[torch.Tensor] = None  # [B] int32
+    seg_vox_off: Optional[torch.Tensor] = None  # [n_seg+1] int32
+    seg_blk_off: Optional[torch.Tensor] = None  # [n_seg+1] int32
+    n_seg: int = 1
 
 
 def voxelize_blocks(xyz: torch.Tensor, rgb: Optional[torch.Tensor], voxel_size: float, block_size: float = 4,
-                    buffer_size: float = 0.4, min_points: int = 20, max_blocks: int = 4096) -> VoxelBatch:
+                    buffer_size: float = 0.4, min_points: int = 20, max_blocks: int = 4096,
+                    seg_off: Optional[torch.Tensor] = None) -> VoxelBatch:
+    """seg_off ([B+1] int32, device): xyz holds B independent clouds; blocks are numbered cloud by cloud and the part of
+    every cloud equals the one-cloud result (block index shifted, `point_index` into the batched array)."""
     L = _lib.lib()
     dev = xyz.device
     xyz = xyz.contiguous().float()
     rgb = rgb.contiguous().float() if rgb is not None else None
     n = xyz.shape[0]
+    nseg = 1 if seg_off is None else int(seg_off.shape[0]) - 1
+    max_blocks = min(max_blocks * nseg, 65535)
     n_vox, n_blk = ctypes.c_int64(0), ctypes.c_int64(0)
+    i32 = lambda k: torch.empty((k,), dtype=torch.int32, device=dev)
+    blk_seg, seg_vox, seg_blk = (i32(max_blocks), i32(nseg + 1), i32(nseg + 1)) if nseg > 1 else (None, None, None)
     for cap in (3 * n + 1024, 8 * n + 1024):  # a point sits in <= 8 halo cubes
         feats = torch.empty((cap, 6), dtype=torch.float32, device=dev)
         coords = torch.empty((cap, 4), dtype=torch.int32, device=dev)
         mask = torch.empty((cap,), dtype=torch.uint8, device=dev)
         pidx = torch.empty((cap,), dtype=torch.int64, device=dev)
         centres = torch.empty((max_blocks, 3), dtype=torch.float32, device=dev)
-        ws = _lib.workspace(L.st_voxelize_workspace_bytes(n, max_blocks, cap), dev)
-        rc = L.st_voxelize_blocks(_lib.ptr(xyz), _lib.ptr(rgb), n, float(voxel_size), float(block_size),
-                                  float(buffer_size), int(min_points), int(max_blocks), cap, _lib.ptr(feats),
-                                  _lib.ptr(coords), _lib.ptr(mask), _lib.ptr(pidx), _lib.ptr(centres),
-                                  ctypes.byref(n_vox), ctypes.byref(n_blk), _lib.ptr(ws), ws.numel(), _lib.stream(dev))
+        ws = _lib.workspace(L.st_voxelize_workspace_bytes_seg(n, max_blocks, cap, nseg), dev)
+        rc = L.st_voxelize_blocks_seg(_lib.ptr(xyz), _lib.ptr(rgb), n, _lib.ptr(seg_off), nseg, float(voxel_size),
+                                      float(block_size), float(buffer_size), int(min_points), int(max_blocks), cap,
+                                      _lib.ptr(feats), _lib.ptr(coords), _lib.ptr(mask), _lib.ptr(pidx), _lib.ptr(centres),
+                                      _lib.ptr(blk_seg), _lib.ptr(seg_vox), _lib.ptr(seg_blk), ctypes.byref(n_vox),
+                                      ctypes.byref(n_blk), _lib.ptr(ws), ws.numel(), _lib.stream(dev))
         if rc == 0 or b"exceed max_voxels" not in L.st_last_error():
             break
     _lib.check(rc)
     m, b = n_vox.value, n_blk.value
-    return VoxelBatch(feats[:m], coords[:m], mask[:m].bool(), pidx[:m], centres[:b])
+    return VoxelBatch(feats[:m], coords[:m], mask[:m].bool(), pidx[:m], centres[:b],
+                      blk_seg[:b] if blk_seg is not None else None, seg_vox, seg_blk, nseg)
 
 
 class SingleTreeInference:
@@ -67,7 +81,8 @@ class SingleTreeInference:
         self.buffer_size = buffer_size
         self.min_points = min_points
         self.file_name = file_name
-        self.batch = voxelize_blocks(cloud.xyz, cloud.rgb, voxel_size, block_size, buffer_size, min_points)
+        self.batch = voxelize_blocks(cloud.xyz, cloud.rgb, voxel_size, block_size, buffer_size, min_points,
+                                     seg_off=cloud.seg_off)
         self.block_centres = self.batch.block_centres
 
     def __len__(self) -> int:

@@ -69,6 +69,7 @@ class Smart_Tree:
                 p = key[: -len(".running_mean")]
                 self.bn[p] = _Affine(sd, p, self.device)
         self.head_params = self._pack_heads(sd).to(self.device)
+        self.trace = None  # set to a dict to record every block's output (input, head{l}, enc{l}, dec{l}, tail{l}): parity tests
 
     # nn.Module look-alikes so reference call sites keep working
     def eval(self):
@@ -118,22 +119,32 @@ class Smart_Tree:
     def _ublock(self, prefix, x, pyr, level):
         """UBlock.forward (model_blocks.py:224-243)."""
         x = self._res_block(prefix + ".Head", x, pyr.subm[level])
+        self._record(f"head{level}", x)
         if level == self.depth:
             return x
         n_fine, n_coarse = x.shape[0], pyr.coords[level + 1].shape[0]
         z = self._conv(prefix + ".Encode.sequence.0", x, pyr.down[level], n_coarse, bn=prefix + ".Encode.sequence.1",
                        relu=True)
+        self._record(f"enc{level}", z)
         z = self._ublock(prefix + ".U", z, pyr, level + 1)
         d = self._conv(prefix + ".Decode.sequence.0", z, pyr.up[level], n_fine, bn=prefix + ".Decode.sequence.1",
                        relu=True, row_order=pyr.up_order[level] if pyr.up_order else None)
-        return self._res_block(prefix + ".Tail", x, pyr.subm[level], x1=d)
+        self._record(f"dec{level}", d)
+        x = self._res_block(prefix + ".Tail", x, pyr.subm[level], x1=d)
+        self._record(f"tail{level}", x)
+        return x
+
+    def _record(self, name, x):
+        if self.trace is not None:
+            self.trace[name] = x
 
     def features(self, sparse_input):
         """input conv + UNet -> [N, planes[0]] features of the finest level."""
         coords = sparse_input.indices.contiguous()
         feats = sparse_input.features.contiguous().float()
-        pyr = ops.build_pyramid(coords, self.depth)
+        pyr = ops.build_pyramid(coords, self.depth, getattr(sparse_input, "blk_seg", None), getattr(sparse_input, "n_seg", 1))
         x = self._conv("input_conv.sequence.0", feats, None, feats.shape[0], bn="input_conv.sequence.1", relu=True)
+        self._record("input", x)
         return self._ublock("UNet", x, pyr, 0)
 
     def forward(self, sparse_input) -> Dict[str, torch.Tensor]:

@@ -15,7 +15,7 @@ import torch
 
 from .. import profiling
 from ..data_types.cloud import Cloud, MaskedCloud
-from ..dataset.dataset import load_dataloader
+from ..dataset.dataset import SingleTreeInference
 from .model import Smart_Tree
 from .sparse import sparse_from_batch
 
@@ -60,24 +60,19 @@ class ModelInference:
     def forward(self, cloud: Cloud, return_masked: bool = True) -> Cloud:
         cloud = cloud.to_device(self.device)
         if cloud.rgb is None:
-            cloud = Cloud(cloud.xyz, torch.zeros_like(cloud.xyz))
-        inputs, masks, medial, classes = [], [], [], []
+            cloud = Cloud(cloud.xyz, torch.zeros_like(cloud.xyz), seg_off=cloud.seg_off)
         with profiling.stage("voxelize"):
-            batches = load_dataloader(cloud, self.voxel_size, self.block_size, self.buffer_size, self.num_workers,
-                                      self.batch_size)
-        for features, coordinates, mask, _ in batches:
-            sparse_input = sparse_from_batch(features[:, :3].contiguous(), coordinates, device=self.device)
-            # radius / direction / class_l come out exactly as model.forward(sparse_input) gives them;
-            # exp(radius)*direction and argmax (reference :87-88) are fused into the head kernel
-            with profiling.stage("unet"):
-                _, _, _, mv, cls = self.model.forward_fused_tail(sparse_input)
-            inputs.append(features)
-            masks.append(mask)
-            medial.append(mv)
-            classes.append(cls)
-        inputs, masks = torch.cat(inputs), torch.cat(masks)
-        lc = Cloud(xyz=inputs[:, :3].contiguous(), rgb=inputs[:, 3:6].contiguous(), medial_vector=torch.cat(medial),
-                   class_l=torch.cat(classes))
+            ds = SingleTreeInference(cloud, self.voxel_size, self.block_size, self.buffer_size)
+        vb = ds.batch  # every block of the cloud -- of every cloud of a batch (Cloud.collate) -- in ONE collated batch
+        sparse_input = sparse_from_batch(vb.feats[:, :3].contiguous(), vb.coords, device=self.device, blk_seg=vb.blk_seg,
+                                         n_seg=vb.n_seg)
+        # radius / direction / class_l come out exactly as model.forward(sparse_input) gives them;
+        # exp(radius)*direction and argmax (reference :87-88) are fused into the head kernel
+        with profiling.stage("unet"):
+            _, _, _, mv, cls = self.model.forward_fused_tail(sparse_input)
+        masks = vb.mask
+        lc = Cloud(xyz=sparse_input.features, rgb=vb.feats[:, 3:6].contiguous(), medial_vector=mv, class_l=cls,
+                   seg_off=vb.seg_vox_off)
         # the inner-block filter (reference :97-100) is handed on as a pending mask: Pipeline's filter_by_class folds into it
         return MaskedCloud(lc, masks) if return_masked else lc
 

@@ -18,14 +18,18 @@ class SparseConvTensor:
         self.spatial_shape = spatial_shape
         self.batch_size = batch_size
         self.indice_dict = {}
+        self.blk_seg = None  # batched clouds (Cloud.collate): cloud of every batch index coords[:,0] -> per-cloud spatial extents
+        self.n_seg = 1
 
     def replace_feature(self, new_features: torch.Tensor) -> "SparseConvTensor":
         out = SparseConvTensor(new_features, self.indices, self.spatial_shape, self.batch_size)
         out.indice_dict = self.indice_dict
+        out.blk_seg, out.n_seg = self.blk_seg, self.n_seg
         return out
 
 
-def sparse_from_batch(features: torch.Tensor, coordinates: torch.Tensor, device) -> SparseConvTensor:
+def sparse_from_batch(features: torch.Tensor, coordinates: torch.Tensor, device, blk_seg: torch.Tensor = None,
+                      n_seg: int = 1) -> SparseConvTensor:
     """Reference sparse.py:9-19, quirks kept on the attributes: spatial_shape = max coordinate (not
     +1) and batch_size = number of voxels.  The kernels derive the true extent from the indices."""
     batch_size = features.shape[0]
@@ -36,7 +40,10 @@ def sparse_from_batch(features: torch.Tensor, coordinates: torch.Tensor, device)
         shape = values[1:]
     else:
         shape = torch.zeros(3, dtype=coordinates.dtype, device=device)
-    return SparseConvTensor(features.contiguous(), coordinates.int().contiguous(), shape, batch_size=batch_size)
+    out = SparseConvTensor(features.contiguous(), coordinates.int().contiguous(), shape, batch_size=batch_size)
+    if blk_seg is not None and n_seg > 1:
+        out.blk_seg, out.n_seg = blk_seg.to(device).int().contiguous(), n_seg
+    return out
 
 
 def batch_collate(batch):

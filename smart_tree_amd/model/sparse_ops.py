@@ -48,10 +48,15 @@ class StridedRulebook:
     up_order: torch.Tensor = None  # [N] fine rows grouped by coordinate parity: the inverse conv's launch order
 
 
-def build_strided_rulebook(coords: torch.Tensor, h: CoordHash) -> StridedRulebook:
+def build_strided_rulebook(coords: torch.Tensor, h: CoordHash, blk_seg: Optional[torch.Tensor] = None,
+                           n_seg: int = 1) -> StridedRulebook:
+    """blk_seg / n_seg (batched clouds): the output set of every cloud is clipped to that cloud's own spatial extent."""
     L = _lib.lib()
     dev = coords.device
     n = coords.shape[0]
+    if blk_seg is None:
+        n_seg = 1
+    ext_dev = torch.empty(3 * n_seg, dtype=torch.int32, device=dev) if n_seg > 1 else None
     ws = _lib.workspace(L.st_strided_workspace_bytes(n), dev)
     n_out = ctypes.c_int64(0)
     extent = (ctypes.c_int32 * 3)()
@@ -61,9 +66,9 @@ def build_strided_rulebook(coords: torch.Tensor, h: CoordHash) -> StridedRuleboo
         ccap = L.st_hash_capacity(max_out)
         ckeys = torch.empty(ccap, dtype=torch.int64, device=dev)
         cvals = torch.empty(ccap, dtype=torch.int32, device=dev)
-        rc = L.st_build_strided_outputs(_lib.ptr(coords), n, max_out, _lib.ptr(out_coords), _lib.ptr(ckeys),
-                                        _lib.ptr(cvals), ccap, ctypes.byref(n_out), extent, _lib.ptr(ws), ws.numel(),
-                                        _lib.stream(dev))
+        rc = L.st_build_strided_outputs_seg(_lib.ptr(coords), n, max_out, _lib.ptr(out_coords), _lib.ptr(ckeys),
+                                            _lib.ptr(cvals), ccap, ctypes.byref(n_out), extent, _lib.ptr(blk_seg) if n_seg > 1 else None,
+                                            n_seg, _lib.ptr(ext_dev), _lib.ptr(ws), ws.numel(), _lib.stream(dev))
         if rc == 0 or b"max_out" not in L.st_last_error():
             break
     _lib.check(rc)
@@ -72,9 +77,10 @@ def build_strided_rulebook(coords: torch.Tensor, h: CoordHash) -> StridedRuleboo
     nbr_down = torch.empty((27, m), dtype=torch.int32, device=dev)
     nbr_up = torch.empty((27, n), dtype=torch.int32, device=dev)
     up_order = torch.empty(n + 16, dtype=torch.int32, device=dev)  # the 16-word tail is the kernel's scratch
-    _lib.check(L.st_build_strided_rulebook(_lib.ptr(coords), n, _lib.ptr(h.keys), _lib.ptr(h.vals), h.cap,
-                                           _lib.ptr(out_coords), m, _lib.ptr(ckeys), _lib.ptr(cvals), ccap, extent,
-                                           _lib.ptr(nbr_down), _lib.ptr(nbr_up), _lib.ptr(up_order), _lib.stream(dev)))
+    _lib.check(L.st_build_strided_rulebook_seg(_lib.ptr(coords), n, _lib.ptr(h.keys), _lib.ptr(h.vals), h.cap,
+                                               _lib.ptr(out_coords), m, _lib.ptr(ckeys), _lib.ptr(cvals), ccap, extent,
+                                               _lib.ptr(nbr_down), _lib.ptr(nbr_up), _lib.ptr(up_order),
+                                               _lib.ptr(blk_seg) if n_seg > 1 else None, _lib.ptr(ext_dev), _lib.stream(dev)))
     return StridedRulebook(out_coords, CoordHash(ckeys, cvals, ccap), nbr_down, nbr_up, up_order[:n])
 
 
@@ -88,7 +94,7 @@ class RulebookPyramid:
     up_order: List[torch.Tensor] = field(default_factory=list)  # up_order[l]: launch order of level l's rows for up[l]
 
 
-def build_pyramid(coords: torch.Tensor, depth: int) -> RulebookPyramid:
+def build_pyramid(coords: torch.Tensor, depth: int, blk_seg: Optional[torch.Tensor] = None, n_seg: int = 1) -> RulebookPyramid:
     pyr = RulebookPyramid()
     h = build_coord_hash(coords)
     for level in range(depth + 1):
@@ -96,7 +102,7 @@ def build_pyramid(coords: torch.Tensor, depth: int) -> RulebookPyramid:
         pyr.subm.append(build_subm_rulebook(coords, h))
         if level == depth:
             break
-        s = build_strided_rulebook(coords, h)
+        s = build_strided_rulebook(coords, h, blk_seg, n_seg)
         pyr.down.append(s.nbr_down)
         pyr.up.append(s.nbr_up)
         pyr.up_order.append(s.up_order)

@@ -63,6 +63,30 @@ class Pipeline:
             write_ply_points(sp / "cloud.ply", lc.xyz.cpu().numpy(), lc.rgb.cpu().numpy() if lc.rgb is not None else None)
         return skeleton
 
+    def process_clouds(self, clouds) -> list:
+        """B independent clouds through ONE set of kernel launches (additive; the reference's unit of work is a batch
+        as well: model/sparse.py:40-61 writes the batch index into coords[:,0], model_inference.py:62-78 runs a batch per
+        forward -- here the batch index is carried through every stage: blocks / voxels, network, kNN graph, components,
+        SSSP, branch selection, post-processing).  Returns one DisjointTreeSkeleton per cloud, each identical to
+        `process_cloud` of that cloud alone (tests/test_batch.py)."""
+        clouds = [c.to_device(self.device) for c in clouds]
+        if not clouds:
+            return []
+        batch = Cloud.collate([Cloud(c.xyz, c.rgb if c.rgb is not None else torch.zeros_like(c.xyz)) for c in clouds])
+        with profiling.stage("preprocess"):
+            batch = self.preprocessing(batch)
+        lc = self.model_inference.forward(batch).to_device(self.device)
+        self.last_labelled_cloud = lc
+        with profiling.stage("class_filter"):
+            branch_cloud = lc.filter_by_class(self.branch_classes)
+        skeleton = self.skeletonizer.forward(branch_cloud)
+        with profiling.stage("post_process"):
+            self.post_process(skeleton)
+            parts = skeleton.split()  # device post-processing of all clouds, ONE device-to-host copy, per-cloud views
+        if self.view_model_output or self.view_skeletons:
+            raise NotImplementedError("viewing needs open3d, which is out of scope of smart_tree_amd")
+        return parts
+
     def post_process(self, skeleton: DisjointTreeSkeleton) -> None:
         if self.prune_skeletons:
             skeleton.prune(min_length=self.min_skeleton_length, min_radius=self.min_skeleton_radius)

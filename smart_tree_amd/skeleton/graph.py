@@ -20,11 +20,14 @@ BOUND_NONE, BOUND_LE, BOUND_LT = 0, 1, 2
 
 
 def knn(src: torch.Tensor, dest: torch.Tensor, K: int = 50, r: float = 1.0, grid=None, bound: Optional[torch.Tensor] = None,
-        bound_mode: int = BOUND_NONE, cell: float = 0.0):
+        bound_mode: int = BOUND_NONE, cell: float = 0.0, src_seg_off: Optional[torch.Tensor] = None,
+        dest_seg_off: Optional[torch.Tensor] = None):
     """The <= K nearest `dest` points of every `src` point with d^2 < r^2, ascending (ties: lower index).
 
     `bound` (per query) additionally keeps only d <= bound[i] (BOUND_LE) or d < bound[i] (BOUND_LT);
     used by nn_graph / outlier_removal, whose own filters make that exact (csrc/knn.hip header).
+    src_seg_off / dest_seg_off ([B+1] int32, device): src and dest hold B independent clouds each; a query only sees
+    its own cloud (additive keywords, Cloud.collate).
     """
     L = _lib.lib()
     dev = src.device
@@ -37,10 +40,14 @@ def knn(src: torch.Tensor, dest: torch.Tensor, K: int = 50, r: float = 1.0, grid
         return idx, dist, grid
     if n2 == 0:
         return idx.fill_(-1), dist.fill_(float("nan")), grid
-    ws = _lib.workspace(L.st_knn_workspace_bytes(n2), dev)
+    nseg = 1 if src_seg_off is None else int(src_seg_off.shape[0]) - 1
+    if (dest_seg_off is None) != (src_seg_off is None):
+        raise ValueError("knn: batched searches need the cloud offsets of both src and dest")
+    ws = _lib.workspace(L.st_knn_workspace_bytes_seg(n2, nseg), dev)
     b = bound.contiguous().float() if bound is not None else None
-    _lib.check(L.st_knn_radius(_lib.ptr(src), n1, _lib.ptr(dest), n2, K, float(r), _lib.ptr(b), bound_mode, float(cell),
-                               _lib.ptr(idx), _lib.ptr(dist), _lib.ptr(ws), ws.numel(), _lib.stream(dev)))
+    _lib.check(L.st_knn_radius_seg(_lib.ptr(src), n1, _lib.ptr(dest), n2, K, float(r), _lib.ptr(b), bound_mode, float(cell),
+                                   _lib.ptr(idx), _lib.ptr(dist), _lib.ptr(src_seg_off), _lib.ptr(dest_seg_off), nseg,
+                                   _lib.ptr(ws), ws.numel(), _lib.stream(dev)))
     return idx, dist, grid
 
 
@@ -71,10 +78,11 @@ def _search_cell(radii: torch.Tensor, r_max: float) -> float:
     return max(r_max / 8.0, 1e-4)
 
 
-def make_edges(dists: torch.Tensor, idxs: torch.Tensor, padded: bool = False):
+def make_edges(dists: torch.Tensor, idxs: torch.Tensor, padded: bool = False, seg_off: Optional[torch.Tensor] = None):
     """graph.py:52-60: edges (i -> idx) for idx > 0 (the reference's filter drops every edge INTO
     vertex 0 and vertex 0's self loop; kept), in (i, k) order.  `padded`: the capacity-sized arrays come back as they
-    are, tail filled with (0, 0) / 0, and the edge count is not read back (data_types.graph.PaddedGraph)."""
+    are, tail filled with (0, 0) / 0, and the edge count is not read back (data_types.graph.PaddedGraph).  seg_off (batched
+    clouds): "vertex 0" is the first vertex of the query's own cloud."""
     L = _lib.lib()
     dev = dists.device
     n, K = dists.shape
@@ -82,21 +90,29 @@ def make_edges(dists: torch.Tensor, idxs: torch.Tensor, padded: bool = False):
     w = torch.empty((max(n * K, 1),), dtype=torch.float32, device=dev)
     ne = ctypes.c_int64(0)
     ws = _lib.workspace(L.st_make_edges_workspace_bytes(n), dev)
-    _lib.check((L.st_make_edges_nowait if padded else L.st_make_edges)(_lib.ptr(idxs.contiguous()), _lib.ptr(dists.contiguous()), n, K, _lib.ptr(edges), _lib.ptr(w),
-                               None if padded else ctypes.byref(ne), _lib.ptr(ws), ws.numel(), _lib.stream(dev)))
+    nseg = 1 if seg_off is None else int(seg_off.shape[0]) - 1
+    _lib.check((L.st_make_edges_seg_nowait if padded else L.st_make_edges_seg)(
+        _lib.ptr(idxs.contiguous()), _lib.ptr(dists.contiguous()), n, K, _lib.ptr(edges), _lib.ptr(w),
+        None if padded else ctypes.byref(ne), _lib.ptr(seg_off), nseg, _lib.ptr(ws), ws.numel(), _lib.stream(dev)))
     if padded:
         return edges[: n * K], w[: n * K]
     return edges[: ne.value], w[: ne.value]
 
 
-def nn_graph(points: torch.Tensor, radii: torch.Tensor, K: int = 40) -> Graph:
-    """graph.py:36-40: kNN with r = max radius, neighbours farther than the point's own radius dropped."""
+def nn_graph(points: torch.Tensor, radii: torch.Tensor, K: int = 40, seg_off: Optional[torch.Tensor] = None) -> Graph:
+    """graph.py:36-40: kNN with r = max radius, neighbours farther than the point's own radius dropped.
+    seg_off (additive): `points` holds several independent clouds -- one graph whose edges never cross clouds."""
     if points.shape[0] == 0:
-        return Graph(points, torch.zeros((0, 2), dtype=torch.int64, device=points.device),
-                     torch.zeros((0,), dtype=torch.float32, device=points.device))
-    idxs, dists, _ = knn(points, points, K=K, r=-1.0, bound=radii, bound_mode=BOUND_LE, cell=-SEARCH_CELL_DIV)
-    edges, edge_weights = make_edges(dists, idxs, padded=True)
-    return PaddedGraph(points, edges, edge_weights)
+        g = Graph(points, torch.zeros((0, 2), dtype=torch.int64, device=points.device),
+                  torch.zeros((0,), dtype=torch.float32, device=points.device))
+        g.seg_off = seg_off
+        return g
+    idxs, dists, _ = knn(points, points, K=K, r=-1.0, bound=radii, bound_mode=BOUND_LE, cell=-SEARCH_CELL_DIV,
+                         src_seg_off=seg_off, dest_seg_off=seg_off)
+    edges, edge_weights = make_edges(dists, idxs, padded=True, seg_off=seg_off)
+    g = PaddedGraph(points, edges, edge_weights)
+    g.seg_off = seg_off
+    return g
 
 
 @dataclass
@@ -112,6 +128,11 @@ class ComponentSet:
     row_off: torch.Tensor  # CSR over the renumbered vertices (undirected, self loops removed)
     col: torch.Tensor
     wgt: torch.Tensor
+    # batched clouds (graph.seg_off): components are ordered cloud by cloud
+    n_seg: int = 1
+    comp_seg: Optional[torch.Tensor] = None  # [C] int32 cloud of each component
+    comp_seg_off: Optional[torch.Tensor] = None  # [n_seg+1] int32 component range of each cloud
+    vert_seg_off: Optional[torch.Tensor] = None  # [n_seg+1] int32 the clouds' ranges in the renumbered vertex space
 
     def __len__(self):
         return self.n_components
@@ -133,18 +154,23 @@ def connected_components(graph: Graph, minimum_vertices: int = 0) -> ComponentSe
     ws = _lib.workspace(L.st_connected_components_workspace_bytes(n), dev)
     _lib.check(L.st_connected_components(_lib.ptr(edges), E, n, _lib.ptr(labels), _lib.ptr(ws), ws.numel(), _lib.stream(dev)))
     comp_size, comp_off, vert_order, new_id = i32(n), i32(n + 1), i32(n), i32(n)
+    seg_off = getattr(graph, "seg_off", None)
+    nseg = 1 if seg_off is None else int(seg_off.shape[0]) - 1
+    comp_seg, comp_seg_off, vert_seg_off = (i32(n), i32(nseg + 1), i32(nseg + 1)) if nseg > 1 else (None, None, None)
     nc, nk = ctypes.c_int64(0), ctypes.c_int64(0)
     ws = _lib.workspace(L.st_component_layout_workspace_bytes(n), dev)
-    _lib.check(L.st_component_layout(_lib.ptr(labels), n, int(minimum_vertices), _lib.ptr(comp_size), _lib.ptr(comp_off),
-                                     _lib.ptr(vert_order), _lib.ptr(new_id), ctypes.byref(nc), ctypes.byref(nk),
-                                     _lib.ptr(ws), ws.numel(), _lib.stream(dev)))
+    _lib.check(L.st_component_layout_seg(_lib.ptr(labels), n, int(minimum_vertices), _lib.ptr(seg_off) if nseg > 1 else None, nseg,
+                                         _lib.ptr(comp_size), _lib.ptr(comp_off), _lib.ptr(vert_order), _lib.ptr(new_id),
+                                         _lib.ptr(comp_seg), _lib.ptr(comp_seg_off), _lib.ptr(vert_seg_off),
+                                         ctypes.byref(nc), ctypes.byref(nk), _lib.ptr(ws), ws.numel(), _lib.stream(dev)))
     C, m = nc.value, nk.value
     row_off, col, wgt = i32(m + 1), i32(2 * E), torch.empty((max(2 * E, 1),), dtype=torch.float32, device=dev)
     if m > 0:
         ws = _lib.workspace(L.st_component_csr_workspace_bytes(m), dev)
         _lib.check(L.st_component_csr(_lib.ptr(edges), _lib.ptr(w), E, _lib.ptr(new_id), m, _lib.ptr(row_off), _lib.ptr(col),
                                       _lib.ptr(wgt), _lib.ptr(ws), ws.numel(), _lib.stream(dev)))
-    return ComponentSet(C, comp_size[:C], comp_off[: C + 1], vert_order[:m], new_id[:n], labels[:n], row_off[: m + 1], col, wgt)
+    return ComponentSet(C, comp_size[:C], comp_off[: C + 1], vert_order[:m], new_id[:n], labels[:n], row_off[: m + 1], col, wgt,
+                        nseg, comp_seg[:C] if comp_seg is not None else None, comp_seg_off, vert_seg_off)
 
 
 def remap_edges(edges: torch.Tensor) -> torch.Tensor:

@@ -66,10 +66,12 @@ def run_components(comps: ComponentSet, medial_pts: torch.Tensor, radius: torch.
     # max(rad) / GRID_DIV reduced on the device (grid_cell < 0), so this stage starts without a read-back
     stats = (ctypes.c_int64 * 8)()
     stats[7] = 1 if profiling.enabled() else 0  # bracket every k_sk_select launch with HIP events
-    ws = _lib.workspace(L.st_skeleton_workspace_bytes(m, C), dev)
+    nseg = comps.n_seg  # batched clouds: every cloud's components use their own slab of the claim grid
+    ws = _lib.workspace(L.st_skeleton_workspace_bytes_seg(m, C, nseg), dev)
     with profiling.stage("skeleton_kernels"):
-        _lib.check(L.st_skeleton_components(
-            C, _lib.ptr(comps.comp_off.contiguous()), None, m, _lib.ptr(pts), _lib.ptr(rad), _lib.ptr(ys),
+        _lib.check(L.st_skeleton_components_seg(
+            C, _lib.ptr(comps.comp_off.contiguous()), _lib.ptr(comps.comp_seg.contiguous()) if nseg > 1 else None,
+            _lib.ptr(comps.vert_seg_off) if nseg > 1 else None, nseg, m, _lib.ptr(pts), _lib.ptr(rad), _lib.ptr(ys),
             _lib.ptr(comps.row_off), _lib.ptr(comps.col), _lib.ptr(comps.wgt), -float(GRID_DIV), int(stages),
             int(block_threads), _lib.ptr(res.dist), _lib.ptr(res.pred), _lib.ptr(res.root_local), _lib.ptr(res.tree_dist),
             _lib.ptr(res.branch_parent), _lib.ptr(res.branch_off), _lib.ptr(res.branch_len), _lib.ptr(res.n_branches),
@@ -105,14 +107,16 @@ class Skeletonizer:
         self.block_threads = 0  # 0 = library default (1024 lanes in the per-component select workgroup)
 
     def forward(self, cloud: Cloud) -> DisjointTreeSkeleton:
+        """`cloud` may be a batch of independent clouds (Cloud.collate): every stage below then runs ONCE for all of
+        them, and `.split()` of the result gives each cloud's skeleton -- identical to what it gets on its own."""
         with profiling.stage("outlier_removal"):
             medial, radius = medial_points(cloud.xyz, cloud.medial_vector)
-            mask = outlier_removal(medial, radius.unsqueeze(1), nb_points=8)
+            mask = outlier_removal(medial, radius.unsqueeze(1), nb_points=8, seg_off=cloud.seg_off)
             keep = mask.nonzero().view(-1)  # one compaction (one host sync) shared by every field
             cloud = cloud.filter(keep)
             medial, radius = medial.index_select(0, keep), radius.index_select(0, keep)
         with profiling.stage("nn_graph"):
-            graph = nn_graph(medial, radius.clamp(min=self.min_connection_length), K=self.K)
+            graph = nn_graph(medial, radius.clamp(min=self.min_connection_length), K=self.K, seg_off=cloud.seg_off)
         with profiling.stage("components"):
             comps = graph.connected_cugraph_components(minimum_vertices=self.minimum_graph_vertices)
         with profiling.stage("sssp_sample_tree"):
@@ -152,11 +156,13 @@ class DeviceSkeleton(DisjointTreeSkeleton):
     table copied to the host (one copy each) and the BranchSkeleton objects built.  Any other call
     order materialises first and falls back to the host implementations of the base class."""
 
-    def __init__(self, tree_off, parent, start, length, xyz, rad):
+    def __init__(self, tree_off, parent, start, length, xyz, rad, comp_seg_off=None):
         self._dev = (tree_off, parent, start, length, xyz, rad)  # device tensors (flat branch layout)
         self._ops = {}
         self._trees = None
         self._host = None  # packed host arrays of the materialised skeleton (valid while nobody has touched the objects)
+        self._seg = comp_seg_off  # batched clouds: [n_seg+1] int32 (device) tree range of every cloud
+        self._seg_host = None
 
     # -- construction ---------------------------------------------------------------------------
     @staticmethod
@@ -169,7 +175,8 @@ class DeviceSkeleton(DisjointTreeSkeleton):
         i32 = dict(dtype=torch.int32, device=dev)
         if C == 0:
             z = torch.zeros(0, **i32)
-            return DeviceSkeleton(torch.zeros(1, **i32), z, z, z, torch.zeros((0, 3), device=dev), torch.zeros(0, device=dev))
+            return DeviceSkeleton(torch.zeros(1, **i32), z, z, z, torch.zeros((0, 3), device=dev), torch.zeros(0, device=dev),
+                                  comps.comp_seg_off if comps.n_seg > 1 else None)
         L = _lib.lib()
         m = comps.vert_order.shape[0]
         cap_b, cap_p = max(m, 1), max(2 * m, 1)  # every branch has >= 2 vertices; slots = path vertices + branches
@@ -193,7 +200,8 @@ class DeviceSkeleton(DisjointTreeSkeleton):
             B, P = counts[0], counts[1]
             if res.stats is not None and "branches" in res.stats:
                 assert (B, P) == (res.stats["branches"], res.stats["path_vertices"] + res.stats["branches"]), "select totals disagree"
-        return DeviceSkeleton(tree_off, parent[:B], start[:B], length[:B], xyz[:P], rad[:P])
+        return DeviceSkeleton(tree_off, parent[:B], start[:B], length[:B], xyz[:P], rad[:P],
+                              comps.comp_seg_off if comps.n_seg > 1 else None)
 
     # -- deferred post-processing ---------------------------------------------------------------
     def _can_defer(self, op: str) -> bool:
@@ -240,6 +248,8 @@ class DeviceSkeleton(DisjointTreeSkeleton):
         tree_off, parent, start, length, xyz, rad = self._dev
         T, B = tree_off.shape[0] - 1, parent.shape[0]
         if B == 0:
+            if self._seg is not None:
+                self._seg_host = self._seg.cpu().tolist()
             return [TreeSkeleton(t, {}) for t in range(T)]
         dev = xyz.device
         u8 = lambda: torch.empty(B, dtype=torch.uint8, device=dev)
@@ -249,11 +259,13 @@ class DeviceSkeleton(DisjointTreeSkeleton):
         xyz = xyz.clone()
         pr = self._ops.get("prune")
         L = _lib.lib()
-        _lib.check(L.st_post_process(T, _lib.ptr(tree_off), _lib.ptr(parent), _lib.ptr(start), _lib.ptr(length), _lib.ptr(xyz),
-                                     _lib.ptr(rad), _lib.ptr(rad_out), _lib.ptr(keep), _lib.ptr(repaired), _lib.ptr(smoothed),
-                                     _lib.ptr(depth), int(pr is not None), pr[0] if pr else 0.0, pr[1] if pr else 0.0,
-                                     int("repair" in self._ops), int("smooth" in self._ops), self._ops.get("smooth", 0),
-                                     _lib.stream(dev)))
+        # batched clouds: `prune` works on skeleton 0 OF EVERY CLOUD (tree.py:164-168); the first trees are comp_seg_off[:-1]
+        first, n_first = (self._seg, int(self._seg.shape[0]) - 1) if self._seg is not None else (None, 0)
+        _lib.check(L.st_post_process_seg(T, _lib.ptr(tree_off), _lib.ptr(parent), _lib.ptr(start), _lib.ptr(length), _lib.ptr(xyz),
+                                         _lib.ptr(rad), _lib.ptr(rad_out), _lib.ptr(keep), _lib.ptr(repaired), _lib.ptr(smoothed),
+                                         _lib.ptr(depth), int(pr is not None), pr[0] if pr else 0.0, pr[1] if pr else 0.0,
+                                         int("repair" in self._ops), int("smooth" in self._ops), self._ops.get("smooth", 0),
+                                         _lib.ptr(first), n_first, _lib.stream(dev)))
         # two copies (geometry, branch table).  Branch k's geometry is the slot range [a_k, b_k) of the packed host arrays;
         # the TreeSkeleton / BranchSkeleton objects are only built when somebody reads `.branches` (_PackedTree), their
         # tensors are views cut on first access (_PackedBranch): a few hundred Python objects per cloud are pure
@@ -262,10 +274,15 @@ class DeviceSkeleton(DisjointTreeSkeleton):
         # geometry, radii, branch table and tree offsets travel as one float32 buffer (the integers bit-cast)
         P = xyz.shape[0]
         table = torch.stack((parent, start, length, keep.int(), repaired.int(), smoothed.int()), dim=1)
-        blob = torch.cat((xyz.reshape(-1), rad_out, table.reshape(-1).view(torch.float32), tree_off.view(torch.float32))).cpu()
+        parts = [xyz.reshape(-1), rad_out, table.reshape(-1).view(torch.float32), tree_off.view(torch.float32)]
+        if self._seg is not None:
+            parts.append(self._seg.view(torch.float32))
+        blob = torch.cat(parts).cpu()
         xyz_h, rad_h = blob[: 3 * P].view(P, 3), blob[3 * P: 4 * P]
         rows = blob[4 * P: 4 * P + 6 * B].view(torch.int32).view(B, 6)
-        offs = blob[4 * P + 6 * B:].view(torch.int32).tolist()
+        offs = blob[4 * P + 6 * B: 4 * P + 6 * B + T + 1].view(torch.int32).tolist()
+        if self._seg is not None:
+            self._seg_host = blob[4 * P + 6 * B + T + 1:].view(torch.int32).tolist()
         self._host = (xyz_h, rad_h, rows, offs)
         trees = []
         for t in range(T):
@@ -275,6 +292,32 @@ class DeviceSkeleton(DisjointTreeSkeleton):
             trees.append(tree)
         return trees
 
+    def split(self) -> List[DisjointTreeSkeleton]:
+        """Batched clouds: the skeleton of every cloud of the batch, trees renumbered from 0 inside each (what
+        `Skeletonizer.forward` returns for that cloud alone).  A single cloud gives [self]."""
+        if self._seg is None:
+            return [self]
+        trees = self.skeletons
+        seg = self._seg_host
+        out = []
+        for b in range(len(seg) - 1):
+            part = _CloudSkeleton.__new__(_CloudSkeleton)
+            part._dev, part._ops, part._seg, part._seg_host = None, {}, None, None
+            mine = []
+            for local, t in enumerate(trees[seg[b]: seg[b + 1]]):
+                if isinstance(t, _PackedTree):
+                    tree = _PackedTree.__new__(_PackedTree)
+                    tree._lazy = t._lazy
+                else:
+                    tree = TreeSkeleton(local, t.branches)
+                tree._id = local
+                mine.append(tree)
+            part._trees = mine
+            part._host = self._host
+            part._tree_range = (seg[b], seg[b + 1])
+            out.append(part)
+        return out
+
     def pack(self, cloud_id: int = 0):
         """What sharding.pack_skeleton builds branch by branch -- (table int64 [B,6], geom float32 [P,4]) -- cut out of
         the packed host arrays with a dozen tensor operations instead of five per branch."""
@@ -282,6 +325,8 @@ class DeviceSkeleton(DisjointTreeSkeleton):
         if self._host is None or any("_branches" in t.__dict__ for t in trees):
             return None  # host-side edits may have happened: the caller walks the objects instead
         xyz_h, rad_h, rows, offs = self._host
+        t0, t1 = getattr(self, "_tree_range", (0, len(offs) - 1))  # one cloud of a batch: its slice of the branch table
+        rows, offs = rows[offs[t0]: offs[t1]], [o - offs[t0] for o in offs[t0: t1 + 1]]
         B = rows.shape[0]
         if B == 0:
             return torch.zeros((0, 6), dtype=torch.int64), torch.zeros((0, 4), dtype=torch.float32)
@@ -297,6 +342,10 @@ class DeviceSkeleton(DisjointTreeSkeleton):
         idx = torch.arange(int(n.sum())) + torch.repeat_interleave(a - off, n)
         geom = torch.cat((xyz_h[idx].float(), rad_h[idx].reshape(-1, 1).float()), dim=1)
         return table, geom
+
+
+class _CloudSkeleton(DeviceSkeleton):
+    """One cloud's share of a batched DeviceSkeleton (already materialised: host objects only)."""
 
 
 class _PackedTree(TreeSkeleton):

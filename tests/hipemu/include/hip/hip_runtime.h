@@ -199,14 +199,15 @@ inline void run_block(unsigned nthreads) {
 template <class F>
 inline void launch(dim3 grid, dim3 block, F&& body) {
     Runtime& r = rt();
-    if (grid.y != 1 || grid.z != 1 || block.y != 1 || block.z != 1) die("only 1-D launches are emulated");
+    if (grid.z != 1 || block.y != 1 || block.z != 1) die("only launches with 1-D workgroups and 2-D grids are emulated");
     r.gdim = grid;
     r.bdim = block;
     r.body = body;
-    for (unsigned i = 0; i < grid.x; i++) {
-        r.bid = dim3(sched_order() == 0 ? i : grid.x - 1 - i);
-        run_block(block.x);
-    }
+    for (unsigned j = 0; j < grid.y; j++)
+        for (unsigned i = 0; i < grid.x; i++) {
+            r.bid = dim3(sched_order() == 0 ? i : grid.x - 1 - i, sched_order() == 0 ? j : grid.y - 1 - j);
+            run_block(block.x);
+        }
 }
 
 // wave rendezvous: deposit two 64-bit words, get everyone's words back
