@@ -132,6 +132,8 @@ def sparse_conv(x0: torch.Tensor, w: torch.Tensor, nbr: Optional[torch.Tensor], 
     L = _lib.lib()
     K, cin, cout = w.shape
     c0 = x0.shape[1]
+    if n_out == 0:  # an empty active set (a cloud without a block of > 20 points): nothing to launch
+        return torch.empty((0, cout), dtype=torch.float16 if out_half else torch.float32, device=x0.device)
     in_half = x0.dtype == torch.float16
     if in_half or out_half:
         both = in_half and out_half
@@ -193,6 +195,8 @@ def mlp_heads(x: torch.Tensor, params: torch.Tensor, with_tail: bool = False):
     class_l = torch.empty((n, 2), dtype=torch.float32, device=dev)
     mv = torch.empty((n, 3), dtype=torch.float32, device=dev) if with_tail else None
     cls = torch.empty((n, 1), dtype=torch.int64, device=dev) if with_tail else None
+    if n == 0:
+        return radius, direction, class_l, mv, cls
     _lib.check(L.st_pointwise_mlp_heads(_lib.ptr(x), n, _lib.ptr(params), _lib.ptr(radius), _lib.ptr(direction),
                                         _lib.ptr(class_l), _lib.ptr(mv), _lib.ptr(cls), _lib.stream(dev)))
     return radius, direction, class_l, mv, cls
