@@ -88,26 +88,30 @@ __global__ void k_grid_dims(StGrid* g, float cell, int64_t max_cells, float r, i
     g->ncell = (int64_t)g->dim[0] * g->dim[1] * g->dim[2];
 }
 
+// The counting pass hands every point its rank inside its cell (the value its atomicAdd returns), so the fill pass needs
+// neither a second round of atomics nor a cursor copy of the (tens of millions of words long) cell table.
 __global__ void __launch_bounds__(KNN_BLOCK) k_grid_count(const float* pts, int64_t n, const StGrid* g, uint32_t* counts,
-                                                          const int* seg_off, int nseg) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        atomicAdd(&counts[st_grid_cell(g, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], st_seg_find(seg_off, nseg, i))], 1u);
+                                                          const int* seg_off, int nseg, uint32_t* pt_cell, uint32_t* pt_rank) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t c = st_grid_cell(g, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], st_seg_find(seg_off, nseg, i));
+        pt_cell[i] = (uint32_t)c;
+        pt_rank[i] = atomicAdd(&counts[c], 1u);
+    }
 }
 
-__global__ void __launch_bounds__(KNN_BLOCK) k_grid_fill(const float* pts, int64_t n, const StGrid* g, uint32_t* cursor,
-                                                         float4* recs, const int* seg_off, int nseg) {
+__global__ void __launch_bounds__(KNN_BLOCK) k_grid_fill(const float* pts, int64_t n, const uint32_t* cell_start,
+                                                         const uint32_t* pt_cell, const uint32_t* pt_rank, float4* recs) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        int64_t c = st_grid_cell(g, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], st_seg_find(seg_off, nseg, i));
-        uint32_t pos = atomicAdd(&cursor[c], 1u);
+        const uint32_t pos = cell_start[pt_cell[i]] + pt_rank[i];
         recs[pos] = make_float4(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], __uint_as_float((unsigned)i));
     }
 }
 
 int64_t st_grid_ws_bytes(int64_t n, int64_t max_cells) {
     StArena a(nullptr, 0);
-    a.take<uint32_t>(max_cells + 1);               // cursor
+    a.take<uint32_t>(n);                           // cell of every point
+    a.take<uint32_t>(n);                           // its rank inside the cell
     a.take<char>(st_scan_ws_bytes(max_cells + 1)); // scan scratch
-    (void)n;
     return a.used;
 }
 
@@ -118,10 +122,11 @@ int st_grid_build(const float* pts, int64_t n, float cell, int64_t max_cells, St
     if (nseg < 1 || nseg > ST_MAX_SEG) { st_set_error("grid: 1 <= clouds per batch <= %d (got %d)", ST_MAX_SEG, nseg); return ST_ERR_INVALID; }
     if (!seg_off) nseg = 1;
     StArena a(ws, ws_bytes);
-    uint32_t* cursor = a.take<uint32_t>(max_cells + 1);
+    uint32_t* pt_cell = a.take<uint32_t>(n);
+    uint32_t* pt_rank = a.take<uint32_t>(n);
     int64_t scan_bytes = st_scan_ws_bytes(max_cells + 1);
     char* scan_ws = a.take<char>(scan_bytes);
-    if (!cursor || !scan_ws) {
+    if (!pt_cell || !pt_rank || !scan_ws) {
         st_set_error("grid: workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)a.used);
         return ST_ERR_WORKSPACE;
     }
@@ -146,10 +151,11 @@ int st_grid_build(const float* pts, int64_t n, float cell, int64_t max_cells, St
                 (long long)ncell, h.dim[0], h.dim[1], h.dim[2]);
     }
     (void)hipMemsetAsync(cell_start, 0, (ncell + 1) * sizeof(uint32_t), stream);
-    hipLaunchKernelGGL(k_grid_count, dim3(gb), dim3(KNN_BLOCK), 0, stream, pts, n, (const StGrid*)g, cell_start, seg_off, nseg);
+    hipLaunchKernelGGL(k_grid_count, dim3(gb), dim3(KNN_BLOCK), 0, stream, pts, n, (const StGrid*)g, cell_start, seg_off, nseg,
+                       pt_cell, pt_rank);
     ST_TRY(st_exclusive_scan_u32(cell_start, cell_start, ncell + 1, nullptr, scan_ws, scan_bytes, stream));
-    (void)hipMemcpyAsync(cursor, cell_start, (ncell + 1) * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream);
-    hipLaunchKernelGGL(k_grid_fill, dim3(gb), dim3(KNN_BLOCK), 0, stream, pts, n, (const StGrid*)g, cursor, recs, seg_off, nseg);
+    hipLaunchKernelGGL(k_grid_fill, dim3(gb), dim3(KNN_BLOCK), 0, stream, pts, n, (const uint32_t*)cell_start,
+                       (const uint32_t*)pt_cell, (const uint32_t*)pt_rank, recs);
     ST_CHECK_LAUNCH();
     return ST_OK;
 }

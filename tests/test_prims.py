@@ -6,8 +6,12 @@ import torch
 from smart_tree_amd import _lib
 
 
-@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 2047, 2048, 2049, 70001])
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 2047, 2048, 2049, 4095, 4096, 4097, 70001,
+                               pytest.param(4_300_003, marks=pytest.mark.gpu),  # > 1024 tiles: the recursive tile-offset scan
+                               pytest.param(51_000_001, marks=pytest.mark.gpu)])  # the cell table of a batched kNN grid
 def test_exclusive_scan(backend, n):
+    if n > 1_000_000 and backend.type == "cpu":
+        pytest.skip("large scans run on the GPU")
     L = _lib.lib()
     a = np.random.RandomState(n).randint(0, 7, n).astype(np.int32)
     t = torch.from_numpy(a).to(backend)
