@@ -283,11 +283,16 @@ static int conv_launch_mfma(const float* x0, int c0, const float* x1, const int3
                             const float* scale, const float* shift, const float* residual, int relu, float* y,
                             hipStream_t stream, const int32_t* row_order) {
     int v = g_mfma_variant;
-    if (v == 0) v = 1;  // measured on MI355X (tools/bench_conv.py): RT = 1 with direct weight loads wins at every level
+    // measured on MI355X (tools/bench_conv.py, profiles/r02_conv_variants_batch8.txt): one row tile per wave with the weights
+    // straight from L2 wins while a level has too few rows to fill the chip (one cloud: <= 90k rows below level 0) and for the
+    // parity-ordered inverse convs; from ~150k rows on (a batch of clouds, the 5M-point cloud) two row tiles per wave with
+    // W_k staged once per workgroup in LDS is 5-20 % faster (B fragments reused, a quarter of the weight traffic from L2)
+    if (v == 0) v = (row_order == nullptr && n_out >= 150000) ? 18 : 1;
 #define MFMA_V(RT_, L_) conv_launch_mfma_v<CIN, COUT, RT_, L_>(x0, c0, x1, nbr, K, n_out, wp, scale, shift, residual, relu, y, stream, row_order)
     switch (v) {
         case 1: MFMA_V(1, false); break;
         case 2: MFMA_V(2, false); break;
+        case 4: MFMA_V(4, false); break;
         case 17: MFMA_V(1, true); break;
         default: MFMA_V(2, true); break;
     }

@@ -117,10 +117,14 @@ __device__ __forceinline__ unsigned long long st_hash_next(unsigned long long sl
 
 // Open-addressing table: keys[cap] (u64), vals[cap] (u32).  cap is a power of two (>= 8).
 // insert-with-min: the smallest value ever offered for a key wins (deterministic).
+// An insert gives up (returns false = "table full", the caller flags it and the host retries with a larger table) after
+// ST_HASH_MAX_PROBE slots: below the 50 % load the callers size for, probe sequences are a handful of slots long, and
+// without the limit every insert into a table that did fill up would walk ALL of it.
+#define ST_HASH_MAX_PROBE 4096ull
 __device__ __forceinline__ bool st_hash_insert_min(unsigned long long* keys, unsigned* vals, unsigned long long cap,
                                                    unsigned long long key, unsigned val) {
     unsigned long long slot = st_hash_slot(key, cap);
-    for (unsigned long long probe = 0; probe < cap; probe++) {
+    for (unsigned long long probe = 0; probe < cap && probe < ST_HASH_MAX_PROBE; probe++) {
         unsigned long long prev = atomicCAS(&keys[slot], (unsigned long long)ST_EMPTY_KEY, key);
         if (prev == ST_EMPTY_KEY || prev == key) {
             atomicMin(&vals[slot], val);
@@ -136,7 +140,7 @@ __device__ __forceinline__ bool st_hash_insert_min(unsigned long long* keys, uns
 __device__ __forceinline__ bool st_hash_insert_min_dup(unsigned long long* keys, unsigned* vals, unsigned long long cap,
                                                        unsigned long long key, unsigned val) {
     unsigned long long slot = st_hash_slot(key, cap);
-    for (unsigned long long probe = 0; probe < cap; probe++) {
+    for (unsigned long long probe = 0; probe < cap && probe < ST_HASH_MAX_PROBE; probe++) {
         unsigned long long prev = keys[slot];
         if (prev == ST_EMPTY_KEY) prev = atomicCAS(&keys[slot], (unsigned long long)ST_EMPTY_KEY, key);
         if (prev == ST_EMPTY_KEY || prev == key) {
@@ -150,7 +154,7 @@ __device__ __forceinline__ bool st_hash_insert_min_dup(unsigned long long* keys,
 __device__ __forceinline__ int st_hash_find(const unsigned long long* keys, const unsigned* vals, unsigned long long cap,
                                             unsigned long long key) {
     unsigned long long slot = st_hash_slot(key, cap);
-    for (unsigned long long probe = 0; probe < cap; probe++) {
+    for (unsigned long long probe = 0; probe < cap && probe < ST_HASH_MAX_PROBE; probe++) {
         unsigned long long k = keys[slot];
         if (k == key) return (int)vals[slot];
         if (k == ST_EMPTY_KEY) return -1;
@@ -175,7 +179,7 @@ __device__ __forceinline__ void st_hash_find_batch(const unsigned long long* key
     for (int j = 0; j < N; j++) {
         if (got[j] != key[j] && got[j] != ST_EMPTY_KEY) {  // displaced: follow the probe sequence
             unsigned long long s = slot[j], g = got[j];
-            for (unsigned long long probe = 1; probe < cap && g != key[j] && g != ST_EMPTY_KEY; probe++) {
+            for (unsigned long long probe = 1; probe < cap && probe < ST_HASH_MAX_PROBE && g != key[j] && g != ST_EMPTY_KEY; probe++) {
                 s = st_hash_next(s, key[j], cap);
                 g = keys[s];
             }

@@ -289,6 +289,9 @@ __global__ void __launch_bounds__(VX_BLOCK) k_vx_pass(const float* xyz, int64_t 
         return;
     }
     vx_stream_points(xyz, n, i0, i1, [&](int64_t i, float x, float y, float z) {
+        // a table that filled up (the host's capacity guess was too small: it retries with a larger one) makes every further
+        // insert walk its probe limit for nothing
+        if (__hip_atomic_load(&st->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4u) return;
         const float pt[3] = {x, y, z};
         uint32_t mine = 0, won = 0u;
         int j = 0;

@@ -21,6 +21,9 @@ from .. import _lib
 from ..data_types.cloud import Cloud
 
 
+_VOXELS_PER_POINT = {}  # (voxel, block, buffer) -> voxels per input point of the last call: sizes the next call's hash table
+
+
 @dataclass
 class VoxelBatch:
     feats: torch.Tensor  # [M,6] float32 representative point (xyz, rgb)
@@ -50,7 +53,13 @@ def voxelize_blocks(xyz: torch.Tensor, rgb: Optional[torch.Tensor], voxel_size: 
     n_vox, n_blk = ctypes.c_int64(0), ctypes.c_int64(0)
     i32 = lambda k: torch.empty((k,), dtype=torch.int32, device=dev)
     blk_seg, seg_vox, seg_blk = (i32(max_blocks), i32(nseg + 1), i32(nseg + 1)) if nseg > 1 else (None, None, None)
-    for cap in (3 * n + 1024, 8 * n + 1024):  # a point sits in <= 8 halo cubes
+    # Output capacity = hash-table size / 2: a table sized for the worst case (a point sits in <= 8 halo cubes) is ~40x
+    # larger than what a tree cloud needs, and every probe into it is a cache miss.  First guess: 1.5 x the voxels-per-point
+    # ratio the last call with these parameters saw (0.5 the first time); the kernel flags an overflow, then the worst-case
+    # sizes follow.
+    key = (float(voxel_size), float(block_size), float(buffer_size))
+    guess = int(n * min(1.5 * _VOXELS_PER_POINT.get(key, 1.0 / 3.0), 8.0)) + 4096
+    for cap in sorted({min(guess, 8 * n + 1024), 3 * n + 1024, 8 * n + 1024}):
         feats = torch.empty((cap, 6), dtype=torch.float32, device=dev)
         coords = torch.empty((cap, 4), dtype=torch.int32, device=dev)
         mask = torch.empty((cap,), dtype=torch.uint8, device=dev)
@@ -66,6 +75,8 @@ def voxelize_blocks(xyz: torch.Tensor, rgb: Optional[torch.Tensor], voxel_size: 
             break
     _lib.check(rc)
     m, b = n_vox.value, n_blk.value
+    if n > 0:
+        _VOXELS_PER_POINT[key] = max(m / n, 1e-3)
     return VoxelBatch(feats[:m], coords[:m], mask[:m].bool(), pidx[:m], centres[:b],
                       blk_seg[:b] if blk_seg is not None else None, seg_vox, seg_blk, nseg)
 

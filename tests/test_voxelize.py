@@ -45,3 +45,19 @@ def test_voxelize_empty_result(backend):
     xyz = np.random.RandomState(2).uniform(0, 3, (10, 3)).astype(np.float32)  # no block has > 20 points
     out = _compare(xyz, np.zeros_like(xyz), 0.02, backend)
     assert out.coords.shape[0] == 0 and out.block_centres.shape[0] == 0
+
+
+def test_voxelize_sparse_cloud_takes_the_capacity_retry(backend):
+    """More voxels than the first capacity guess (half a voxel per point): points farther apart than a voxel, each sitting in
+    up to eight halo cubes.  The hash table fills, inserts give up after the probe limit, the kernel flags it, the host retries
+    with the worst-case sizes -- and the next call with the same parameters starts from the ratio it has seen."""
+    from smart_tree_amd.dataset import dataset as ds
+
+    rng = np.random.RandomState(5)
+    xyz = rng.uniform(-0.3, 0.3, (6000, 3)).astype(np.float32)  # around a block corner: every point is in 8 halo cubes
+    kw = dict(block_size=1.0, buffer_size=0.4)
+    ds._VOXELS_PER_POINT.pop((0.001, 1.0, 0.4), None)
+    out = _compare(xyz, np.zeros_like(xyz), 0.001, backend, **kw)
+    assert out.coords.shape[0] > 3 * xyz.shape[0]  # > the second guess as well: the 8n capacity was needed
+    assert ds._VOXELS_PER_POINT[(0.001, 1.0, 0.4)] > 3
+    _compare(xyz, np.zeros_like(xyz), 0.001, backend, **kw)  # second call: first guess already large enough

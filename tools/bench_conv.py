@@ -16,10 +16,15 @@ pipe = bench.build_pipeline(dev)
 NPTS = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 VOX = float(sys.argv[2]) if len(sys.argv) > 2 else 0.02
 FOL = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
-c = sample_tree_cloud(NPTS, seed=3 if FOL else 0, **({"foliage_fraction": FOL} if FOL else {}))
-cloud = pipe.preprocessing(Cloud(xyz=torch.from_numpy(c["xyz"]).to(dev), rgb=torch.from_numpy(c["rgb"]).to(dev)))
-vb = voxelize_blocks(cloud.xyz, cloud.rgb, VOX)
-pyr = ops.build_pyramid(vb.coords, 3)
+BATCH = int(sys.argv[4]) if len(sys.argv) > 4 else 1  # clouds per launch set (Cloud.collate): the batched pipeline's sizes
+VARIANTS = [int(v) for v in sys.argv[5].split(",")] if len(sys.argv) > 5 else [1]
+clouds = []
+for b in range(BATCH):
+    c = sample_tree_cloud(NPTS, seed=(3 if FOL else 0) + b, **({"foliage_fraction": FOL} if FOL else {}))
+    clouds.append(Cloud(xyz=torch.from_numpy(c["xyz"]).to(dev), rgb=torch.from_numpy(c["rgb"]).to(dev)))
+cloud = pipe.preprocessing(Cloud.collate(clouds) if BATCH > 1 else clouds[0])
+vb = voxelize_blocks(cloud.xyz, cloud.rgb, VOX, seg_off=cloud.seg_off)
+pyr = ops.build_pyramid(vb.coords, 3, vb.blk_seg, vb.n_seg)
 N = [x.shape[0] for x in pyr.coords]
 print("levels", N)
 def timeit(fn, reps=20):
@@ -49,12 +54,12 @@ for lvl in range(4):
             from smart_tree_amd import _lib
             L = _lib.lib(); L.st_debug_set_mfma_variant.argtypes = [ctypes.c_int]
             ya = ops.sparse_conv(x, w, tbl, nout, row_order=ro)
-            for var, tag in ((1, "rt1"),):
+            for var, tag in [(v, f"v{v}") for v in VARIANTS]:
                 L.st_debug_set_mfma_variant(var)
                 t_m = timeit(lambda: ops.sparse_conv(x, w, tbl, nout, wp=wp, row_order=ro))
                 yb = ops.sparse_conv(x, w, tbl, nout, wp=wp, row_order=ro)
                 err = (ya - yb).abs().max().item() / (ya.abs().max().item() + 1e-30)
-                line += f" | mfma {t_m:6.1f} us ({bytes_/t_m/1e3:7.1f} GB/s = {bytes_/t_m/1e3/80:4.1f} % of 8 TB/s) {flops/t_m/1e6:5.1f} TF e={err:.0e}"
+                line += f" | mfma[{tag}] {t_m:6.1f} us ({bytes_/t_m/1e3:7.1f} GB/s = {bytes_/t_m/1e3/80:4.1f} % of 8 TB/s) {flops/t_m/1e6:5.1f} TF e={err:.0e}"
             L.st_debug_set_mfma_variant(0)
             # half-precision storage (config 5): f16 matrix-core kernel, half the gather bytes
             xh, wph = x.half(), wp.half()
