@@ -39,9 +39,12 @@ def main(argv=None):
     pipeline = instantiate(cfg["pipeline"])
     if "path" in cfg:
         pipeline.process_cloud(Path(cfg["path"]))
-    elif "directory" in cfg:
-        for p in sorted(Path(cfg["directory"]).glob("*.npz")):
-            pipeline.process_cloud(p)
+    elif "directory" in cfg:  # every entry of the directory, as cli.py:22-23 (sorted; files load_cloud cannot read are named and skipped)
+        for p in sorted(Path(cfg["directory"]).iterdir()):
+            if p.is_file() and p.suffix in (".npz", ".ply"):
+                pipeline.process_cloud(p)
+            elif p.is_file():
+                print(f"skipping {p}: not a point cloud format this build reads (.npz / .ply)")
     else:
         print("Please supply a path or directory.")
 

@@ -15,7 +15,7 @@ import torch
 from . import profiling
 from .data_types.cloud import Cloud
 from .data_types.tree import DisjointTreeSkeleton
-from .util.file import load_cloud, save_skeleton_npz, write_ply_points, write_ply_skeleton
+from .util.file import load_cloud, save_skeleton, save_skeleton_npz, write_ply_points, write_ply_skeleton
 
 
 class Pipeline:
@@ -59,6 +59,9 @@ class Pipeline:
         if self.save_outputs:  # reference pipeline.py:85-93 (skeleton.ply / cloud.ply; meshes need open3d)
             sp = Path(self.save_path)
             save_skeleton_npz(sp / "skeleton.npz", skeleton)
+            for tree in skeleton.skeletons:  # the reference's own per-tree layout (util/file.py:73-94), readable by its load_skeleton
+                if tree.branches:
+                    save_skeleton(tree, sp / f"skeleton_{tree._id}.npz")
             write_ply_skeleton(sp / "skeleton.ply", skeleton)
             write_ply_points(sp / "cloud.ply", lc.xyz.cpu().numpy(), lc.rgb.cpu().numpy() if lc.rgb is not None else None)
         return skeleton

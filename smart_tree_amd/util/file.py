@@ -121,6 +121,41 @@ def save_cloud(path, cloud: Cloud) -> None:
     np.savez(path, **{k: v.detach().cpu().numpy() for k, v in fields.items() if v is not None})
 
 
+def save_skeleton(skeleton, save_location) -> None:
+    """One TreeSkeleton in the reference's `.npz` layout (util/file.py:73-94): tree_id, skeleton_xyz [P,3], skeleton_radii
+    (the branches' radii concatenated, plus a trailing axis), branch_id / branch_parent_id / branch_num_elements [B]."""
+    branches = list(skeleton.branches.values())
+    as_np = lambda t: t.detach().cpu().numpy() if hasattr(t, "detach") else np.asarray(t)
+    data = {"tree_id": skeleton._id,
+            "skeleton_xyz": np.concatenate([as_np(b.xyz) for b in branches]),
+            "skeleton_radii": np.concatenate([as_np(b.radii) for b in branches])[..., np.newaxis],
+            "branch_id": np.asarray([b._id for b in branches]),
+            "branch_parent_id": np.asarray([b.parent_id for b in branches]),
+            "branch_num_elements": np.asarray([len(b) for b in branches])}
+    Path(save_location).parent.mkdir(parents=True, exist_ok=True)
+    np.savez(save_location, **data)
+
+
+def load_skeleton(path):
+    """Reference util/file.py:97-116: -> TreeSkeleton(0, {branch_id: BranchSkeleton(id, parent, xyz, radii)}).  The file holds
+    radii as [P,1,1] (save adds an axis the loader never removes: the reference hands BranchSkeleton a [m,1,1] numpy array);
+    here they come back as the [m,1] tensors every other producer of BranchSkeleton uses."""
+    import torch
+
+    from ..data_types.branch import BranchSkeleton
+    from ..data_types.tree import TreeSkeleton
+
+    with np.load(path) as data:
+        branch_id, parent_id = data["branch_id"], data["branch_parent_id"]
+        xyz, radii, sizes = data["skeleton_xyz"], data["skeleton_radii"], data["branch_num_elements"]
+    offsets = np.cumsum(np.append([0], sizes))
+    branches = {}
+    for size, off, _id, par in zip(sizes, offsets, branch_id, parent_id):
+        branches[int(_id)] = BranchSkeleton(int(_id), int(par), torch.from_numpy(np.ascontiguousarray(xyz[off: off + size])),
+                                            torch.from_numpy(np.ascontiguousarray(radii[off: off + size]).reshape(-1, 1)))
+    return TreeSkeleton(0, branches)
+
+
 def save_skeleton_npz(path, skeleton) -> None:
     """Flat arrays: per branch (tree id, branch id, parent id, offset, length) + concatenated xyz / radii."""
     rows, xyz, radii, off = [], [], [], 0

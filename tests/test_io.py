@@ -1,4 +1,6 @@
 """Cloud / skeleton file formats: .npz keys, PLY round trips, CLI overrides."""
+from pathlib import Path
+
 import numpy as np
 import torch
 
@@ -51,3 +53,47 @@ def test_cli_overrides():
     cfg = cli.load_config(["+path=tree.npz", "pipeline.skeletonizer.K=8", "pipeline.repair_skeletons=False"])
     assert cfg["path"] == "tree.npz" and cfg["pipeline"]["skeletonizer"]["K"] == 8
     assert cfg["pipeline"]["repair_skeletons"] is False and cfg["pipeline"]["model_inference"]["block_size"] == 4
+
+
+def test_skeleton_npz_is_the_reference_layout(tmp_path):
+    """tests/golden/ref_saved_skeleton.npz was written by the reference's own save_skeleton (tools/make_goldens.py):
+    our load_skeleton reads it, and our save_skeleton writes the same keys, shapes, dtypes and values."""
+    from smart_tree_amd.util.file import load_skeleton, save_skeleton
+
+    gold = Path(__file__).resolve().parent / "golden"
+    ref_file = gold / "ref_saved_skeleton.npz"
+    tree = load_skeleton(ref_file)
+    g = np.load(gold / "skeleton_y_tree.npz")
+    assert list(tree.branches) == g["branch_ids"].tolist()
+    for k, par in zip(g["branch_ids"].tolist(), g["branch_parent"].tolist()):
+        b = tree.branches[k]
+        assert b.parent_id == par
+        np.testing.assert_array_equal(b.xyz.numpy(), g[f"branch_{k}_xyz"])
+        np.testing.assert_array_equal(b.radii.numpy().reshape(-1), g[f"branch_{k}_radii"].reshape(-1))
+    # write what the reference wrote: rebuild the tree it saved (radii [m,1], tree id 3)
+    for k in tree.branches:
+        tree.branches[k].radii = torch.from_numpy(g[f"branch_{k}_radii"])
+    tree._id = 3
+    save_skeleton(tree, tmp_path / "mine.npz")
+    with np.load(ref_file) as a, np.load(tmp_path / "mine.npz") as b:
+        assert sorted(a.files) == sorted(b.files)
+        for key in a.files:
+            assert a[key].shape == b[key].shape and a[key].dtype == b[key].dtype, key
+            np.testing.assert_array_equal(a[key], b[key])
+
+
+def test_cli_directory_runs_every_cloud_file(tmp_path, monkeypatch):
+    """`+directory=` walks every entry (reference cli.py:22-23), .npz and .ply alike; other files are named and skipped."""
+    from smart_tree_amd import cli
+
+    seen = []
+
+    class FakePipeline:
+        def process_cloud(self, path):
+            seen.append(Path(path).name)
+
+    monkeypatch.setattr(cli, "instantiate", lambda node: FakePipeline())
+    for name in ("b.npz", "a.ply", "notes.txt"):
+        (tmp_path / name).write_bytes(b"")
+    cli.main([f"+directory={tmp_path}"])
+    assert seen == ["a.ply", "b.npz"]

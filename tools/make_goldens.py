@@ -241,6 +241,22 @@ def nearest_tube_case():
     print("nearest_tube", n, "points", m, "tubes")
 
 
+def skeleton_file_case():
+    """A skeleton written by the reference's own save_skeleton and read back by its load_skeleton (util/file.py:73-116)."""
+    r_file = reference("smart_tree.util.file")
+    r_branch = reference("smart_tree.data_types.branch")
+    r_tree = reference("smart_tree.data_types.tree")
+    g = np.load(OUT / "skeleton_y_tree.npz")
+    branches = {}
+    for k, par in zip(g["branch_ids"].tolist(), g["branch_parent"].tolist()):
+        branches[k] = r_branch.BranchSkeleton(k, par, torch.from_numpy(g[f"branch_{k}_xyz"]), torch.from_numpy(g[f"branch_{k}_radii"]))
+    tree = r_tree.TreeSkeleton(3, branches)
+    r_file.save_skeleton(tree, OUT / "ref_saved_skeleton.npz")
+    back = r_file.load_skeleton(OUT / "ref_saved_skeleton.npz")
+    assert list(back.branches) == list(branches)
+    print("ref_saved_skeleton", len(branches), "branches", {k: v.shape for k, v in np.load(OUT / "ref_saved_skeleton.npz").items()})
+
+
 def y_tree(seed=0):
     """A small trunk + two limbs with exact medial vectors and a little noise."""
     rng = np.random.RandomState(seed)
@@ -275,6 +291,7 @@ def main():
     skeleton_case("skeleton_small_tree", vx["feats"][m, :3], c["medial_vector"][vx["point"][m]])
     blocking_case()
     nearest_tube_case()
+    skeleton_file_case()
 
 
 if __name__ == "__main__":
