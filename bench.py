@@ -35,7 +35,8 @@ N_POINTS = 1_000_000
 VOXEL = 0.02
 WEIGHTS = ROOT / "smart_tree_amd" / "model" / "weights"
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-MAX_BATCH = 8
+MAX_BATCH = 16  # clouds per launch set  } measured on one MI355X (tools/sweep_batch.sh, profiles/r02_sweep_batch.txt):
+STREAMS = 3     # batches in flight      } 3 x 16 = 2.4 ms per cloud, 2 x 8 = 3.4, 2 x 32 = 2.4, 4 x 16 = 2.8
 N_SEEDS = 4  # distinct clouds per rank, cycled
 
 
@@ -256,7 +257,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the configs[3] / configs[4] single-cloud timings")
     ap.add_argument("--batch", type=int, default=MAX_BATCH, help="clouds per launch set (Pipeline.process_clouds); 1 = one cloud per call")
-    ap.add_argument("--streams", type=int, default=2, help="batches in flight per GPU (one host thread + HIP stream each)")
+    ap.add_argument("--streams", type=int, default=STREAMS, help="batches in flight per GPU (one host thread + HIP stream each)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -331,6 +332,20 @@ def main():
     gather()
     fence()
     dt_up = time.perf_counter() - t1
+    # for the record: ONE batch at a time on one stream with the kernel timers on -- solo kernel durations (in the timed region
+    # the kernels of the batches in flight share the chip, which inflates every bracket)
+    roof_solo = None
+    if world == 1:
+        solo = CloudWorker.__new__(CloudWorker)
+        solo.__dict__.update(worker.__dict__)
+        solo.S = 1
+        profiling.enable(True)
+        solo.run([min(B, max(args.steps, 1))], collect=False)
+        torch.cuda.synchronize()
+        profiling.enable(False)
+        full = profiling.roofline(HBM_PEAK_GBS)
+        roof_solo = {"note": "one batch of %d clouds alone on the GPU (untimed extra pass)" % min(B, max(args.steps, 1)),
+                     "gather_gemm": full.get("gather_gemm"), "all_kernels": full.get("all_kernels")}
     if world > 1:
         t = torch.tensor([dt, dt_up], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -353,6 +368,7 @@ def main():
                        "single_cloud_latency_ms": None if serial_ms is None else round(serial_ms, 3)},
             "value_incl_host_upload": world * args.steps * args.points / dt_up,
             "roofline": roof,
+            "roofline_solo": roof_solo,
             "stage_ms": stage_ms,
             "last_result": last,
         }

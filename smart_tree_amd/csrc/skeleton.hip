@@ -1266,6 +1266,14 @@ extern "C" int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, c
     A.s_cursor = s.s_cursor; A.s_wide = s.s_wide; A.order = s.order; A.order_init = s.order_init; A.pos = s.pos;
     A.ticks = g_debug_ticks;
     A.prune_factor = g_prune_factor; A.small_work = g_small_work; A.iters_per_launch = g_iters_per_launch; A.local_items = g_local_items; A.wave_work = g_wave_work;
+    // A batch of clouds advances in lockstep: a launch lasts as long as its slowest component, and a component that hands a
+    // long path to the chip-wide claim kernel waits for everybody else's rounds.  Fewer hand-overs (the workgroup claims
+    // paths up to 16x larger by itself) and shorter launches measured 2.98 -> 2.48 ms of skeleton stage per cloud at 8 clouds
+    // per batch (tools/sweep_select.sh, profiles/r02_sweep_select.txt); one cloud alone keeps the round-1 optimum.
+    if (nseg > 1) {
+        if (g_small_work == SK_SMALL_WORK) A.small_work = 1 << 22;
+        if (g_iters_per_launch == SK_ITERS_PER_LAUNCH) A.iters_per_launch = 16;
+    }
 
     const unsigned vg = sk_vgrid(m);
     const unsigned fg = (unsigned)st_min64(st_div_up(m, SK_WIDE_BLOCK), SK_SSSP_BLOCKS);

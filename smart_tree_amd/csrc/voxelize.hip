@@ -36,6 +36,7 @@ struct VxParams {
     float half_inner;  // block/2
     float bs_half;     // block/2 (centre offset)
     float vs;          // voxel size
+    float vs_inv;      // fl(1 / vs) (vx_floor_div)
     int min_points;
     int max_blocks;
     int nseg;
@@ -241,15 +242,35 @@ __global__ void __launch_bounds__(VX_BLOCK) k_vx_minmax(const float* xyz, int64_
         }
 }
 
+// Per block, once (instead of per point and block): the voxel origin as a float and the grid size roundf((hi - lo) / v).
+__global__ void __launch_bounds__(VX_BLOCK) k_vx_block_grid(const VxState* st, int max_blocks, const unsigned* blk_lo,
+                                                            const unsigned* blk_hi, float vs, float* blk_lof, int* blk_grid) {
+    const int nb = (int)st_min<uint32_t>(st->n_blocks, (uint32_t)max_blocks);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 3 * nb; i += gridDim.x * blockDim.x) {
+        const float lo = st_ord2f(blk_lo[i]), hi = st_ord2f(blk_hi[i]);
+        blk_lof[i] = lo;
+        blk_grid[i] = (int)roundf((hi - lo) / vs);
+    }
+}
+
+// (int)floorf(q / v), bit for bit, mostly without the division: t = q * fl(1/v) differs from the correctly rounded
+// quotient by < 2e-7 |t| (three roundings), so unless an integer lies within 1e-6 |t| of t both have the same floor; the
+// rare lane that is that close to an integer evaluates the exact expression.
+__device__ __forceinline__ int vx_floor_div(float q, float v, float inv_v) {
+    const float t = q * inv_v;
+    const float f = floorf(t);
+    const float frac = t - f, tol = fabsf(t) * 1e-6f + 1e-30f;
+    if (frac < tol || 1.0f - frac < tol) return (int)floorf(q / v);
+    return (int)f;
+}
+
 // voxel coordinate of p inside block b: floorf((p - lo) / v), valid iff 0 <= c < roundf((hi - lo) / v)
-__device__ __forceinline__ bool vx_coord(const float* pt, int b, const unsigned* blk_lo, const unsigned* blk_hi, float vs,
+__device__ __forceinline__ bool vx_coord(const float* pt, int b, const float* blk_lof, const int* blk_grid, float vs, float inv_vs,
                                          int* c) {
     bool ok = true;
     for (int a = 0; a < 3; a++) {
-        float lo = st_ord2f(blk_lo[3 * b + a]), hi = st_ord2f(blk_hi[3 * b + a]);
-        int grid = (int)roundf((hi - lo) / vs);
-        c[a] = (int)floorf((pt[a] - lo) / vs);
-        ok = ok && c[a] >= 0 && c[a] < grid;
+        c[a] = vx_floor_div(pt[a] - blk_lof[3 * b + a], vs, inv_vs);
+        ok = ok && c[a] >= 0 && c[a] < blk_grid[3 * b + a];
     }
     return ok;
 }
@@ -259,8 +280,8 @@ __device__ __forceinline__ bool vx_coord(const float* pt, int b, const unsigned*
 // second round of hash look-ups.
 template <int PASS>
 __global__ void __launch_bounds__(VX_BLOCK) k_vx_pass(const float* xyz, int64_t n, const int* seg_off, VxState* st,
-                                                      const int* table, VxParams p, const unsigned* blk_lo,
-                                                      const unsigned* blk_hi, unsigned long long* keys, unsigned* vals,
+                                                      const int* table, VxParams p, const float* blk_lof,
+                                                      const int* blk_grid, unsigned long long* keys, unsigned* vals,
                                                       unsigned long long cap, uint32_t* cnt_or_off, uint32_t* win,
                                                       uint32_t* rec_b, uint32_t* rec_pt, int64_t max_voxels) {
     int d[3];
@@ -298,7 +319,7 @@ __global__ void __launch_bounds__(VX_BLOCK) k_vx_pass(const float* xyz, int64_t 
         vx_for_each_block(pt, st, d, tab, p, [&](int b) {
             const uint32_t bit = 1u << j++;
             int c[3];
-            if (!vx_coord(pt, b, blk_lo, blk_hi, p.vs, c)) return;
+            if (!vx_coord(pt, b, blk_lof, blk_grid, p.vs, p.vs_inv, c)) return;
             unsigned long long key = st_pack_key(b, c[2], c[1], c[0]);
             if (PASS == 0) {
                 if (!st_hash_insert_min_dup(keys, vals, cap, key, (unsigned)i)) atomicOr(&st->overflow, 4u);
@@ -319,7 +340,7 @@ __global__ void __launch_bounds__(VX_BLOCK) k_vx_iota(uint32_t* v, int64_t n) {
 // blk_seg (batched calls): cloud of every block -> the first voxel of every cloud lands in st->seg_vox_off
 __global__ void __launch_bounds__(VX_BLOCK) k_vx_gather(const float* xyz, const float* rgb, int64_t m, const uint32_t* sorted_b,
                                                         const uint32_t* order, const uint32_t* rec_pt, const float* centres,
-                                                        VxParams p, const unsigned* blk_lo, const unsigned* blk_hi,
+                                                        VxParams p, const float* blk_lof, const int* blk_grid,
                                                         float* feats, int32_t* coords, uint8_t* mask, int64_t* point_index,
                                                         const int32_t* blk_seg, VxState* st) {
     for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += (int64_t)gridDim.x * blockDim.x) {
@@ -327,7 +348,7 @@ __global__ void __launch_bounds__(VX_BLOCK) k_vx_gather(const float* xyz, const 
         int64_t i = rec_pt[order[j]];
         float pt[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
         int c[3];
-        vx_coord(pt, b, blk_lo, blk_hi, p.vs, c);
+        vx_coord(pt, b, blk_lof, blk_grid, p.vs, p.vs_inv, c);
         bool inner = true;
         for (int a = 0; a < 3; a++) {
             float ctr = centres[3 * b + a];
@@ -369,7 +390,7 @@ static inline dim3 vx_grid_seg(int64_t n, int nseg, int64_t cap) {
 }
 
 static int64_t vx_layout(StArena& a, int64_t n, int max_blocks, int64_t max_voxels, int nseg, VxState** st, int** table,
-                         unsigned** blk_lo, unsigned** blk_hi, unsigned long long** keys, unsigned** vals, uint32_t** cnt, uint32_t** win,
+                         unsigned** blk_lo, unsigned** blk_hi, float** blk_lof, int** blk_grid, unsigned long long** keys, unsigned** vals, uint32_t** cnt, uint32_t** win,
                          uint32_t** rec_b, uint32_t** rec_pt, uint32_t** order, char** sub, int64_t* sub_bytes,
                          int64_t* cap) {
     *cap = st_next_pow2(2 * (max_voxels > 8 ? max_voxels : 8));
@@ -377,6 +398,8 @@ static int64_t vx_layout(StArena& a, int64_t n, int max_blocks, int64_t max_voxe
     *table = a.take<int>((int64_t)VX_TABLE_CAP * nseg);
     *blk_lo = a.take<unsigned>(3 * (int64_t)max_blocks);
     *blk_hi = a.take<unsigned>(3 * (int64_t)max_blocks);
+    *blk_lof = a.take<float>(3 * (int64_t)max_blocks);
+    *blk_grid = a.take<int>(3 * (int64_t)max_blocks);
     *keys = a.take<unsigned long long>(*cap);
     *vals = a.take<unsigned>(*cap);
     *cnt = a.take<uint32_t>(n);
@@ -392,10 +415,10 @@ static int64_t vx_layout(StArena& a, int64_t n, int max_blocks, int64_t max_voxe
 
 extern "C" int64_t st_voxelize_workspace_bytes_seg(int64_t n_points, int max_blocks, int64_t max_voxels, int nseg) {
     StArena a(nullptr, 0);
-    VxState* st; int* table; unsigned *lo, *hi; unsigned long long* keys; unsigned* vals;
+    VxState* st; int* table; unsigned *lo, *hi; float* lof; int* grd; unsigned long long* keys; unsigned* vals;
     uint32_t *cnt, *win, *rb, *rp, *ord; char* sub; int64_t sb, cap;
-    return vx_layout(a, n_points, max_blocks, max_voxels, nseg < 1 ? 1 : nseg, &st, &table, &lo, &hi, &keys, &vals, &cnt, &win, &rb,
-                     &rp, &ord, &sub, &sb, &cap);
+    return vx_layout(a, n_points, max_blocks, max_voxels, nseg < 1 ? 1 : nseg, &st, &table, &lo, &hi, &lof, &grd, &keys, &vals, &cnt,
+                     &win, &rb, &rp, &ord, &sub, &sb, &cap);
 }
 extern "C" int64_t st_voxelize_workspace_bytes(int64_t n_points, int max_blocks, int64_t max_voxels) {
     return st_voxelize_workspace_bytes_seg(n_points, max_blocks, max_voxels, 1);
@@ -427,10 +450,10 @@ extern "C" int st_voxelize_blocks_seg(const float* xyz, const float* rgb, int64_
     }
 
     StArena a(ws, ws_bytes);
-    VxState* st; int* table; unsigned *blk_lo, *blk_hi; unsigned long long* keys; unsigned* vals;
+    VxState* st; int* table; unsigned *blk_lo, *blk_hi; float* blk_lof; int* blk_grid; unsigned long long* keys; unsigned* vals;
     uint32_t *cnt, *win, *rec_b, *rec_pt, *order; char* sub; int64_t sub_bytes, cap;
-    vx_layout(a, n, max_blocks, max_voxels, nseg, &st, &table, &blk_lo, &blk_hi, &keys, &vals, &cnt, &win, &rec_b, &rec_pt, &order,
-              &sub, &sub_bytes, &cap);
+    vx_layout(a, n, max_blocks, max_voxels, nseg, &st, &table, &blk_lo, &blk_hi, &blk_lof, &blk_grid, &keys, &vals, &cnt, &win, &rec_b,
+              &rec_pt, &order, &sub, &sub_bytes, &cap);
     if (!a.ok() || !sub) {
         st_set_error("voxelize: workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)a.used);
         return ST_ERR_WORKSPACE;
@@ -446,6 +469,7 @@ extern "C" int st_voxelize_blocks_seg(const float* xyz, const float* rgb, int64_
     p.half_inner = (float)(block_size / 2);
     p.bs_half = (float)(block_size / 2);
     p.vs = (float)voxel_size;
+    p.vs_inv = 1.0f / p.vs;
     p.min_points = min_points;
     p.max_blocks = max_blocks;
     p.nseg = nseg;
@@ -461,15 +485,17 @@ extern "C" int st_voxelize_blocks_seg(const float* xyz, const float* rgb, int64_
     hipLaunchKernelGGL(k_vx_blocks, dim3(1), dim3(VX_BLOCK), 0, stream, st, table, p, block_centres, blk_lo, blk_hi, blk_seg);
     hipLaunchKernelGGL(k_vx_minmax, gr, dim3(VX_BLOCK), 0, stream, xyz, n, seg_off, (const VxState*)st, (const int*)table, p, blk_lo,
                        blk_hi);
+    hipLaunchKernelGGL(k_vx_block_grid, dim3((unsigned)st_min64(st_div_up(3 * (int64_t)max_blocks, VX_BLOCK), 64)), dim3(VX_BLOCK), 0, stream,
+                       (const VxState*)st, max_blocks, (const unsigned*)blk_lo, (const unsigned*)blk_hi, p.vs, blk_lof, blk_grid);
     hipLaunchKernelGGL((k_vx_pass<0>), gs, dim3(VX_BLOCK), 0, stream, xyz, n, seg_off, st, (const int*)table, p,
-                       (const unsigned*)blk_lo, (const unsigned*)blk_hi, keys, vals, (unsigned long long)cap, cnt, win, rec_b,
+                       (const float*)blk_lof, (const int*)blk_grid, keys, vals, (unsigned long long)cap, cnt, win, rec_b,
                        rec_pt, max_voxels);
     hipLaunchKernelGGL((k_vx_pass<1>), gs, dim3(VX_BLOCK), 0, stream, xyz, n, seg_off, st, (const int*)table, p,
-                       (const unsigned*)blk_lo, (const unsigned*)blk_hi, keys, vals, (unsigned long long)cap, cnt, win, rec_b,
+                       (const float*)blk_lof, (const int*)blk_grid, keys, vals, (unsigned long long)cap, cnt, win, rec_b,
                        rec_pt, max_voxels);
     ST_TRY(st_exclusive_scan_u32(cnt, cnt, n, &st->n_vox, sub, sub_bytes, stream));
     hipLaunchKernelGGL((k_vx_pass<2>), g1, dim3(VX_BLOCK), 0, stream, xyz, n, seg_off, st, (const int*)table, p,
-                       (const unsigned*)blk_lo, (const unsigned*)blk_hi, keys, vals, (unsigned long long)cap, cnt, win, rec_b,
+                       (const float*)blk_lof, (const int*)blk_grid, keys, vals, (unsigned long long)cap, cnt, win, rec_b,
                        rec_pt, max_voxels);
     if (nseg > 1) hipLaunchKernelGGL(k_vx_seg_vox_init, dim3(1), dim3(128), 0, stream, st, nseg, (const uint32_t*)&st->n_vox);
     ST_CHECK_LAUNCH();
@@ -493,7 +519,7 @@ extern "C" int st_voxelize_blocks_seg(const float* xyz, const float* rgb, int64_
         ST_TRY(st_radix_sort_pairs_u32(rec_b, order, m, bits, sub, sub_bytes, stream));
         hipLaunchKernelGGL(k_vx_gather, dim3(vx_grid(m)), dim3(VX_BLOCK), 0, stream, xyz, rgb, m, (const uint32_t*)rec_b,
                            (const uint32_t*)order, (const uint32_t*)rec_pt, (const float*)block_centres, p,
-                           (const unsigned*)blk_lo, (const unsigned*)blk_hi, feats, coords, mask, point_index,
+                           (const float*)blk_lof, (const int*)blk_grid, feats, coords, mask, point_index,
                            (const int32_t*)(nseg > 1 ? blk_seg : nullptr), st);
     }
     if (nseg > 1) hipLaunchKernelGGL(k_vx_seg_out, dim3(1), dim3(128), 0, stream, (const VxState*)st, nseg, seg_vox_off, seg_blk_off);
