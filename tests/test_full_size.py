@@ -268,7 +268,7 @@ def test_config5_half_precision_network_full_size_live_weights(million_point_vox
     vx = million_point_voxels
     dev = torch.device("cuda:0")
     peach = WEIGHTS.parent / "peach-forest-65.npz"
-    w = random_state_dict(uo.load_weights(peach), seed=2)
+    w = random_state_dict(uo.load_weights(peach), seed=5)  # a draw whose three heads are alive on > 98 % of the voxels
     o16 = uo.OracleNet(w, dtype=torch.float64, fp16=True)
     ref16 = o16.forward(vx["feats"][:, :3], vx["coords"])
     o32 = uo.OracleNet(w, dtype=torch.float64)
@@ -286,9 +286,19 @@ def test_config5_half_precision_network_full_size_live_weights(million_point_vox
         assert _rms(g - r) <= 1.5e-3 * _rms(r), (name, _rms(g - r) / _rms(r))
     g, r16, r32 = net.trace["tail0"].cpu().numpy(), o16.trace["tail0"].numpy(), o32.trace["tail0"].numpy()
     assert _rms(g - r16) < 0.8 * _rms(g - r32), (_rms(g - r16), _rms(g - r32))  # measured 2.3e-4 against 3.5e-4
-    for k in out:
+    for k in ("radius", "class_l"):
         err = np.abs(out[k].cpu().numpy() - ref16[k]).max()
-        assert err <= 5e-3 * np.abs(ref16[k]).max(), f"{k}: {err:.2e}"  # heads: F.normalize amplifies small vectors
+        assert err <= 5e-3 * np.abs(ref16[k]).max(), f"{k}: {err:.2e}"
+    # direction = F.normalize(v): the error of v is amplified by 1 / |v|, and a voxel whose head is dead (v == 0 exactly in the
+    # restatement -> direction 0) becomes a unit vector under any perturbation: bar = 5e-3 x (typical |v| / |v|), rows with
+    # |v| below a thousandth of the typical length are not comparable
+    v = o16.head(o16.trace["tail0"], "direction_head").numpy()
+    length = np.linalg.norm(v, axis=1)
+    typical = _rms(length)
+    rows = length > 1e-3 * typical
+    assert rows.mean() > 0.5, "the direction head is dead on this input"
+    err = np.abs(out["direction"].cpu().numpy() - ref16["direction"])[rows].max(axis=1)
+    assert (err <= 5e-3 * np.maximum(1.0, typical / length[rows])).all(), float((err / np.maximum(1.0, typical / length[rows])).max())
 
 
 def test_config5_half_precision_pipeline_with_the_shipped_checkpoint():

@@ -1,5 +1,7 @@
 """Cloud sharding + skeleton gather with a world_size-2 gloo process group on CPU."""
+import importlib.util
 import os
+from pathlib import Path
 import socket
 
 import torch
@@ -82,15 +84,17 @@ def test_gather_world_size_2_gloo():
         _same(unpack_skeletons(t, g)[i], _fake_skeleton(i))
 
 
-def test_bench_auto_streams_bounds(monkeypatch):
-    """bench.py's default clouds-in-flight: at most 8, at least 1, >= 3 clouds per worker, two host cores per worker and rank."""
-    import importlib.util
-    from pathlib import Path
+def test_bench_batch_plan():
+    """bench.py deals its K clouds out as batches (clouds per launch set): every cloud exactly once, no batch above the cap,
+    a multiple of the stream count where K allows it (no ragged tail), never an empty batch."""
     spec = importlib.util.spec_from_file_location("bench_mod", Path(__file__).resolve().parents[1] / "bench.py")
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    monkeypatch.setattr(bench, "usable_cores", lambda: 128)
-    assert bench.auto_streams(24, 1) == 8 and bench.auto_streams(24, 8) == 8
-    assert bench.auto_streams(10, 1) == 3 and bench.auto_streams(1, 1) == 1 and bench.auto_streams(0, 1) == 1
-    monkeypatch.setattr(bench, "usable_cores", lambda: 16)
-    assert bench.auto_streams(24, 1) == 8 and bench.auto_streams(24, 8) == 1 and bench.auto_streams(24, 2) == 4
+    for steps in (0, 1, 2, 5, 20, 47, 48, 96, 1000):
+        for streams in (1, 2, 3, 4):
+            for cap in (1, 8, 16):
+                plan = bench.plan_batches(steps, streams, cap)
+                assert sum(plan) == steps and all(0 < b <= cap for b in plan)
+                if plan:
+                    assert max(plan) - min(plan) <= 1 and (len(plan) % streams == 0 or len(plan) == steps)
+    assert bench.plan_batches(20, 3, 16) == [7, 7, 6] and bench.plan_batches(96, 3, 16) == [16] * 6
