@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(RB_BLOCK) k_rb_down_pass(const int32_t* coords
                     unsigned long long key = st_pack_key(b, oz, oy, ox);
                     unsigned cand = (unsigned)(i * 27 + k);
                     // ~6 fine voxels offer themselves for every coarse one: look before touching the slot with atomics
-                    if (!st_hash_insert_min_dup(keys, vals, cap, key, cand)) atomicOr(&st->fail, 1u);
+                    if (!st_hash_insert_min_dup(keys, vals, cap, key, cand, &st->fail, 1u)) atomicOr(&st->fail, 1u);
                 }
     }
 }

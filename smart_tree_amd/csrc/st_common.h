@@ -137,10 +137,15 @@ __device__ __forceinline__ bool st_hash_insert_min(unsigned long long* keys, uns
 // Same contract for a stream with MANY duplicates per key (voxelisation: ~9 points per voxel): look before
 // touching the slot with atomics.  A key never changes once written and a value only decreases, so a stale read
 // can only send us down the atomic path needlessly, never skip a needed update.
+// give_up / give_up_bit (optional): a flag word another insert sets when the table is full -- a probe sequence that has
+// grown long looks at it every 64 slots and stops (a full table would otherwise cost every insert its whole probe limit).
 __device__ __forceinline__ bool st_hash_insert_min_dup(unsigned long long* keys, unsigned* vals, unsigned long long cap,
-                                                       unsigned long long key, unsigned val) {
+                                                       unsigned long long key, unsigned val, const unsigned* give_up = nullptr,
+                                                       unsigned give_up_bit = 0u) {
     unsigned long long slot = st_hash_slot(key, cap);
     for (unsigned long long probe = 0; probe < cap && probe < ST_HASH_MAX_PROBE; probe++) {
+        if (give_up && (probe & 63ull) == 63ull &&
+            (__hip_atomic_load(give_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & give_up_bit)) return false;
         unsigned long long prev = keys[slot];
         if (prev == ST_EMPTY_KEY) prev = atomicCAS(&keys[slot], (unsigned long long)ST_EMPTY_KEY, key);
         if (prev == ST_EMPTY_KEY || prev == key) {

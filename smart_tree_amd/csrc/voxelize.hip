@@ -309,10 +309,10 @@ __global__ void __launch_bounds__(VX_BLOCK) k_vx_pass(const float* xyz, int64_t 
         }
         return;
     }
+    // a table that filled up (the host's capacity guess was too small: it retries with a larger one): pass 1 has nothing to
+    // do, and pass 0 stops inserting as soon as it sees the flag (checked where a probe sequence gets long, below)
+    if (PASS == 1 && (st->overflow & 4u)) return;
     vx_stream_points(xyz, n, i0, i1, [&](int64_t i, float x, float y, float z) {
-        // a table that filled up (the host's capacity guess was too small: it retries with a larger one) makes every further
-        // insert walk its probe limit for nothing
-        if (__hip_atomic_load(&st->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4u) return;
         const float pt[3] = {x, y, z};
         uint32_t mine = 0, won = 0u;
         int j = 0;
@@ -322,7 +322,7 @@ __global__ void __launch_bounds__(VX_BLOCK) k_vx_pass(const float* xyz, int64_t 
             if (!vx_coord(pt, b, blk_lof, blk_grid, p.vs, p.vs_inv, c)) return;
             unsigned long long key = st_pack_key(b, c[2], c[1], c[0]);
             if (PASS == 0) {
-                if (!st_hash_insert_min_dup(keys, vals, cap, key, (unsigned)i)) atomicOr(&st->overflow, 4u);
+                if (!st_hash_insert_min_dup(keys, vals, cap, key, (unsigned)i, &st->overflow, 4u)) atomicOr(&st->overflow, 4u);
             } else if (st_hash_find(keys, vals, cap, key) == (int)i) {
                 won |= bit;
                 mine++;

@@ -1,0 +1,16 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (through gpurun): the official bench line, the rocprofv3 kernel statistics of the same command, the
+# one-batch-at-a-time statistics, and the two PMC passes the roofline's `traffic` comes from.  Hard timeouts everywhere.
+#   gpurun --timeout 1500 -- 'bash tools/collect_r2.sh r02'   then   python tools/summarize_profiles.py r02
+tag=${1:-r02}
+R=$GRAFT_REPO_ROOT
+mkdir -p $R/gpurun_out
+cd $R
+timeout -s KILL 600 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
+tail -c 400 gpurun_out/${tag}_bench.json
+cd /tmp && export TMPDIR=/tmp
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${tag} -- python $R/bench.py --no-cpu-baseline --no-extras > $R/gpurun_out/prof_${tag}.log 2>&1
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_solo -- python $R/bench.py --streams 1 --steps 64 --warmup 8 --no-cpu-baseline --no-extras > $R/gpurun_out/prof_solo.log 2>&1
+timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_fetch -- python $R/bench.py --streams 1 --steps 16 --warmup 0 --no-cpu-baseline --no-extras > $R/gpurun_out/pmc_fetch.log 2>&1
+timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_write -- python $R/bench.py --streams 1 --steps 16 --warmup 0 --no-cpu-baseline --no-extras > $R/gpurun_out/pmc_write.log 2>&1
+cd $R; ls gpurun_out/prof_${tag}/*/ gpurun_out/prof_solo/*/ gpurun_out/pmc_fetch/*/ gpurun_out/pmc_write/*/ 2>&1 | tail -16
