@@ -36,6 +36,15 @@
 #define SK_ANC 64  // direct ancestors kept per vertex; longer walks hop 64 levels at a time (16 measured slower: every lane
                    // of a 1024-wide chunk hops j/SK_ANC times, so the chunk costs as much as its farthest lane)
 
+// Per-vertex state of the branch selection in ONE 16-byte record: a claimed point is stamped in all four words, and as
+// four separate arrays that was four scattered cache lines per point (rocprofv3 PMC, round 1: 13x the algorithmic bytes).
+struct SkPt {
+    float alloc;    // sample_tree's `distances` (-1 once allocated)
+    unsigned term;  // termination set
+    int branch;     // branch id of the point (-1: none); copied to `branch_of` when the selection is done
+    unsigned mark;  // speculation marks of k_sk_select (bit s: slot s of the current round would allocate the point)
+};
+
 struct SkArgs {
     int C;
     int64_t m;
@@ -67,8 +76,7 @@ struct SkArgs {
     unsigned* stamp;  // SSSP: queued-in-round marker; preds: resolution round; tree distance: visited
     unsigned* q0;
     unsigned* q1;
-    float* alloc;     // sample_tree's `distances` (-1 once allocated)
-    unsigned* term;   // termination set
+    SkPt* pt;         // [m] selection state (see SkPt)
     unsigned long long* best;  // claim race: (d2 bits << 32) | path position
     unsigned* touched;
     int* anc;         // [m][SK_ANC] direct ancestor table (component-local ids)
@@ -335,11 +343,11 @@ __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_lift_init(SkArgs A, const 
     SK_VERTEX_LOOP(v) {
         const int p = A.pred[v];
         A.anc[v * SK_ANC] = p;
-        A.alloc[v] = p > 0 ? distances[v] : -1.0f;  // path.py:71-72
-        A.term[v] = 0u;
-        A.branch_of[v] = -1;
+        A.pt[v].alloc = p > 0 ? distances[v] : -1.0f;  // path.py:71-72
+        A.pt[v].term = 0u;
+        A.pt[v].branch = -1;
         A.best[v] = SK_EMPTY64;
-        A.stamp[v] = 0u;  // speculation marks of k_sk_select
+        A.pt[v].mark = 0u;
     }
     if (blockIdx.x == 0)
         for (int c = threadIdx.x; c < A.C; c += blockDim.x) { A.s_done[c] = 0; A.s_nb[c] = 0; A.s_total[c] = 0; A.s_len[c] = 0; A.s_cursor[c] = 0; A.s_wide[c] = 0; }
@@ -348,7 +356,7 @@ __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_lift_init(SkArgs A, const 
 // sort keys: distance descending (masked vertices, alloc = -1, go last); second pass groups by component
 __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_sort_keys(SkArgs A, uint32_t* keys, uint32_t* vals, int pass) {
     SK_VERTEX_LOOP(v) {
-        if (pass == 0) { keys[v] = ~st_f2ord(A.alloc[v]); vals[v] = (uint32_t)v; }
+        if (pass == 0) { keys[v] = ~st_f2ord(A.pt[v].alloc); vals[v] = (uint32_t)v; }
         else keys[v] = (uint32_t)A.comp_of[vals[v]];
     }
 }
@@ -356,7 +364,7 @@ __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_sort_keys(SkArgs A, uint32
 __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_order_init(SkArgs A, float* order_init, int* pos) {
     SK_VERTEX_LOOP(j) {
         const unsigned v = A.order[j];
-        order_init[j] = A.alloc[v];
+        order_init[j] = A.pt[v].alloc;
         pos[v] = (int)(j - A.comp_off[A.comp_of[v]]);
     }
 }
@@ -461,16 +469,16 @@ __device__ __forceinline__ void sk_finish_branch(const SkArgs& A, int base, int 
         const float d2 = __uint_as_float((unsigned)(pk >> 32));
         const int qi = (int)(pk & 0xffffffffu);
         if (sqrtf(d2) < A.rad[base + (path_in_lds ? path[qi] : ld(&path[qi]))]) {
-            A.alloc[base + p] = -1.0f;
-            A.term[base + p] = 1u;
-            if (id >= 0) A.branch_of[base + p] = id;
+            A.pt[base + p].alloc = -1.0f;
+            A.pt[base + p].term = 1u;
+            if (id >= 0) A.pt[base + p].branch = id;
         }
     }
     for (int qi = threadIdx.x; qi < len; qi += blockDim.x) {
         const int v = path_in_lds ? path[qi] : ld(&path[qi]);
-        A.alloc[base + v] = -1.0f;
-        A.term[base + v] = 1u;
-        if (id >= 0) A.branch_of[base + v] = id;
+        A.pt[base + v].alloc = -1.0f;
+        A.pt[base + v].term = 1u;
+        if (id >= 0) A.pt[base + v].branch = id;
     }
     __syncthreads();  // stores drained (vmcnt) before anyone re-reads through L2
 }
@@ -526,7 +534,7 @@ __device__ __forceinline__ int sk_find_row(const uint32_t* row_off, int nrows, u
 // select: one workgroup per component.  sample_tree (path.py:49-140) is a sequential greedy loop -- take the
 // farthest unallocated vertex, walk to the skeleton, claim the points within the path's radius -- but
 // branches far apart do not interact, so each ROUND speculates: wavefront s takes the s-th farthest
-// unallocated vertex, walks it and marks (bit s of cmask[]) every point its branch would allocate, all
+// unallocated vertex, walks it and marks (bit s of cmask[].mark) every point its branch would allocate, all
 // against the state at the start of the round.  A scan in order then replays the sequential semantics from
 // the marks: a tip already marked by an accepted earlier slot would never have been selected (skipped); a
 // walk (or the vertex the parent id is read from) touched by an accepted earlier slot would have come out
@@ -561,7 +569,7 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
     const unsigned* order = A.order + base;
     const int* pos = A.pos + base;
     unsigned* tmp = A.q0 + base;
-    unsigned* cmask = A.stamp + base;  // speculation marks (zeroed by k_sk_lift_init, zero again after every round)
+    SkPt* cmask = A.pt + base;  // .mark: speculation marks (zeroed by k_sk_lift_init, zero again after every round)
     const float4* __restrict__ recs = A.recs;
     const StGrid* g = A.grid;
     const int xoff = A.comp_seg ? A.comp_seg[c] * g->seg_dim0 : 0;  // this cloud's slab of grid cells (batched call)
@@ -592,7 +600,7 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
                 if (j < n) {
                     wv = (int)order[j] - base;
                     wtail = !(A.order_init[base + j] > 0.0f);
-                    live = !wtail && ld(&A.alloc[base + wv]) > 0.0f;
+                    live = !wtail && ld(&A.pt[base + wv].alloc) > 0.0f;
                     if (live) {
                         const float* pv = A.pts + 3 * (int64_t)(base + wv);
                         wx = pv[0]; wy = pv[1]; wz = pv[2]; wr = A.rad[base + wv];
@@ -672,7 +680,7 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
             SkSelSlot& S = L.slot[wave];
             const int tip = cand_v[my_ent];
             const int node = lane == 0 ? tip : A.anc[(int64_t)(base + tip) * SK_ANC + lane - 1];
-            const bool end = node < 0 || ld(&A.term[base + node]) != 0u;
+            const bool end = node < 0 || ld(&A.pt[base + node].term) != 0u;
             const unsigned long long eb = __ballot(end);
             int big = eb == 0ull, len = 0, termv = -1, nrows = 0, ncand = 0, parent = -1;
             float rp = 0.0f;
@@ -685,7 +693,7 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
                 __builtin_amdgcn_wave_barrier();
                 // the parent id is read BEFORE anything is stamped (path.py:128-136); termination -1 reads
                 // branch_ids[-1] = the last vertex (quirk kept)
-                if (lane == 0 && len >= 2) parent = ld(&A.branch_of[base + (termv < 0 ? n - 1 : termv)]);
+                if (lane == 0 && len >= 2) parent = ld(&A.pt[base + (termv < 0 ? n - 1 : termv)].branch);
                 if (lane < len) {
                     const float r = A.rad[base + node];
                     const float* pv = A.pts + 3 * (int64_t)(base + node);
@@ -763,7 +771,7 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
             const int T = pre[SK_WSLOTS];
             // 3. claims (select_path_points, path.py:19-46), point-centric: the candidates of ALL slots are dealt
             //    out over the workgroup; each finds ITS nearest path vertex from LDS -- no atomics but the mark.
-            if (wave < nc && lane < sl_len[wave]) atomicOr(&cmask[L.slot[wave].path[lane]], 1u << wave);
+            if (wave < nc && lane < sl_len[wave]) atomicOr(&cmask[L.slot[wave].path[lane]].mark, 1u << wave);
             unsigned cl_bits = 0u;  // bit k: my k-th item was claimed but did not fit cl_list
             int cl_n = 0;
             const int nround = (T + W - 1) / W;
@@ -808,7 +816,7 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
                         if (d2 < bd2) { bd2 = d2; bq = qi; }
                     }
                     if (bd2 < rp * rp && sqrtf(bd2) < S.p[bq].w) {  // path.py:35-40
-                        atomicOr(&cmask[p], 1u << ss[u]);
+                        atomicOr(&cmask[p].mark, 1u << ss[u]);
                         if (cl_n < SK_CL_KEEP) cl_list[cl_n][tid] = (unsigned)p | ((unsigned)ss[u] << 28);
                         else cl_bits |= 1u << (k0 + u);
                         cl_n++;
@@ -822,13 +830,13 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
                 const SkSelSlot& S = L.slot[wave];
                 const int len = sl_len[wave], termv = sl_term[wave];
                 unsigned mk = 0u;
-                if (lane < len) mk = ld(&cmask[S.path[lane]]);
-                else if (lane == len) mk = ld(&cmask[termv < 0 ? n - 1 : termv]);
+                if (lane < len) mk = ld(&cmask[S.path[lane]].mark);
+                else if (lane == len) mk = ld(&cmask[termv < 0 ? n - 1 : termv].mark);
                 const unsigned walkm = wave_or_u(mk);
                 if (lane == 0) sl_walkm[wave] = walkm;
             }
             unsigned etip = 0u;
-            if (wave == 0 && lane < ne) etip = ld(&cmask[ent_v]);
+            if (wave == 0 && lane < ne) etip = ld(&cmask[ent_v].mark);
             __syncthreads();
             if (wave == 0) {  // the sequential replay over the entries, lane e holding entry e
                 if (my_slot >= nc) my_slot = -1;
@@ -863,12 +871,12 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
                 const int len = sl_len[wave], id = sl_id[wave];
                 if (lane < len) {
                     const int v = S.path[lane];
-                    atomicAnd(&cmask[v], ~(1u << wave));
+                    atomicAnd(&cmask[v].mark, ~(1u << wave));
                     if (id != -2) {
                         if (id >= 0) A.path_verts[base + sl_off[wave] + lane] = v;  // (a dropped path shares its offset with the next one)
-                        A.alloc[base + v] = -1.0f;
-                        A.term[base + v] = 1u;
-                        if (id >= 0) atomicMax(&A.branch_of[base + v], id);
+                        A.pt[base + v].alloc = -1.0f;
+                        A.pt[base + v].term = 1u;
+                        if (id >= 0) atomicMax(&A.pt[base + v].branch, id);
                         const unsigned q = (unsigned)(pos[v] - win_base);
                         if (q < (unsigned)W) win_live[q] = 0;
                     }
@@ -884,12 +892,12 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
             for (int j = 0; j < kept_n; j++) {
                 const unsigned e = cl_list[j][tid];
                 const int p = (int)(e & 0x0fffffffu), sidx = (int)(e >> 28);
-                atomicAnd(&cmask[p], ~(1u << sidx));
+                atomicAnd(&cmask[p].mark, ~(1u << sidx));
                 if ((alive >> sidx) & 1u) {
                     const int id = sl_id[sidx];
-                    A.alloc[base + p] = -1.0f;
-                    A.term[base + p] = 1u;
-                    if (id >= 0) atomicMax(&A.branch_of[base + p], id);
+                    A.pt[base + p].alloc = -1.0f;
+                    A.pt[base + p].term = 1u;
+                    if (id >= 0) atomicMax(&A.pt[base + p].branch, id);
                     const unsigned q = (unsigned)(pos[p] - win_base);
                     if (q < (unsigned)W) win_live[q] = 0;
                 }
@@ -906,12 +914,12 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
                 const uint32_t t = (uint32_t)(gi - acc);
                 const int row = sk_find_row(S.row_off, sl_nrows[sidx], t);
                 const int p = (int)__float_as_uint(recs[S.row_first[row] + (t - S.row_off[row])].w) - base;
-                atomicAnd(&cmask[p], ~(1u << sidx));
+                atomicAnd(&cmask[p].mark, ~(1u << sidx));
                 if ((alive >> sidx) & 1u) {
                     const int id = sl_id[sidx];
-                    A.alloc[base + p] = -1.0f;
-                    A.term[base + p] = 1u;
-                    if (id >= 0) atomicMax(&A.branch_of[base + p], id);
+                    A.pt[base + p].alloc = -1.0f;
+                    A.pt[base + p].term = 1u;
+                    if (id >= 0) atomicMax(&A.pt[base + p].branch, id);
                     const unsigned q = (unsigned)(pos[p] - win_base);
                     if (q < (unsigned)W) win_live[q] = 0;
                 }
@@ -927,7 +935,7 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
         for (unsigned chunk = 0; len < 0; chunk += blockDim.x) {
             const unsigned j = chunk + tid;
             const int node = sk_ancestor(A, base, far, j);
-            const bool end = node < 0 || ld(&A.term[base + node]) != 0u;
+            const bool end = node < 0 || ld(&A.pt[base + node].term) != 0u;
             if (!end) { if (j < SK_LPATH) L.one.lpath[j] = node; else tmp[j] = (unsigned)node; }
             unsigned long long k = end ? ((unsigned long long)(0xffffffffu - j) << 32) | (unsigned)(node + 1) : 0ull;
             k = block_max_u64(k, s_red);
@@ -942,7 +950,7 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
         // coordinates / radii / cell bounding box into LDS for the claim below.
         const bool keep = len >= 2;
         int parent = -1;
-        if (tid == 0 && keep) parent = ld(&A.branch_of[base + (s_term < 0 ? n - 1 : s_term)]);
+        if (tid == 0 && keep) parent = ld(&A.pt[base + (s_term < 0 ? n - 1 : s_term)].branch);
         int* path_out = A.path_verts + base + total;
         const bool fits = len <= SK_LPATH;
         unsigned long long rk = 0;
@@ -1043,18 +1051,18 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
                 if (d2 < bd2) { bd2 = d2; bq = qi; }
             }
             if (bd2 < rp2 && sqrtf(bd2) < L.one.lpr[bq]) {  // path.py:35-40
-                A.alloc[base + p] = -1.0f;
-                A.term[base + p] = 1u;
-                if (id >= 0) A.branch_of[base + p] = id;
+                A.pt[base + p].alloc = -1.0f;
+                A.pt[base + p].term = 1u;
+                if (id >= 0) A.pt[base + p].branch = id;
                 const unsigned q = (unsigned)(pos[p] - win_base);
                 if (q < (unsigned)W) win_live[q] = 0;
             }
         }
         for (int qi = tid; qi < len; qi += blockDim.x) {  // path.py:112-113,135
             const int v = L.one.lpath[len - 1 - qi];
-            A.alloc[base + v] = -1.0f;
-            A.term[base + v] = 1u;
-            if (id >= 0) A.branch_of[base + v] = id;
+            A.pt[base + v].alloc = -1.0f;
+            A.pt[base + v].term = 1u;
+            if (id >= 0) A.pt[base + v].branch = id;
             const unsigned q = (unsigned)(pos[v] - win_base);
             if (q < (unsigned)W) win_live[q] = 0;
         }
@@ -1063,6 +1071,11 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
     }
     if (tid == 0) { A.s_len[c] = 0; A.s_wide[c] = 0; A.s_cursor[c] = win_base; A.s_total[c] = total; A.s_nb[c] = nb; }
     SK_TICK_FLUSH();
+}
+
+// the selection is done: branch ids of the points -> the caller's array
+__global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_branch_out(SkArgs A) {
+    SK_VERTEX_LOOP(v) A.branch_of[v] = A.pt[v].branch;
 }
 
 __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_claim(SkArgs A) {
@@ -1111,8 +1124,9 @@ __global__ void __launch_bounds__(1024) k_sk_blk_tables(SkArgs A, int* blk_comp,
 #define SK_GRID_CELLS (1ll << 24)
 
 struct SkLayout {
-    unsigned *dist_ord, *stamp, *q0, *q1, *term, *touched, *cnt, *s_ntouched, *sort_keys, *order;
-    float *alloc, *s_rp, *order_init;
+    unsigned *dist_ord, *stamp, *q0, *q1, *touched, *cnt, *s_ntouched, *sort_keys, *order;
+    float *s_rp, *order_init;
+    SkPt* pt;
     int *s_cursor, *s_wide, *pos;
     char* sort_ws;
     int64_t sort_bytes;
@@ -1132,9 +1146,8 @@ static void sk_layout(StArena& a, int64_t m, int64_t C, SkLayout* s, int nseg = 
     s->stamp = a.take<unsigned>(m);
     s->q0 = a.take<unsigned>(m + C);
     s->q1 = a.take<unsigned>(m + C);
-    s->term = a.take<unsigned>(m);
     s->touched = a.take<unsigned>(m);
-    s->alloc = a.take<float>(m);
+    s->pt = a.take<SkPt>(m);
     s->best = a.take<unsigned long long>(m);
     s->anc = a.take<int>((int64_t)SK_ANC * m);
     s->comp_of = a.take<int>(m);
@@ -1258,7 +1271,7 @@ extern "C" int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, c
     A.dist = dist; A.pred = pred; A.root_local = root_local; A.tree_dist = tree_dist;
     A.branch_parent = branch_parent; A.branch_off = branch_off; A.branch_len = branch_len; A.n_branches = n_branches;
     A.path_verts = path_verts; A.branch_of = branch_of;
-    A.dist_ord = s.dist_ord; A.stamp = s.stamp; A.q0 = s.q0; A.q1 = s.q1; A.alloc = s.alloc; A.term = s.term;
+    A.dist_ord = s.dist_ord; A.stamp = s.stamp; A.q0 = s.q0; A.q1 = s.q1; A.pt = s.pt;
     A.best = s.best; A.touched = s.touched; A.anc = s.anc; A.cnt = s.cnt;
     A.s_done = s.s_done; A.s_len = s.s_len; A.s_cur_id = s.s_cur_id; A.s_cur_off = s.s_cur_off; A.s_nb = s.s_nb;
     A.s_total = s.s_total; A.s_rp = s.s_rp; A.s_ntouched = s.s_ntouched;
@@ -1393,8 +1406,11 @@ extern "C" int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, c
                 if (h[5] >= (unsigned)n_comp) break;
                 ST_REQUIRE(iters <= m + 64 && iters < (1 << 26), "skeleton: sample_tree did not terminate");
             }
-            if (!redo) break;
-            // the selection overwrote stamp[] (its speculation marks): recompute the resolved / unresolved marks first
+            if (!redo) {
+                hipLaunchKernelGGL(k_sk_branch_out, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A);
+                break;
+            }
+            // plateau vertices left unresolved: redo the predecessor pass with its resolved / unresolved marks, then the plateaus
             (void)hipMemsetAsync(&s.cnt[3], 0, sizeof(unsigned), stream);
             hipLaunchKernelGGL(k_sk_preds, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A);
             ST_TRY(sk_read(h, s.cnt, sizeof(unsigned) * 8, stream));

@@ -18,8 +18,18 @@ def _single_component(points, edges, edge_weights):
 def shortest_paths(root, edges, edge_weights, renumber=True, points=None, surface_y=None):
     """SSSP from `root` over the undirected weighted graph; only the root's component gets finite
     distances (as with cugraph).  `surface_y` defaults to an indicator that makes `root` the lowest point."""
-    n = int(edges.max().item()) + 1 if edges.numel() else int(root) + 1
+    root = int(root)
+    if root < 0:
+        raise ValueError(f"shortest_paths: root {root} out of range")
+    # vertices = everything any argument mentions: an isolated root (or trailing isolated vertices) has an id above the
+    # largest edge end point, and cugraph.sssp accepts such a source.  `renumber` is accepted for call-site parity: vertex ids
+    # are used as they are (the reference's default renumbering is an internal detail of cugraph).
+    n = max(int(edges.max().item()) + 1 if edges.numel() else 0, root + 1, 0 if points is None else int(points.shape[0]),
+            0 if surface_y is None else int(surface_y.shape[0]))
     dev = edges.device
+    for name, t in (("points", points), ("surface_y", surface_y)):
+        if t is not None and int(t.shape[0]) != n:
+            raise ValueError(f"shortest_paths: {name} has {int(t.shape[0])} rows, the graph has {n} vertices")
     pts = points if points is not None else torch.zeros((n, 3), device=dev)
     comps = _single_component(pts, edges, edge_weights)
     ys = torch.ones(n, device=dev)

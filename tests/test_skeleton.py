@@ -250,3 +250,19 @@ def test_shortest_paths_row_lengths(backend, symmetric):
     assert reach.sum() > n // 2
     np.testing.assert_array_equal(d.cpu().numpy()[reach], ref_d[reach])
     np.testing.assert_array_equal(preds.cpu().numpy()[reach], ref_p[reach])
+
+
+def test_shortest_paths_isolated_root_above_the_largest_edge_id(backend):
+    """cugraph.sssp accepts a source that no edge mentions; its id may exceed every edge end point (advisor, round 1)."""
+    from smart_tree_amd.skeleton.shortest_path import shortest_paths
+
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(backend)
+    edges = np.array([[0, 1], [1, 2], [2, 3]], np.int64)
+    w = np.array([1.0, 2.0, 0.5], np.float32)
+    verts, preds, d = shortest_paths(6, t(edges), t(w))  # vertices 4, 5 and the root 6 are isolated
+    assert verts.shape[0] == 7 and float(d[6]) == 0.0 and int(preds[6]) == -1
+    assert torch.isinf(d[:6]).all()
+    _, preds, d = shortest_paths(0, t(edges), t(w), points=t(np.zeros((9, 3), np.float32)))  # trailing isolated vertices
+    assert d.shape[0] == 9 and d[:4].cpu().tolist() == [0.0, 1.0, 3.0, 3.5] and torch.isinf(d[4:]).all()
+    with pytest.raises(ValueError):
+        shortest_paths(0, t(edges), t(w), surface_y=t(np.zeros(2, np.float32)))
