@@ -195,6 +195,11 @@ int64_t st_knn_workspace_bytes_seg(int64_t n_dst, int nseg);
 int st_knn_radius_seg(const float* src, int64_t n1, const float* dst, int64_t n2, int K, float r, const float* bound,
                       int bound_mode, float cell_hint, int64_t* idx, float* dist, const int32_t* src_seg_off,
                       const int32_t* dst_seg_off, int nseg, void* ws, int64_t ws_bytes, void* stream);
+/* replaces: skeleton/filter.py:6-11 (outlier_removal): mask[i] = the query has >= K neighbours inside its bound, i.e.
+ *           st_knn_radius_seg(...).idx[:, K-1] != -1 without the neighbour lists (K = 8; workspace as st_knn_radius_seg). */
+int st_radius_count_seg(const float* src, int64_t n1, const float* dst, int64_t n2, int K, float r, const float* bound,
+                        int bound_mode, float cell_hint, uint8_t* mask, const int32_t* src_seg_off,
+                        const int32_t* dst_seg_off, int nseg, void* ws, int64_t ws_bytes, void* stream);
 int st_make_edges_seg(const int64_t* idx, const float* dist, int64_t n, int K, int64_t* edges, float* w,
                       int64_t* n_edges_host, const int32_t* seg_off, int nseg, void* ws, int64_t ws_bytes, void* stream);
 int st_component_layout_seg(const int32_t* labels, int64_t n, int min_vertices, const int32_t* seg_off, int nseg,

@@ -72,6 +72,7 @@ SIGNATURES = {
     "st_build_strided_rulebook_seg": (c_int, [P, I64, P, P, I64, P, I64, P, P, I64, ctypes.POINTER(ctypes.c_int32), P, P, P, P, P, P]),
     "st_knn_workspace_bytes_seg": (I64, [I64, c_int]),
     "st_knn_radius_seg": (c_int, [P, I64, P, I64, c_int, c_float, P, c_int, c_float, P, P, P, P, c_int, P, I64, P]),
+    "st_radius_count_seg": (c_int, [P, I64, P, I64, c_int, c_float, P, c_int, c_float, P, P, P, c_int, P, I64, P]),
     "st_make_edges_seg": (c_int, [P, P, I64, c_int, P, P, ctypes.POINTER(I64), P, c_int, P, I64, P]),
     "st_component_layout_seg": (c_int, [P, I64, c_int, P, c_int, P, P, P, P, P, P, P, ctypes.POINTER(I64), ctypes.POINTER(I64), P, I64, P]),
     "st_skeleton_workspace_bytes_seg": (I64, [I64, I64, c_int]),
@@ -96,7 +97,7 @@ ENQUEUE_ONLY = frozenset({
     "st_sparse_conv_mfma_fwd", "st_sparse_conv_f16_fwd", "st_pointwise_mlp_heads", "st_medial_points", "st_centre_cloud",
     "st_connected_components", "st_component_csr", "st_post_process", "st_knn_radius",
     "st_centre_cloud_seg", "st_voxelize_workspace_bytes_seg", "st_build_strided_rulebook_seg", "st_knn_workspace_bytes_seg",
-    "st_knn_radius_seg", "st_skeleton_workspace_bytes_seg", "st_post_process_seg",
+    "st_knn_radius_seg", "st_skeleton_workspace_bytes_seg", "st_post_process_seg", "st_radius_count_seg",
 })
 
 

@@ -208,7 +208,10 @@ __device__ __forceinline__ int knn_cut(unsigned long long* keys, int n, int lane
     return n < K ? n : K;
 }
 
-template <int K>
+// COUNT = true: only "does the query have at least K neighbours (itself included) inside its bound?" -- the whole of
+// outlier_removal (filter.py:6-11: all nb_points slots filled).  No key list, no ranking, and the scan stops at the K-th hit;
+// idx_out is then a byte mask [n1].  The predicates are the search's own, so the mask equals idx[:, K-1] != -1.
+template <int K, bool COUNT = false>
 __global__ void __launch_bounds__(KNN_BLOCK) k_knn(const float* __restrict__ src, int64_t n1, const StGrid* __restrict__ g,
                                                    const uint32_t* __restrict__ cell_start, const float4* __restrict__ recs,
                                                    float r, const float* __restrict__ bound, int mode,
@@ -245,7 +248,7 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn(const float* __restrict__ src
     const float rs = reach_r * 1.0001f + 1e-7f, rs2 = rs * rs;
     const int ny = y1 - y0 + 1, nrows = (x1 >= x0 && ny > 0 && z1 >= z0) ? (x1 - x0 + 1) * ny : 0;
     int nkeys = 0;  // wave-uniform
-    for (int rbase = 0; rbase < nrows; rbase += 64) {
+    for (int rbase = 0; rbase < nrows && !(COUNT && nkeys >= K); rbase += 64) {
         const int rowi = rbase + lane;
         uint32_t first = 0, cnt = 0;
         if (rowi < nrows) {
@@ -271,7 +274,7 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn(const float* __restrict__ src
         rfirst[lane] = first;
         if (lane == 63) roff[64] = incl;
         __builtin_amdgcn_wave_barrier();
-        for (int cb = 0; cb < total; cb += 64) {
+        for (int cb = 0; cb < total && !(COUNT && nkeys >= K); cb += 64) {
             const int t = cb + lane;
             bool ok = false;
             unsigned long long key = 0ull;
@@ -291,10 +294,14 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn(const float* __restrict__ src
                 key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned long long)__float_as_uint(q.w);  // d2 >= 0: bits order like values
             }
             const unsigned long long bal = __ballot(ok);
-            if (ok) keys[nkeys + __popcll(bal & ((1ull << lane) - 1ull))] = key;
+            if (!COUNT && ok) keys[nkeys + __popcll(bal & ((1ull << lane) - 1ull))] = key;
             nkeys += __popcll(bal);
-            if (nkeys > KNN_CAP - 64) nkeys = knn_cut<K>(keys, nkeys, lane);
+            if (!COUNT && nkeys > KNN_CAP - 64) nkeys = knn_cut<K>(keys, nkeys, lane);
         }
+    }
+    if (COUNT) {
+        if (lane == 0) reinterpret_cast<uint8_t*>(idx_out)[i] = nkeys >= K ? 1 : 0;
+        return;
     }
     // output: rank = slot.  (d2, index) ascending, -1 / NaN padding.
     __builtin_amdgcn_wave_barrier();
@@ -387,6 +394,39 @@ extern "C" int st_knn_radius_seg(const float* src, int64_t n1, const float* dst,
     else
         hipLaunchKernelGGL((k_knn<16>), grid, block, 0, stream, src, n1, (const StGrid*)g, (const uint32_t*)cell_start,
                            (const float4*)recs, r, bound, bound_mode, idx, dist, src_seg_off, nseg);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}
+
+// mask [n1] uint8: 1 iff the query has at least K points of its own cloud (itself included when src == dst) with
+// d2 < r*r and, per bound_mode, sqrtf(d2) <= / < bound[i] -- i.e. st_knn_radius_seg(...).idx[:, K-1] != -1 without building
+// the neighbour lists.  replaces: skeleton/filter.py:6-11 (outlier_removal's FRNN query + mask arithmetic).
+extern "C" int st_radius_count_seg(const float* src, int64_t n1, const float* dst, int64_t n2, int K, float r, const float* bound,
+                                   int bound_mode, float cell_hint, uint8_t* mask, const int32_t* src_seg_off,
+                                   const int32_t* dst_seg_off, int nseg, void* ws, int64_t ws_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    ST_REQUIRE(K == 8, "radius_count: K must be 8 (outlier_removal's nb_points; got %d)", K);
+    ST_REQUIRE(bound_mode == 0 || bound != nullptr, "radius_count: bound_mode needs a bound array");
+    ST_REQUIRE(r >= 0.0f || bound != nullptr, "radius_count: r < 0 (radius = max(bound)) needs a bound array");
+    ST_REQUIRE(cell_hint >= 0.0f || r < 0.0f, "radius_count: a relative cell size (cell_hint < 0) goes with r < 0");
+    ST_REQUIRE(n2 < (1ll << 31), "radius_count: too many points");
+    ST_REQUIRE(nseg >= 1 && nseg <= ST_MAX_SEG, "radius_count: 1 <= clouds per batch <= %d", ST_MAX_SEG);
+    ST_REQUIRE(nseg == 1 || (src_seg_off && dst_seg_off), "radius_count: a batch needs the cloud offsets of src and dst");
+    if (nseg == 1) { src_seg_off = nullptr; dst_seg_off = nullptr; }
+    if (n1 <= 0) return ST_OK;
+    StArena a(ws, ws_bytes);
+    StGrid* g; uint32_t* cell_start; float4* recs; char* sub; int64_t sub_bytes;
+    knn_layout(a, n2, nseg, &g, &cell_start, &recs, &sub, &sub_bytes);
+    if (!a.ok() || !sub) {
+        st_set_error("radius_count: workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)a.used);
+        return ST_ERR_WORKSPACE;
+    }
+    const float cell_arg = cell_hint != 0.0f ? cell_hint : (r >= 0.0f ? r : -1.0f);
+    ST_TRY(st_grid_build(dst, n2, cell_arg, knn_max_cells(nseg), g, cell_start, recs, sub, sub_bytes, stream, r, bound, n1,
+                         dst_seg_off, nseg, src_seg_off));
+    hipLaunchKernelGGL((k_knn<8, true>), dim3((unsigned)st_div_up(n1, KNN_WAVES)), dim3(KNN_BLOCK), 0, stream, src, n1,
+                       (const StGrid*)g, (const uint32_t*)cell_start, (const float4*)recs, r, bound, bound_mode,
+                       reinterpret_cast<int64_t*>(mask), (float*)nullptr, src_seg_off, nseg);
     ST_CHECK_LAUNCH();
     return ST_OK;
 }

@@ -12,9 +12,23 @@ def outlier_removal(points: torch.Tensor, radii: torch.Tensor, nb_points: int = 
     The strict per-point bound runs inside the search, so "all nb_points slots filled" is the test."""
     if points.shape[0] == 0:
         return torch.zeros((0,), dtype=torch.bool, device=points.device)
-    bound = radii.reshape(-1)
-    # r = -1: the search radius max(radii) is reduced on the device (one host round trip less); cell = r / 8
-    # seg_off (additive): `points` holds several independent clouds; neighbours are searched inside a point's own cloud
-    idxs, _, _ = knn(points, points, K=nb_points, r=-1.0, bound=bound, bound_mode=BOUND_LT, cell=-SEARCH_CELL_DIV,
-                     src_seg_off=seg_off, dest_seg_off=seg_off)
-    return idxs[:, nb_points - 1] != -1
+    bound = radii.reshape(-1).contiguous().float()
+    if nb_points != 8:  # the counting kernel is instantiated for the pipeline's nb_points; anything else takes the search
+        idxs, _, _ = knn(points, points, K=nb_points, r=-1.0, bound=bound, bound_mode=BOUND_LT, cell=-SEARCH_CELL_DIV,
+                         src_seg_off=seg_off, dest_seg_off=seg_off)
+        return idxs[:, nb_points - 1] != -1
+    # r = -1: the search radius max(radii) is reduced on the device (one host round trip less); cell = r / 8.
+    # seg_off (additive): `points` holds several independent clouds; neighbours are counted inside a point's own cloud.
+    # st_radius_count_seg = the same search, but it only counts and stops at the nb_points-th hit (no neighbour lists).
+    from .. import _lib
+
+    L = _lib.lib()
+    pts = points.contiguous().float()
+    n, dev = pts.shape[0], pts.device
+    nseg = 1 if seg_off is None else int(seg_off.shape[0]) - 1
+    mask = torch.empty(n, dtype=torch.uint8, device=dev)
+    ws = _lib.workspace(L.st_knn_workspace_bytes_seg(n, nseg), dev)
+    _lib.check(L.st_radius_count_seg(_lib.ptr(pts), n, _lib.ptr(pts), n, nb_points, -1.0, _lib.ptr(bound), BOUND_LT,
+                                     -float(SEARCH_CELL_DIV), _lib.ptr(mask), _lib.ptr(seg_off), _lib.ptr(seg_off), nseg,
+                                     _lib.ptr(ws), ws.numel(), _lib.stream(dev)))
+    return mask.bool()

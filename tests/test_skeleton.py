@@ -266,3 +266,27 @@ def test_shortest_paths_isolated_root_above_the_largest_edge_id(backend):
     assert d.shape[0] == 9 and d[:4].cpu().tolist() == [0.0, 1.0, 3.0, 3.5] and torch.isinf(d[4:]).all()
     with pytest.raises(ValueError):
         shortest_paths(0, t(edges), t(w), surface_y=t(np.zeros(2, np.float32)))
+
+
+def test_outlier_removal_count_kernel_equals_the_search(backend):
+    """outlier_removal (filter.py:6-11) through the counting kernel (stops at the 8th hit, builds no lists) == the
+    reference's formulation over the full search: the 8th slot of knn(K=8, bound = own radius, strict) is filled."""
+    from smart_tree_amd.skeleton import graph as G
+    from smart_tree_amd.skeleton.filter import outlier_removal
+
+    rng = np.random.RandomState(11)
+    pts = np.concatenate([rng.rand(1500, 3) * [0.3, 1.0, 0.3], rng.rand(40, 3) * 3.0]).astype(np.float32)  # dense core + stragglers
+    rad = (0.02 + 0.08 * rng.rand(len(pts))).astype(np.float32)
+    rad[::7] = 0.0  # radius 0: not even itself (d = 0 < 0 fails)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(backend)
+    got = outlier_removal(t(pts), t(rad).unsqueeze(1), nb_points=8)
+    idx, _, _ = G.knn(t(pts), t(pts), K=8, r=-1.0, bound=t(rad), bound_mode=G.BOUND_LT, cell=-G.SEARCH_CELL_DIV)
+    ref = idx[:, 7] != -1
+    assert torch.equal(got.cpu(), ref.cpu()) and 0 < int(ref.sum()) < len(pts)
+    np.testing.assert_array_equal(got.cpu().numpy(), so.outlier_removal(pts, rad, 8))
+    # two clouds in one call: each counts inside itself only
+    off = torch.tensor([0, 700, len(pts)], dtype=torch.int32, device=backend)
+    both = outlier_removal(t(pts), t(rad).unsqueeze(1), nb_points=8, seg_off=off)
+    for a, b in ((0, 700), (700, len(pts))):
+        one = outlier_removal(t(pts[a:b]), t(rad[a:b]).unsqueeze(1), nb_points=8)
+        assert torch.equal(both[a:b].cpu(), one.cpu())
