@@ -15,6 +15,7 @@ import torch
 from . import profiling
 from .data_types.cloud import Cloud
 from .data_types.tree import DisjointTreeSkeleton
+from .util.mesh import skeleton_mesh, write_ply_mesh
 from .util.file import load_cloud, save_skeleton, save_skeleton_npz, write_ply_points, write_ply_skeleton
 
 
@@ -63,6 +64,8 @@ class Pipeline:
                 if tree.branches:
                     save_skeleton(tree, sp / f"skeleton_{tree._id}.npz")
             write_ply_skeleton(sp / "skeleton.ply", skeleton)
+            verts, tris = skeleton_mesh(skeleton)  # reference pipeline.py:90: mesh.ply = the skeleton's tube mesh
+            write_ply_mesh(sp / "mesh.ply", verts, tris)
             write_ply_points(sp / "cloud.ply", lc.xyz.cpu().numpy(), lc.rgb.cpu().numpy() if lc.rgb is not None else None)
         return skeleton
 

@@ -97,3 +97,28 @@ def test_cli_directory_runs_every_cloud_file(tmp_path, monkeypatch):
         (tmp_path / name).write_bytes(b"")
     cli.main([f"+directory={tmp_path}"])
     assert seen == ["a.ply", "b.npz"]
+
+
+def test_tube_mesh_matches_the_reference_functions(tmp_path):
+    """tests/golden/tube_mesh.npz: the reference's own tube_vertices / cylinder_triangles (geometries.py:157-189) on a golden
+    branch with the random start vector pinned -- ring vertices and the triangle list are reproduced exactly."""
+    from smart_tree_amd.util import mesh
+
+    g = np.load(Path(__file__).resolve().parent / "golden" / "tube_mesh.npz")
+    v = mesh.tube_vertices(g["points"], g["radii"], 10, g["start"])
+    np.testing.assert_array_equal(v, g["vertices"])
+    np.testing.assert_array_equal(mesh.cylinder_triangles(v.shape[1], v.shape[0]), g["triangles"])
+    verts, tris = mesh.tube_mesh(g["points"], g["radii"], 10, g["start"])
+    assert verts.shape == (400, 3) and tris.max() == 399 and tris.shape == (780, 3)
+    # ring vertices sit at the branch radius from the axis
+    d = np.linalg.norm(v - g["points"][:, None, :], axis=2)
+    np.testing.assert_allclose(d, np.broadcast_to(g["radii"][:, None], d.shape), rtol=1e-5)
+    # merged mesh of a two-branch skeleton + PLY writer
+    b0 = BranchSkeleton(0, -1, torch.from_numpy(g["points"]), torch.from_numpy(g["radii"]).reshape(-1, 1))
+    b1 = BranchSkeleton(1, 0, torch.from_numpy(g["points"][:5] + 1.0), torch.from_numpy(g["radii"][:5]).reshape(-1, 1))
+    sk = DisjointTreeSkeleton([TreeSkeleton(0, {0: b0, 1: b1})])
+    mv, mt = mesh.skeleton_mesh(sk, start=g["start"])
+    assert mv.shape == (450, 3) and mt.shape == (780 + 80, 3) and mt[780:].min() == 400
+    mesh.write_ply_mesh(tmp_path / "mesh.ply", mv, mt)
+    head = (tmp_path / "mesh.ply").read_bytes()[:200].decode("ascii", "replace")
+    assert "element vertex 450" in head and "element face 860" in head

@@ -257,6 +257,21 @@ def skeleton_file_case():
     print("ref_saved_skeleton", len(branches), "branches", {k: v.shape for k, v in np.load(OUT / "ref_saved_skeleton.npz").items()})
 
 
+def tube_mesh_case():
+    """Reference tube_vertices / cylinder_triangles (o3d_abstractions/geometries.py:157-189) on a golden branch; the random
+    start vector of the tangent frame is pinned."""
+    r_geo = reference("smart_tree.o3d_abstractions.geometries")
+    g = np.load(OUT / "skeleton_y_tree.npz")
+    k = int(g["branch_ids"][0])
+    pts, rad = g[f"branch_{k}_xyz"][:40], g[f"branch_{k}_radii"][:40].reshape(-1)
+    start = np.array([0.36, -0.48, 0.8], np.float32)
+    r_geo.random_unit = lambda dtype=np.float32: start
+    verts = r_geo.tube_vertices(pts, rad, 10)
+    tris = r_geo.cylinder_triangles(verts.shape[1], verts.shape[0])
+    np.savez_compressed(OUT / "tube_mesh.npz", points=pts, radii=rad, start=start, vertices=verts, triangles=tris)
+    print("tube_mesh", verts.shape, tris.shape)
+
+
 def y_tree(seed=0):
     """A small trunk + two limbs with exact medial vectors and a little noise."""
     rng = np.random.RandomState(seed)
@@ -292,6 +307,7 @@ def main():
     blocking_case()
     nearest_tube_case()
     skeleton_file_case()
+    tube_mesh_case()
 
 
 if __name__ == "__main__":
