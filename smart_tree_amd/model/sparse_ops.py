@@ -54,7 +54,7 @@ def build_strided_rulebook(coords: torch.Tensor, h: CoordHash, blk_seg: Optional
     L = _lib.lib()
     dev = coords.device
     n = coords.shape[0]
-    if blk_seg is None:
+    if blk_seg is None or blk_seg.numel() == 0:  # (a batch without a single block: nothing to clip)
         n_seg = 1
     ext_dev = torch.empty(3 * n_seg, dtype=torch.int32, device=dev) if n_seg > 1 else None
     ws = _lib.workspace(L.st_strided_workspace_bytes(n), dev)

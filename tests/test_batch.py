@@ -170,3 +170,16 @@ def test_config2_batch_of_million_point_trees_equals_one_at_a_time():
         parts = pipe.process_clouds(clouds)
         for one, got in zip(serial, parts):
             assert len(one) > 100 and _signature(got) == one
+
+
+def test_process_clouds_edge_cases(backend):
+    """An empty list, a batch of one, and a batch whose clouds give no skeleton at all (too few points for a block)."""
+    pipe = _pipeline(backend, 0.04)
+    assert pipe.process_clouds([]) == []
+    clouds = _clouds(backend, sizes=(4000,), scale=0.4)
+    one = pipe.process_cloud(cloud=Cloud(clouds[0].xyz, clouds[0].rgb))
+    (got,) = pipe.process_clouds([Cloud(clouds[0].xyz, clouds[0].rgb)])
+    assert _signature(got) == _signature(one) and len(_signature(one)) > 0
+    tiny = _clouds(backend, sizes=(25, 30))
+    parts = pipe.process_clouds([Cloud(c.xyz, c.rgb) for c in tiny])
+    assert len(parts) == 2 and all(len(p.skeletons) == 0 for p in parts)
