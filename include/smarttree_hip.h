@@ -56,6 +56,10 @@ int64_t st_hash_capacity(int64_t n);
 int st_build_coord_hash(const int32_t* coords, int64_t n, unsigned long long* keys, unsigned* vals, int64_t cap, void* stream);
 int st_build_subm_rulebook(const int32_t* coords, int64_t n, const unsigned long long* keys, const unsigned* vals,
                            int64_t cap, int32_t* nbr /*[27,n]*/, void* stream);
+/* (no reference counterpart: spconv orders its voxels by hash) the permutation that sorts the voxels by (batch index,
+ * Morton code); running the network on the permuted set and scattering the outputs back gives the same values faster. */
+int64_t st_spatial_order_workspace_bytes(int64_t n);
+int st_spatial_order(const int32_t* coords, int64_t n, int32_t* order /*[n]*/, void* ws, int64_t ws_bytes, void* stream);
 int64_t st_strided_workspace_bytes(int64_t n_fine);
 int st_build_strided_outputs(const int32_t* coords, int64_t n, int64_t max_out, int32_t* out_coords,
                              unsigned long long* ckeys, unsigned* cvals, int64_t ccap, int64_t* n_out_host,

@@ -398,3 +398,57 @@ extern "C" int st_build_strided_rulebook(const int32_t* coords, int64_t n, const
     return st_build_strided_rulebook_seg(coords, n, fkeys, fvals, fcap, out_coords, n_out, ckeys, cvals, ccap, extent_host,
                                          nbr_down, nbr_up, up_order, nullptr, nullptr, stream_);
 }
+
+// ------------------------------------------------------------------------ spatial row order ---
+// The network does not care in which order the voxels are stored: every output row is computed on its own, in k order,
+// from the rows its neighbour table names.  The order decides speed, though: voxels arrive in "first point of the cloud"
+// order (spatially incoherent), so the 27 rows a voxel gathers are scattered over the feature array and the 16 rows of a
+// matrix-core tile have little in common (every tile needs nearly all 27 offsets, most of its rows padded with zeros).
+// st_spatial_order returns the permutation that sorts the voxels by (batch index, Morton code of z, y, x): the caller runs
+// the network on the permuted set -- coarser levels inherit the order, their sets being built in first-appearance order --
+// and scatters the outputs back.  Same values, bit for bit (tests/test_unet.py::test_spatial_order_is_invisible).
+__device__ __forceinline__ uint32_t rb_spread3(uint32_t v) {  // 10 bits -> every third bit
+    v &= 0x3ffu;
+    v = (v | (v << 16)) & 0x030000ffu;
+    v = (v | (v << 8)) & 0x0300f00fu;
+    v = (v | (v << 4)) & 0x030c30c3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+__global__ void __launch_bounds__(RB_BLOCK) k_rb_morton_keys(const int32_t* coords, int64_t n, uint32_t* keys, uint32_t* vals) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        keys[i] = (rb_spread3((uint32_t)coords[4 * i + 1]) << 2) | (rb_spread3((uint32_t)coords[4 * i + 2]) << 1) |
+                  rb_spread3((uint32_t)coords[4 * i + 3]);
+        vals[i] = (uint32_t)i;
+    }
+}
+__global__ void __launch_bounds__(RB_BLOCK) k_rb_block_keys(const int32_t* coords, int64_t n, const uint32_t* vals, uint32_t* keys) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        keys[i] = (uint32_t)coords[4 * (int64_t)vals[i]];
+}
+
+extern "C" int64_t st_spatial_order_workspace_bytes(int64_t n) {
+    StArena a(nullptr, 0);
+    a.take<uint32_t>(n);
+    a.take<char>(st_sort_ws_bytes(n));
+    return a.used;
+}
+
+// order [n] int32: position p of the spatial order holds input row order[p].  Stable: equal keys keep their input order.
+extern "C" int st_spatial_order(const int32_t* coords, int64_t n, int32_t* order, void* ws, int64_t ws_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n <= 0) return ST_OK;
+    ST_REQUIRE(n < (1ll << 31), "spatial_order: too many voxels");
+    StArena a(ws, ws_bytes);
+    uint32_t* keys = a.take<uint32_t>(n);
+    const int64_t sb = st_sort_ws_bytes(n);
+    char* sw = a.take<char>(sb);
+    if (!keys || !sw) { st_set_error("spatial_order: workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)a.used); return ST_ERR_WORKSPACE; }
+    uint32_t* vals = reinterpret_cast<uint32_t*>(order);
+    hipLaunchKernelGGL(k_rb_morton_keys, dim3(rb_grid(n)), dim3(RB_BLOCK), 0, stream, coords, n, keys, vals);
+    ST_TRY(st_radix_sort_pairs_u32(keys, vals, n, 30, sw, sb, stream));
+    hipLaunchKernelGGL(k_rb_block_keys, dim3(rb_grid(n)), dim3(RB_BLOCK), 0, stream, coords, n, (const uint32_t*)vals, keys);
+    ST_TRY(st_radix_sort_pairs_u32(keys, vals, n, 16, sw, sb, stream));  // stable: Morton order inside every block
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}

@@ -69,6 +69,7 @@ class Smart_Tree:
                 p = key[: -len(".running_mean")]
                 self.bn[p] = _Affine(sd, p, self.device)
         self.head_params = self._pack_heads(sd).to(self.device)
+        self.spatial_order = True  # run the network on Morton-ordered rows (same values; see features()); traces keep input order
         self.trace = None  # set to a dict to record every block's output (input, head{l}, enc{l}, dec{l}, tail{l}): parity tests
 
     # nn.Module look-alikes so reference call sites keep working
@@ -139,13 +140,22 @@ class Smart_Tree:
             self.trace[name] = x
 
     def features(self, sparse_input):
-        """input conv + UNet -> [N, planes[0]] features of the finest level."""
+        """input conv + UNet -> [N, planes[0]] features of the finest level, rows in the input's order.
+        Internally the voxels are processed in a spatially coherent order (`spatial_order`, on by default): every output row
+        is computed on its own from the rows its neighbour table names, so the values do not depend on the row order, but
+        gathers hit rows that are close in memory and the 16 rows of a matrix-core tile share their live offsets."""
         coords = sparse_input.indices.contiguous()
         feats = sparse_input.features.contiguous().float()
+        order = ops.spatial_order(coords) if self.spatial_order and self.trace is None and coords.shape[0] > 1 else None
+        if order is not None:
+            coords, feats = coords.index_select(0, order), feats.index_select(0, order)
         pyr = ops.build_pyramid(coords, self.depth, getattr(sparse_input, "blk_seg", None), getattr(sparse_input, "n_seg", 1))
         x = self._conv("input_conv.sequence.0", feats, None, feats.shape[0], bn="input_conv.sequence.1", relu=True)
         self._record("input", x)
-        return self._ublock("UNet", x, pyr, 0)
+        x = self._ublock("UNet", x, pyr, 0)
+        if order is not None:
+            x = torch.empty_like(x).index_copy_(0, order, x)
+        return x
 
     def forward(self, sparse_input) -> Dict[str, torch.Tensor]:
         radius, direction, class_l, _, _ = ops.mlp_heads(self.features(sparse_input), self.head_params)

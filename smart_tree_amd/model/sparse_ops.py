@@ -110,6 +110,17 @@ def build_pyramid(coords: torch.Tensor, depth: int, blk_seg: Optional[torch.Tens
     return pyr
 
 
+def spatial_order(coords: torch.Tensor) -> torch.Tensor:
+    """[N] int64 permutation: voxels sorted by (batch index, Morton code of z, y, x) (csrc/rulebook.hip st_spatial_order)."""
+    L = _lib.lib()
+    n = coords.shape[0]
+    order = torch.empty(n, dtype=torch.int32, device=coords.device)
+    if n:
+        ws = _lib.workspace(L.st_spatial_order_workspace_bytes(n), coords.device)
+        _lib.check(L.st_spatial_order(_lib.ptr(coords), n, _lib.ptr(order), _lib.ptr(ws), ws.numel(), _lib.stream(coords.device)))
+    return order.long()
+
+
 def mfma_weight(w: torch.Tensor) -> torch.Tensor:
     """[K, Cin, Cout] -> the MFMA operand order wp[K][Cin/16][4][Cout][4] = W[k][16c + 4kg + s][co]."""
     K, cin, cout = w.shape

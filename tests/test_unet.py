@@ -185,3 +185,27 @@ def test_unet_half_precision_storage_mode(backend):
     out = net.forward(sp)
     for k in out:
         np.testing.assert_allclose(out[k].cpu().numpy(), ref16[k], rtol=0, atol=5e-3 * np.abs(ref16[k]).max())  # heads: F.normalize amplifies
+
+
+def test_spatial_order_is_invisible(backend):
+    """Smart_Tree runs the network on Morton-ordered rows (st_spatial_order) and scatters the result back: every output must
+    equal, bit for bit, the one computed in the input's own order -- in float32 and in half-precision storage mode."""
+    vx = _small_batch(n=5000, seed=9)
+    coords = torch.from_numpy(vx["coords"]).to(backend)
+    order = ops.spatial_order(coords).cpu().numpy()
+    assert sorted(order.tolist()) == list(range(len(order)))
+    c = vx["coords"][order].astype(np.int64)
+    assert (np.diff(c[:, 0]) >= 0).all()  # blocks stay together ...
+    same_block = np.diff(c[:, 0]) == 0
+    step = np.abs(np.diff(c[:, 1:], axis=0)).sum(1)[same_block]
+    assert np.median(step) <= 3  # ... and consecutive rows are spatial neighbours (input order: far apart)
+    for fp16 in (False, True):
+        w = random_state_dict(uo.load_weights(WEIGHTS / "noble-elevator-58.npz"), seed=4)
+        sp = sparse_from_batch(torch.from_numpy(vx["feats"][:, :3]), torch.from_numpy(vx["coords"]), backend)
+        net = Smart_Tree(w, device=backend, fp16=fp16)
+        assert net.spatial_order
+        a = net.forward(sp)
+        net.spatial_order = False
+        b = net.forward(sp)
+        for k in a:
+            assert torch.equal(a[k], b[k]), (k, fp16)
