@@ -216,12 +216,16 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn(const float* __restrict__ src
                                                    const uint32_t* __restrict__ cell_start, const float4* __restrict__ recs,
                                                    float r, const float* __restrict__ bound, int mode,
                                                    int64_t* __restrict__ idx_out, float* __restrict__ dist_out,
-                                                   const int* __restrict__ seg_off, int nseg) {
+                                                   const int* __restrict__ seg_off, int nseg, int cell_order) {
     __shared__ uint32_t s_roff[KNN_WAVES][65], s_rfirst[KNN_WAVES][64];
     __shared__ unsigned long long s_keys[KNN_WAVES][KNN_CAP];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t i = (int64_t)blockIdx.x * KNN_WAVES + wave;
+    int64_t i = (int64_t)blockIdx.x * KNN_WAVES + wave;
     if (i >= n1) return;  // wave-uniform; the kernel has no workgroup barrier
+    // cell_order (src IS dst): wavefront p takes the p-th record of the cell-sorted point list instead of point p, so
+    // neighbouring wavefronts search the same cells (their rows stay in L1 / L2); rows are written by original index, the
+    // result does not depend on which wavefront computed it
+    if (cell_order) i = (int64_t)__float_as_uint(recs[i].w);
     uint32_t* roff = s_roff[wave];
     uint32_t* rfirst = s_rfirst[wave];
     unsigned long long* keys = s_keys[wave];
@@ -385,15 +389,16 @@ extern "C" int st_knn_radius_seg(const float* src, int64_t n1, const float* dst,
     ST_TRY(st_grid_build(dst, n2, cell_arg, knn_max_cells(nseg), g, cell_start, recs, sub, sub_bytes, stream, r, bound, n1,
                          dst_seg_off, nseg, src_seg_off));
     dim3 grid((unsigned)st_div_up(n1, KNN_WAVES)), block(KNN_BLOCK);
+    const int cell_order = src == dst && n1 == n2 ? 1 : 0;
     if (K == 1)
         hipLaunchKernelGGL((k_knn<1>), grid, block, 0, stream, src, n1, (const StGrid*)g, (const uint32_t*)cell_start,
-                           (const float4*)recs, r, bound, bound_mode, idx, dist, src_seg_off, nseg);
+                           (const float4*)recs, r, bound, bound_mode, idx, dist, src_seg_off, nseg, cell_order);
     else if (K == 8)
         hipLaunchKernelGGL((k_knn<8>), grid, block, 0, stream, src, n1, (const StGrid*)g, (const uint32_t*)cell_start,
-                           (const float4*)recs, r, bound, bound_mode, idx, dist, src_seg_off, nseg);
+                           (const float4*)recs, r, bound, bound_mode, idx, dist, src_seg_off, nseg, cell_order);
     else
         hipLaunchKernelGGL((k_knn<16>), grid, block, 0, stream, src, n1, (const StGrid*)g, (const uint32_t*)cell_start,
-                           (const float4*)recs, r, bound, bound_mode, idx, dist, src_seg_off, nseg);
+                           (const float4*)recs, r, bound, bound_mode, idx, dist, src_seg_off, nseg, cell_order);
     ST_CHECK_LAUNCH();
     return ST_OK;
 }
@@ -426,7 +431,7 @@ extern "C" int st_radius_count_seg(const float* src, int64_t n1, const float* ds
                          dst_seg_off, nseg, src_seg_off));
     hipLaunchKernelGGL((k_knn<8, true>), dim3((unsigned)st_div_up(n1, KNN_WAVES)), dim3(KNN_BLOCK), 0, stream, src, n1,
                        (const StGrid*)g, (const uint32_t*)cell_start, (const float4*)recs, r, bound, bound_mode,
-                       reinterpret_cast<int64_t*>(mask), (float*)nullptr, src_seg_off, nseg);
+                       reinterpret_cast<int64_t*>(mask), (float*)nullptr, src_seg_off, nseg, src == dst && n1 == n2 ? 1 : 0);
     ST_CHECK_LAUNCH();
     return ST_OK;
 }
