@@ -305,11 +305,12 @@ def main():
         torch.cuda.synchronize()
 
     fence()  # inputs and weights are resident before any worker stream touches them
-    warm = max(args.warmup, S * min(B, 2)) if args.warmup > 0 else 0  # every worker runs at least once before the clock starts
+    # warm-up: at least --warmup clouds, and every worker runs one batch of the size the timed region will use (allocator
+    # pools and workspaces reach their timed-region size before the clock starts)
+    plan = plan_batches(args.steps, S, B)
+    warm = max(args.warmup, S * max(plan)) if args.warmup > 0 and plan else 0
     if warm:
-        run_steps(warm)
-        if args.steps >= S * B:  # also one full-size batch per stream: allocator pools and workspaces reach their timed-region size
-            run_steps(S * B)
+        finished.extend(worker.run([max(plan)] * S + plan_batches(warm - S * max(plan), S, B), collect=world > 1))
     gather()
     fence()
     serial_ms = worker.serial_ms() if warm > 0 else None
