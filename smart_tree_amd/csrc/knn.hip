@@ -90,6 +90,8 @@ __global__ void k_grid_dims(StGrid* g, float cell, int64_t max_cells, float r, i
 
 // The counting pass hands every point its rank inside its cell (the value its atomicAdd returns), so the fill pass needs
 // neither a second round of atomics nor a cursor copy of the (tens of millions of words long) cell table.
+__global__ void k_grid_ncell1(const StGrid* g, int64_t* out) { *out = g->ncell + 1; }
+
 __global__ void __launch_bounds__(KNN_BLOCK) k_grid_count(const float* pts, int64_t n, const StGrid* g, uint32_t* counts,
                                                           const int* seg_off, int nseg, uint32_t* pt_cell, uint32_t* pt_rank) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -111,6 +113,7 @@ int64_t st_grid_ws_bytes(int64_t n, int64_t max_cells) {
     StArena a(nullptr, 0);
     a.take<uint32_t>(n);                           // cell of every point
     a.take<uint32_t>(n);                           // its rank inside the cell
+    a.take<int64_t>(1);                            // cells in use + 1 (device-side length of the table)
     a.take<char>(st_scan_ws_bytes(max_cells + 1)); // scan scratch
     return a.used;
 }
@@ -124,9 +127,10 @@ int st_grid_build(const float* pts, int64_t n, float cell, int64_t max_cells, St
     StArena a(ws, ws_bytes);
     uint32_t* pt_cell = a.take<uint32_t>(n);
     uint32_t* pt_rank = a.take<uint32_t>(n);
+    int64_t* ncell1_dev = a.take<int64_t>(1);
     int64_t scan_bytes = st_scan_ws_bytes(max_cells + 1);
     char* scan_ws = a.take<char>(scan_bytes);
-    if (!pt_cell || !pt_rank || !scan_ws) {
+    if (!pt_cell || !pt_rank || !ncell1_dev || !scan_ws) {
         st_set_error("grid: workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)a.used);
         return ST_ERR_WORKSPACE;
     }
@@ -150,10 +154,13 @@ int st_grid_build(const float* pts, int64_t n, float cell, int64_t max_cells, St
         fprintf(stderr, "grid: n=%lld cell=%g ncell=%lld of %lld dims=%d,%d,%d\n", (long long)n, h.cell, (long long)h.ncell,
                 (long long)ncell, h.dim[0], h.dim[1], h.dim[2]);
     }
-    (void)hipMemsetAsync(cell_start, 0, (ncell + 1) * sizeof(uint32_t), stream);
+    // the cell table is cleared and scanned over the cells the grid really has (g->ncell + 1, a device-side number), not over
+    // the host's bound: a batch of 16 clouds is bounded at 134M cells and uses 18M
+    hipLaunchKernelGGL(k_grid_ncell1, dim3(1), dim3(1), 0, stream, (const StGrid*)g, ncell1_dev);
+    st_fill_u32_dev(cell_start, ncell + 1, ncell1_dev, 0u, stream);
     hipLaunchKernelGGL(k_grid_count, dim3(gb), dim3(KNN_BLOCK), 0, stream, pts, n, (const StGrid*)g, cell_start, seg_off, nseg,
                        pt_cell, pt_rank);
-    ST_TRY(st_exclusive_scan_u32(cell_start, cell_start, ncell + 1, nullptr, scan_ws, scan_bytes, stream));
+    ST_TRY(st_exclusive_scan_u32(cell_start, cell_start, ncell + 1, nullptr, scan_ws, scan_bytes, stream, ncell1_dev));
     hipLaunchKernelGGL(k_grid_fill, dim3(gb), dim3(KNN_BLOCK), 0, stream, pts, n, (const uint32_t*)cell_start,
                        (const uint32_t*)pt_cell, (const uint32_t*)pt_rank, recs);
     ST_CHECK_LAUNCH();

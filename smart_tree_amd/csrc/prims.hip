@@ -59,8 +59,15 @@ __device__ __forceinline__ void scan_load(const uint32_t* in, int64_t base, int6
     }
 }
 
-__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_reduce(const uint32_t* in, uint32_t* block_sums, int64_t n) {
+// n_dev (optional): the number of elements actually in use, known on the device only (e.g. the cell count of a grid
+// whose bounding box never visits the host); the launch is sized for the bound n, tiles past *n_dev do (almost) nothing.
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_reduce(const uint32_t* in, uint32_t* block_sums, int64_t n, const int64_t* n_dev) {
     __shared__ uint32_t lds[SCAN_BLOCK / 64 + 1];
+    if (n_dev) {
+        const int64_t m = *n_dev;
+        n = m < n ? m : n;
+        if ((int64_t)blockIdx.x * SCAN_TILE >= n) { if (threadIdx.x == 0) block_sums[blockIdx.x] = 0u; return; }
+    }
     int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
     uint32_t v[SCAN_ITEMS];
     scan_load(in, base, n, v);
@@ -76,8 +83,17 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_reduce(const uint32_t* in, 
 // SCAN_DIRECT_BLOCKS words, L2 resident) -- one launch less per scan, and a pipeline pass runs ~20 scans; true: block_sums
 // has been scanned (recursively) and holds each tile's offset, block_sums[gridDim.x] the grand total.
 __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_apply(const uint32_t* in, uint32_t* out, const uint32_t* block_sums,
-                                                           int64_t n, uint32_t* total_out, int sums_scanned) {
+                                                           int64_t n, uint32_t* total_out, int sums_scanned, const int64_t* n_dev) {
     __shared__ uint32_t lds[SCAN_BLOCK / 64 + 1];
+    if (n_dev) {  // elements past *n_dev are neither read nor written; the total still lands in total_out
+        const int64_t m = *n_dev;
+        n = m < n ? m : n;
+        const bool last_live = (int64_t)blockIdx.x * SCAN_TILE < n && ((int64_t)blockIdx.x + 1) * SCAN_TILE >= n;
+        if ((int64_t)blockIdx.x * SCAN_TILE >= n && !(n == 0 && blockIdx.x == 0)) return;
+        if (total_out && !last_live && !(n == 0)) total_out = nullptr;
+    } else if (blockIdx.x != gridDim.x - 1) {
+        total_out = nullptr;
+    }
     uint32_t carry;
     if (sums_scanned) {
         carry = block_sums[blockIdx.x];
@@ -112,7 +128,7 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_apply(const uint32_t* in, u
             ex += v[i];
         }
     }
-    if (total_out && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total_out = carry + total;
+    if (total_out && threadIdx.x == 0) *total_out = carry + total;
 }
 
 int64_t st_scan_ws_bytes(int64_t n) {
@@ -124,31 +140,46 @@ int64_t st_scan_ws_bytes(int64_t n) {
     return a.used;
 }
 
-static int scan_level(const uint32_t* in, uint32_t* out, int64_t n, uint32_t* total, StArena& a, hipStream_t stream) {
+static int scan_level(const uint32_t* in, uint32_t* out, int64_t n, uint32_t* total, StArena& a, hipStream_t stream,
+                      const int64_t* n_dev = nullptr) {
     const int64_t nb = st_div_up(n, SCAN_TILE);
     uint32_t* sums = a.take<uint32_t>(nb + 1);
     if (!sums) {
         st_set_error("scan: workspace too small (%lld < %lld)", (long long)a.size, (long long)a.used);
         return ST_ERR_WORKSPACE;
     }
-    hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, stream, in, sums, n);
+    hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, stream, in, sums, n, n_dev);
     const bool deep = nb > SCAN_DIRECT_BLOCKS;
     if (deep) ST_TRY(scan_level(sums, sums, nb, sums + nb, a, stream));  // tile totals -> tile offsets, in place
     hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, stream, in, out, (const uint32_t*)sums, n, total,
-                       deep ? 1 : 0);
+                       deep ? 1 : 0, n_dev);
     return ST_OK;
 }
 
 int st_exclusive_scan_u32(const uint32_t* in, uint32_t* out, int64_t n, uint32_t* total, void* ws, int64_t ws_bytes,
-                          hipStream_t stream) {
+                          hipStream_t stream, const int64_t* n_dev) {
     if (n <= 0) {
         if (total) (void)hipMemsetAsync(total, 0, sizeof(uint32_t), stream);
         return ST_OK;
     }
     StArena a(ws, ws_bytes);
-    ST_TRY(scan_level(in, out, n, total, a, stream));
+    ST_TRY(scan_level(in, out, n, total, a, stream, n_dev));
     ST_CHECK_LAUNCH();
     return ST_OK;
+}
+
+// p[0 .. min(n, *n_dev)) = value (a memset whose length lives on the device)
+__global__ void __launch_bounds__(SCAN_BLOCK) k_fill_u32_dev(uint32_t* p, int64_t n, const int64_t* n_dev, uint32_t value) {
+    const int64_t m = *n_dev < n ? *n_dev : n;
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < m; i += (int64_t)gridDim.x * blockDim.x * 4) {
+        if (i + 4 <= m && ((((uintptr_t)p) & 15) == 0)) *reinterpret_cast<uint4*>(p + i) = make_uint4(value, value, value, value);
+        else for (int64_t j = i; j < m && j < i + 4; j++) p[j] = value;
+    }
+}
+void st_fill_u32_dev(uint32_t* p, int64_t n, const int64_t* n_dev, uint32_t value, hipStream_t stream) {
+    if (n <= 0) return;
+    const int64_t g = st_div_up(st_div_up(n, 4), SCAN_BLOCK);
+    hipLaunchKernelGGL(k_fill_u32_dev, dim3((unsigned)(g < 16384 ? g : 16384)), dim3(SCAN_BLOCK), 0, stream, p, n, n_dev, value);
 }
 
 // ------------------------------------------------------------------------------ radix sort ---

@@ -227,8 +227,10 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* l
 // ---- internal primitives (prims.hip) --------------------------------------------------------------
 int64_t st_scan_ws_bytes(int64_t n);
 // out[i] = sum_{j<i} in[j]; if total != nullptr, *total = sum of all (device pointer). in may alias out.
+// n_dev (optional, device): only the first min(n, *n_dev) elements are in use -- the launch is sized for n, the rest is skipped.
 int st_exclusive_scan_u32(const uint32_t* in, uint32_t* out, int64_t n, uint32_t* total, void* ws, int64_t ws_bytes,
-                          hipStream_t stream);
+                          hipStream_t stream, const int64_t* n_dev = nullptr);
+void st_fill_u32_dev(uint32_t* p, int64_t n, const int64_t* n_dev, uint32_t value, hipStream_t stream);
 int64_t st_sort_ws_bytes(int64_t n);
 // Stable LSD radix sort of (key, val) pairs on key bits [0, key_bits).  Result lands in keys/vals.
 int st_radix_sort_pairs_u32(uint32_t* keys, uint32_t* vals, int64_t n, int key_bits, void* ws, int64_t ws_bytes,
