@@ -174,9 +174,11 @@ __global__ void __launch_bounds__(VX_BLOCK) k_vx_blocks(VxState* st, int* table,
 
 // Calls fn(b) for every kept block whose halo cube [c - half_outer, c + half_outer) holds p, in (x, y, z) block order.
 // The test is separable: per axis, which of the three neighbouring block columns hold the coordinate (the centre is
-// recomputed with the expression k_vx_blocks stores, so the decision is bit-identical to testing `centres`); only the
-// surviving combinations -- one for an interior point, up to eight near a block corner -- touch the block table
-// (`table` = the slice of the point's own cloud).
+// recomputed with the expression k_vx_blocks stores, so the decision is bit-identical to testing `centres`).  With a halo
+// narrower than half a block at most TWO columns per axis qualify, i.e. at most eight blocks: their table entries are
+// requested together (eight independent loads), then fn runs for the hits -- eight uniform steps per point.  (Walking the 27
+// combinations and calling fn inside cost a wavefront 27 serialised bodies, each with its own chain of dependent loads: some
+// lane of 64 scattered points sits near every face.)  `table` = the slice of the point's own cloud.
 template <class F>
 __device__ __forceinline__ void vx_for_each_block(const float* pt, const VxState* st, const int* d, const int* table,
                                                   const VxParams& p, F fn) {
@@ -193,7 +195,25 @@ __device__ __forceinline__ void vx_for_each_block(const float* pt, const VxState
         }
     }
     if (!(ok[0] && ok[1] && ok[2])) return;
-    for (int dx = -1; dx <= 1; dx++) {
+    if (__popc(ok[0]) <= 2 && __popc(ok[1]) <= 2 && __popc(ok[2]) <= 2) {
+        int lo_opt[3], hi_opt[3];  // column offsets (-1, 0, 1) of the first / second qualifying column, hi = 2: none
+        for (int a = 0; a < 3; a++) {
+            lo_opt[a] = __ffs(ok[a]) - 2;
+            const unsigned rest = ok[a] & (ok[a] - 1u);
+            hi_opt[a] = rest ? __ffs(rest) - 2 : 2;
+        }
+        int blk[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {  // j = (x choice, y choice, z choice): ascending (x, y, z) order
+            const int ox = (j & 4) ? hi_opt[0] : lo_opt[0], oy = (j & 2) ? hi_opt[1] : lo_opt[1], oz = (j & 1) ? hi_opt[2] : lo_opt[2];
+            blk[j] = (ox == 2 || oy == 2 || oz == 2) ? -1 : table[((q[0] + ox) * d[1] + (q[1] + oy)) * d[2] + (q[2] + oz)];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (blk[j] >= 0) fn(blk[j]);
+        return;
+    }
+    for (int dx = -1; dx <= 1; dx++) {  // halo >= half a block: up to 27 blocks
         if (!((ok[0] >> (dx + 1)) & 1u)) continue;
         for (int dy = -1; dy <= 1; dy++) {
             if (!((ok[1] >> (dy + 1)) & 1u)) continue;

@@ -58,8 +58,9 @@ def voxelize_blocks(xyz: torch.Tensor, rgb: Optional[torch.Tensor], voxel_size: 
     # ratio the last call with these parameters saw (0.5 the first time); the kernel flags an overflow, then the worst-case
     # sizes follow.
     key = (float(voxel_size), float(block_size), float(buffer_size))
-    guess = int(n * min(1.5 * _VOXELS_PER_POINT.get(key, 1.0 / 3.0), 8.0)) + 4096
-    for cap in sorted({min(guess, 8 * n + 1024), 3 * n + 1024, 8 * n + 1024}):
+    worst = (8 if 2 * buffer_size < block_size else 27) * n + 1024  # halo cubes a point can sit in
+    guess = int(n * 1.5 * _VOXELS_PER_POINT.get(key, 1.0 / 3.0)) + 4096
+    for cap in sorted({min(guess, worst), min(3 * n + 1024, worst), worst}):
         feats = torch.empty((cap, 6), dtype=torch.float32, device=dev)
         coords = torch.empty((cap, 4), dtype=torch.int32, device=dev)
         mask = torch.empty((cap,), dtype=torch.uint8, device=dev)

@@ -61,3 +61,12 @@ def test_voxelize_sparse_cloud_takes_the_capacity_retry(backend):
     assert out.coords.shape[0] > 3 * xyz.shape[0]  # > the second guess as well: the 8n capacity was needed
     assert ds._VOXELS_PER_POINT[(0.001, 1.0, 0.4)] > 3
     _compare(xyz, np.zeros_like(xyz), 0.001, backend, **kw)  # second call: first guess already large enough
+
+
+def test_voxelize_halo_wider_than_half_a_block(backend):
+    """buffer >= block / 2: a point can sit in all three block columns of an axis (up to 27 halo cubes) -- the general walk,
+    not the eight-block fast path."""
+    rng = np.random.RandomState(8)
+    xyz = rng.uniform(-1.5, 1.5, (5000, 3)).astype(np.float32)
+    out = _compare(xyz, np.zeros_like(xyz), 0.05, backend, block_size=1.0, buffer_size=0.6)
+    assert out.block_centres.shape[0] >= 27 and out.coords.shape[0] > 5 * xyz.shape[0]
