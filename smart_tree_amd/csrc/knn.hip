@@ -345,8 +345,10 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn(const float* __restrict__ src
 }
 
 #define KNN_MAX_CELLS (1ll << 24)
-// a batch of clouds gets one slab of cells per cloud: the cap grows with the batch (up to 8 x)
-static inline int64_t knn_max_cells(int nseg) { return KNN_MAX_CELLS * (nseg < 1 ? 1 : (nseg > 8 ? 8 : nseg)); }
+// a batch of clouds gets one slab of cells per cloud: the cap grows with the batch (up to 32 x = 2 GiB of cell table; the
+// table is cleared and scanned over the cells in use only).  With the cap at 8 x, a batch of 24 clouds searched cells twice
+// as coarse -- eight times the candidates -- as one cloud alone.
+static inline int64_t knn_max_cells(int nseg) { return KNN_MAX_CELLS * (nseg < 1 ? 1 : (nseg > 32 ? 32 : nseg)); }
 
 static void knn_layout(StArena& a, int64_t n2, int nseg, StGrid** g, uint32_t** cell_start, float4** recs, char** sub, int64_t* sub_bytes) {
     *g = a.take<StGrid>(1);

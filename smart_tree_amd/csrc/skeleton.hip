@@ -1139,7 +1139,7 @@ struct SkLayout {
     int64_t gws_bytes;
 };
 
-static inline int64_t sk_grid_cells(int nseg) { return SK_GRID_CELLS * (nseg < 1 ? 1 : (nseg > 8 ? 8 : nseg)); }
+static inline int64_t sk_grid_cells(int nseg) { return SK_GRID_CELLS * (nseg < 1 ? 1 : (nseg > 32 ? 32 : nseg)); }
 
 static void sk_layout(StArena& a, int64_t m, int64_t C, SkLayout* s, int nseg = 1) {
     s->dist_ord = a.take<unsigned>(m);
