@@ -70,16 +70,17 @@ def test_network_batch_equals_single_with_live_weights(backend):
     from oracle import unet_oracle as uo
     from test_unet import random_state_dict
 
-    clouds = _clouds(backend, sizes=(3000, 1500, 2200))
+    clouds = _clouds(backend, sizes=(900, 500) if backend.type == "cpu" else (30000, 12000, 20000))
+    vs = 0.09 if backend.type == "cpu" else 0.05  # (the sanitizer build runs every conv of five forward passes on fibers)
     centred = CentreCloud()(Cloud.collate([Cloud(c.xyz, c.rgb) for c in clouds]))
-    vb = voxelize_blocks(centred.xyz, centred.rgb, 0.05, block_size=2.0, buffer_size=0.2, seg_off=centred.seg_off)
+    vb = voxelize_blocks(centred.xyz, centred.rgb, vs, block_size=2.0, buffer_size=0.2, seg_off=centred.seg_off)
     net = Smart_Tree(random_state_dict(uo.load_weights(WEIGHTS), seed=3), device=backend)
     out = net.forward(sparse_from_batch(vb.feats[:, :3].contiguous(), vb.coords, backend, blk_seg=vb.blk_seg, n_seg=vb.n_seg))
     vo, bo = vb.seg_vox_off.cpu().tolist(), vb.seg_blk_off.cpu().tolist()
     differs_without_segments = False
     plain = net.forward(sparse_from_batch(vb.feats[:, :3].contiguous(), vb.coords, backend))  # one extent for the whole batch
     for s, part in enumerate(centred.split()):
-        ref = voxelize_blocks(part.xyz, part.rgb, 0.05, block_size=2.0, buffer_size=0.2)
+        ref = voxelize_blocks(part.xyz, part.rgb, vs, block_size=2.0, buffer_size=0.2)
         one = net.forward(sparse_from_batch(ref.feats[:, :3].contiguous(), ref.coords, backend))
         for k in one:
             assert _eq(out[k][vo[s]: vo[s + 1]], one[k]), (s, k)
@@ -136,8 +137,8 @@ def test_process_clouds_equals_process_cloud(backend):
     """End to end, including prune (skeleton 0 of EVERY cloud), repair, smooth and the packed result gather."""
     from smart_tree_amd import sharding
 
-    clouds = _clouds(backend, sizes=(5000, 30, 3500) if backend.type == "cpu" else (60000, 20000, 30, 45000),
-                     scale=0.4 if backend.type == "cpu" else 0.8)
+    clouds = _clouds(backend, sizes=(3000, 30, 2000) if backend.type == "cpu" else (60000, 20000, 30, 45000),
+                     scale=0.35 if backend.type == "cpu" else 0.8)
     pipe = _pipeline(backend, 0.04 if backend.type == "cpu" else 0.03)
     serial = [pipe.process_cloud(cloud=Cloud(c.xyz, c.rgb)) for c in clouds]
     parts = pipe.process_clouds([Cloud(c.xyz, c.rgb) for c in clouds])
@@ -146,9 +147,14 @@ def test_process_clouds_equals_process_cloud(backend):
     for one, got in zip(serial, parts):
         assert _signature(got) == _signature(one)
         n_branches += len(_signature(one))
-    assert n_branches > 20
+    assert n_branches > (5 if backend.type == "cpu" else 20)
     # the gather's fast path on a cloud of a batch against the branch-by-branch walk of the one-cloud result
-    parts = pipe.process_clouds([Cloud(c.xyz, c.rgb) for c in clouds])
+    if backend.type != "cpu":  # (a second pass through the sanitizer build costs minutes; the fast path is host code)
+        parts = pipe.process_clouds([Cloud(c.xyz, c.rgb) for c in clouds])
+    else:
+        for p in parts:  # forget the objects handed out above: the packed host arrays are untouched
+            for t in p._trees:
+                t.__dict__.pop("_branches", None)
     for k, (one, got) in enumerate(zip(serial, parts)):
         fast = got.pack(cloud_id=k)
         from smart_tree_amd.data_types.tree import DisjointTreeSkeleton
@@ -176,7 +182,7 @@ def test_process_clouds_edge_cases(backend):
     """An empty list, a batch of one, and a batch whose clouds give no skeleton at all (too few points for a block)."""
     pipe = _pipeline(backend, 0.04)
     assert pipe.process_clouds([]) == []
-    clouds = _clouds(backend, sizes=(4000,), scale=0.4)
+    clouds = _clouds(backend, sizes=(2500,), scale=0.35)
     one = pipe.process_cloud(cloud=Cloud(clouds[0].xyz, clouds[0].rgb))
     (got,) = pipe.process_clouds([Cloud(clouds[0].xyz, clouds[0].rgb)])
     assert _signature(got) == _signature(one) and len(_signature(one)) > 0

@@ -199,7 +199,7 @@ def test_spatial_order_is_invisible(backend):
     same_block = np.diff(c[:, 0]) == 0
     step = np.abs(np.diff(c[:, 1:], axis=0)).sum(1)[same_block]
     assert np.median(step) <= 3  # ... and consecutive rows are spatial neighbours (input order: far apart)
-    for fp16 in (False, True):
+    for fp16 in ((False,) if backend.type == "cpu" else (False, True)):  # (half-precision mode: on the GPU only, for time)
         w = random_state_dict(uo.load_weights(WEIGHTS / "noble-elevator-58.npz"), seed=4)
         sp = sparse_from_batch(torch.from_numpy(vx["feats"][:, :3]), torch.from_numpy(vx["coords"]), backend)
         net = Smart_Tree(w, device=backend, fp16=fp16)
