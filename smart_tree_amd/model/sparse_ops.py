@@ -190,7 +190,7 @@ _pairs_cache = {}
 
 def _pair_count(nbr: torch.Tensor) -> int:
     """Active (input, output) pairs of a neighbour table (profiling only; cached per table)."""
-    key = id(nbr)  # the thunk keeps the tensor alive, so the id is stable
+    key = (id(nbr), profiling.generation())  # the thunk keeps the tensor alive, so the id is stable within one collection
     if key not in _pairs_cache:
         if len(_pairs_cache) > 4096:
             _pairs_cache.clear()

@@ -16,10 +16,18 @@ _stages = defaultdict(list)  # name -> [(start, end)]
 _kernels = defaultdict(list)  # name -> [(start, end, algorithmic_bytes)]
 
 
+_generation = 0  # bumped by every enable(True): caches of per-launch facts (pair counts keyed by tensor id) start afresh
+
+
+def generation() -> int:
+    return _generation
+
+
 def enable(flag: bool) -> None:
-    global _enabled
+    global _enabled, _generation
     _enabled = bool(flag) and torch.cuda.is_available()
     if flag:
+        _generation += 1
         _stages.clear()
         _kernels.clear()
         _external.clear()
