@@ -245,6 +245,30 @@ extern "C" int st_make_edges(const int64_t* idx, const float* dist, int64_t n, i
     return st_make_edges_seg(idx, dist, n, K, edges, w, n_edges_host, nullptr, 1, ws, ws_bytes, stream_);
 }
 
+// ---------------------------------------------------------------------------- edge sources ---
+// The component / CSR kernels take their edges either from an explicit list (edges [E,2] int64 + w [E], st_make_edges'
+// output: what the reference's Graph holds) or straight from the neighbour search (idx / dist [n,K]): edge e = (e / K,
+// idx[e]), kept iff idx[e] > first vertex of the source's cloud -- make_edges' own rule (graph.py:59), so both sources
+// describe the same edge set and the int64 edge list (20 bytes per edge, written once and read three times) need not exist.
+struct GrEdges {
+    const int64_t* edges;  // explicit list (or nullptr)
+    const float* w;
+    const int64_t* idx;    // neighbour table (or nullptr)
+    const float* dist;
+    int K;
+    const int* seg_off;
+    int nseg;
+};
+// the two ends of edge e; u == v marks "no edge" (padding, self loop, filtered neighbour)
+__device__ __forceinline__ void gr_edge(const GrEdges& G, int64_t e, int64_t* u, int64_t* v) {
+    if (G.idx == nullptr) { *u = G.edges[2 * e]; *v = G.edges[2 * e + 1]; return; }
+    const int64_t i = e / G.K, j = G.idx[e];
+    const int64_t first = G.seg_off ? G.seg_off[st_seg_find(G.seg_off, G.nseg, i)] : 0;
+    *u = i;
+    *v = j > first ? j : i;
+}
+__device__ __forceinline__ float gr_edge_weight(const GrEdges& G, int64_t e) { return G.idx ? G.dist[e] : G.w[e]; }
+
 // ------------------------------------------------------------------ connected components ---
 // Union-find over the edge list.  A root with the larger KEY is hooked under the one with the smaller key, where
 // key(x) = x * CC_MUL mod 2^32 (a bijection; idx() is its inverse).  With the vertex id itself as key the spatial
@@ -275,10 +299,12 @@ __global__ void __launch_bounds__(GR_BLOCK) k_cc_init(unsigned* label, int64_t n
 // Afforest-style schedule: a sampled eighth of the edges is linked first, the forest is flattened, and
 // the full pass then dismisses almost every edge with two loads (both ends already carry the same root:
 // a tree cloud is one giant component) instead of chasing pointers for it.
-__global__ void __launch_bounds__(GR_BLOCK) k_cc_hook(const int64_t* edges, int64_t E, unsigned* label, int sample) {
+__global__ void __launch_bounds__(GR_BLOCK) k_cc_hook(GrEdges G, int64_t E, unsigned* label, int sample) {
     GR_LOOP(e, E) {
         if (sample && (e & 7) != 0) continue;
-        const unsigned u = (unsigned)edges[2 * e], v = (unsigned)edges[2 * e + 1];
+        int64_t u64, v64;
+        gr_edge(G, e, &u64, &v64);
+        const unsigned u = (unsigned)u64, v = (unsigned)v64;
         if (u == v) continue;
         if (!sample) {  // labels were flattened by the preceding compress
             // plain (cacheable) loads: a stale pair that still compares equal was and stays in one tree; anything else
@@ -324,8 +350,24 @@ __global__ void __launch_bounds__(GR_BLOCK) k_cc_relabel(unsigned* label, int64_
 extern "C" int64_t st_connected_components_workspace_bytes(int64_t n) { return (n > 0 ? n : 1) * (int64_t)sizeof(unsigned) + 256; }
 
 // labels [n] int32 out: smallest vertex id of each vertex's component.
+static int cc_run(GrEdges G, int64_t E, int64_t n, int32_t* labels, void* ws, int64_t ws_bytes, void* stream_);
+
 extern "C" int st_connected_components(const int64_t* edges, int64_t E, int64_t n, int32_t* labels, void* ws,
                                        int64_t ws_bytes, void* stream_) {
+    GrEdges G = {edges, nullptr, nullptr, nullptr, 0, nullptr, 1};
+    return cc_run(G, E, n, labels, ws, ws_bytes, stream_);
+}
+
+// The same components straight from the neighbour search: idx [n,K] (st_knn_radius_seg's output after the caller's radius
+// filter), seg_off / nseg = the clouds of a batched call (NULL / 1: one cloud).
+extern "C" int st_connected_components_knn(const int64_t* idx, int64_t n, int K, const int32_t* seg_off, int nseg,
+                                           int32_t* labels, void* ws, int64_t ws_bytes, void* stream_) {
+    ST_REQUIRE(K >= 1 && nseg >= 1 && nseg <= ST_MAX_SEG && (nseg == 1 || seg_off), "cc(knn): bad K or cloud offsets");
+    GrEdges G = {nullptr, nullptr, idx, nullptr, K, nseg > 1 ? seg_off : nullptr, nseg};
+    return cc_run(G, n * (int64_t)K, n, labels, ws, ws_bytes, stream_);
+}
+
+static int cc_run(GrEdges G, int64_t E, int64_t n, int32_t* labels, void* ws, int64_t ws_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     ST_REQUIRE(n < (1ll << 31), "cc: too many vertices");
     if (n <= 0) return ST_OK;
@@ -338,9 +380,9 @@ extern "C" int st_connected_components(const int64_t* edges, int64_t E, int64_t 
     unsigned* label = (unsigned*)labels;
     hipLaunchKernelGGL(k_cc_init, dim3(gr_grid(n)), dim3(GR_BLOCK), 0, stream, label, n);
     if (E > 0) {
-        hipLaunchKernelGGL(k_cc_hook, dim3(gr_grid(E)), dim3(GR_BLOCK), 0, stream, edges, E, label, 1);
+        hipLaunchKernelGGL(k_cc_hook, dim3(gr_grid(E)), dim3(GR_BLOCK), 0, stream, G, E, label, 1);
         hipLaunchKernelGGL(k_cc_compress, dim3(gr_grid(n)), dim3(GR_BLOCK), 0, stream, label, n);
-        hipLaunchKernelGGL(k_cc_hook, dim3(gr_grid(E)), dim3(GR_BLOCK), 0, stream, edges, E, label, 0);
+        hipLaunchKernelGGL(k_cc_hook, dim3(gr_grid(E)), dim3(GR_BLOCK), 0, stream, G, E, label, 0);
     }
     hipLaunchKernelGGL(k_cc_compress, dim3(gr_grid(n)), dim3(GR_BLOCK), 0, stream, label, n);
     hipLaunchKernelGGL(k_cc_minid_init, dim3(gr_grid(n)), dim3(GR_BLOCK), 0, stream, minid, n);
@@ -539,34 +581,35 @@ __device__ __forceinline__ uint32_t gr_run_add(uint32_t* ctr, int key) {
 }
 
 // the two ends of edge e in the renumbered vertex space, -1/-1 when the edge is dropped
-__device__ __forceinline__ void csr_edge_ends(const int64_t* edges, int64_t E, const int* new_id, int64_t e, int* a, int* b) {
+__device__ __forceinline__ void csr_edge_ends(const GrEdges& G, int64_t E, const int* new_id, int64_t e, int* a, int* b) {
     *a = -1; *b = -1;
     if (e >= E) return;
-    const int64_t u = edges[2 * e], v = edges[2 * e + 1];
+    int64_t u, v;
+    gr_edge(G, e, &u, &v);
     if (u == v) return;  // self loops (every vertex but 0 has one) never matter for paths
     const int x = new_id[u], y = new_id[v];
     if (x < 0 || y < 0) return;
     *a = x; *b = y;
 }
 
-__global__ void __launch_bounds__(GR_BLOCK) k_csr_count(const int64_t* edges, int64_t E, const int* new_id, uint32_t* deg) {
+__global__ void __launch_bounds__(GR_BLOCK) k_csr_count(GrEdges G, int64_t E, const int* new_id, uint32_t* deg) {
     const int lane = threadIdx.x & 63;
     for (int64_t base = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x - lane); base < E; base += (int64_t)gridDim.x * blockDim.x) {
         int a, b;
-        csr_edge_ends(edges, E, new_id, base + lane, &a, &b);
+        csr_edge_ends(G, E, new_id, base + lane, &a, &b);
         gr_run_add(deg, a);
         if (b >= 0) atomicAdd(&deg[b], 1u);  // targets are scattered: no runs to aggregate
     }
 }
-__global__ void __launch_bounds__(GR_BLOCK) k_csr_fill(const int64_t* edges, const float* w, int64_t E, const int* new_id,
+__global__ void __launch_bounds__(GR_BLOCK) k_csr_fill(GrEdges G, int64_t E, const int* new_id,
                                                        uint32_t* cursor, uint32_t* col, float* wgt) {
     const int lane = threadIdx.x & 63;
     for (int64_t base = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x - lane); base < E; base += (int64_t)gridDim.x * blockDim.x) {
         int a, b;
-        csr_edge_ends(edges, E, new_id, base + lane, &a, &b);
+        csr_edge_ends(G, E, new_id, base + lane, &a, &b);
         const uint32_t pa = gr_run_add(cursor, a);
         if (a < 0) continue;
-        const float we = w[base + lane];
+        const float we = gr_edge_weight(G, base + lane);
         col[pa] = (uint32_t)b; wgt[pa] = we;
         const uint32_t pb = atomicAdd(&cursor[b], 1u);
         col[pb] = (uint32_t)a; wgt[pb] = we;
@@ -582,8 +625,26 @@ extern "C" int64_t st_component_csr_workspace_bytes(int64_t m) {
 
 // row_off [m+1] uint32, col / wgt capacity 2*E.  Adjacency order inside a row is unspecified
 // (atomic cursors); every consumer is order independent.
+static int csr_run(GrEdges G, int64_t E, const int32_t* new_id, int64_t m, uint32_t* row_off, uint32_t* col, float* wgt, void* ws,
+                   int64_t ws_bytes, void* stream_);
+
 extern "C" int st_component_csr(const int64_t* edges, const float* w, int64_t E, const int32_t* new_id, int64_t m,
                                 uint32_t* row_off, uint32_t* col, float* wgt, void* ws, int64_t ws_bytes, void* stream_) {
+    GrEdges G = {edges, w, nullptr, nullptr, 0, nullptr, 1};
+    return csr_run(G, E, new_id, m, row_off, col, wgt, ws, ws_bytes, stream_);
+}
+
+// The same adjacency straight from the neighbour search (idx / dist [n,K]); col / wgt capacity 2 * n * K.
+extern "C" int st_component_csr_knn(const int64_t* idx, const float* dist, int64_t n, int K, const int32_t* seg_off, int nseg,
+                                    const int32_t* new_id, int64_t m, uint32_t* row_off, uint32_t* col, float* wgt, void* ws,
+                                    int64_t ws_bytes, void* stream_) {
+    ST_REQUIRE(K >= 1 && nseg >= 1 && nseg <= ST_MAX_SEG && (nseg == 1 || seg_off), "csr(knn): bad K or cloud offsets");
+    GrEdges G = {nullptr, nullptr, idx, dist, K, nseg > 1 ? seg_off : nullptr, nseg};
+    return csr_run(G, n * (int64_t)K, new_id, m, row_off, col, wgt, ws, ws_bytes, stream_);
+}
+
+static int csr_run(GrEdges G, int64_t E, const int32_t* new_id, int64_t m, uint32_t* row_off, uint32_t* col, float* wgt, void* ws,
+                   int64_t ws_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (m <= 0) return ST_OK;
     StArena a(ws, ws_bytes);
@@ -592,10 +653,10 @@ extern "C" int st_component_csr(const int64_t* edges, const float* w, int64_t E,
     char* sw = a.take<char>(sb);
     if (!cursor || !sw) { st_set_error("component_csr: workspace too small"); return ST_ERR_WORKSPACE; }
     (void)hipMemsetAsync(row_off, 0, (m + 1) * sizeof(uint32_t), stream);
-    if (E > 0) hipLaunchKernelGGL(k_csr_count, dim3(gr_grid(E)), dim3(GR_BLOCK), 0, stream, edges, E, new_id, row_off);
+    if (E > 0) hipLaunchKernelGGL(k_csr_count, dim3(gr_grid(E)), dim3(GR_BLOCK), 0, stream, G, E, new_id, row_off);
     ST_TRY(st_exclusive_scan_u32(row_off, row_off, m + 1, nullptr, sw, sb, stream));
     (void)hipMemcpyAsync(cursor, row_off, (m + 1) * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream);
-    if (E > 0) hipLaunchKernelGGL(k_csr_fill, dim3(gr_grid(E)), dim3(GR_BLOCK), 0, stream, edges, w, E, new_id, cursor, col, wgt);
+    if (E > 0) hipLaunchKernelGGL(k_csr_fill, dim3(gr_grid(E)), dim3(GR_BLOCK), 0, stream, G, E, new_id, cursor, col, wgt);
     ST_CHECK_LAUNCH();
     return ST_OK;
 }

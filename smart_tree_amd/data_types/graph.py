@@ -64,3 +64,28 @@ class PaddedGraph(Graph):
     def __repr__(self):
         return f"PaddedGraph(vertices={tuple(self.vertices.shape)}, capacity={self._cap[0].shape[0]})"
 
+
+
+class KnnGraph(PaddedGraph):
+    """What `nn_graph` returns since round 2: the neighbour search's own tables `idxs` / `dists` [n,K] (after the radius
+    filter).  The reference's edge list -- (i, idx) for idx > vertex 0 of i's cloud, graph.py:52-60 -- is the same
+    information; `connected_cugraph_components` builds labels and adjacency from the tables directly, and `edges` /
+    `edge_weights` / `padded` materialise the int64 edge list only if somebody asks for it."""
+
+    def __init__(self, vertices: torch.Tensor, idxs: torch.Tensor, dists: torch.Tensor, seg_off=None):
+        self.vertices = vertices
+        self.idxs, self.dists = idxs, dists
+        self.seg_off = seg_off
+        self._cap_cache = None
+        self._cut = None
+
+    @property
+    def _cap(self):
+        if self._cap_cache is None:
+            from ..skeleton.graph import make_edges
+
+            self._cap_cache = make_edges(self.dists, self.idxs, padded=True, seg_off=self.seg_off)
+        return self._cap_cache
+
+    def __repr__(self):
+        return f"KnnGraph(vertices={tuple(self.vertices.shape)}, K={self.idxs.shape[1]})"

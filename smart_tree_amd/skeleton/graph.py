@@ -14,7 +14,7 @@ from typing import Optional
 import torch
 
 from .. import _lib
-from ..data_types.graph import Graph, PaddedGraph
+from ..data_types.graph import Graph, KnnGraph, PaddedGraph
 
 BOUND_NONE, BOUND_LE, BOUND_LT = 0, 1, 2
 
@@ -109,10 +109,7 @@ def nn_graph(points: torch.Tensor, radii: torch.Tensor, K: int = 40, seg_off: Op
         return g
     idxs, dists, _ = knn(points, points, K=K, r=-1.0, bound=radii, bound_mode=BOUND_LE, cell=-SEARCH_CELL_DIV,
                          src_seg_off=seg_off, dest_seg_off=seg_off)
-    edges, edge_weights = make_edges(dists, idxs, padded=True, seg_off=seg_off)
-    g = PaddedGraph(points, edges, edge_weights)
-    g.seg_off = seg_off
-    return g
+    return KnnGraph(points, idxs, dists, seg_off)  # the edge list (make_edges) is cut only if somebody reads .edges
 
 
 @dataclass
@@ -146,16 +143,24 @@ def connected_components(graph: Graph, minimum_vertices: int = 0) -> ComponentSe
     L = _lib.lib()
     dev = graph.vertices.device
     n = graph.vertices.shape[0]
-    edges, w = graph.padded if isinstance(graph, PaddedGraph) else (graph.edges, graph.edge_weights)
-    edges, w = edges.contiguous(), w.contiguous()
-    E = edges.shape[0]
+    seg_off = getattr(graph, "seg_off", None)
+    nseg = 1 if seg_off is None else int(seg_off.shape[0]) - 1
+    from_knn = isinstance(graph, KnnGraph) and graph._cap_cache is None  # labels / adjacency straight from the search tables
     i32 = lambda k: torch.empty((max(k, 1),), dtype=torch.int32, device=dev)
     labels = i32(n)
     ws = _lib.workspace(L.st_connected_components_workspace_bytes(n), dev)
-    _lib.check(L.st_connected_components(_lib.ptr(edges), E, n, _lib.ptr(labels), _lib.ptr(ws), ws.numel(), _lib.stream(dev)))
+    if from_knn:
+        idxs, dists = graph.idxs.contiguous(), graph.dists.contiguous()
+        K = idxs.shape[1]
+        E = n * K
+        _lib.check(L.st_connected_components_knn(_lib.ptr(idxs), n, K, _lib.ptr(seg_off) if nseg > 1 else None, nseg,
+                                                 _lib.ptr(labels), _lib.ptr(ws), ws.numel(), _lib.stream(dev)))
+    else:
+        edges, w = graph.padded if isinstance(graph, PaddedGraph) else (graph.edges, graph.edge_weights)
+        edges, w = edges.contiguous(), w.contiguous()
+        E = edges.shape[0]
+        _lib.check(L.st_connected_components(_lib.ptr(edges), E, n, _lib.ptr(labels), _lib.ptr(ws), ws.numel(), _lib.stream(dev)))
     comp_size, comp_off, vert_order, new_id = i32(n), i32(n + 1), i32(n), i32(n)
-    seg_off = getattr(graph, "seg_off", None)
-    nseg = 1 if seg_off is None else int(seg_off.shape[0]) - 1
     comp_seg, comp_seg_off, vert_seg_off = (i32(n), i32(nseg + 1), i32(nseg + 1)) if nseg > 1 else (None, None, None)
     nc, nk = ctypes.c_int64(0), ctypes.c_int64(0)
     ws = _lib.workspace(L.st_component_layout_workspace_bytes(n), dev)
@@ -167,8 +172,13 @@ def connected_components(graph: Graph, minimum_vertices: int = 0) -> ComponentSe
     row_off, col, wgt = i32(m + 1), i32(2 * E), torch.empty((max(2 * E, 1),), dtype=torch.float32, device=dev)
     if m > 0:
         ws = _lib.workspace(L.st_component_csr_workspace_bytes(m), dev)
-        _lib.check(L.st_component_csr(_lib.ptr(edges), _lib.ptr(w), E, _lib.ptr(new_id), m, _lib.ptr(row_off), _lib.ptr(col),
-                                      _lib.ptr(wgt), _lib.ptr(ws), ws.numel(), _lib.stream(dev)))
+        if from_knn:
+            _lib.check(L.st_component_csr_knn(_lib.ptr(idxs), _lib.ptr(dists), n, K, _lib.ptr(seg_off) if nseg > 1 else None, nseg,
+                                              _lib.ptr(new_id), m, _lib.ptr(row_off), _lib.ptr(col), _lib.ptr(wgt), _lib.ptr(ws),
+                                              ws.numel(), _lib.stream(dev)))
+        else:
+            _lib.check(L.st_component_csr(_lib.ptr(edges), _lib.ptr(w), E, _lib.ptr(new_id), m, _lib.ptr(row_off), _lib.ptr(col),
+                                          _lib.ptr(wgt), _lib.ptr(ws), ws.numel(), _lib.stream(dev)))
     return ComponentSet(C, comp_size[:C], comp_off[: C + 1], vert_order[:m], new_id[:n], labels[:n], row_off[: m + 1], col, wgt,
                         nseg, comp_seg[:C] if comp_seg is not None else None, comp_seg_off, vert_seg_off)
 
