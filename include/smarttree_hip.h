@@ -207,9 +207,9 @@ int st_radius_count_seg(const float* src, int64_t n1, const float* dst, int64_t 
 /* components / adjacency straight from the neighbour search (idx / dist [n,K] of st_knn_radius_seg after the caller's radius
  * filter): the edge set is make_edges' (graph.py:52-60: (i, idx) for idx > vertex 0 of i's cloud) without materialising
  * the int64 edge list.  Same labels / CSR as st_connected_components / st_component_csr on st_make_edges_seg's output. */
-int st_connected_components_knn(const int64_t* idx, int64_t n, int K, const int32_t* seg_off, int nseg, int32_t* labels,
-                                void* ws, int64_t ws_bytes, void* stream);
-int st_component_csr_knn(const int64_t* idx, const float* dist, int64_t n, int K, const int32_t* seg_off, int nseg,
+int st_connected_components_knn(const int64_t* idx, int64_t n, int K, const int32_t* first_of /*[n] first vertex of the
+                                vertex's cloud; NULL = one cloud*/, int32_t* labels, void* ws, int64_t ws_bytes, void* stream);
+int st_component_csr_knn(const int64_t* idx, const float* dist, int64_t n, int K, const int32_t* first_of,
                          const int32_t* new_id, int64_t m, uint32_t* row_off, uint32_t* col, float* wgt, void* ws,
                          int64_t ws_bytes, void* stream);
 int st_make_edges_seg(const int64_t* idx, const float* dist, int64_t n, int K, int64_t* edges, float* w,

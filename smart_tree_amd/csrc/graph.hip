@@ -255,15 +255,15 @@ struct GrEdges {
     const float* w;
     const int64_t* idx;    // neighbour table (or nullptr)
     const float* dist;
-    int K;
-    const int* seg_off;
-    int nseg;
+    int K, k_shift;        // k_shift >= 0: K == 1 << k_shift
+    const int* first_of;   // [n] first vertex of every vertex's cloud (batched calls; nullptr: vertex 0)
 };
+static inline int gr_shift_of(int K) { int sh = 0; while ((1 << sh) < K) sh++; return (1 << sh) == K ? sh : -1; }
 // the two ends of edge e; u == v marks "no edge" (padding, self loop, filtered neighbour)
 __device__ __forceinline__ void gr_edge(const GrEdges& G, int64_t e, int64_t* u, int64_t* v) {
     if (G.idx == nullptr) { *u = G.edges[2 * e]; *v = G.edges[2 * e + 1]; return; }
-    const int64_t i = e / G.K, j = G.idx[e];
-    const int64_t first = G.seg_off ? G.seg_off[st_seg_find(G.seg_off, G.nseg, i)] : 0;
+    const int64_t i = G.k_shift >= 0 ? (e >> G.k_shift) : e / G.K, j = G.idx[e];
+    const int64_t first = G.first_of ? G.first_of[i] : 0;  // (the K lanes of a source read one word)
     *u = i;
     *v = j > first ? j : i;
 }
@@ -354,16 +354,16 @@ static int cc_run(GrEdges G, int64_t E, int64_t n, int32_t* labels, void* ws, in
 
 extern "C" int st_connected_components(const int64_t* edges, int64_t E, int64_t n, int32_t* labels, void* ws,
                                        int64_t ws_bytes, void* stream_) {
-    GrEdges G = {edges, nullptr, nullptr, nullptr, 0, nullptr, 1};
+    GrEdges G = {edges, nullptr, nullptr, nullptr, 0, -1, nullptr};
     return cc_run(G, E, n, labels, ws, ws_bytes, stream_);
 }
 
 // The same components straight from the neighbour search: idx [n,K] (st_knn_radius_seg's output after the caller's radius
-// filter), seg_off / nseg = the clouds of a batched call (NULL / 1: one cloud).
-extern "C" int st_connected_components_knn(const int64_t* idx, int64_t n, int K, const int32_t* seg_off, int nseg,
+// filter); first_of [n] (batched calls) = the first vertex of every vertex's cloud, NULL = one cloud (vertex 0).
+extern "C" int st_connected_components_knn(const int64_t* idx, int64_t n, int K, const int32_t* first_of,
                                            int32_t* labels, void* ws, int64_t ws_bytes, void* stream_) {
-    ST_REQUIRE(K >= 1 && nseg >= 1 && nseg <= ST_MAX_SEG && (nseg == 1 || seg_off), "cc(knn): bad K or cloud offsets");
-    GrEdges G = {nullptr, nullptr, idx, nullptr, K, nseg > 1 ? seg_off : nullptr, nseg};
+    ST_REQUIRE(K >= 1, "cc(knn): K must be positive");
+    GrEdges G = {nullptr, nullptr, idx, nullptr, K, gr_shift_of(K), first_of};
     return cc_run(G, n * (int64_t)K, n, labels, ws, ws_bytes, stream_);
 }
 
@@ -630,16 +630,16 @@ static int csr_run(GrEdges G, int64_t E, const int32_t* new_id, int64_t m, uint3
 
 extern "C" int st_component_csr(const int64_t* edges, const float* w, int64_t E, const int32_t* new_id, int64_t m,
                                 uint32_t* row_off, uint32_t* col, float* wgt, void* ws, int64_t ws_bytes, void* stream_) {
-    GrEdges G = {edges, w, nullptr, nullptr, 0, nullptr, 1};
+    GrEdges G = {edges, w, nullptr, nullptr, 0, -1, nullptr};
     return csr_run(G, E, new_id, m, row_off, col, wgt, ws, ws_bytes, stream_);
 }
 
 // The same adjacency straight from the neighbour search (idx / dist [n,K]); col / wgt capacity 2 * n * K.
-extern "C" int st_component_csr_knn(const int64_t* idx, const float* dist, int64_t n, int K, const int32_t* seg_off, int nseg,
+extern "C" int st_component_csr_knn(const int64_t* idx, const float* dist, int64_t n, int K, const int32_t* first_of,
                                     const int32_t* new_id, int64_t m, uint32_t* row_off, uint32_t* col, float* wgt, void* ws,
                                     int64_t ws_bytes, void* stream_) {
-    ST_REQUIRE(K >= 1 && nseg >= 1 && nseg <= ST_MAX_SEG && (nseg == 1 || seg_off), "csr(knn): bad K or cloud offsets");
-    GrEdges G = {nullptr, nullptr, idx, dist, K, nseg > 1 ? seg_off : nullptr, nseg};
+    ST_REQUIRE(K >= 1, "csr(knn): K must be positive");
+    GrEdges G = {nullptr, nullptr, idx, dist, K, gr_shift_of(K), first_of};
     return csr_run(G, n * (int64_t)K, new_id, m, row_off, col, wgt, ws, ws_bytes, stream_);
 }
 

@@ -153,8 +153,12 @@ def connected_components(graph: Graph, minimum_vertices: int = 0) -> ComponentSe
         idxs, dists = graph.idxs.contiguous(), graph.dists.contiguous()
         K = idxs.shape[1]
         E = n * K
-        _lib.check(L.st_connected_components_knn(_lib.ptr(idxs), n, K, _lib.ptr(seg_off) if nseg > 1 else None, nseg,
-                                                 _lib.ptr(labels), _lib.ptr(ws), ws.numel(), _lib.stream(dev)))
+        first_of = None
+        if nseg > 1:  # first vertex of every vertex's cloud ("vertex 0" of make_edges' idx > 0 rule)
+            cloud_of = torch.bucketize(torch.arange(n, device=dev, dtype=torch.int32), seg_off[1:].contiguous(), right=True)
+            first_of = seg_off[cloud_of.clamp(max=nseg - 1)].contiguous()
+        _lib.check(L.st_connected_components_knn(_lib.ptr(idxs), n, K, _lib.ptr(first_of), _lib.ptr(labels), _lib.ptr(ws),
+                                                 ws.numel(), _lib.stream(dev)))
     else:
         edges, w = graph.padded if isinstance(graph, PaddedGraph) else (graph.edges, graph.edge_weights)
         edges, w = edges.contiguous(), w.contiguous()
@@ -173,7 +177,7 @@ def connected_components(graph: Graph, minimum_vertices: int = 0) -> ComponentSe
     if m > 0:
         ws = _lib.workspace(L.st_component_csr_workspace_bytes(m), dev)
         if from_knn:
-            _lib.check(L.st_component_csr_knn(_lib.ptr(idxs), _lib.ptr(dists), n, K, _lib.ptr(seg_off) if nseg > 1 else None, nseg,
+            _lib.check(L.st_component_csr_knn(_lib.ptr(idxs), _lib.ptr(dists), n, K, _lib.ptr(first_of),
                                               _lib.ptr(new_id), m, _lib.ptr(row_off), _lib.ptr(col), _lib.ptr(wgt), _lib.ptr(ws),
                                               ws.numel(), _lib.stream(dev)))
         else:
