@@ -301,7 +301,9 @@ __global__ void __launch_bounds__(GR_BLOCK) k_cc_init(unsigned* label, int64_t n
 // a tree cloud is one giant component) instead of chasing pointers for it.
 __global__ void __launch_bounds__(GR_BLOCK) k_cc_hook(GrEdges G, int64_t E, unsigned* label, int sample) {
     GR_LOOP(e, E) {
-        if (sample && (e & 7) != 0) continue;
+        // a pseudo-random eighth of the edges (not every eighth: in a neighbour table entries 0 and 8 of every row would be
+        // picked, and entry 0 is the vertex itself)
+        if (sample && (((uint32_t)e * 2654435761u) >> 29) != 0u) continue;
         int64_t u64, v64;
         gr_edge(G, e, &u64, &v64);
         const unsigned u = (unsigned)u64, v = (unsigned)v64;
