@@ -35,8 +35,8 @@ N_POINTS = 1_000_000
 VOXEL = 0.02
 WEIGHTS = ROOT / "smart_tree_amd" / "model" / "weights"
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-MAX_BATCH = 24  # clouds per launch set  } measured on one MI355X (tools/sweep_batch.sh, profiles/r02_sweep_batch.txt, 192 steps):
-STREAMS = 4     # batches in flight      } 4 x 24 = 1.72 ms per cloud, 3 x 32 = 1.74, 3 x 24 = 1.81, 3 x 16 = 1.89, 2 x 32 = 1.93, 5 x 16 = 2.06
+MAX_BATCH = 48  # clouds per launch set  } measured on one MI355X (tools/sweep_batch.sh, profiles/r02_sweep_batch.txt, 384 steps):
+STREAMS = 3     # batches in flight      } 3 x 48 = 1.51 ms per cloud, 2 x 64 = 1.55, 4 x 24 = 1.60, 4 x 48 = 1.59, 4 x 64 = 1.59
 N_SEEDS = 4  # distinct clouds per rank, cycled
 
 
@@ -254,7 +254,7 @@ def extra_configs(device):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=192)
+    ap.add_argument("--steps", type=int, default=384)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--points", type=int, default=N_POINTS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
