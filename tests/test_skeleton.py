@@ -290,3 +290,30 @@ def test_outlier_removal_count_kernel_equals_the_search(backend):
     for a, b in ((0, 700), (700, len(pts))):
         one = outlier_removal(t(pts[a:b]), t(rad[a:b]).unsqueeze(1), nb_points=8)
         assert torch.equal(both[a:b].cpu(), one.cpu())
+
+
+def test_components_from_knn_tables_equal_components_from_the_edge_list(backend):
+    """KnnGraph: labels, layout and adjacency built straight from the search tables (st_connected_components_knn /
+    st_component_csr_knn) against the same graph through make_edges' int64 edge list -- one cloud and a batch of two."""
+    from smart_tree_amd.data_types.graph import KnnGraph
+    from smart_tree_amd.skeleton import graph as G
+
+    rng = np.random.RandomState(3)
+    pts = np.concatenate([rng.rand(900, 3) * [0.4, 2.0, 0.4], 5 + rng.rand(300, 3) * 0.5, rng.rand(40, 3) * 9]).astype(np.float32)
+    rad = (0.05 + 0.1 * rng.rand(len(pts))).astype(np.float32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(backend)
+    for seg in (None, torch.tensor([0, 700, len(pts)], dtype=torch.int32, device=backend)):
+        a = G.nn_graph(t(pts), t(rad), K=16, seg_off=seg)
+        assert isinstance(a, KnnGraph) and a._cap_cache is None
+        ca = a.connected_cugraph_components(minimum_vertices=8)  # from the tables
+        b = G.nn_graph(t(pts), t(rad), K=16, seg_off=seg)
+        _ = b.padded  # materialise the edge list first: the edge-list path
+        cb = b.connected_cugraph_components(minimum_vertices=8)
+        assert ca.n_components == cb.n_components > 1
+        for name in ("comp_size", "comp_off", "vert_order", "new_id", "labels", "row_off"):
+            assert torch.equal(getattr(ca, name).cpu(), getattr(cb, name).cpu()), name
+        ro = ca.row_off.cpu().numpy().astype(np.int64)
+        for v in range(0, len(ro) - 1, 7):  # rows as multisets (the order inside a row is unspecified)
+            ra = sorted(zip(ca.col[ro[v]: ro[v + 1]].cpu().tolist(), ca.wgt[ro[v]: ro[v + 1]].cpu().tolist()))
+            rb = sorted(zip(cb.col[ro[v]: ro[v + 1]].cpu().tolist(), cb.wgt[ro[v]: ro[v + 1]].cpu().tolist()))
+            assert ra == rb
