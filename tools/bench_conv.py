@@ -24,7 +24,10 @@ for b in range(BATCH):
     clouds.append(Cloud(xyz=torch.from_numpy(c["xyz"]).to(dev), rgb=torch.from_numpy(c["rgb"]).to(dev)))
 cloud = pipe.preprocessing(Cloud.collate(clouds) if BATCH > 1 else clouds[0])
 vb = voxelize_blocks(cloud.xyz, cloud.rgb, VOX, seg_off=cloud.seg_off)
-pyr = ops.build_pyramid(vb.coords, 3, vb.blk_seg, vb.n_seg)
+coords0 = vb.coords
+if "--input-order" not in sys.argv:  # as Smart_Tree.features does: Morton-ordered rows (st_spatial_order)
+    coords0 = coords0.index_select(0, ops.spatial_order(coords0))
+pyr = ops.build_pyramid(coords0, 3, vb.blk_seg, vb.n_seg)
 N = [x.shape[0] for x in pyr.coords]
 print("levels", N)
 def timeit(fn, reps=20):
