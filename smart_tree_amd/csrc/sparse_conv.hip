@@ -162,7 +162,8 @@ static int conv_launch(const TIN* x0, int c0, const TIN* x1, const int32_t* nbr,
 
 // ------------------------------------------------------------------------- MFMA rule-GEMM ---
 // For Cin, Cout multiples of 16 the per-offset contraction [16 voxels x Cin] . [Cin x Cout] runs on the
-// matrix cores with v_mfma_f32_16x16x4_f32 (f32 in / f32 accumulate: bit-for-bit a k-ordered fmaf chain,
+// matrix cores with v_mfma_f32_16x16x4_f32 (f32 in / f32 accumulate; NOT bit-identical to the vector kernel's fmaf chain -- measured in round 2: last-bit differences --
+// so a layer must use the same kernel family at every size,
 // cdna_hip_programming.md section 3), still output-stationary and atomics-free:
 //   wave   = MF_RT row tiles of 16 output voxels x all Cout (Cout/16 column tiles), accumulators in VGPRs
 //   A      = gathered input rows: lane (i = l&15, kg = l>>4) loads ONE float4 = channels 16c+4kg .. +3 of row i

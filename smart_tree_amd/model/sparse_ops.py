@@ -162,10 +162,12 @@ def sparse_conv(x0: torch.Tensor, w: torch.Tensor, nbr: Optional[torch.Tensor], 
                                                 _lib.ptr(residual), int(relu), _lib.ptr(y), int(in_half), int(out_half),
                                                 _lib.ptr(row_order), _lib.stream(x0.device)))
         return y
-    # 16 -> 16 on many rows: the vector kernel (lane = voxel, weights from scalar registers) beats the matrix-core kernel once
-    # the rows are Morton-ordered and the level fills the chip (67 % against 53 % of the HBM peak at 1.5M rows,
-    # profiles/r02_conv_layers_batch16.txt); both compute every row as the same k-ordered float32 FMA chain
-    big_16 = cin == 16 and cout == 16 and nbr is not None and row_order is None and n_out >= 150000
+    # 16 -> 16 submanifold convs run on the vector kernel (lane = voxel, weights from scalar registers): with Morton-ordered
+    # rows it beats the matrix-core kernel wherever the level fills the chip (67 % against 53 % of the HBM peak at 1.5M rows,
+    # profiles/r02_conv_layers_batch16.txt).  At EVERY size, not only the large ones: the two kernels round differently in
+    # the last bit (the matrix core does not evaluate a k-ordered fmaf chain exactly), and a cloud must get the same values
+    # alone and inside a batch (tests/test_batch.py).
+    big_16 = cin == 16 and cout == 16 and nbr is not None and row_order is None and x1 is None
     if wp is not None and mfma_eligible(cin, cout, c0) and not big_16:
         y = torch.empty((n_out, cout), dtype=torch.float32, device=x0.device)
         nbytes = (lambda: (_pair_count(nbr) if nbr is not None else n_out) * (cin * 4 + (4 if nbr is not None else 0))
