@@ -326,7 +326,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     profiling.enable(False)
-    roof = profiling.roofline(HBM_PEAK_GBS)
+    roof = profiling.roofline(HBM_PEAK_GBS, clouds_per_launch=max(plan_batches(args.steps, S, B)))
     stage_ms = profiling.stage_ms(args.steps)
     sk = worker.last
     last = {"trees": len(sk.skeletons), "branches": int(sum(len(t.branches) for t in sk.skeletons))}

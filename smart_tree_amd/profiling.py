@@ -114,7 +114,17 @@ def _pmc_traffic(kernel_name: str):
     return None
 
 
-def roofline(peak_gbs: float, peak_f32_tflops: float = 157.3):
+PMC_CLOUDS_PER_LAUNCH = 48  # batch size of the committed PMC passes (tools/collect_r2.sh: --streams 1 --batch 48 --steps 48)
+
+
+def _scaled_traffic(name: str, clouds_per_launch: int):
+    t = _pmc_traffic(name)
+    if t is None or not clouds_per_launch:
+        return t
+    return t * clouds_per_launch / PMC_CLOUDS_PER_LAUNCH
+
+
+def roofline(peak_gbs: float, peak_f32_tflops: float = 157.3, clouds_per_launch: int = 0):
     """Roofline entry of the kernel class with the largest total time in the timed region, plus (as `gather_gemm`) the
     AGGREGATE over every sparse-conv launch -- sum of algorithmic bytes / sum of kernel time: the gather / rule-GEMM /
     scatter the path is named for -- with the per-class table in `all_kernels`."""
@@ -126,7 +136,10 @@ def roofline(peak_gbs: float, peak_f32_tflops: float = 157.3):
     achieved = r["bytes_per_launch"] / (r["avg_us"] * 1e-6) / 1e9
     latency_bound = name == "k_sk_select"
     out = {"kernel": name, "bound": "latency" if latency_bound else "hbm", "achieved": achieved, "peak": peak_gbs, "unit": "GB/s",
-           "frac": achieved / peak_gbs, "traffic": _pmc_traffic(name), "launches": r["launches"], "avg_us": r["avg_us"],
+           "frac": achieved / peak_gbs, "traffic": _scaled_traffic(name, clouds_per_launch), "launches": r["launches"], "avg_us": r["avg_us"],
+           "traffic_note": f"HBM bytes per launch (FETCH_SIZE + WRITE_SIZE, two rocprofv3 PMC passes, profiles/*_pmc_summary.csv) "
+                           f"measured at {PMC_CLOUDS_PER_LAUNCH} clouds per launch set and scaled linearly to this run's "
+                           f"{clouds_per_launch or PMC_CLOUDS_PER_LAUNCH}; no gfx950 x2 correction (scattered accesses)",
            "algorithmic_bytes_per_launch": r["bytes_per_launch"],
            "note": "latency-bound branch selection (priced against the HBM peak all the same): one workgroup per tree "
                    "component runs speculative rounds (each of its 16 wavefronts walks one candidate tip; ~25 us of dependent "
