@@ -114,7 +114,7 @@ def _pmc_traffic(kernel_name: str):
     return None
 
 
-PMC_CLOUDS_PER_LAUNCH = 48  # batch size of the committed PMC passes (tools/collect_r2.sh: --streams 1 --batch 48 --steps 48)
+PMC_CLOUDS_PER_LAUNCH = 16  # batch size of the committed PMC passes (tools/pmc_select.sh, tools/collect_r2.sh: --streams 1 --steps 16)
 
 
 def _scaled_traffic(name: str, clouds_per_launch: int):
