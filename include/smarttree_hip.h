@@ -60,6 +60,8 @@ int st_build_subm_rulebook(const int32_t* coords, int64_t n, const unsigned long
  * Morton code); running the network on the permuted set and scattering the outputs back gives the same values faster. */
 int64_t st_spatial_order_workspace_bytes(int64_t n);
 int st_spatial_order(const int32_t* coords, int64_t n, int32_t* order /*[n]*/, void* ws, int64_t ws_bytes, void* stream);
+/* rows of `row_words` 32-bit words moved by a permutation: dst[p] = src[order[p]] (scatter = 0) / dst[order[p]] = src[p] */
+int st_move_rows(const void* src, int row_words, const int32_t* order, int64_t n, void* dst, int scatter, void* stream);
 int64_t st_strided_workspace_bytes(int64_t n_fine);
 int st_build_strided_outputs(const int32_t* coords, int64_t n, int64_t max_out, int32_t* out_coords,
                              unsigned long long* ckeys, unsigned* cvals, int64_t ccap, int64_t* n_out_host,

@@ -39,6 +39,7 @@ SIGNATURES = {
     "st_strided_workspace_bytes": (I64, [I64]),
     "st_spatial_order_workspace_bytes": (I64, [I64]),
     "st_spatial_order": (c_int, [P, I64, P, P, I64, P]),
+    "st_move_rows": (c_int, [P, c_int, P, I64, P, c_int, P]),
     "st_build_strided_outputs": (c_int, [P, I64, I64, P, P, P, I64, ctypes.POINTER(I64), ctypes.POINTER(ctypes.c_int32),
                                          P, I64, P]),
     "st_build_strided_rulebook": (c_int, [P, I64, P, P, I64, P, I64, P, P, I64, ctypes.POINTER(ctypes.c_int32), P, P, P, P]),
@@ -102,7 +103,7 @@ ENQUEUE_ONLY = frozenset({
     "st_connected_components", "st_component_csr", "st_post_process", "st_knn_radius",
     "st_centre_cloud_seg", "st_voxelize_workspace_bytes_seg", "st_build_strided_rulebook_seg", "st_knn_workspace_bytes_seg",
     "st_knn_radius_seg", "st_skeleton_workspace_bytes_seg", "st_post_process_seg", "st_radius_count_seg",
-    "st_spatial_order_workspace_bytes", "st_spatial_order", "st_connected_components_knn", "st_component_csr_knn",
+    "st_spatial_order_workspace_bytes", "st_spatial_order", "st_connected_components_knn", "st_component_csr_knn", "st_move_rows",
 })
 
 

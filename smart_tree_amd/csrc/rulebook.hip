@@ -452,3 +452,37 @@ extern "C" int st_spatial_order(const int32_t* coords, int64_t n, int32_t* order
     ST_CHECK_LAUNCH();
     return ST_OK;
 }
+
+// dst[p] = src[order[p]] (scatter == 0) or dst[order[p]] = src[p] (scatter != 0) for rows of `row_words` 32-bit words:
+// the permutation of the voxel rows into / out of the spatial order (torch's index_select needs an int64 index and ran the
+// 12- and 16-byte rows at a tenth of the HBM rate).
+template <int VEC>
+__global__ void __launch_bounds__(RB_BLOCK) k_rb_move_rows(const uint32_t* __restrict__ src, int row_words, const int32_t* __restrict__ order,
+                                                           int64_t n, uint32_t* __restrict__ dst, int scatter) {
+    const int per_row = row_words / VEC;
+    const int64_t total = n * per_row;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = t / per_row;
+        const int c = (int)(t % per_row) * VEC;
+        const int64_t o = order[p];
+        const int64_t from = (scatter ? p : o) * row_words + c, to = (scatter ? o : p) * row_words + c;
+        if (VEC == 4) *reinterpret_cast<uint4*>(dst + to) = *reinterpret_cast<const uint4*>(src + from);
+        else dst[to] = src[from];
+    }
+}
+
+extern "C" int st_move_rows(const void* src, int row_words, const int32_t* order, int64_t n, void* dst, int scatter, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n <= 0) return ST_OK;
+    ST_REQUIRE(row_words >= 1 && row_words <= 256, "move_rows: rows of 1..256 words");
+    const bool vec = row_words % 4 == 0 && ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0;
+    const int64_t total = n * (vec ? row_words / 4 : row_words);
+    if (vec)
+        hipLaunchKernelGGL((k_rb_move_rows<4>), dim3(rb_grid(total)), dim3(RB_BLOCK), 0, stream, (const uint32_t*)src, row_words, order, n,
+                           (uint32_t*)dst, scatter);
+    else
+        hipLaunchKernelGGL((k_rb_move_rows<1>), dim3(rb_grid(total)), dim3(RB_BLOCK), 0, stream, (const uint32_t*)src, row_words, order, n,
+                           (uint32_t*)dst, scatter);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
+}

@@ -148,13 +148,13 @@ class Smart_Tree:
         feats = sparse_input.features.contiguous().float()
         order = ops.spatial_order(coords) if self.spatial_order and self.trace is None and coords.shape[0] > 1 else None
         if order is not None:
-            coords, feats = coords.index_select(0, order), feats.index_select(0, order)
+            coords, feats = ops.move_rows(coords, order), ops.move_rows(feats, order)
         pyr = ops.build_pyramid(coords, self.depth, getattr(sparse_input, "blk_seg", None), getattr(sparse_input, "n_seg", 1))
         x = self._conv("input_conv.sequence.0", feats, None, feats.shape[0], bn="input_conv.sequence.1", relu=True)
         self._record("input", x)
         x = self._ublock("UNet", x, pyr, 0)
         if order is not None:
-            x = torch.empty_like(x).index_copy_(0, order, x)
+            x = ops.move_rows(x, order, scatter=True)
         return x
 
     def forward(self, sparse_input) -> Dict[str, torch.Tensor]:

@@ -111,14 +111,24 @@ def build_pyramid(coords: torch.Tensor, depth: int, blk_seg: Optional[torch.Tens
 
 
 def spatial_order(coords: torch.Tensor) -> torch.Tensor:
-    """[N] int64 permutation: voxels sorted by (batch index, Morton code of z, y, x) (csrc/rulebook.hip st_spatial_order)."""
+    """[N] int32 permutation: voxels sorted by (batch index, Morton code of z, y, x) (csrc/rulebook.hip st_spatial_order)."""
     L = _lib.lib()
     n = coords.shape[0]
     order = torch.empty(n, dtype=torch.int32, device=coords.device)
     if n:
         ws = _lib.workspace(L.st_spatial_order_workspace_bytes(n), coords.device)
         _lib.check(L.st_spatial_order(_lib.ptr(coords), n, _lib.ptr(order), _lib.ptr(ws), ws.numel(), _lib.stream(coords.device)))
-    return order.long()
+    return order
+
+
+def move_rows(x: torch.Tensor, order: torch.Tensor, scatter: bool = False) -> torch.Tensor:
+    """x[order] (gather) or the inverse (out[order] = x, scatter) for a [N, C] tensor of 4-byte elements, order int32 [N]."""
+    L = _lib.lib()
+    x = x.contiguous()
+    assert x.element_size() == 4 and x.ndim == 2 and order.dtype == torch.int32
+    out = torch.empty_like(x)
+    _lib.check(L.st_move_rows(_lib.ptr(x), x.shape[1], _lib.ptr(order), x.shape[0], _lib.ptr(out), int(scatter), _lib.stream(x.device)))
+    return out
 
 
 def mfma_weight(w: torch.Tensor) -> torch.Tensor:

@@ -192,7 +192,7 @@ def test_spatial_order_is_invisible(backend):
     equal, bit for bit, the one computed in the input's own order -- in float32 and in half-precision storage mode."""
     vx = _small_batch(n=5000, seed=9)
     coords = torch.from_numpy(vx["coords"]).to(backend)
-    order = ops.spatial_order(coords).cpu().numpy()
+    order = ops.spatial_order(coords).cpu().numpy().astype(np.int64)
     assert sorted(order.tolist()) == list(range(len(order)))
     c = vx["coords"][order].astype(np.int64)
     assert (np.diff(c[:, 0]) >= 0).all()  # blocks stay together ...

@@ -26,7 +26,7 @@ cloud = pipe.preprocessing(Cloud.collate(clouds) if BATCH > 1 else clouds[0])
 vb = voxelize_blocks(cloud.xyz, cloud.rgb, VOX, seg_off=cloud.seg_off)
 coords0 = vb.coords
 if "--input-order" not in sys.argv:  # as Smart_Tree.features does: Morton-ordered rows (st_spatial_order)
-    coords0 = coords0.index_select(0, ops.spatial_order(coords0))
+    coords0 = ops.move_rows(coords0, ops.spatial_order(coords0))
 pyr = ops.build_pyramid(coords0, 3, vb.blk_seg, vb.n_seg)
 N = [x.shape[0] for x in pyr.coords]
 print("levels", N)
