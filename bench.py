@@ -288,6 +288,10 @@ def main():
     from smart_tree_amd import profiling
     from smart_tree_amd.sharding import gather_skeletons
 
+    # host side of the GPU phase: a few Python threads issuing launches; torch's CPU ops here are tiny (offset lists), and an
+    # OpenMP pool spinning on every core beside them only takes cycles from the launch threads (the CPU baseline sets its own)
+    torch.set_num_threads(int(os.environ.get("ST_BENCH_TORCH_THREADS", "1")))
+
     S = max(1, min(args.streams, max(1, usable_cores() // max(world, 1))))
     S = max(1, min(S, args.steps // 16), min(S, 3, args.steps // 6))  # see plan_batches
     B = max(1, min(args.batch, 64))
