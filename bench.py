@@ -185,6 +185,7 @@ class CloudWorker:
 
         def work(w):
             try:
+                torch.cuda.set_device(self.device)  # the current device is thread-local: a new thread starts on device 0
                 with torch.cuda.stream(self.streams[w]):
                     while True:
                         with lock:
