@@ -14,7 +14,12 @@
 #include "st_grid.h"  // ST_MAX_SEG
 
 #define VX_BLOCK 256
-#define VX_TABLE_CAP 32768  // max cells of the block-id bounding box of ONE cloud (32^3 blocks of 4 m = 128 m)
+#define VX_TABLE_CAP 32768  // least capacity of the block table: cells of the block-id bounding box of ONE cloud (32^3 blocks
+                            // of 4 m = 128 m per axis); the table grows with max_blocks (vx_table_cells) for larger plots
+static inline int64_t vx_table_cells(int max_blocks, int nseg) {  // per cloud: max_blocks is the capacity of the whole batch
+    const int64_t want = 8ll * ((max_blocks + nseg - 1) / (nseg > 0 ? nseg : 1));
+    return want > VX_TABLE_CAP ? want : VX_TABLE_CAP;
+}
 #define VX_LDS_BLOCKS 128
 
 // Batched calls: `nseg` independent clouds in one point array, cloud s = points [seg_off[s], seg_off[s+1]).  Every
@@ -25,6 +30,7 @@ struct VxState {
     uint32_t n_blocks;
     uint32_t n_vox;
     uint32_t overflow;   // bit0: block table, bit1: max_blocks, bit2: hash full
+    int table_cells;     // capacity of the block table per cloud (vx_table_cells)
     uint32_t seg_blk_off[ST_MAX_SEG + 1];  // first block of every cloud
     uint32_t seg_vox_off[ST_MAX_SEG + 1];  // first voxel of every cloud (written by the gather pass)
 };
@@ -72,8 +78,9 @@ __device__ __forceinline__ void vx_stream_points(const float* __restrict__ xyz, 
     }
 }
 
-__global__ void k_vx_init(VxState* st) {
+__global__ void k_vx_init(VxState* st, int table_cells) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
+        st->table_cells = table_cells;
         for (int a = 0; a < 3; a++) { st->lo[a] = 0x7fffffff; st->hi[a] = (int)0x80000000; }
         st->n_blocks = 0; st->n_vox = 0; st->overflow = 0;
     }
@@ -105,7 +112,7 @@ __global__ void __launch_bounds__(VX_BLOCK) k_vx_bbox(const float* xyz, int64_t 
 __device__ __forceinline__ bool vx_dims(const VxState* st, int* d) {
     int64_t total = 1;
     for (int a = 0; a < 3; a++) { d[a] = st->hi[a] - st->lo[a] + 1; if (d[a] < 1) return false; total *= d[a]; }
-    return total <= VX_TABLE_CAP;
+    return total <= st->table_cells;
 }
 
 #define VX_LDS_CELLS 2048
@@ -453,7 +460,7 @@ static int64_t vx_layout(StArena& a, int64_t n, int max_blocks, int64_t max_voxe
                          int64_t* cap) {
     *cap = st_next_pow2((max_voxels > 8 ? max_voxels : 8) + (max_voxels > 8 ? max_voxels : 8) / 2);  // load <= 2/3 at max_voxels
     *st = a.take<VxState>(1);
-    *table = a.take<int>((int64_t)VX_TABLE_CAP * nseg);
+    *table = a.take<int>(vx_table_cells(max_blocks, nseg) * nseg);
     *blk_lo = a.take<unsigned>(3 * (int64_t)max_blocks);
     *blk_hi = a.take<unsigned>(3 * (int64_t)max_blocks);
     *blk_lof = a.take<float>(3 * (int64_t)max_blocks);
@@ -533,8 +540,8 @@ extern "C" int st_voxelize_blocks_seg(const float* xyz, const float* rgb, int64_
 
     const dim3 gs = vx_grid_seg(n, nseg, 4096), gr = vx_grid_seg(n, nseg, 512 / (nseg < 8 ? nseg : 8) + 8);
     const dim3 g1((unsigned)st_min64(st_div_up(st_div_up(n, nseg), VX_BLOCK) + 1, 4096), (unsigned)nseg);  // one lane per point
-    hipLaunchKernelGGL(k_vx_init, dim3(1), dim3(64), 0, stream, st);
-    (void)hipMemsetAsync(table, 0, (int64_t)VX_TABLE_CAP * nseg * sizeof(int), stream);
+    hipLaunchKernelGGL(k_vx_init, dim3(1), dim3(64), 0, stream, st, (int)vx_table_cells(max_blocks, nseg));
+    (void)hipMemsetAsync(table, 0, vx_table_cells(max_blocks, nseg) * nseg * sizeof(int), stream);
     (void)hipMemsetAsync(slots, 0xff, cap * sizeof(VxSlot), stream);  // empty key, value = "no point yet"
     hipLaunchKernelGGL(k_vx_bbox, gr, dim3(VX_BLOCK), 0, stream, xyz, n, seg_off, p, st);
     hipLaunchKernelGGL(k_vx_hist, gr, dim3(VX_BLOCK), 0, stream, xyz, n, seg_off, p, st, table);
@@ -560,7 +567,8 @@ extern "C" int st_voxelize_blocks_seg(const float* xyz, const float* rgb, int64_
     (void)hipMemcpyAsync(&h, st, sizeof(VxState), hipMemcpyDeviceToHost, stream);
     st_stream_wait(stream);
     ST_CHECK_LAUNCH();
-    ST_REQUIRE(!(h.overflow & 1u), "voxelize: cloud spans more than %d blocks", VX_TABLE_CAP);
+    ST_REQUIRE(!(h.overflow & 1u), "voxelize: the block-id bounding box of a cloud has more than %lld cells (raise max_blocks)",
+               (long long)vx_table_cells(max_blocks, nseg));
     ST_REQUIRE(!(h.overflow & 2u), "voxelize: %u blocks exceed max_blocks=%d", h.n_blocks, max_blocks);
     ST_REQUIRE(!(h.overflow & 4u) && (int64_t)h.n_vox <= max_voxels, "voxelize: %u voxels exceed max_voxels=%lld",
                h.n_vox, (long long)max_voxels);

@@ -49,6 +49,13 @@ def voxelize_blocks(xyz: torch.Tensor, rgb: Optional[torch.Tensor], voxel_size: 
     rgb = rgb.contiguous().float() if rgb is not None else None
     n = xyz.shape[0]
     nseg = 1 if seg_off is None else int(seg_off.shape[0]) - 1
+    return _voxelize_blocks(xyz, rgb, n, nseg, seg_off, voxel_size, block_size, buffer_size, min_points, max_blocks)
+
+
+def _voxelize_blocks(xyz, rgb, n, nseg, seg_off, voxel_size, block_size, buffer_size, min_points, max_blocks):
+    L = _lib.lib()
+    dev = xyz.device
+    per_cloud_blocks = max_blocks
     max_blocks = min(max_blocks * nseg, 65535)
     n_vox, n_blk = ctypes.c_int64(0), ctypes.c_int64(0)
     i32 = lambda k: torch.empty((k,), dtype=torch.int32, device=dev)
@@ -74,6 +81,12 @@ def voxelize_blocks(xyz: torch.Tensor, rgb: Optional[torch.Tensor], voxel_size: 
                                       ctypes.byref(n_blk), _lib.ptr(ws), ws.numel(), _lib.stream(dev))
         if rc == 0 or b"exceed max_voxels" not in L.st_last_error():
             break
+    if rc != 0 and (b"bounding box of a cloud has more than" in L.st_last_error() or b"exceed max_blocks" in L.st_last_error()) \
+            and per_cloud_blocks * nseg < 65535:
+        # a plot larger than the default block table (8 x max_blocks cells, >= 32768: e.g. a stray point far away, or hundreds
+        # of metres of forest): the reference's torch.unique handles any extent -- retry with a larger table
+        return _voxelize_blocks(xyz, rgb, n, nseg, seg_off, voxel_size, block_size, buffer_size, min_points,
+                                min(per_cloud_blocks * 8, 65535))
     _lib.check(rc)
     m, b = n_vox.value, n_blk.value
     if n > 0:

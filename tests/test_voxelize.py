@@ -70,3 +70,14 @@ def test_voxelize_halo_wider_than_half_a_block(backend):
     xyz = rng.uniform(-1.5, 1.5, (5000, 3)).astype(np.float32)
     out = _compare(xyz, np.zeros_like(xyz), 0.05, backend, block_size=1.0, buffer_size=0.6)
     assert out.block_centres.shape[0] >= 27 and out.coords.shape[0] > 5 * xyz.shape[0]
+
+
+def test_voxelize_plot_larger_than_the_default_block_table(backend):
+    """A cloud whose block-id bounding box has more cells than the default table (32768): the reference's torch.unique-based
+    compute_blocks takes any extent; here the call is retried with a larger table (advisor, round 1)."""
+    rng = np.random.RandomState(4)
+    a = rng.uniform(0, 2, (400, 3)).astype(np.float32)
+    far = (a[:300] + np.array([150.0, 10.0, 170.0], np.float32)).astype(np.float32)  # 38 x 3 x 43 blocks of 4 m... x 8 = > 32768 cells
+    xyz = np.concatenate([a, far, a[:50] + np.array([0.0, 130.0, 0.0], np.float32)])
+    out = _compare(xyz, np.zeros_like(xyz), 0.1, backend)
+    assert out.block_centres.shape[0] >= 2
