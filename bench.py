@@ -314,12 +314,29 @@ def main():
         torch.cuda.synchronize()
 
     fence()  # inputs and weights are resident before any worker stream touches them
-    # warm-up: at least --warmup clouds, and every worker runs one batch of the size the timed region will use (allocator
-    # pools and workspaces reach their timed-region size before the clock starts)
+    # warm-up: at least --warmup clouds, and one untimed pass over the very batches the timed region will run.  Every stream
+    # has its own allocator pool, and batches differ a little in their voxel / vertex counts: a pool that has seen only one
+    # batch still grows during the next few (hipMalloc synchronises the device: measured 2.1 instead of 1.55 ms per cloud
+    # when the timed region started after one warm-up batch per stream)
     plan = plan_batches(args.steps, S, B)
-    warm = max(args.warmup, S * max(plan)) if args.warmup > 0 and plan else 0
+    warm = max(args.warmup, sum(plan)) if args.warmup > 0 and plan else 0
     if warm:
-        finished.extend(worker.run([max(plan)] * S + plan_batches(warm - S * max(plan), S, B), collect=world > 1))
+        finished.extend(worker.run(plan + plan_batches(warm - sum(plan), S, B), collect=world > 1))
+        # ... repeated until two consecutive passes agree to 5 % (at most 6 more passes / 10 s): a process that starts right
+        # after another GPU process has exited runs with inflated host round trips for its first seconds (measured on the
+        # gpurun boxes: 3.0 instead of 1.55 ms per cloud, gone a few seconds later).  Warm-up is untimed; the K steps
+        # are timed once.
+        prev, t_start = None, time.perf_counter()
+        for _ in range(6):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            finished.extend(worker.run(plan, collect=world > 1))
+            torch.cuda.synchronize()
+            cur = time.perf_counter() - t0
+            warm += sum(plan)
+            if (prev is not None and abs(cur - prev) <= 0.05 * prev) or time.perf_counter() - t_start > 10.0:
+                break
+            prev = cur
     gather()
     fence()
     serial_ms = worker.serial_ms() if warm > 0 else None
