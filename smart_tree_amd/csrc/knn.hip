@@ -182,22 +182,21 @@ int st_grid_build(const float* pts, int64_t n, float cell, int64_t max_cells, St
 //      slot -- the K nearest come out sorted by (d2, index) without a sort.  If the list fills up it is cut
 //      back to its K smallest the same way and the scan goes on.
 #define KNN_WAVES (KNN_BLOCK / 64)
-#define KNN_CAP 256  // keys per query held in LDS between cuts
+#define KNN_CAP 128  // keys per query held in LDS between cuts: a cut happens when a chunk of 64 might not fit any more
 
 __device__ __forceinline__ uint32_t knn_wave_scan(uint32_t v, int lane) {  // inclusive
     for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(v, (unsigned)d); if (lane >= d) v += o; }
     return v;
 }
 
-// Keep the K smallest of keys[0..n): rank = number of smaller keys (keys are unique: the index is part of them).
-// Returns the new count.  All 64 lanes call.
-template <int K>
-__device__ __forceinline__ int knn_cut(unsigned long long* keys, int n, int lane) {
-    __builtin_amdgcn_wave_barrier();
-    unsigned long long mine[KNN_CAP / 64];
-    int rank[KNN_CAP / 64];
+// rank of every key = number of smaller keys (keys are unique: the index is part of them); emit(key, rank) for the n keys.
+// NCH = 64-key chunks a lane holds (n <= 64 * NCH).  All 64 lanes call.
+template <int NCH, class F>
+__device__ __forceinline__ void knn_rank(const unsigned long long* keys, int n, int lane, F emit) {
+    unsigned long long mine[NCH];
+    int rank[NCH];
 #pragma unroll
-    for (int c = 0; c < KNN_CAP / 64; c++) {
+    for (int c = 0; c < NCH; c++) {
         const int j = c * 64 + lane;
         mine[c] = j < n ? keys[j] : ~0ull;
         rank[c] = 0;
@@ -205,12 +204,20 @@ __device__ __forceinline__ int knn_cut(unsigned long long* keys, int n, int lane
     for (int t = 0; t < n; t++) {
         const unsigned long long kt = keys[t];  // same address in every lane: a broadcast
 #pragma unroll
-        for (int c = 0; c < KNN_CAP / 64; c++) rank[c] += kt < mine[c] ? 1 : 0;
+        for (int c = 0; c < NCH; c++) rank[c] += kt < mine[c] ? 1 : 0;
     }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int c = 0; c < KNN_CAP / 64; c++)
-        if (c * 64 + lane < n && rank[c] < K) keys[rank[c]] = mine[c];
+    for (int c = 0; c < NCH; c++)
+        if (c * 64 + lane < n) emit(mine[c], rank[c]);
+}
+
+// Keep the K smallest of keys[0..n), in ascending order.  Returns the new count.  All 64 lanes call.
+template <int K>
+__device__ __forceinline__ int knn_cut(unsigned long long* keys, int n, int lane) {
+    __builtin_amdgcn_wave_barrier();
+    auto put = [&](unsigned long long key, int rank) { if (rank < K) keys[rank] = key; };
+    if (n <= 64) knn_rank<1>(keys, n, lane, put); else knn_rank<KNN_CAP / 64>(keys, n, lane, put);
     __builtin_amdgcn_wave_barrier();
     return n < K ? n : K;
 }
@@ -259,6 +266,9 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn(const float* __restrict__ src
     const float rs = reach_r * 1.0001f + 1e-7f, rs2 = rs * rs;
     const int ny = y1 - y0 + 1, nrows = (x1 >= x0 && ny > 0 && z1 >= z0) ? (x1 - x0 + 1) * ny : 0;
     int nkeys = 0;  // wave-uniform
+    // once K keys are known, a candidate that is not smaller than the K-th of them cannot be among the K nearest: it is
+    // dropped before it reaches the list (around a trunk a query sees thousands of points inside its bound)
+    unsigned long long thr = ~0ull;
     for (int rbase = 0; rbase < nrows && !(COUNT && nkeys >= K); rbase += 64) {
         const int rowi = rbase + lane;
         uint32_t first = 0, cnt = 0;
@@ -303,11 +313,15 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn(const float* __restrict__ src
                 if (mode == 1) ok = ok && sqrtf(d2) <= bnd;
                 if (mode == 2) ok = ok && sqrtf(d2) < bnd;
                 key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned long long)__float_as_uint(q.w);  // d2 >= 0: bits order like values
+                if (!COUNT) ok = ok && key < thr;
             }
             const unsigned long long bal = __ballot(ok);
             if (!COUNT && ok) keys[nkeys + __popcll(bal & ((1ull << lane) - 1ull))] = key;
             nkeys += __popcll(bal);
-            if (!COUNT && nkeys > KNN_CAP - 64) nkeys = knn_cut<K>(keys, nkeys, lane);
+            if (!COUNT && nkeys > KNN_CAP - 64) {
+                nkeys = knn_cut<K>(keys, nkeys, lane);
+                if (nkeys == K) thr = keys[K - 1];
+            }
         }
     }
     if (COUNT) {
@@ -317,25 +331,13 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn(const float* __restrict__ src
     // output: rank = slot.  (d2, index) ascending, -1 / NaN padding.
     __builtin_amdgcn_wave_barrier();
     {
-        unsigned long long mine[KNN_CAP / 64];
-        int rank[KNN_CAP / 64];
-#pragma unroll
-        for (int c = 0; c < KNN_CAP / 64; c++) {
-            const int j = c * 64 + lane;
-            mine[c] = j < nkeys ? keys[j] : ~0ull;
-            rank[c] = 0;
-        }
-        for (int t = 0; t < nkeys; t++) {
-            const unsigned long long kt = keys[t];
-#pragma unroll
-            for (int c = 0; c < KNN_CAP / 64; c++) rank[c] += kt < mine[c] ? 1 : 0;
-        }
-#pragma unroll
-        for (int c = 0; c < KNN_CAP / 64; c++)
-            if (c * 64 + lane < nkeys && rank[c] < K) {
-                idx_out[i * K + rank[c]] = (int64_t)(unsigned)(mine[c] & 0xffffffffull);
-                dist_out[i * K + rank[c]] = sqrtf(__uint_as_float((unsigned)(mine[c] >> 32)));
+        auto put = [&](unsigned long long key, int rank) {
+            if (rank < K) {
+                idx_out[i * K + rank] = (int64_t)(unsigned)(key & 0xffffffffull);
+                dist_out[i * K + rank] = sqrtf(__uint_as_float((unsigned)(key >> 32)));
             }
+        };
+        if (nkeys <= 64) knn_rank<1>(keys, nkeys, lane, put); else knn_rank<KNN_CAP / 64>(keys, nkeys, lane, put);
         const int found = nkeys < K ? nkeys : K;
         if (lane >= found && lane < K) {
             idx_out[i * K + lane] = (int64_t)-1;

@@ -40,6 +40,30 @@ def test_knn_matches_oracle(backend, K):
     np.testing.assert_array_equal(d.cpu().numpy(), ref_d)  # NaN == NaN under assert_array_equal
 
 
+@pytest.mark.parametrize("cell", [0.0, 0.03], ids=["cell=r", "cell=3cm"])
+@pytest.mark.parametrize("K", [1, 16])
+def test_knn_dense_neighbourhoods(backend, K, cell):
+    """Hundreds of points inside the radius: the key list in LDS is cut back to its K smallest several times and later
+    candidates are dropped against the K-th key so far -- same rows as the oracle's exhaustive search, duplicates included.
+    With 3 cm cells the search box is ~20 cells wide: the 3 x 3 x 3 cells around the query go first, and the rest is skipped
+    when the K-th key is already closer than a cell edge (the clustered queries) or searched without the cube (the others)."""
+    rng = np.random.RandomState(7 + K)
+    dst = rng.uniform(0, 1, (1200, 3)).astype(np.float32)
+    dst[200:330] = dst[10]  # 131 copies of one point: more equal keys than K, cut in the middle of a tie
+    dst[400:420, 2] = dst[400, 2]
+    dst[600:700] = dst[600] + rng.uniform(-0.004, 0.004, (100, 3)).astype(np.float32)  # a tight cluster: early exit
+    src = np.concatenate([dst[:260], dst[590:620]])
+    bound = rng.uniform(0.2, 0.6, len(src)).astype(np.float32)
+    ref_idx, ref_d = so.knn(src, dst, K, 0.5)
+    far = ref_d > bound[:, None]  # graph.py:38-40: neighbours beyond the query's own bound are dropped afterwards
+    ref_idx[far], ref_d[far] = -1, np.nan
+    idx, d, _ = G.knn(torch.from_numpy(src).to(backend), torch.from_numpy(dst).to(backend), K=K, r=0.5,
+                      bound=torch.from_numpy(bound).to(backend), bound_mode=G.BOUND_LE, cell=cell)
+    assert (ref_idx[:, -1] >= 0).mean() > 0.9
+    np.testing.assert_array_equal(idx.cpu().numpy(), ref_idx)
+    np.testing.assert_array_equal(d.cpu().numpy(), ref_d)
+
+
 def test_outlier_and_graph_match_oracle(backend):
     pts, mv = _tree()
     medial = pts + mv
