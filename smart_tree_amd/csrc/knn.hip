@@ -29,6 +29,12 @@ __global__ void k_grid_init(StGrid* g) {
     if (blockIdx.x == 0 && threadIdx.x < ST_MAX_SEG) { g->seg_rmax_ord[threadIdx.x] = 0u; g->seg_r[threadIdx.x] = 0.0f; }
 }
 
+__device__ __forceinline__ unsigned grid_wave_min(unsigned v) { for (int d = 32; d > 0; d >>= 1) { const unsigned o = __shfl_xor(v, d); v = o < v ? o : v; } return v; }
+__device__ __forceinline__ unsigned grid_wave_max(unsigned v) { for (int d = 32; d > 0; d >>= 1) { const unsigned o = __shfl_xor(v, d); v = o > v ? o : v; } return v; }
+
+// Both reductions end in atomics on a handful of words of *g: a few hundred workgroups with a private running value per lane,
+// one shuffle reduction per wavefront and one global atomic per workgroup and word (thousands of workgroups, each with its
+// own atomics on the same six addresses, spent 90 us on a 17 MB array -- the atomics, not the loads).
 // blockIdx.y = cloud (gridDim.y = 1, seg_off == nullptr: the whole array is one cloud)
 __global__ void __launch_bounds__(KNN_BLOCK) k_bound_max(const float* bound, int64_t n, StGrid* g, const int* seg_off) {
     __shared__ unsigned m;
@@ -41,7 +47,8 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_bound_max(const float* bound, int
         const unsigned o = st_f2ord(bound[i]);
         if (o > mine) mine = o;
     }
-    if (mine > m) atomicMax(&m, mine);
+    mine = grid_wave_max(mine);
+    if ((threadIdx.x & 63) == 0 && mine) atomicMax(&m, mine);
     __syncthreads();
     if (threadIdx.x == 0 && m) { atomicMax(&g->rmax_ord, m); atomicMax(&g->seg_rmax_ord[seg], m); }
 }
@@ -50,14 +57,27 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_grid_bbox(const float* pts, int64
     __shared__ unsigned lo[3], hi[3];
     if (threadIdx.x < 3) { lo[threadIdx.x] = 0xffffffffu; hi[threadIdx.x] = 0u; }
     __syncthreads();
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        for (int a = 0; a < 3; a++) {
-            unsigned o = st_f2ord(pts[3 * i + a]);
-            if (o < lo[a]) atomicMin(&lo[a], o);
-            if (o > hi[a]) atomicMax(&hi[a], o);
-        }
+    unsigned l[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, h[3] = {0u, 0u, 0u};
+    // the flat array of 3n floats, one per lane and step (coalesced dwords): element e belongs to axis e % 3
+    const int64_t total = 3 * n, step = (int64_t)gridDim.x * blockDim.x;
+    const int64_t e0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int step3 = (int)(step % 3);
+    int a = (int)(e0 % 3);
+    for (int64_t e = e0; e < total; e += step, a = (a + step3) % 3) {
+        const unsigned o = st_f2ord(pts[e]);
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+            if (a == k) { l[k] = o < l[k] ? o : l[k]; h[k] = o > h[k] ? o : h[k]; }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++) { l[a] = grid_wave_min(l[a]); h[a] = grid_wave_max(h[a]); }
+    if ((threadIdx.x & 63) == 0)
+        for (int a = 0; a < 3; a++) { atomicMin(&lo[a], l[a]); atomicMax(&hi[a], h[a]); }
     __syncthreads();
-    if (threadIdx.x < 3) { atomicMin(&g->lo_ord[threadIdx.x], lo[threadIdx.x]); atomicMax(&g->hi_ord[threadIdx.x], hi[threadIdx.x]); }
+    if (threadIdx.x < 3 && lo[threadIdx.x] <= hi[threadIdx.x]) {
+        atomicMin(&g->lo_ord[threadIdx.x], lo[threadIdx.x]);
+        atomicMax(&g->hi_ord[threadIdx.x], hi[threadIdx.x]);
+    }
 }
 
 __global__ void k_grid_dims(StGrid* g, float cell, int64_t max_cells, float r, int nseg) {
@@ -137,14 +157,14 @@ int st_grid_build(const float* pts, int64_t n, float cell, int64_t max_cells, St
     unsigned gb = (unsigned)st_min64(st_div_up(n > 0 ? n : 1, KNN_BLOCK), 4096);
     hipLaunchKernelGGL(k_grid_init, dim3(1), dim3(64), 0, stream, g);
     static_assert(ST_MAX_SEG <= 64, "k_grid_init clears the per-cloud radii with one wavefront");
-    hipLaunchKernelGGL(k_grid_bbox, dim3(gb), dim3(KNN_BLOCK), 0, stream, pts, n, g);
+    hipLaunchKernelGGL(k_grid_bbox, dim3((unsigned)st_min64(st_div_up(3 * (n > 0 ? n : 1), (int64_t)KNN_BLOCK * 8), 512)), dim3(KNN_BLOCK), 0, stream, pts, n, g);
     // No read-back of the cell count (a blocking round trip costs ~1 ms beside other clouds' kernels):
     // the grid is limited to 128 cells per point -- a 2 cm kNN grid over a tree has ~65 -- and histogram, scan and cursor
     // copy run over that bound; cells past the real count stay empty.  A cloud that would need more gets a coarser grid
     // (k_grid_dims doubles the cell), which changes the speed of a search, never its result.
     const int64_t ncell = st_min64(max_cells, 128 * n + 65536);
     if (r < 0.0f && bound && n_bound > 0)
-        hipLaunchKernelGGL(k_bound_max, dim3((unsigned)st_min64(st_div_up(n_bound, (int64_t)KNN_BLOCK * nseg), 1024), (unsigned)nseg),
+        hipLaunchKernelGGL(k_bound_max, dim3((unsigned)st_min64(st_div_up(n_bound, (int64_t)KNN_BLOCK * nseg * 8), 512 / nseg + 1), (unsigned)nseg),
                            dim3(KNN_BLOCK), 0, stream, bound, n_bound, g, nseg > 1 ? (bound_seg_off ? bound_seg_off : seg_off) : (const int*)nullptr);
     hipLaunchKernelGGL(k_grid_dims, dim3(1), dim3(64), 0, stream, g, cell, ncell, r, nseg);
     if (getenv("ST_GRID_DEBUG")) {
@@ -189,6 +209,20 @@ __device__ __forceinline__ uint32_t knn_wave_scan(uint32_t v, int lane) {  // in
     return v;
 }
 
+// largest d2 >= 0 with sqrtf(d2) <= bound (strict: < bound); -1 if there is none (negative or NaN bound, or bound 0 and strict)
+__device__ __forceinline__ float knn_d2_max(float bound, bool strict) {
+    if (!(bound >= 0.0f)) return -1.0f;
+    if (bound == __uint_as_float(0x7f800000u)) return strict ? __uint_as_float(0x7f7fffffu) : bound;
+    auto pass = [&](float x) { const float s = sqrtf(x); return strict ? s < bound : s <= bound; };
+    unsigned b = __float_as_uint(bound * bound);  // non-negative floats order like their bit patterns
+    if (b > 0x7f7fffffu) b = 0x7f7fffffu;         // bound^2 overflowed: start from the largest finite float
+    while (!pass(__uint_as_float(b))) { if (b == 0u) return -1.0f; b--; }
+    while (b < 0x7f7fffffu && pass(__uint_as_float(b + 1u))) b++;
+    return __uint_as_float(b);
+}
+
+struct __attribute__((aligned(16))) KnnPair { unsigned long long x, y; };
+
 // rank of every key = number of smaller keys (keys are unique: the index is part of them); emit(key, rank) for the n keys.
 // NCH = 64-key chunks a lane holds (n <= 64 * NCH).  All 64 lanes call.
 template <int NCH, class F>
@@ -201,7 +235,14 @@ __device__ __forceinline__ void knn_rank(const unsigned long long* keys, int n, 
         mine[c] = j < n ? keys[j] : ~0ull;
         rank[c] = 0;
     }
-    for (int t = 0; t < n; t++) {
+    int t = 0;
+    for (; t + 4 <= n; t += 4) {  // four keys per step, two 16-byte broadcast reads in flight together
+        const KnnPair a = *reinterpret_cast<const KnnPair*>(keys + t), b = *reinterpret_cast<const KnnPair*>(keys + t + 2);
+#pragma unroll
+        for (int c = 0; c < NCH; c++)
+            rank[c] += (a.x < mine[c] ? 1 : 0) + (a.y < mine[c] ? 1 : 0) + (b.x < mine[c] ? 1 : 0) + (b.y < mine[c] ? 1 : 0);
+    }
+    for (; t < n; t++) {
         const unsigned long long kt = keys[t];  // same address in every lane: a broadcast
 #pragma unroll
         for (int c = 0; c < NCH; c++) rank[c] += kt < mine[c] ? 1 : 0;
@@ -232,26 +273,37 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn(const float* __restrict__ src
                                                    int64_t* __restrict__ idx_out, float* __restrict__ dist_out,
                                                    const int* __restrict__ seg_off, int nseg, int cell_order) {
     __shared__ uint32_t s_roff[KNN_WAVES][65], s_rfirst[KNN_WAVES][64];
-    __shared__ unsigned long long s_keys[KNN_WAVES][KNN_CAP];
+    __shared__ __attribute__((aligned(16))) unsigned long long s_keys[KNN_WAVES][KNN_CAP];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int64_t i = (int64_t)blockIdx.x * KNN_WAVES + wave;
     if (i >= n1) return;  // wave-uniform; the kernel has no workgroup barrier
     // cell_order (src IS dst): wavefront p takes the p-th record of the cell-sorted point list instead of point p, so
     // neighbouring wavefronts search the same cells (their rows stay in L1 / L2); rows are written by original index, the
     // result does not depend on which wavefront computed it
-    if (cell_order) i = (int64_t)__float_as_uint(recs[i].w);
+    // (the record carries the point's coordinates as well: one dependent load less before the cell rows can be requested)
+    float px, py, pz;
+    if (cell_order) {
+        const float4 me = recs[i];
+        px = me.x; py = me.y; pz = me.z;
+        i = (int64_t)__float_as_uint(me.w);
+    } else {
+        px = src[3 * i]; py = src[3 * i + 1]; pz = src[3 * i + 2];
+    }
     uint32_t* roff = s_roff[wave];
     uint32_t* rfirst = s_rfirst[wave];
     unsigned long long* keys = s_keys[wave];
-    const float px = src[3 * i], py = src[3 * i + 1], pz = src[3 * i + 2];
     const int seg = st_seg_find(seg_off, nseg, i);  // wave-uniform: one query per wavefront
     if (r < 0.0f) r = g->seg_r[seg];  // radius reduced on the device (st_knn_radius with r < 0): max(bound) over the query's cloud
     const float r2 = r * r;
     float reach_r = r;
-    float bnd = 0.0f;
+    // The per-query bound is defined on the rounded root -- sqrtf(d2) <= bound (mode 1) or < bound (mode 2), graph.py:38-40 /
+    // filter.py:9-10 -- and sqrtf is monotone, so it is the same as d2 <= d2_max with d2_max = the largest float whose root
+    // still passes: found once per query (a few steps around bound^2), and no candidate needs a root.
+    float d2_max = __uint_as_float(0x7f800000u);
     if (mode != 0) {
-        bnd = bound[i];
+        const float bnd = bound[i];
         if (bnd < reach_r) reach_r = bnd;
+        d2_max = knn_d2_max(bnd, mode == 2);
     }
     const float cell = g->cell;
     int reach = reach_r > 0.0f ? (int)ceilf(reach_r / cell) : 0;
@@ -290,6 +342,7 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn(const float* __restrict__ src
         }
         const uint32_t incl = knn_wave_scan(cnt, lane);
         const int total = (int)__shfl(incl, 63);
+        const int nr = st_min(nrows - rbase, 64);  // wave-uniform: a 3 x 3 neighbourhood is searched in four steps, not six
         __builtin_amdgcn_wave_barrier();  // the previous chunk's reads of roff / rfirst are done
         roff[lane] = incl - cnt;
         rfirst[lane] = first;
@@ -300,7 +353,7 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn(const float* __restrict__ src
             bool ok = false;
             unsigned long long key = 0ull;
             if (t < total) {
-                int lo = 0, hi = 64;  // row with roff[row] <= t < roff[row + 1]
+                int lo = 0, hi = nr;  // row with roff[row] <= t < roff[row + 1] (rows past the chunk's last one hold no candidates)
                 while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (roff[mid] <= (uint32_t)t) lo = mid; else hi = mid; }
                 const float4 q = recs[rfirst[lo] + ((uint32_t)t - roff[lo])];
                 const float dx = px - q.x, dy = py - q.y, dz = pz - q.z;
@@ -309,9 +362,7 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn(const float* __restrict__ src
                 d2 = d2 + tt;
                 tt = dz * dz;
                 d2 = d2 + tt;
-                ok = d2 < r2;
-                if (mode == 1) ok = ok && sqrtf(d2) <= bnd;
-                if (mode == 2) ok = ok && sqrtf(d2) < bnd;
+                ok = d2 < r2 && d2 <= d2_max;
                 key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned long long)__float_as_uint(q.w);  // d2 >= 0: bits order like values
                 if (!COUNT) ok = ok && key < thr;
             }

@@ -14,21 +14,31 @@ from smart_tree_amd.skeleton.filter import outlier_removal
 from smart_tree_amd.skeleton.graph import medial_points, nn_graph
 from smart_tree_amd.synthetic import sample_tree_cloud
 
+import os
+from smart_tree_amd.skeleton import graph as G
+from smart_tree_amd.skeleton import filter as F
+if os.environ.get("ST_CELL_DIV"): G.SEARCH_CELL_DIV = G.GRAPH_CELL_DIV = F.SEARCH_CELL_DIV = float(os.environ["ST_CELL_DIV"])
 dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 24
-pipe = bench.build_pipeline(dev)
+CACHE = Path(f"/tmp/bench_knn_{B}.pt")  # the captured input: experimental builds of the search need not survive the pipeline
 clouds = []
-for b in range(B):
+for b in range(0 if CACHE.exists() else B):
     c = sample_tree_cloud(1_000_000, seed=b)
     clouds.append(Cloud(xyz=torch.from_numpy(c["xyz"]).to(dev), rgb=torch.from_numpy(c["rgb"]).to(dev)))
-seen = {}
-orig = sk.Skeletonizer.forward
-def capture(self, cloud):
-    seen["cloud"] = cloud
-    return orig(self, cloud)
-sk.Skeletonizer.forward = capture
-pipe.process_clouds(clouds)
-cloud = seen["cloud"]
+if CACHE.exists():
+    d = torch.load(CACHE)
+    cloud = Cloud(xyz=d["xyz"].to(dev), medial_vector=d["mv"].to(dev))
+    cloud.seg_off = d["seg_off"].to(dev)
+else:
+    seen = {}
+    orig = sk.Skeletonizer.forward
+    def capture(self, cloud):
+        seen["cloud"] = cloud
+        return orig(self, cloud)
+    sk.Skeletonizer.forward = capture
+    bench.build_pipeline(dev).process_clouds(clouds)
+    cloud = seen["cloud"]
+    torch.save({"xyz": cloud.xyz.cpu(), "mv": cloud.medial_vector.cpu(), "seg_off": cloud.seg_off.cpu()}, CACHE)
 medial, radius = medial_points(cloud.xyz, cloud.medial_vector)
 
 def timeit(fn, reps=10):
