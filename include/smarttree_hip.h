@@ -197,6 +197,16 @@ int st_build_strided_rulebook_seg(const int32_t* coords, int64_t n, const unsign
                                   const unsigned* cvals, int64_t ccap, const int32_t* extent_host, int32_t* nbr_down,
                                   int32_t* nbr_up, int32_t* up_order, const int32_t* blk_seg, const int32_t* ext_dev,
                                   void* stream);
+/* Whole-cloud voxelisation of `nseg` clouds (the training / evaluation data path).
+ * replaces: TreeDataset.process_cloud's PointToVoxel call (smart_tree/dataset/dataset.py:103-131: range = the cloud's own
+ *           bounding box, one point per voxel) + batch_collate's batch column (model/sparse.py:40-61).
+ * coords [M,4] = (cloud, z, y, x); feats [M,6] = xyz, rgb of the representative point; point_index [M] = its position in the
+ * input (gather any other per-point feature with it); mask [M] = 1 (loss_mask); seg_vox_off [nseg+1] device, may be null for
+ * one cloud.  Voxels come out cloud by cloud in order of first appearance. */
+int64_t st_voxelize_cloud_workspace_bytes(int64_t n_points, int64_t max_voxels, int nseg);
+int st_voxelize_cloud_seg(const float* xyz, const float* rgb, int64_t n, const int32_t* seg_off, int nseg, double voxel_size,
+                          int64_t max_voxels, float* feats, int32_t* coords, uint8_t* mask, int64_t* point_index,
+                          int32_t* seg_vox_off, int64_t* n_voxels_host, void* ws, int64_t ws_bytes, void* stream);
 int64_t st_knn_workspace_bytes_seg(int64_t n_dst, int nseg);
 int st_knn_radius_seg(const float* src, int64_t n1, const float* dst, int64_t n2, int K, float r, const float* bound,
                       int bound_mode, float cell_hint, int64_t* idx, float* dist, const int32_t* src_seg_off,
@@ -233,6 +243,17 @@ int st_post_process_seg(int n_trees, const int32_t* tree_off, const int32_t* par
                         int32_t* depth_scratch, int do_prune, float min_radius, float min_length, int do_repair,
                         int do_smooth, int kernel_size, const int32_t* first_tree /*[n_first] first tree of every cloud*/,
                         int n_first, void* stream);
+
+/* ---- evaluation-side losses, forward only ----------------------------------
+ * replaces: compute_loss + L1Loss + cosine_similarity_loss + focal_loss + dice_loss (smart_tree/model/loss.py:7-97) as ONE
+ *           pass over the voxels.  radius [n], direction [n,3], class_l [n,C] are the network's outputs; targets [n,5] =
+ *           (radius, direction xyz, class id); mask [n] uint8 or NULL; vector_class < 0 = None.
+ * out_host[8] (the call waits for the stream): radius, direction, focal, dice loss; vector rows; class rows; 0; 0.
+ * An empty selection gives NaN (mean of an empty tensor).  A target class id outside [0, C) is an error (torch raises). */
+int64_t st_loss_workspace_bytes(void);
+int st_loss_forward(const float* radius, const float* direction, const float* class_l, int n_classes, const float* targets,
+                    int target_cols, const uint8_t* mask, int64_t n, int vector_class, int target_radius_log,
+                    double* out_host, void* ws, int64_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -70,6 +70,10 @@ SIGNATURES = {
     "st_voxelize_workspace_bytes_seg": (I64, [I64, c_int, I64, c_int]),
     "st_voxelize_blocks_seg": (c_int, [P, P, I64, P, c_int, c_double, c_double, c_double, c_int, c_int, I64, P, P, P, P, P, P, P, P,
                                        ctypes.POINTER(I64), ctypes.POINTER(I64), P, I64, P]),
+    "st_voxelize_cloud_workspace_bytes": (I64, [I64, I64, c_int]),
+    "st_voxelize_cloud_seg": (c_int, [P, P, I64, P, c_int, c_double, I64, P, P, P, P, P, ctypes.POINTER(I64), P, I64, P]),
+    "st_loss_workspace_bytes": (I64, []),
+    "st_loss_forward": (c_int, [P, P, P, c_int, P, c_int, P, I64, c_int, c_int, ctypes.POINTER(ctypes.c_double), P, I64, P]),
     "st_build_strided_outputs_seg": (c_int, [P, I64, I64, P, P, P, I64, ctypes.POINTER(I64), ctypes.POINTER(ctypes.c_int32),
                                              P, c_int, P, P, I64, P]),
     "st_build_strided_rulebook_seg": (c_int, [P, I64, P, P, I64, P, I64, P, P, I64, ctypes.POINTER(ctypes.c_int32), P, P, P, P, P, P]),
@@ -103,7 +107,7 @@ ENQUEUE_ONLY = frozenset({
     "st_connected_components", "st_component_csr", "st_post_process", "st_knn_radius",
     "st_centre_cloud_seg", "st_voxelize_workspace_bytes_seg", "st_build_strided_rulebook_seg", "st_knn_workspace_bytes_seg",
     "st_knn_radius_seg", "st_skeleton_workspace_bytes_seg", "st_post_process_seg", "st_radius_count_seg",
-    "st_spatial_order_workspace_bytes", "st_spatial_order", "st_connected_components_knn", "st_component_csr_knn", "st_move_rows",
+    "st_voxelize_cloud_workspace_bytes", "st_loss_workspace_bytes", "st_spatial_order_workspace_bytes", "st_spatial_order", "st_connected_components_knn", "st_component_csr_knn", "st_move_rows",
 })
 
 

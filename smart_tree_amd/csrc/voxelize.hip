@@ -46,9 +46,11 @@ struct VxParams {
     int min_points;
     int max_blocks;
     int nseg;
+    int whole;         // st_voxelize_cloud: no blocks -- every cloud is ONE block holding all of its points (TreeDataset.process_cloud)
 };
 
 __device__ __forceinline__ int vx_block_id(float v, const VxParams& p) {
+    if (p.whole) return 0;
     return (int)floorf(p.bs_inv != 0.0f ? v * p.bs_inv : v / p.bs);
 }
 
@@ -189,6 +191,10 @@ __global__ void __launch_bounds__(VX_BLOCK) k_vx_blocks(VxState* st, int* table,
 template <class F>
 __device__ __forceinline__ void vx_for_each_block(const float* pt, const VxState* st, const int* d, const int* table,
                                                   const VxParams& p, F fn) {
+    if (p.whole) {  // the cloud's only block
+        if (table[0] >= 0) fn(table[0]);
+        return;
+    }
     int q[3];
     unsigned ok[3];
     for (int a = 0; a < 3; a++) {
@@ -421,6 +427,7 @@ __global__ void __launch_bounds__(VX_BLOCK) k_vx_gather(const float* xyz, const 
             feats[6 * j + 3 + a] = rgb ? rgb[3 * i + a] : 0.0f;
             inner = inner && pt[a] >= ctr - p.half_inner && pt[a] < ctr + p.half_inner;
         }
+        if (p.whole) inner = true;  // dataset.py:131: loss_mask = ones
         coords[4 * j] = b;
         coords[4 * j + 1] = c[2];
         coords[4 * j + 2] = c[1];
@@ -457,7 +464,7 @@ static inline dim3 vx_grid_seg(int64_t n, int nseg, int64_t cap) {
 static int64_t vx_layout(StArena& a, int64_t n, int max_blocks, int64_t max_voxels, int nseg, VxState** st, int** table,
                          unsigned** blk_lo, unsigned** blk_hi, float** blk_lof, int** blk_grid, VxSlot** slots, uint32_t** cnt, uint32_t** win,
                          uint32_t** rec_b, uint32_t** rec_pt, uint32_t** order, char** sub, int64_t* sub_bytes,
-                         int64_t* cap) {
+                         int64_t* cap, float** spare_centres = nullptr, int32_t** spare_i32 = nullptr) {
     *cap = st_next_pow2((max_voxels > 8 ? max_voxels : 8) + (max_voxels > 8 ? max_voxels : 8) / 2);  // load <= 2/3 at max_voxels
     *st = a.take<VxState>(1);
     *table = a.take<int>(vx_table_cells(max_blocks, nseg) * nseg);
@@ -474,6 +481,10 @@ static int64_t vx_layout(StArena& a, int64_t n, int max_blocks, int64_t max_voxe
     int64_t s1 = st_scan_ws_bytes(n), s2 = st_sort_ws_bytes(max_voxels);
     *sub_bytes = s1 > s2 ? s1 : s2;
     *sub = a.take<char>(*sub_bytes);
+    float* sc = a.take<float>(3 * (int64_t)max_blocks);   // st_voxelize_cloud_seg: block centres and per-cloud block tables nobody asked for
+    int32_t* si = a.take<int32_t>(max_blocks + 2 * ((int64_t)nseg + 1));
+    if (spare_centres) *spare_centres = sc;
+    if (spare_i32) *spare_i32 = si;
     return a.used;
 }
 
@@ -492,18 +503,18 @@ extern "C" int64_t st_voxelize_workspace_bytes(int64_t n_points, int max_blocks,
 // voxels come out cloud by cloud; extra outputs (device, optional for nseg == 1): blk_seg [max_blocks] = cloud of every
 // block, seg_vox_off / seg_blk_off [nseg + 1] = first voxel / block of every cloud.  point_index holds positions in the
 // batched point array.  The part of cloud s equals what the one-cloud call returns for it (block ids shifted).
-extern "C" int st_voxelize_blocks_seg(const float* xyz, const float* rgb, int64_t n, const int32_t* seg_off, int nseg,
-                                      double voxel_size, double block_size, double buffer_size, int min_points, int max_blocks,
-                                      int64_t max_voxels, float* feats, int32_t* coords, uint8_t* mask, int64_t* point_index,
-                                      float* block_centres, int32_t* blk_seg, int32_t* seg_vox_off, int32_t* seg_blk_off,
-                                      int64_t* n_voxels_out, int64_t* n_blocks_out, void* ws, int64_t ws_bytes, void* stream_) {
+static int vx_voxelize(const float* xyz, const float* rgb, int64_t n, const int32_t* seg_off, int nseg, double voxel_size,
+                       double block_size, double buffer_size, int min_points, int max_blocks, int64_t max_voxels, float* feats,
+                       int32_t* coords, uint8_t* mask, int64_t* point_index, float* block_centres, int32_t* blk_seg,
+                       int32_t* seg_vox_off, int32_t* seg_blk_off, int64_t* n_voxels_out, int64_t* n_blocks_out, void* ws,
+                       int64_t ws_bytes, void* stream_, int whole) {
     hipStream_t stream = (hipStream_t)stream_;
     ST_REQUIRE(n >= 0 && n < (1ll << 31), "voxelize: n_points out of range");
     ST_REQUIRE(voxel_size > 0 && block_size > 0 && buffer_size >= 0 && buffer_size < block_size,
                "voxelize: need voxel_size > 0, 0 <= buffer_size < block_size");
     ST_REQUIRE(max_blocks > 0 && max_blocks < 65536 && max_voxels > 0, "voxelize: bad capacities");
     ST_REQUIRE(nseg >= 1 && nseg <= ST_MAX_SEG, "voxelize: 1 <= clouds per batch <= %d", ST_MAX_SEG);
-    ST_REQUIRE(nseg == 1 || (seg_off && blk_seg && seg_vox_off && seg_blk_off), "voxelize: a batch needs seg_off and the per-cloud outputs");
+    ST_REQUIRE(nseg == 1 || (seg_off && seg_vox_off && (whole || (blk_seg && seg_blk_off))), "voxelize: a batch needs seg_off and the per-cloud outputs");
     if (nseg == 1) seg_off = nullptr;
     *n_voxels_out = 0;
     *n_blocks_out = 0;
@@ -516,13 +527,18 @@ extern "C" int st_voxelize_blocks_seg(const float* xyz, const float* rgb, int64_
     StArena a(ws, ws_bytes);
     VxState* st; int* table; unsigned *blk_lo, *blk_hi; float* blk_lof; int* blk_grid; VxSlot* slots;
     uint32_t *cnt, *win, *rec_b, *rec_pt, *order; char* sub; int64_t sub_bytes, cap;
+    float* spare_centres = nullptr; int32_t* spare_i32 = nullptr;
     vx_layout(a, n, max_blocks, max_voxels, nseg, &st, &table, &blk_lo, &blk_hi, &blk_lof, &blk_grid, &slots, &cnt, &win, &rec_b,
-              &rec_pt, &order, &sub, &sub_bytes, &cap);
-    if (!a.ok() || !sub) {
+              &rec_pt, &order, &sub, &sub_bytes, &cap, &spare_centres, &spare_i32);
+    if (!a.ok() || !sub || !spare_centres || !spare_i32) {
         st_set_error("voxelize: workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)a.used);
         return ST_ERR_WORKSPACE;
     }
+    if (!block_centres) block_centres = spare_centres;
+    if (nseg > 1 && !blk_seg) blk_seg = spare_i32;
+    if (nseg > 1 && !seg_blk_off) seg_blk_off = spare_i32 + max_blocks;
     VxParams p;
+    p.whole = whole;
     p.bs = (float)block_size;
     {
         int e = 0;
@@ -589,6 +605,36 @@ extern "C" int st_voxelize_blocks_seg(const float* xyz, const float* rgb, int64_
     if (nseg > 1) hipLaunchKernelGGL(k_vx_seg_out, dim3(1), dim3(128), 0, stream, (const VxState*)st, nseg, seg_vox_off, seg_blk_off);
     ST_CHECK_LAUNCH();
     return ST_OK;
+}
+
+extern "C" int st_voxelize_blocks_seg(const float* xyz, const float* rgb, int64_t n, const int32_t* seg_off, int nseg,
+                                      double voxel_size, double block_size, double buffer_size, int min_points, int max_blocks,
+                                      int64_t max_voxels, float* feats, int32_t* coords, uint8_t* mask, int64_t* point_index,
+                                      float* block_centres, int32_t* blk_seg, int32_t* seg_vox_off, int32_t* seg_blk_off,
+                                      int64_t* n_voxels_out, int64_t* n_blocks_out, void* ws, int64_t ws_bytes, void* stream_) {
+    ST_REQUIRE(block_centres != nullptr, "voxelize: block_centres is an output of the blocked call");
+    ST_REQUIRE(nseg == 1 || (blk_seg && seg_blk_off), "voxelize: a batch needs the per-cloud block outputs");
+    return vx_voxelize(xyz, rgb, n, seg_off, nseg, voxel_size, block_size, buffer_size, min_points, max_blocks, max_voxels, feats,
+                       coords, mask, point_index, block_centres, blk_seg, seg_vox_off, seg_blk_off, n_voxels_out, n_blocks_out, ws,
+                       ws_bytes, stream_, 0);
+}
+
+// Whole-cloud voxelisation, the training / evaluation side's data path: replaces TreeDataset.process_cloud's PointToVoxel call
+// (smart_tree/dataset/dataset.py:103-131: range = the cloud's own bounding box, one point per voxel) and batch_collate's
+// batch column (model/sparse.py:40-61) for `nseg` clouds at once.  Same kernels as the blocked call with every cloud as
+// its own single block: coords[:, 0] = cloud, (z, y, x) = floorf((p - min) / v) inside roundf((max - min) / v) cells, first
+// point in input order represents a voxel, voxels in order of first appearance; mask = 1 (loss_mask, dataset.py:131).
+// seg_vox_off [nseg + 1] (device, may be null for one cloud) = first voxel of every cloud.
+extern "C" int64_t st_voxelize_cloud_workspace_bytes(int64_t n_points, int64_t max_voxels, int nseg) {
+    return st_voxelize_workspace_bytes_seg(n_points, nseg < 1 ? 1 : nseg, max_voxels, nseg);
+}
+extern "C" int st_voxelize_cloud_seg(const float* xyz, const float* rgb, int64_t n, const int32_t* seg_off, int nseg,
+                                     double voxel_size, int64_t max_voxels, float* feats, int32_t* coords, uint8_t* mask,
+                                     int64_t* point_index, int32_t* seg_vox_off, int64_t* n_voxels_out, void* ws, int64_t ws_bytes,
+                                     void* stream_) {
+    int64_t n_blocks = 0;
+    return vx_voxelize(xyz, rgb, n, seg_off, nseg, voxel_size, 1.0, 0.0, -1, nseg < 1 ? 1 : nseg, max_voxels, feats, coords, mask,
+                       point_index, nullptr, nullptr, seg_vox_off, nullptr, n_voxels_out, &n_blocks, ws, ws_bytes, stream_, 1);
 }
 
 extern "C" int st_voxelize_blocks(const float* xyz, const float* rgb, int64_t n, double voxel_size, double block_size,

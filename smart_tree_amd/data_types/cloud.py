@@ -111,6 +111,16 @@ class Cloud:
     def cat(self) -> torch.Tensor:
         return torch.cat((self.xyz, self.rgb), 1)
 
+    def voxel_down_sample(self, voxel_size) -> "Cloud":
+        """cloud.py:190-192 with util/misc.py:61-79: one point per occupied voxel of the lattice floor(xyz / voxel_size), voxels in
+        lexicographic order, the first point (input order) of each -- except that the reference's index arithmetic skips the
+        first voxel (`ind_sorted[cum_sum[1:]]`); kept."""
+        q = torch.div(self.xyz, voxel_size, rounding_mode="floor")
+        _, inverse, counts = torch.unique(q, dim=0, sorted=True, return_inverse=True, return_counts=True)
+        _, by_voxel = torch.sort(inverse, stable=True)
+        starts = counts.cumsum(0)[:-1]
+        return self.filter(by_voxel[starts])
+
     # -- geometry (these drop every field but xyz/rgb, as the reference does: cloud.py:194-202)
     def scale(self, factor) -> "Cloud":
         return Cloud(self.xyz * factor, self.rgb)

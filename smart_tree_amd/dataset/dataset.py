@@ -95,6 +95,101 @@ def _voxelize_blocks(xyz, rgb, n, nseg, seg_off, voxel_size, block_size, buffer_
                       blk_seg[:b] if blk_seg is not None else None, seg_vox, seg_blk, nseg)
 
 
+def voxelize_cloud(xyz: torch.Tensor, rgb: Optional[torch.Tensor], voxel_size: float,
+                   seg_off: Optional[torch.Tensor] = None) -> VoxelBatch:
+    """Whole-cloud voxelisation (st_voxelize_cloud_seg): every cloud is one block spanning its own bounding box, one
+    representative point per voxel -- TreeDataset.process_cloud's PointToVoxel call (dataset.py:103-131) and, for a batch
+    (seg_off), batch_collate's batch column (model/sparse.py:40-61).  `point_index` gathers any other per-point feature."""
+    L = _lib.lib()
+    dev = xyz.device
+    xyz = xyz.contiguous().float()
+    rgb = rgb.contiguous().float() if rgb is not None else None
+    n = xyz.shape[0]
+    nseg = 1 if seg_off is None else int(seg_off.shape[0]) - 1
+    cap = n + 8  # a voxel needs a point
+    feats = torch.empty((cap, 6), dtype=torch.float32, device=dev)
+    coords = torch.empty((cap, 4), dtype=torch.int32, device=dev)
+    mask = torch.empty((cap,), dtype=torch.uint8, device=dev)
+    pidx = torch.empty((cap,), dtype=torch.int64, device=dev)
+    seg_vox = torch.empty((nseg + 1,), dtype=torch.int32, device=dev) if nseg > 1 else None
+    n_vox = ctypes.c_int64(0)
+    ws = _lib.workspace(L.st_voxelize_cloud_workspace_bytes(n, cap, nseg), dev)
+    _lib.check(L.st_voxelize_cloud_seg(_lib.ptr(xyz), _lib.ptr(rgb), n, _lib.ptr(seg_off), nseg, float(voxel_size), cap,
+                                       _lib.ptr(feats), _lib.ptr(coords), _lib.ptr(mask), _lib.ptr(pidx), _lib.ptr(seg_vox),
+                                       ctypes.byref(n_vox), _lib.ptr(ws), ws.numel(), _lib.stream(dev)))
+    m = n_vox.value
+    return VoxelBatch(feats[:m], coords[:m], mask[:m].bool(), pidx[:m], torch.zeros((nseg, 3), dtype=torch.float32, device=dev),
+                      None, seg_vox, None, nseg)
+
+
+def at_least_2d(t: torch.Tensor) -> torch.Tensor:
+    """util/misc.py:13-21."""
+    return t.unsqueeze(1) if t.dim() == 1 else t
+
+
+class TreeDataset:
+    """Training / evaluation-side dataset (reference dataset.py:18-141): labelled clouds listed in a json split file, one
+    augmentation pipeline, whole-cloud voxelisation with one representative point per voxel whose input AND target features
+    are carried along.  Same constructor and item layout as the reference: `((input_feats, target_feats), coords, loss_mask,
+    filename)` with coords [M,4] = (0, z, y, x); `model.sparse.batch_collate` writes the sample index into column 0.
+    The voxeliser is st_voxelize_cloud_seg (csrc/voxelize.hip) instead of spconv's PointToVoxel; the feature columns are one
+    gather by the representative point's index."""
+
+    def __init__(self, voxel_size, json_path, directory, mode: str, input_features, target_features, augmentation=None,
+                 cache: bool = False, device=None):
+        import json
+        from pathlib import Path
+
+        self.voxel_size = voxel_size
+        self.mode = mode
+        self.augmentation = augmentation
+        self.directory = directory
+        self.device = device if device is not None else torch.device("cuda:0")
+        self.input_features = list(input_features)
+        self.target_features = list(target_features)
+        if not Path(json_path).is_file():
+            raise AssertionError(f"json metadata does not exist at '{json_path}'")
+        if mode not in ("train", "validation", "test"):
+            raise ValueError(f"TreeDataset: mode must be train / validation / test, got {mode!r}")
+        with open(json_path) as f:
+            self.tree_paths = json.load(f)[mode]
+        missing = [p for p in self.tree_paths if not Path(f"{self.directory}/{p}").is_file()]
+        if missing:
+            raise AssertionError(f"Missing {len(missing)} files: {missing}")
+        self.cache = {} if cache else None
+
+    def load(self, filename) -> Cloud:
+        from ..util.file import load_cloud
+
+        if self.cache is None:
+            return load_cloud(filename)
+        if filename not in self.cache:
+            cld = load_cloud(filename)
+            self.cache[filename] = cld.pin_memory() if torch.cuda.is_available() else cld
+        return self.cache[filename]
+
+    def __getitem__(self, idx):
+        from pathlib import Path
+
+        return self.process_cloud(self.load(Path(f"{self.directory}/{self.tree_paths[idx]}")), self.tree_paths[idx])
+
+    def process_cloud(self, cld: Cloud, filename):
+        cld = cld.to_device(self.device)
+        if self.augmentation is not None:
+            cld = self.augmentation(cld)
+        inputs = torch.cat([at_least_2d(getattr(cld, a)) for a in self.input_features], dim=1)
+        targets = torch.cat([at_least_2d(getattr(cld, a)) for a in self.target_features], dim=1)
+        if inputs.shape[0] == 0:
+            raise AssertionError(f"Empty cloud after augmentation: {filename}")
+        vb = voxelize_cloud(cld.xyz, None, self.voxel_size)
+        rep = vb.point_index
+        loss_mask = torch.ones(rep.shape[0], dtype=torch.bool, device=rep.device)
+        return (inputs.index_select(0, rep), targets.float().index_select(0, rep)), vb.coords, loss_mask, filename
+
+    def __len__(self) -> int:
+        return len(self.tree_paths)
+
+
 class SingleTreeInference:
     """Same constructor surface as the reference class (dataset.py:145-164)."""
 

@@ -47,11 +47,16 @@ def sparse_from_batch(features: torch.Tensor, coordinates: torch.Tensor, device,
 
 
 def batch_collate(batch):
-    """Reference sparse.py:40-61 (inference form): write the sample index into coords[:,0], concatenate."""
+    """Reference sparse.py:40-61: write the sample index into coords[:,0], concatenate.  Items whose features are an
+    (input, target) pair -- TreeDataset -- come back as ((inputs, targets), coords, mask, names), the inference form as
+    (feats, coords, mask, names)."""
     feats, coords, masks, names = zip(*batch)
     coords = [c.clone() for c in coords]
     for i, c in enumerate(coords):
         c[:, 0] = i
+    if isinstance(feats[0], tuple):
+        inputs, targets = zip(*feats)
+        return [(torch.cat(inputs), torch.cat(targets)), torch.cat(coords), torch.cat(masks), names]
     return [torch.cat(feats), torch.cat(coords), torch.cat(masks), names]
 
 

@@ -103,7 +103,7 @@ def install_stubs():
     from oracle import voxel_oracle as vo
 
     class PointToVoxel:
-        def __init__(self, vsize_xyz, coors_range_xyz, num_point_features, max_num_voxels, max_num_points_per_voxel):
+        def __init__(self, vsize_xyz, coors_range_xyz, num_point_features, max_num_voxels, max_num_points_per_voxel, device=None):
             assert max_num_points_per_voxel == 1 and len(set(float(v) for v in vsize_xyz)) == 1
             self.v, self.range = float(vsize_xyz[0]), [float(c) for c in coors_range_xyz]
 
@@ -272,6 +272,64 @@ def tube_mesh_case():
     print("tube_mesh", verts.shape, tris.shape)
 
 
+def loss_case():
+    """The reference's own compute_loss / L1Loss / cosine_similarity_loss / focal_loss / dice_loss (model/loss.py, pure torch) on
+    seeded inputs: no mask, a loss mask, a loss mask + vector class, raw (non-log) radius targets."""
+    r_loss = reference("smart_tree.model.loss")
+    g = torch.Generator().manual_seed(7)
+    n = 4000
+    preds = {"radius": torch.randn(n, 1, generator=g) - 3.0, "direction": torch.nn.functional.normalize(torch.randn(n, 3, generator=g)),
+             "class_l": torch.randn(n, 2, generator=g) * 2.0}
+    preds["direction"][:5] = 0.0  # zero vectors: the eps clamp of CosineSimilarity
+    t_dir = torch.nn.functional.normalize(torch.randn(n, 3, generator=g))
+    t_dir[3:8] = 0.0
+    targets = torch.cat([torch.rand(n, 1, generator=g) * 0.2 + 0.005, t_dir, (torch.rand(n, 1, generator=g) < 0.3).float()], 1)
+    mask = torch.rand(n, generator=g) < 0.8
+    out = {"radius": preds["radius"].numpy(), "direction": preds["direction"].numpy(), "class_l": preds["class_l"].numpy(),
+           "targets": targets.numpy(), "mask": mask.numpy()}
+    fns = dict(radius_loss_fn=r_loss.L1Loss, direction_loss_fn=r_loss.cosine_similarity_loss)
+    cases = {"plain": dict(mask=None, vector_class=None, target_radius_log=True),
+             "masked": dict(mask=mask, vector_class=None, target_radius_log=True),
+             "masked_vector0": dict(mask=mask, vector_class=0, target_radius_log=True),
+             "vector1_rawradius": dict(mask=None, vector_class=1, target_radius_log=False)}
+    for name, kw in cases.items():
+        for cls_name, cls in (("focal", r_loss.focal_loss), ("dice", r_loss.dice_loss)):
+            if cls_name == "dice":  # dice_loss one-hots targets of shape [n] (a [n,1] target makes [n,1,C]: same numbers after .view(-1))
+                res = r_loss.compute_loss(preds, targets, class_loss_fn=lambda o, t: cls(o, t.view(-1)), **fns, **kw)
+            else:
+                res = r_loss.compute_loss(preds, targets, class_loss_fn=cls, **fns, **kw)
+            out[f"{name}_{cls_name}"] = np.array([float(res["radius"]), float(res["direction"]), float(res["class_l"])], np.float64)
+    np.savez_compressed(OUT / "loss_vectors.npz", **out)
+    print("loss_vectors", {k: v.tolist() for k, v in out.items() if k.endswith(("focal", "dice"))})
+
+
+def tree_dataset_case():
+    """The reference's TreeDataset.process_cloud (dataset.py:82-138) on a labelled cloud, no augmentation, with spconv's
+    PointToVoxel served by the stand-in (canonical semantics of oracle/voxel_oracle.voxelize_block), then batch_collate of two
+    items."""
+    from smart_tree_amd.synthetic import sample_tree_cloud
+
+    r_cloud = reference("smart_tree.data_types.cloud")
+    r_ds = reference("smart_tree.dataset.dataset")
+    r_sparse = reference("smart_tree.model.sparse")
+    sys.modules["py_structs.torch"].map_tensors = lambda t, f: f(t)
+    ds = r_ds.TreeDataset.__new__(r_ds.TreeDataset)
+    ds.voxel_size, ds.augmentation, ds.device = 0.03, None, torch.device("cpu")
+    ds.input_features, ds.target_features = ["xyz"], ["radius", "direction", "class_l"]
+    items, out = [], {}
+    for k, seed in enumerate((2, 5)):
+        c = sample_tree_cloud(30_000, seed=seed, scale=0.7, max_depth=4, foliage_fraction=0.3)
+        cloud = r_cloud.Cloud(xyz=torch.from_numpy(c["xyz"]), rgb=torch.from_numpy(c["rgb"]),
+                              medial_vector=torch.from_numpy(c["medial_vector"]), class_l=torch.from_numpy(c["class_l"]).float().view(-1, 1))
+        item = ds.process_cloud(cloud, f"tree_{k}.npz")
+        items.append(item)
+        out[f"seed_{k}"] = np.int64(seed)
+    (inputs, targets), coords, mask, names = r_sparse.batch_collate(items)
+    out.update(inputs=inputs.numpy(), targets=targets.numpy(), coords=coords.numpy().astype(np.int32), mask=mask.numpy())
+    np.savez_compressed(OUT / "tree_dataset.npz", **out)
+    print("tree_dataset", inputs.shape, targets.shape, coords.shape)
+
+
 def y_tree(seed=0):
     """A small trunk + two limbs with exact medial vectors and a little noise."""
     rng = np.random.RandomState(seed)
@@ -308,6 +366,8 @@ def main():
     nearest_tube_case()
     skeleton_file_case()
     tube_mesh_case()
+    loss_case()
+    tree_dataset_case()
 
 
 if __name__ == "__main__":
