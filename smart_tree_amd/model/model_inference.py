@@ -15,7 +15,7 @@ import torch
 
 from .. import profiling
 from ..data_types.cloud import Cloud, MaskedCloud
-from ..dataset.dataset import SingleTreeInference
+from ..dataset.dataset import SingleTreeInference, voxelize_cloud
 from .model import Smart_Tree
 from .sparse import sparse_from_batch
 
@@ -45,7 +45,17 @@ def load_model(model_path, weights_path, device=torch.device("cuda:0"), fp16: bo
 
 class ModelInference:
     def __init__(self, model_path, weights_path, voxel_size: float, block_size: float, buffer_size: float,
-                 num_workers=8, batch_size=4, device=torch.device("cuda:0"), verbose=False, fp16: bool = False):
+                 num_workers=8, batch_size=4, device=torch.device("cuda:0"), verbose=False, fp16: bool = False,
+                 blocking: str = "blocks"):
+        """blocking (additive keyword): "blocks" = the reference's scheme (4 m cubes + halo, every block on its
+        own voxel grid, halo voxels evaluated and thrown away: ~1.5x the voxels); "whole" = OPT-IN approximate mode: the cloud
+        is voxelised once on one grid anchored at its own bounding box (st_voxelize_cloud_seg) and the network sees every
+        voxel exactly once with its true neighbourhood.  NOT result-preserving: the reference's grids are anchored per block
+        (dataset.py:196-212) and its halo (0.4 m) is shorter than the network's receptive field, so the per-block outputs
+        are themselves an approximation of this mode's (tests/test_whole_cloud_mode.py quantifies the difference)."""
+        if blocking not in ("blocks", "whole"):
+            raise ValueError(f"ModelInference: blocking must be 'blocks' or 'whole', got {blocking!r}")
+        self.blocking = blocking
         self.device = torch.device(device)
         self.verbose = verbose
         self.voxel_size = voxel_size
@@ -62,8 +72,13 @@ class ModelInference:
         if cloud.rgb is None:
             cloud = Cloud(cloud.xyz, torch.zeros_like(cloud.xyz), seg_off=cloud.seg_off)
         with profiling.stage("voxelize"):
-            ds = SingleTreeInference(cloud, self.voxel_size, self.block_size, self.buffer_size)
-        vb = ds.batch  # every block of the cloud -- of every cloud of a batch (Cloud.collate) -- in ONE collated batch
+            if self.blocking == "whole":  # SURVEY 8f.2, opt-in: one grid per cloud, no halo duplicates, every voxel is "inner"
+                vb = voxelize_cloud(cloud.xyz, cloud.rgb, self.voxel_size, seg_off=cloud.seg_off)
+                if vb.n_seg > 1:  # batch index = cloud: per-cloud spatial extents in the strided rulebooks
+                    vb.blk_seg = torch.arange(vb.n_seg, dtype=torch.int32, device=self.device)
+            else:
+                vb = SingleTreeInference(cloud, self.voxel_size, self.block_size, self.buffer_size).batch
+        # every block of the cloud -- of every cloud of a batch (Cloud.collate) -- in ONE collated batch
         sparse_input = sparse_from_batch(vb.feats[:, :3].contiguous(), vb.coords, device=self.device, blk_seg=vb.blk_seg,
                                          n_seg=vb.n_seg)
         # radius / direction / class_l come out exactly as model.forward(sparse_input) gives them;
@@ -80,4 +95,4 @@ class ModelInference:
     def from_cfg(cfg):
         return ModelInference(model_path=cfg.model_path, weights_path=cfg.weights_path, voxel_size=cfg.voxel_size,
                               block_size=cfg.block_size, buffer_size=cfg.buffer_size, num_workers=cfg.num_workers,
-                              batch_size=cfg.batch_size)
+                              batch_size=cfg.batch_size, blocking=getattr(cfg, "blocking", "blocks"))
