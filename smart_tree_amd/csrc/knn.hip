@@ -19,11 +19,14 @@
 
 #define KNN_BLOCK 256
 
+float g_knn_mean_mult = 0.45f;  // (0.45 x the mean radius = the max / 12 cell of a 1M-point tree at 2 cm: that tuning, without the outliers)
+
 // ------------------------------------------------------------------------------- grid build ---
 __global__ void k_grid_init(StGrid* g) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         for (int a = 0; a < 3; a++) { g->lo_ord[a] = 0xffffffffu; g->hi_ord[a] = 0u; }
         g->rmax_ord = 0u;
+        g->bound_sum_fix = 0ull;
         g->r = 0.0f;
     }
     if (blockIdx.x == 0 && threadIdx.x < ST_MAX_SEG) { g->seg_rmax_ord[threadIdx.x] = 0u; g->seg_r[threadIdx.x] = 0.0f; }
@@ -38,19 +41,27 @@ __device__ __forceinline__ unsigned grid_wave_max(unsigned v) { for (int d = 32;
 // blockIdx.y = cloud (gridDim.y = 1, seg_off == nullptr: the whole array is one cloud)
 __global__ void __launch_bounds__(KNN_BLOCK) k_bound_max(const float* bound, int64_t n, StGrid* g, const int* seg_off) {
     __shared__ unsigned m;
-    if (threadIdx.x == 0) m = 0u;
+    __shared__ unsigned long long sum;
+    if (threadIdx.x == 0) { m = 0u; sum = 0ull; }
     __syncthreads();
     const int seg = blockIdx.y;
     const int64_t i0 = seg_off ? seg_off[seg] : 0, i1 = seg_off ? seg_off[seg + 1] : n;
     unsigned mine = 0u;
+    unsigned long long fix = 0ull;  // sum of the bounds in 2^-16 units (a bound is a radius: metres; clamped so 2^40 of them fit)
     for (int64_t i = i0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < i1; i += (int64_t)gridDim.x * blockDim.x) {
-        const unsigned o = st_f2ord(bound[i]);
+        const float b = bound[i];
+        const unsigned o = st_f2ord(b);
         if (o > mine) mine = o;
+        fix += (unsigned long long)(fminf(fmaxf(b, 0.0f), 128.0f) * 65536.0f);  // (NaN -> 0)
     }
     mine = grid_wave_max(mine);
-    if ((threadIdx.x & 63) == 0 && mine) atomicMax(&m, mine);
+    for (int d = 32; d > 0; d >>= 1) fix += __shfl_xor(fix, d);
+    if ((threadIdx.x & 63) == 0) { if (mine) atomicMax(&m, mine); atomicAdd(&sum, fix); }
     __syncthreads();
-    if (threadIdx.x == 0 && m) { atomicMax(&g->rmax_ord, m); atomicMax(&g->seg_rmax_ord[seg], m); }
+    if (threadIdx.x == 0) {
+        if (m) { atomicMax(&g->rmax_ord, m); atomicMax(&g->seg_rmax_ord[seg], m); }
+        if (sum) atomicAdd(&g->bound_sum_fix, sum);
+    }
 }
 
 __global__ void __launch_bounds__(KNN_BLOCK) k_grid_bbox(const float* pts, int64_t n, StGrid* g) {
@@ -80,14 +91,21 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_grid_bbox(const float* pts, int64
     }
 }
 
-__global__ void k_grid_dims(StGrid* g, float cell, int64_t max_cells, float r, int nseg) {
+__global__ void k_grid_dims(StGrid* g, float cell, int64_t max_cells, float r, int nseg, float mean_mult, int64_t n_bound) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     float lo[3], hi[3];
     for (int a = 0; a < 3; a++) { lo[a] = st_ord2f(g->lo_ord[a]); hi[a] = st_ord2f(g->hi_ord[a]); g->lo[a] = lo[a]; }
     for (int s = 0; s < nseg; s++) g->seg_r[s] = r < 0.0f ? st_ord2f(g->seg_rmax_ord[s]) : r;
     if (r < 0.0f) r = st_ord2f(g->rmax_ord);  // the largest per-query bound, reduced by k_bound_max
     g->r = r;
-    if (cell < 0.0f) cell = fmaxf(r / -cell, 1e-4f);
+    if (cell < 0.0f) {
+        cell = r / -cell;
+        if (mean_mult > 0.0f && n_bound > 0) {  // ... but no coarser than mean_mult x the mean bound
+            const float mean = (float)((double)g->bound_sum_fix / 65536.0 / (double)n_bound);
+            if (mean > 0.0f) cell = fminf(cell, mean_mult * mean);
+        }
+        cell = fmaxf(cell, 1e-4f);
+    }
     if (!(cell > 0.0f)) cell = 1.0f;
     g->nseg = nseg;
     for (;;) {
@@ -141,7 +159,7 @@ int64_t st_grid_ws_bytes(int64_t n, int64_t max_cells) {
 // Builds grid over pts[n]; g (device struct), cell_start[max_cells+1], recs[n] are caller arrays.
 int st_grid_build(const float* pts, int64_t n, float cell, int64_t max_cells, StGrid* g, uint32_t* cell_start, float4* recs,
                   void* ws, int64_t ws_bytes, hipStream_t stream, float r, const float* bound, int64_t n_bound,
-                  const int* seg_off, int nseg, const int* bound_seg_off) {
+                  const int* seg_off, int nseg, const int* bound_seg_off, float mean_mult) {
     if (nseg < 1 || nseg > ST_MAX_SEG) { st_set_error("grid: 1 <= clouds per batch <= %d (got %d)", ST_MAX_SEG, nseg); return ST_ERR_INVALID; }
     if (!seg_off) nseg = 1;
     StArena a(ws, ws_bytes);
@@ -166,7 +184,8 @@ int st_grid_build(const float* pts, int64_t n, float cell, int64_t max_cells, St
     if (r < 0.0f && bound && n_bound > 0)
         hipLaunchKernelGGL(k_bound_max, dim3((unsigned)st_min64(st_div_up(n_bound, (int64_t)KNN_BLOCK * nseg * 8), 512 / nseg + 1), (unsigned)nseg),
                            dim3(KNN_BLOCK), 0, stream, bound, n_bound, g, nseg > 1 ? (bound_seg_off ? bound_seg_off : seg_off) : (const int*)nullptr);
-    hipLaunchKernelGGL(k_grid_dims, dim3(1), dim3(64), 0, stream, g, cell, ncell, r, nseg);
+    hipLaunchKernelGGL(k_grid_dims, dim3(1), dim3(64), 0, stream, g, cell, ncell, r, nseg, mean_mult,
+                       (r < 0.0f && bound) ? n_bound : (int64_t)0);
     if (getenv("ST_GRID_DEBUG")) {
         StGrid h;
         (void)hipMemcpyAsync(&h, g, sizeof(StGrid), hipMemcpyDeviceToHost, stream);
@@ -449,7 +468,7 @@ extern "C" int st_knn_radius_seg(const float* src, int64_t n1, const float* dst,
     }
     const float cell_arg = cell_hint != 0.0f ? cell_hint : (r >= 0.0f ? r : -1.0f);
     ST_TRY(st_grid_build(dst, n2, cell_arg, knn_max_cells(nseg), g, cell_start, recs, sub, sub_bytes, stream, r, bound, n1,
-                         dst_seg_off, nseg, src_seg_off));
+                         dst_seg_off, nseg, src_seg_off, cell_hint < 0.0f ? g_knn_mean_mult : 0.0f));
     dim3 grid((unsigned)st_div_up(n1, KNN_WAVES)), block(KNN_BLOCK);
     const int cell_order = src == dst && n1 == n2 ? 1 : 0;
     if (K == 1)
@@ -490,7 +509,7 @@ extern "C" int st_radius_count_seg(const float* src, int64_t n1, const float* ds
     }
     const float cell_arg = cell_hint != 0.0f ? cell_hint : (r >= 0.0f ? r : -1.0f);
     ST_TRY(st_grid_build(dst, n2, cell_arg, knn_max_cells(nseg), g, cell_start, recs, sub, sub_bytes, stream, r, bound, n1,
-                         dst_seg_off, nseg, src_seg_off));
+                         dst_seg_off, nseg, src_seg_off, cell_hint < 0.0f ? g_knn_mean_mult : 0.0f));
     hipLaunchKernelGGL((k_knn<8, true>), dim3((unsigned)st_div_up(n1, KNN_WAVES)), dim3(KNN_BLOCK), 0, stream, src, n1,
                        (const StGrid*)g, (const uint32_t*)cell_start, (const float4*)recs, r, bound, bound_mode,
                        reinterpret_cast<int64_t*>(mask), (float*)nullptr, src_seg_off, nseg, src == dst && n1 == n2 ? 1 : 0);

@@ -1180,15 +1180,18 @@ static void sk_layout(StArena& a, int64_t m, int64_t C, SkLayout* s, int nseg = 
 
 static long long* g_debug_ticks = nullptr;
 static float g_prune_factor = 1.0f;
-static int g_sssp_hops = 4, g_sssp_batch = 32, g_sssp_lanes = 64, g_sssp_first = 2;
+static float g_grid_mean_mult = 1.0f;  // claim-grid cell <= this x the mean radius (0: max radius / GRID_DIV alone)
+static int g_sssp_hops = 4, g_sssp_batch = 32, g_sssp_lanes = 64, g_sssp_first = 2, g_sssp_blocks = SK_SSSP_BLOCKS;
 #define SK_MAX_LAUNCH_BATCH 32
 static int g_small_work = SK_SMALL_WORK, g_iters_per_launch = SK_ITERS_PER_LAUNCH, g_launch_batch = 24, g_local_items = 0, g_wave_work = SK_WAVE_WORK;
 // developer aid / test hook (forces every claim strategy): 0 prune factor (x1000), 1 small_work, 2 rounds per launch,
-// 3 launches per host read-back, 4 local_items, 5 wave_work, 6 SSSP levels per launch, 7 SSSP launches per read-back, 9 length of the first SSSP batch (in batches); a negative `which` restores the defaults
+// 3 launches per host read-back, 4 local_items, 5 wave_work, 6 SSSP levels per launch, 7 SSSP launches per read-back, 9 length of the first SSSP batch (in batches), 10 SSSP workgroups,
+// 11 / 12 claim-grid / search-grid cell cap in hundredths of the mean radius; a negative `which` restores the defaults
 extern "C" void st_debug_set_skeleton_param(int which, int value) {
     if (which < 0) {
         g_prune_factor = 1.0f; g_small_work = SK_SMALL_WORK; g_iters_per_launch = SK_ITERS_PER_LAUNCH; g_launch_batch = 24;
         g_local_items = 0; g_wave_work = SK_WAVE_WORK; g_sssp_hops = 4; g_sssp_batch = 32; g_sssp_lanes = 64; g_sssp_first = 2;
+        g_sssp_blocks = SK_SSSP_BLOCKS; g_grid_mean_mult = 1.0f; g_knn_mean_mult = 0.45f;
     }
     if (which == 0) g_prune_factor = value / 1000.0f;
     if (which == 1) g_small_work = value;
@@ -1200,6 +1203,9 @@ extern "C" void st_debug_set_skeleton_param(int which, int value) {
     if (which == 8) g_sssp_lanes = value == 64 ? 64 : (value == 32 ? 32 : 16);
     if (which == 7) g_sssp_batch = value < 1 ? 1 : (value > 64 ? 64 : value);
     if (which == 9) g_sssp_first = value < 1 ? 1 : (value > 8 ? 8 : value);
+    if (which == 11) g_grid_mean_mult = value / 100.0f;
+    if (which == 12) g_knn_mean_mult = value / 100.0f;
+    if (which == 10) g_sssp_blocks = value < 1 ? 1 : (value > 8192 ? 8192 : value);  // workgroups of the SSSP frontier launches
 }
 extern "C" void st_debug_set_ticks(long long* device_ptr) { g_debug_ticks = device_ptr; }
 
@@ -1289,7 +1295,7 @@ extern "C" int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, c
     }
 
     const unsigned vg = sk_vgrid(m);
-    const unsigned fg = (unsigned)st_min64(st_div_up(m, SK_WIDE_BLOCK), SK_SSSP_BLOCKS);
+    const unsigned fg = (unsigned)st_min64(st_div_up(m, SK_WIDE_BLOCK), g_sssp_blocks);
     unsigned h[8];
     int64_t sssp_rounds = 0;
     const bool defer_plateaus = (stages & 1) && (stages & 4) && !(stages & 2);
@@ -1349,7 +1355,7 @@ extern "C" int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, c
         // grid_cell < 0: cell = max(rad) / -grid_cell with the maximum reduced on the device (no host round trip)
         ST_TRY(st_grid_build(pts, m, grid_cell, sk_grid_cells(nseg), s.g, s.cell_start, s.recs, s.gws, s.gws_bytes, stream,
                              grid_cell < 0.0f ? -1.0f : 0.0f, grid_cell < 0.0f ? rad : nullptr, grid_cell < 0.0f ? m : 0,
-                             vert_seg_off, nseg, vert_seg_off));
+                             vert_seg_off, nseg, vert_seg_off, g_grid_mean_mult));
         int64_t iters = 0;
         struct EventSet {  // destroyed on every way out of the select loop (early error returns included)
             hipEvent_t e[2 * SK_MAX_LAUNCH_BATCH];

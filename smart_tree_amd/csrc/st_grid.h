@@ -19,6 +19,7 @@ struct StGrid {
     int64_t ncell;
     unsigned rmax_ord;  // largest per-query bound (order-preserving bits), when the search radius is taken from the device
     float r;            // search radius the kNN kernels use (one cloud) / largest of seg_r (cell sizing)
+    unsigned long long bound_sum_fix;  // sum of the per-query bounds in 2^-16 units (integer: the same in every run)
     unsigned seg_rmax_ord[ST_MAX_SEG];
     float seg_r[ST_MAX_SEG];  // per-cloud search radius = max(bound) over THAT cloud, as the one-cloud call computes it
 };
@@ -44,10 +45,14 @@ __device__ __forceinline__ int64_t st_grid_cell(const StGrid* g, float x, float 
     return ((int64_t)(st_grid_axis(g, x, 0) + seg * g->seg_dim0) * g->dim[1] + st_grid_axis(g, y, 1)) * g->dim[2] + st_grid_axis(g, z, 2);
 }
 
+extern float g_knn_mean_mult;  // neighbour-search grids: cell <= this x the mean per-query bound (0: off); developer knob 12
 int64_t st_grid_ws_bytes(int64_t n, int64_t max_cells);
 // r < 0: the search radius is max(bound[0 .. n_bound)), reduced on the device (no host round trip); cell < 0: the
 // cell size is max(r / -cell, 1e-4).  seg_off / nseg: the clouds of a batched call (pts index space; bound_seg_off the
-// same for the bound array), nullptr / 1 = one cloud.
+// same for the bound array), nullptr / 1 = one cloud.  mean_mult > 0 (with cell < 0, r < 0): the cell is at most mean_mult x
+// the MEAN bound -- one far-too-large bound (a radius the network got wrong) would otherwise make every cell, and with it
+// every search, as coarse as that one needs.  The cell size changes the speed of a search, never its result.
 int st_grid_build(const float* pts, int64_t n, float cell, int64_t max_cells, StGrid* g, uint32_t* cell_start, float4* recs,
                   void* ws, int64_t ws_bytes, hipStream_t stream, float r = 0.0f, const float* bound = nullptr,
-                  int64_t n_bound = 0, const int* seg_off = nullptr, int nseg = 1, const int* bound_seg_off = nullptr);
+                  int64_t n_bound = 0, const int* seg_off = nullptr, int nseg = 1, const int* bound_seg_off = nullptr,
+                  float mean_mult = 0.0f);

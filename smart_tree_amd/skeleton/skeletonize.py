@@ -9,6 +9,7 @@ branches come back in a single device-to-host copy.
 from __future__ import annotations
 
 import ctypes
+import os
 from dataclasses import dataclass
 from typing import List
 
@@ -62,6 +63,9 @@ def run_components(comps: ComponentSet, medial_pts: torch.Tensor, radius: torch.
     res = ComponentResult(f32(m), i32(m), i32(C), f32(m), i32(m), i32(m), i32(m), i32(C), i32(m), i32(m))
     if C == 0:
         return res
+    if os.environ.get("ST_DIAG_STAGES"):  # developer aid (tools/sweep_stages.sh): leave stages out to see what they cost
+        stages = int(os.environ["ST_DIAG_STAGES"])
+        res.n_branches.zero_()
     # no host-side facts needed: the library lays out the claim grid from comp_off and takes the grid cell as
     # max(rad) / GRID_DIV reduced on the device (grid_cell < 0), so this stage starts without a read-back
     stats = (ctypes.c_int64 * 8)()

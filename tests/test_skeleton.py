@@ -173,6 +173,24 @@ def test_sample_tree_strategies_agree(backend, params):
         hook(-1, 0)
 
 
+@pytest.mark.parametrize("mults", [(0, 0), (100, 45), (25, 15)], ids=["max-only", "default", "fine"])
+def test_grid_cell_size_is_invisible_with_radius_outliers(backend, mults):
+    """The search grids take their cell from the radii (max / DIV, capped at a multiple of the MEAN so that one radius the
+    network got wrong does not coarsen every cell -- csrc/st_grid.h).  The cell changes the speed of a search, never its
+    result: a cloud with a few 15x radius outliers gives the oracle's graph and skeleton under every setting."""
+    from smart_tree_amd import _lib
+    hook = _lib.lib().st_debug_set_skeleton_param
+    pts, mv = _tree()
+    mv = mv.copy()
+    mv[::97] *= 15.0  # ~1 % of the points with a far-too-large radius
+    try:
+        hook(11, mults[0])
+        hook(12, mults[1])
+        assert _compare_components(backend, pts, mv, block_threads=256) >= 2
+    finally:
+        hook(-1, 0)
+
+
 def test_components_with_duplicates_and_plateaus(backend):
     pts, mv = _tree(n=2000, seed=8, exact_medial=True)
     _compare_components(backend, pts, mv, block_threads=64)
