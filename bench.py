@@ -40,14 +40,14 @@ STREAMS = 3     # batches in flight      } 3 x 48 = 1.51 ms per cloud, 2 x 64 = 
 N_SEEDS = 4  # distinct clouds per rank, cycled
 
 
-def build_pipeline(device, weights="noble-elevator-58", voxel=VOXEL, fp16=False):
+def build_pipeline(device, weights="noble-elevator-58", voxel=VOXEL, fp16=False, blocking="blocks"):
     from smart_tree_amd.dataset.augmentations import AugmentationPipeline, CentreCloud
     from smart_tree_amd.model.model_inference import ModelInference
     from smart_tree_amd.pipeline import Pipeline
     from smart_tree_amd.skeleton.skeletonize import Skeletonizer
 
     mi = ModelInference(f"{weights}_model.pt", WEIGHTS / f"{weights}.npz", voxel_size=voxel, block_size=4, buffer_size=0.4,
-                        device=device, fp16=fp16)
+                        device=device, fp16=fp16, blocking=blocking)
     sk = Skeletonizer(K=16, min_connection_length=0.02, minimum_graph_vertices=32, device=device)
     return Pipeline(AugmentationPipeline([CentreCloud()]), mi, sk, repair_skeletons=True, smooth_skeletons=True,
                     smooth_kernel_size=11, prune_skeletons=True, min_skeleton_radius=0.01, min_skeleton_length=0.02,
@@ -233,7 +233,9 @@ def extra_configs(device):
 
     out = {}
     for key, n, kw, pk in (("configs[4] peach-forest-65 fp16 storage, 1M pts, 2 cm", 1_000_000, {}, dict(weights="peach-forest-65", fp16=True)),
-                           ("configs[3] dense canopy, 5M pts, 1 cm", 5_000_000, dict(seed=3, foliage_fraction=0.6), dict(voxel=0.01))):
+                           ("configs[3] dense canopy, 5M pts, 1 cm", 5_000_000, dict(seed=3, foliage_fraction=0.6), dict(voxel=0.01)),
+                           ("configs[3] in the opt-in whole-cloud voxelisation mode (SURVEY 8f.2: no halo copies; NOT the reference's "
+                            "per-block results)", 5_000_000, dict(seed=3, foliage_fraction=0.6), dict(voxel=0.01, blocking="whole"))):
         c = sample_tree_cloud(n, **({"seed": 0} | kw))
         cloud = Cloud(xyz=torch.from_numpy(c["xyz"]).to(device), rgb=torch.from_numpy(c["rgb"]).to(device))
         pipe = build_pipeline(device, **pk)

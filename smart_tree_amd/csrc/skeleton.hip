@@ -31,7 +31,8 @@
 #define SK_MAX_WAVES 16
 #define SK_EMPTY64 0xffffffffffffffffull
 #define SK_WIDE_BLOCK 256  // block size of the vertex / frontier kernels
-#define SK_SSSP_BLOCKS 256  // upper bound; small graphs launch fewer (one wave per frontier vertex)
+#define SK_SSSP_BLOCKS 2048  // upper bound; small graphs launch fewer (one wave per frontier vertex).  A batch of clouds has a frontier of ~10k vertices:
+                             // with 256 workgroups a launch took 81 us, with 2048 (and the look before the atomic) 40 us (24 clouds)
 #define SK_MARK 0xfffffffeu
 #define SK_ANC 64  // direct ancestors kept per vertex; longer walks hop 64 levels at a time (16 measured slower: every lane
                    // of a 1024-wide chunk hops j/SK_ANC times, so the chunk costs as much as its farthest lane)
@@ -183,7 +184,7 @@ __global__ void __launch_bounds__(1024) k_sk_fill_comp_of(SkArgs A) {
 // whatever the order of relaxations (atomicMin; every improvement is queued again), so the result is the same
 // as one level per launch -- at 1/hops of the launches.
 #define SK_LQ 1024  // entries per local generation; overflow goes straight to the global queue
-__global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_sssp_round(SkArgs A, int r, int hops, int glanes) {
+__global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_sssp_round(SkArgs A, int r, int hops, int glanes, int lcap) {
     __shared__ unsigned lq[2][SK_LQ];
     __shared__ unsigned ln[3], lq_base;  // generation h fills lq[h & 1], counted by ln[h % 3]
     const unsigned count = A.cnt[r % 3];
@@ -194,6 +195,8 @@ __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_sssp_round(SkArgs A, int r
     const unsigned* q = (r & 1) ? A.q1 : A.q0;
     unsigned* qn = (r & 1) ? A.q0 : A.q1;
     unsigned* cnt_out = &A.cnt[(r + 1) % 3];
+    const bool lookfirst = lcap >= 0;
+    if (lcap < 0) lcap = -lcap;
     const unsigned round = (unsigned)r + 1u;  // stamp[v] == round: v already sits in the next global frontier
     const int lane = threadIdx.x & (glanes - 1);  // `glanes` lanes share one vertex (rows hold ~16 edges)
     const unsigned wave = threadIdx.x / glanes, nwv = blockDim.x / glanes;
@@ -205,6 +208,7 @@ __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_sssp_round(SkArgs A, int r
         for (uint32_t t = s_ + lane; t < e_; t += glanes) {                                                    \
             const unsigned v = A.col[t];                                                                   \
             const unsigned o = st_f2ord((du) + A.wgt[t]);                                                  \
+            if (lookfirst && o >= A.dist_ord[v]) continue; /* plain load: a stale line holds an OLDER, larger value */ \
             const unsigned old = atomicMin(&A.dist_ord[v], o);                                             \
             if (o < old) {                                                                                 \
                 const unsigned slot = atomicAdd(out_n, 1u);                                                \
@@ -222,11 +226,20 @@ __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_sssp_round(SkArgs A, int r
     for (; h < hops; h++) {
         __syncthreads();  // generation h-1 is complete; nobody still reads generation h-2
         const unsigned have = ln[(h - 1) % 3];
-        const unsigned ncur = have < SK_LQ ? have : SK_LQ;
+        unsigned ncur = have < SK_LQ ? have : SK_LQ;
         if (ncur == 0) break;  // uniform
         if (threadIdx.x == 0) ln[(h + 1) % 3] = 0;  // counter of the generation after this one (last read two barriers ago)
         const unsigned* in = lq[(h - 1) & 1];
         unsigned* out = lq[h & 1];
+        if (ncur > (unsigned)lcap) {
+            // a launch lasts as long as its busiest workgroup: what exceeds `lcap` vertices per level goes back to the global
+            // frontier, where the next launch deals it out over all workgroups
+            for (unsigned i = lcap + threadIdx.x; i < ncur; i += blockDim.x) {
+                const unsigned v = in[i];
+                if (atomicExch(&A.stamp[v], round) != round) qn[atomicAdd(cnt_out, 1u)] = v;
+            }
+            ncur = (unsigned)lcap;
+        }
         for (unsigned i = wave; i < ncur; i += nwv) {
             const unsigned u = in[i];
             const float du = st_ord2f(ld(&A.dist_ord[u]));  // improved during this launch: read it where the atomics act
@@ -1181,7 +1194,7 @@ static void sk_layout(StArena& a, int64_t m, int64_t C, SkLayout* s, int nseg = 
 static long long* g_debug_ticks = nullptr;
 static float g_prune_factor = 1.0f;
 static float g_grid_mean_mult = 1.0f;  // claim-grid cell <= this x the mean radius (0: max radius / GRID_DIV alone)
-static int g_sssp_hops = 4, g_sssp_batch = 32, g_sssp_lanes = 64, g_sssp_first = 2, g_sssp_blocks = SK_SSSP_BLOCKS;
+static int g_sssp_hops = 4, g_sssp_batch = 32, g_sssp_lanes = 64, g_sssp_first = 2, g_sssp_blocks = SK_SSSP_BLOCKS, g_sssp_lcap = SK_LQ;
 #define SK_MAX_LAUNCH_BATCH 32
 static int g_small_work = SK_SMALL_WORK, g_iters_per_launch = SK_ITERS_PER_LAUNCH, g_launch_batch = 24, g_local_items = 0, g_wave_work = SK_WAVE_WORK;
 // developer aid / test hook (forces every claim strategy): 0 prune factor (x1000), 1 small_work, 2 rounds per launch,
@@ -1191,7 +1204,7 @@ extern "C" void st_debug_set_skeleton_param(int which, int value) {
     if (which < 0) {
         g_prune_factor = 1.0f; g_small_work = SK_SMALL_WORK; g_iters_per_launch = SK_ITERS_PER_LAUNCH; g_launch_batch = 24;
         g_local_items = 0; g_wave_work = SK_WAVE_WORK; g_sssp_hops = 4; g_sssp_batch = 32; g_sssp_lanes = 64; g_sssp_first = 2;
-        g_sssp_blocks = SK_SSSP_BLOCKS; g_grid_mean_mult = 1.0f; g_knn_mean_mult = 0.45f;
+        g_sssp_blocks = SK_SSSP_BLOCKS; g_sssp_lcap = SK_LQ; g_grid_mean_mult = 1.0f; g_knn_mean_mult = 0.45f;
     }
     if (which == 0) g_prune_factor = value / 1000.0f;
     if (which == 1) g_small_work = value;
@@ -1203,6 +1216,7 @@ extern "C" void st_debug_set_skeleton_param(int which, int value) {
     if (which == 8) g_sssp_lanes = value == 64 ? 64 : (value == 32 ? 32 : 16);
     if (which == 7) g_sssp_batch = value < 1 ? 1 : (value > 64 ? 64 : value);
     if (which == 9) g_sssp_first = value < 1 ? 1 : (value > 8 ? 8 : value);
+    if (which == 13) g_sssp_lcap = value == 0 ? -SK_LQ : (value > SK_LQ ? SK_LQ : value);  // 0: no look before the atomic; else cap  // SSSP: vertices a workgroup relaxes per local level
     if (which == 11) g_grid_mean_mult = value / 100.0f;
     if (which == 12) g_knn_mean_mult = value / 100.0f;
     if (which == 10) g_sssp_blocks = value < 1 ? 1 : (value > 8192 ? 8192 : value);  // workgroups of the SSSP frontier launches
@@ -1319,7 +1333,7 @@ extern "C" int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, c
             // a tree of a million points needs 65-96 launches, an empty round costs ~4 us, a read-back beside other clouds ~1 ms
             const int batch = r == 0 ? g_sssp_first * g_sssp_batch : g_sssp_batch;
             for (int b = 0; b < batch; b++, r++)
-                hipLaunchKernelGGL(k_sk_sssp_round, dim3(fg), dim3(SK_WIDE_BLOCK), 0, stream, A, r, g_sssp_hops, g_sssp_lanes);
+                hipLaunchKernelGGL(k_sk_sssp_round, dim3(fg), dim3(SK_WIDE_BLOCK), 0, stream, A, r, g_sssp_hops, g_sssp_lanes, g_sssp_lcap);
             ST_TRY(sk_read(h, s.cnt, sizeof(unsigned) * 8, stream));
             sssp_rounds = r;
             if (h[r % 3] == 0) break;

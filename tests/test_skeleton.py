@@ -159,7 +159,8 @@ def test_components_match_oracle(backend):
     {5: 300, 1: 2000, 4: 200},   # a mix of all of them
     {6: 1, 8: 16},               # SSSP: one level per launch, 16 lanes per vertex
     {6: 7, 7: 2},                # SSSP: seven levels per launch, read-back every second launch
-], ids=["noprune", "prune4", "relaunch", "one", "local", "wide", "mixed", "sssp-rows", "sssp-hops"])
+    {6: 6, 13: 2, 10: 3},        # SSSP: three workgroups, at most two vertices per workgroup and local level (the rest goes back)
+], ids=["noprune", "prune4", "relaunch", "one", "local", "wide", "mixed", "sssp-rows", "sssp-hops", "sssp-cap"])
 def test_sample_tree_strategies_agree(backend, params):
     """Branch selection has four claim strategies picked by size; each one alone must reproduce the oracle."""
     from smart_tree_amd import _lib

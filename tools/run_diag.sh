@@ -1,6 +1,9 @@
 cd $GRAFT_REPO_ROOT
-for p in "12=0" "12=30" "12=45" "12=60" "12=80"; do
-echo "== $p"
-ST_SKELETON_PARAMS=$p python tools/time_config3.py 2>&1 | grep -A1 "blocking=blocks" | grep -o "'outlier_removal[^}]*components': [0-9.]*\|[0-9.]* ms per cloud"
-ST_SKELETON_PARAMS=$p python tools/bench_knn.py 2>&1 | tail -3
-done
+python tools/diag_phases.py 1000000 0.02 0 0 2>&1 | grep "^params" | cut -c1-120
+python tools/diag_phases.py 5000000 0.01 0.6 3 2>&1 | grep "^params" | cut -c1-120
+python tools/diag_phases.py 5000000 0.01 0.6 3 "10=256" 2>&1 | grep "^params" | cut -c1-120
+python tools/diag_phases.py 5000000 0.01 0.6 3 "10=4096,8=32" 2>&1 | grep "^params" | cut -c1-120
+python -m pytest tests/test_skeleton.py tests/test_batch.py tests/test_golden.py tests/test_full_size.py -m gpu -x -q 2>&1 | tail -2
+for i in 1 2; do python bench.py --no-cpu-baseline --no-extras | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('bench: %.3f ms/cloud, single %.2f ms, stages %s' % (d['ms_per_step'], d['config']['single_cloud_latency_ms'], d['stage_ms']))"; done
