@@ -271,20 +271,28 @@ __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_dist_out(SkArgs A) {
     SK_VERTEX_LOOP(v) A.dist[v] = st_ord2f(A.dist_ord[v]);
 }
 
-// canonical predecessors (oracle so_sssp): smallest tight in-neighbour with smaller distance
+// canonical predecessors (oracle so_sssp): smallest tight in-neighbour with smaller distance.
+// Eight lanes per vertex: a row (~32 entries) is read as coalesced 32-byte pieces and its distance gathers are in flight
+// together (one lane per vertex walked its row alone: 64 rows per wavefront, one dependent gather after the other).
+#define SK_PRED_LANES 8
 __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_preds(SkArgs A) {
-    SK_VERTEX_LOOP(v) {
+    const int sub = threadIdx.x & (SK_PRED_LANES - 1);
+    const int64_t groups = ((int64_t)gridDim.x * blockDim.x) / SK_PRED_LANES;
+    // (every lane of a group runs the same number of iterations: v depends on the group only)
+    for (int64_t v = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / SK_PRED_LANES; v < A.m; v += groups) {
         const int c = A.comp_of[v], base = A.comp_off[c];
         const bool is_root = (int)(v - base) == A.root_local[c];
         const float dv = A.dist[v];
         unsigned best = 0xffffffffu;
         if (!is_root)
-            for (uint32_t t = A.row_off[v]; t < A.row_off[v + 1]; t++) {
+            for (uint32_t t = A.row_off[v] + sub, e = A.row_off[v + 1]; t < e; t += SK_PRED_LANES) {
                 const unsigned u = A.col[t];
                 if (u == (unsigned)v) continue;
                 const float du = A.dist[u];
                 if (du < dv && du + A.wgt[t] == dv && u < best) best = u;
             }
+        for (int d = SK_PRED_LANES / 2; d > 0; d >>= 1) { const unsigned o = __shfl_xor(best, d); best = o < best ? o : best; }
+        if (sub != 0) continue;
         const bool ok = is_root || best != 0xffffffffu;
         A.pred[v] = (is_root || !ok) ? -1 : (int)best - base;
         A.stamp[v] = ok ? 1u : 0u;
@@ -1340,7 +1348,7 @@ extern "C" int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, c
             ST_REQUIRE(r < (1 << 24), "skeleton: SSSP did not converge");
         }
         hipLaunchKernelGGL(k_sk_dist_out, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A);
-        hipLaunchKernelGGL(k_sk_preds, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A);
+        hipLaunchKernelGGL(k_sk_preds, dim3((unsigned)st_min64(st_div_up(m * SK_PRED_LANES, SK_WIDE_BLOCK), 8192)), dim3(SK_WIDE_BLOCK), 0, stream, A);
         // Vertices whose tight in-neighbours all sit on their own distance plateau (cnt[3]) are rare; with sample_tree
         // next, their count is not read back here (a blocking round trip costs ~1 ms beside other clouds' kernels,
         // DESIGN.md section 5) but arrives with the first progress read-back of the select loop, which is then redone.
@@ -1432,7 +1440,7 @@ extern "C" int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, c
             }
             // plateau vertices left unresolved: redo the predecessor pass with its resolved / unresolved marks, then the plateaus
             (void)hipMemsetAsync(&s.cnt[3], 0, sizeof(unsigned), stream);
-            hipLaunchKernelGGL(k_sk_preds, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A);
+            hipLaunchKernelGGL(k_sk_preds, dim3((unsigned)st_min64(st_div_up(m * SK_PRED_LANES, SK_WIDE_BLOCK), 8192)), dim3(SK_WIDE_BLOCK), 0, stream, A);
             ST_TRY(sk_read(h, s.cnt, sizeof(unsigned) * 8, stream));
             ST_TRY(resolve_plateaus(h[3]));
         }

@@ -317,23 +317,25 @@ struct __attribute__((aligned(16))) VxSlot {
     unsigned pad;
 };
 struct __attribute__((aligned(16))) VxRaw { unsigned long long x, y; };  // one 16-byte load of a slot: key | (val, pad)
-__device__ __forceinline__ bool vx_insert_min(VxSlot* slots, unsigned long long cap, unsigned long long key, unsigned val,
-                                              const unsigned* give_up) {
+// returns 0: table full / gave up; 1: an earlier point already holds the voxel (this point can never win it); 2: this point
+// raced for the voxel with an atomic -- only such points can be the final winner, so pass 1 looks up nothing else
+__device__ __forceinline__ int vx_insert_min(VxSlot* slots, unsigned long long cap, unsigned long long key, unsigned val,
+                                             const unsigned* give_up) {
     unsigned long long slot = st_hash_slot(key, cap);
     for (unsigned long long probe = 0; probe < cap && probe < ST_HASH_MAX_PROBE; probe++) {
-        if ((probe & 63ull) == 63ull && (__hip_atomic_load(give_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4u)) return false;
+        if ((probe & 63ull) == 63ull && (__hip_atomic_load(give_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4u)) return 0;
         // look before touching the slot with atomics (~9 points per voxel: most find an earlier winner).  A key never changes
         // once written and a value only decreases, so a stale read can only send us down the atomic path needlessly.
         const VxRaw seen = *reinterpret_cast<const VxRaw*>(&slots[slot]);
         unsigned long long prev = seen.x;
         if (prev == ST_EMPTY_KEY) prev = atomicCAS(&slots[slot].key, (unsigned long long)ST_EMPTY_KEY, key);
         if (prev == ST_EMPTY_KEY || prev == key) {
-            if (seen.x != key || (unsigned)(seen.y & 0xffffffffull) > val) atomicMin(&slots[slot].val, val);
-            return true;
+            if (seen.x != key || (unsigned)(seen.y & 0xffffffffull) > val) { atomicMin(&slots[slot].val, val); return 2; }
+            return 1;
         }
         slot = st_hash_next(slot, key, cap);
     }
-    return false;
+    return 0;
 }
 __device__ __forceinline__ int vx_find(const VxSlot* slots, unsigned long long cap, unsigned long long key) {
     unsigned long long slot = st_hash_slot(key, cap);
@@ -386,20 +388,28 @@ __global__ void __launch_bounds__(VX_BLOCK) k_vx_pass(const float* xyz, int64_t 
     vx_stream_points(xyz, n, i0, i1, [&](int64_t i, float x, float y, float z) {
         const float pt[3] = {x, y, z};
         uint32_t mine = 0, won = 0u;
+        // pass 0 leaves in win[i] the blocks in which point i raced for a voxel; pass 1 checks only those (a point that
+        // found an earlier point in the slot cannot be the smallest index of that voxel): ~1 membership in 4 is looked up again
+        const uint32_t cand = PASS == 1 ? win[i] : 0u;
+        if (PASS == 1 && cand == 0u) { cnt_or_off[i] = 0u; return; }
         int j = 0;
         vx_for_each_block(pt, st, d, tab, p, [&](int b) {
             const uint32_t bit = 1u << j++;
+            if (PASS == 1 && !(cand & bit)) return;
             int c[3];
             if (!vx_coord(pt, b, blk_lof, blk_grid, p.vs, p.vs_inv, c)) return;
             unsigned long long key = st_pack_key(b, c[2], c[1], c[0]);
             if (PASS == 0) {
-                if (!vx_insert_min(slots, cap, key, (unsigned)i, &st->overflow)) atomicOr(&st->overflow, 4u);
+                const int r = vx_insert_min(slots, cap, key, (unsigned)i, &st->overflow);
+                if (r == 0) atomicOr(&st->overflow, 4u);
+                if (r == 2) won |= bit;
             } else if (vx_find(slots, cap, key) == (int)i) {
                 won |= bit;
                 mine++;
             }
         });
-        if (PASS == 1) { cnt_or_off[i] = mine; win[i] = won; }
+        if (PASS == 1) cnt_or_off[i] = mine;
+        win[i] = won;
     });
 }
 
