@@ -35,8 +35,8 @@ N_POINTS = 1_000_000
 VOXEL = 0.02
 WEIGHTS = ROOT / "smart_tree_amd" / "model" / "weights"
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-MAX_BATCH = 48  # clouds per launch set  } measured on one MI355X (tools/sweep_batch.sh, profiles/r02_sweep_batch.txt, 384 steps):
-STREAMS = 3     # batches in flight      } 3 x 48 = 1.51 ms per cloud, 2 x 64 = 1.55, 4 x 24 = 1.60, 4 x 48 = 1.59, 4 x 64 = 1.59
+MAX_BATCH = 64  # clouds per launch set  } measured on one MI355X (tools/sweep_batch.sh, profiles/r02_sweep_batch.txt, 384 steps, final kernels):
+STREAMS = 3     # batches in flight      } 3 x 64 = 1.25-1.27 ms per cloud, 3 x 48 = 1.30, 2 x 64 = 1.29, 4 x 32 = 1.29, 4 x 48 = 1.32
 N_SEEDS = 4  # distinct clouds per rank, cycled
 
 

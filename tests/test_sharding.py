@@ -100,4 +100,4 @@ def test_bench_batch_plan():
                     assert max(plan) - min(plan) <= 1 and (len(plan) % eff == 0 or len(plan) == steps)
     assert bench.plan_batches(20, 3, 16) == [7, 7, 6] and bench.plan_batches(96, 3, 16) == [16] * 6
     assert bench.plan_batches(20, 4, 24) == [7, 7, 6] and bench.plan_batches(192, 4, 24) == [24] * 8 and bench.plan_batches(5, 4, 24) == [5]
-    assert bench.plan_batches(384, 3, 48) == [43] * 6 + [42] * 3
+    assert bench.plan_batches(384, 3, 48) == [43] * 6 + [42] * 3 and bench.plan_batches(384, 3, 64) == [64] * 6

@@ -1,7 +1,7 @@
 # GPU box: average duration of the SSSP / select launches of one batch of 24 clouds at a time under different launch shapes
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-for p in "10=2048" "10=4096" "10=2048,8=32" "10=4096,8=16" "10=2048,6=6" "10=1024,8=32"; do
+for p in "6=4" "6=6" "6=8" "6=12" "6=8,8=32"; do
   rm -rf /tmp/prof_x
   ST_SKELETON_PARAMS=$p timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_x -- python $R/bench.py --streams 1 --steps 48 --warmup 8 --batch 24 --no-cpu-baseline --no-extras > /tmp/prof_x.log 2>&1
   f=$(ls /tmp/prof_x/*/*kernel_stats.csv | head -1)
