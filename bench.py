@@ -36,8 +36,10 @@ VOXEL = 0.02
 WEIGHTS = ROOT / "smart_tree_amd" / "model" / "weights"
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MAX_BATCH = 64  # clouds per launch set  } measured on one MI355X (tools/sweep_batch.sh, profiles/r02_sweep_batch.txt, 384 steps, final kernels):
-STREAMS = 3     # batches in flight      } 3 x 64 = 1.25-1.27 ms per cloud, 3 x 48 = 1.30, 2 x 64 = 1.29, 4 x 32 = 1.29, 4 x 48 = 1.32
+STREAMS = 2     # batches in flight      } ordered phases: 2 x 64 = 1.32 ms per cloud, 3 x 64 = 1.33, 3 x 48 = 1.37, 4 x 48 = 1.40;
+FREE_STREAMS = 3  #                       } free-running: 3 x 64 = 1.25-1.27, 3 x 48 = 1.30, 2 x 64 = 1.29, 4 x 32 = 1.29, 4 x 48 = 1.32
 N_SEEDS = 4  # distinct clouds per rank, cycled
+ORDERED = int(os.environ.get("ST_BENCH_ORDERED", "1"))  # 1 (default): voxelise .. adjacency of the batches in flight take turns; 0: free-running; 2: only the conv sequences
 
 
 def build_pipeline(device, weights="noble-elevator-58", voxel=VOXEL, fp16=False, blocking="blocks"):
@@ -174,14 +176,44 @@ class CloudWorker:
         return [Cloud(xyz=self.host[i][0].to(self.device, non_blocking=True), rgb=self.host[i][1].to(self.device, non_blocking=True))
                 for i in ids]
 
-    def run(self, batches, collect, upload=False):
-        """`batches`: list of batch sizes, dealt to the S worker threads from a shared counter."""
+    def run(self, batches, collect, upload=False, streams=None, mode=None):
+        """`batches`: list of batch sizes, dealt to the worker threads from a shared counter.  streams: worker threads / HIP
+        streams to use (default: all); mode: ORDERED for this call (default: the module setting)."""
+        S = self.S if streams is None else max(1, min(int(streams), self.S))
+        mode = ORDERED if mode is None else mode
         from smart_tree_amd.sharding import pack_skeleton
 
         starts = np.concatenate([[0], np.cumsum(batches)]).tolist()
-        state = {"next": 0, "error": None}
+        state = {"next": 0, "error": None, "wide_done": None}
         lock = threading.Lock()
         finished = []
+        # Ordered chip-filling phases (ST_BENCH_ORDERED=1): the batches in flight take turns with the part of the pipeline whose
+        # kernels fill the chip (voxelise .. adjacency): two such kernels gain nothing from sharing it, they only make each
+        # other's launches last longer.  What overlaps with a batch's chip-filling phase is the others' skeleton stage (one
+        # compute unit per tree).  `wide` is held from the start of a batch to Skeletonizer.on_wide_phase_done; the event makes
+        # the order hold on the GPU as well.
+        ordered = mode == 1 and S > 1
+        conv_ordered = mode == 2 and S > 1
+        wide = threading.Lock()
+
+        import contextlib
+
+        def conv_gate_for(w):
+            @contextlib.contextmanager
+            def gate():
+                with wide:
+                    if state["wide_done"] is not None:
+                        self.streams[w].wait_event(state["wide_done"])
+                    try:
+                        yield
+                    finally:
+                        ev = torch.cuda.Event()
+                        ev.record(self.streams[w])
+                        state["wide_done"] = ev
+            return gate
+
+        for w in range(self.S):
+            self.pipes[w].model_inference.model.conv_gate = conv_gate_for(w) if conv_ordered else None
 
         def work(w):
             try:
@@ -194,7 +226,27 @@ class CloudWorker:
                         if i >= len(batches):
                             break
                         clouds = self.batch_clouds(starts[i], batches[i], upload)
-                        parts = self.pipes[w].process_clouds(clouds) if batches[i] > 1 else [self.pipes[w].process_cloud(cloud=clouds[0])]
+                        if ordered:
+                            wide.acquire()
+                            held = [True]
+                            if state["wide_done"] is not None:
+                                self.streams[w].wait_event(state["wide_done"])
+
+                            def release(held=held, w=w):
+                                if held[0]:
+                                    ev = torch.cuda.Event()
+                                    ev.record(self.streams[w])
+                                    state["wide_done"] = ev
+                                    held[0] = False
+                                    wide.release()
+
+                            self.pipes[w].skeletonizer.on_wide_phase_done = release
+                        try:
+                            parts = self.pipes[w].process_clouds(clouds) if batches[i] > 1 else [self.pipes[w].process_cloud(cloud=clouds[0])]
+                        finally:
+                            if ordered:
+                                release()  # (a batch without a single graph vertex never reaches the hook)
+                                self.pipes[w].skeletonizer.on_wide_phase_done = None
                         self.last = parts[-1]
                         if collect:
                             for k, sk in enumerate(parts):
@@ -203,10 +255,10 @@ class CloudWorker:
             except BaseException as e:  # noqa: BLE001 -- re-raised on the calling thread
                 state["error"] = e
 
-        if self.S == 1:
+        if S == 1:
             work(0)
         else:
-            threads = [threading.Thread(target=work, args=(w,)) for w in range(self.S)]
+            threads = [threading.Thread(target=work, args=(w,)) for w in range(S)]
             for t in threads:
                 t.start()
             for t in threads:
@@ -300,10 +352,13 @@ def main():
     B = max(1, min(args.batch, 64))
     finished = []  # packed skeletons of this rank, gathered to rank 0 once per timed region (no per-step rendezvous:
     #                 clouds differ in cost, a collective per step would make every step as slow as its slowest rank)
-    worker = CloudWorker(device, S, args.points, rank)
+    # for the record (one GPU only): the same K steps free-running -- the chip-filling phases of the batches in flight overlap,
+    # which fills the bubbles at their host round trips (a few % more throughput) and stretches every kernel's launch bracket
+    S_free = max(1, min(FREE_STREAMS, usable_cores(), max(1, args.steps // 16))) if world == 1 and ORDERED == 1 and args.streams == STREAMS else 0
+    worker = CloudWorker(device, max(S, S_free), args.points, rank)
 
     def run_steps(total, upload=False):
-        finished.extend(worker.run(plan_batches(total, S, B), collect=world > 1, upload=upload))
+        finished.extend(worker.run(plan_batches(total, S, B), collect=world > 1, upload=upload, streams=S))
 
     def gather():
         if world > 1:
@@ -323,7 +378,7 @@ def main():
     plan = plan_batches(args.steps, S, B)
     warm = max(args.warmup, sum(plan)) if args.warmup > 0 and plan else 0
     if warm:
-        finished.extend(worker.run(plan + plan_batches(warm - sum(plan), S, B), collect=world > 1))
+        finished.extend(worker.run(plan + plan_batches(warm - sum(plan), S, B), collect=world > 1, streams=S))
         # ... repeated until two consecutive passes agree to 5 % (at most 6 more passes / 10 s): a process that starts right
         # after another GPU process has exited runs with inflated host round trips for its first seconds (measured on the
         # gpurun boxes: 3.0 instead of 1.55 ms per cloud, gone a few seconds later).  Warm-up is untimed; the K steps
@@ -332,7 +387,7 @@ def main():
         for _ in range(6):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            finished.extend(worker.run(plan, collect=world > 1))
+            finished.extend(worker.run(plan, collect=world > 1, streams=S))
             torch.cuda.synchronize()
             cur = time.perf_counter() - t0
             warm += sum(plan)
@@ -361,20 +416,35 @@ def main():
     gather()
     fence()
     dt_up = time.perf_counter() - t1
+    free = None
+    if S_free > 1:
+        plan_free = plan_batches(args.steps, S_free, B)
+        worker.run(plan_free, collect=False, streams=S_free, mode=0)  # untimed: the third stream's allocator pool
+        torch.cuda.synchronize()
+        profiling.enable(True)
+        t2 = time.perf_counter()
+        worker.run(plan_free, collect=False, streams=S_free, mode=0)
+        torch.cuda.synchronize()
+        dt_free = time.perf_counter() - t2
+        profiling.enable(False)
+        rf = profiling.roofline(HBM_PEAK_GBS, clouds_per_launch=max(plan_free))
+        free = {"note": "the same %d steps with %d batches in flight and NO ordering of their chip-filling phases (untimed extra "
+                        "pass): kernels of different batches share the chip, brackets stretch" % (args.steps, S_free),
+                "value": args.steps * args.points / dt_free, "ms_per_step": 1e3 * dt_free / args.steps,
+                "batches_in_flight": S_free, "roofline_kernel": rf["kernel"], "roofline_frac": rf["frac"],
+                "gather_gemm_hbm_frac": (rf.get("gather_gemm") or {}).get("hbm_frac")}
     # for the record: ONE batch at a time on one stream with the kernel timers on -- solo kernel durations (in the timed region
     # the kernels of the batches in flight share the chip, which inflates every bracket)
     roof_solo = None
     if world == 1:
-        solo = CloudWorker.__new__(CloudWorker)
-        solo.__dict__.update(worker.__dict__)
-        solo.S = 1
         profiling.enable(True)
-        solo.run([min(B, max(args.steps, 1))], collect=False)
+        worker.run([min(B, max(args.steps, 1))], collect=False, streams=1)
         torch.cuda.synchronize()
         profiling.enable(False)
         full = profiling.roofline(HBM_PEAK_GBS)
-        roof_solo = {"note": "one batch of %d clouds alone on the GPU (untimed extra pass)" % min(B, max(args.steps, 1)),
-                     "gather_gemm": full.get("gather_gemm"), "all_kernels": full.get("all_kernels")}
+        roof_solo = {"note": "one batch of %d clouds alone on the GPU (untimed extra pass): solo launch durations" % min(B, max(args.steps, 1))}
+        roof_solo.update({k: full.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "launches", "avg_us",
+                                                  "algorithmic_bytes_per_launch", "branch_selection", "gather_gemm", "all_kernels")})
     if world > 1:
         t = torch.tensor([dt, dt_up], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -394,6 +464,9 @@ def main():
                        "distinct_clouds_per_rank": N_SEEDS, "parallelism": f"cloud-sharded x{world}",
                        "clouds_per_launch_set": max(batches), "batches_in_timed_region": len(batches),
                        "batches_in_flight_per_gpu": S, "host_threads_per_gpu": S, "warmup_steps_run": warm,
+                       "schedule": {1: "the chip-filling phases (voxelise .. adjacency) of the batches in flight take turns; a batch's "
+                                       "skeleton stage (one compute unit per tree) overlaps with the other batch's chip-filling phase",
+                                    0: "free-running", 2: "conv sequences take turns"}.get(ORDERED if S > 1 else 0),
                        "single_cloud_latency_ms": None if serial_ms is None else round(serial_ms, 3)},
             "value_incl_host_upload": world * args.steps * args.points / dt_up,
             "parity_note": "results are checked against oracle/ (a CPU restatement pinned by goldens that the reference's own "
@@ -401,6 +474,7 @@ def main():
                            "voxel drop rule / hash order, FRNN tie order, cugraph tie-breaks) are restated, not pinned",
             "roofline": roof,
             "roofline_solo": roof_solo,
+            "free_running": free,
             "stage_ms": stage_ms,
             "last_result": last,
         }

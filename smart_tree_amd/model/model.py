@@ -9,6 +9,8 @@ input exposes `.features [N,3]` / `.indices [N,4] int32 (b,z,y,x)`, output is th
 """
 from __future__ import annotations
 
+import contextlib
+
 from typing import Dict, Mapping
 
 import numpy as np
@@ -150,9 +152,13 @@ class Smart_Tree:
         if order is not None:
             coords, feats = ops.move_rows(coords, order), ops.move_rows(feats, order)
         pyr = ops.build_pyramid(coords, self.depth, getattr(sparse_input, "blk_seg", None), getattr(sparse_input, "n_seg", 1))
-        x = self._conv("input_conv.sequence.0", feats, None, feats.shape[0], bn="input_conv.sequence.1", relu=True)
-        self._record("input", x)
-        x = self._ublock("UNet", x, pyr, 0)
+        gate = getattr(self, "conv_gate", None)  # optional context-manager factory around the convolution launches (no host
+        #                                            synchronisation inside): a caller with several batches in flight can keep
+        #                                            their conv sequences from sharing the chip (bench.py)
+        with (gate() if gate is not None else contextlib.nullcontext()):
+            x = self._conv("input_conv.sequence.0", feats, None, feats.shape[0], bn="input_conv.sequence.1", relu=True)
+            self._record("input", x)
+            x = self._ublock("UNet", x, pyr, 0)
         if order is not None:
             x = ops.move_rows(x, order, scatter=True)
         return x

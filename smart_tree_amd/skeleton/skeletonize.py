@@ -109,6 +109,10 @@ class Skeletonizer:
         self.minimum_graph_vertices = minimum_graph_vertices
         self.device = device
         self.block_threads = 0  # 0 = library default (1024 lanes in the per-component select workgroup)
+        # optional callable, invoked once per forward() when the last chip-filling kernel of the call (the adjacency build) has been
+        # enqueued: what follows (SSSP, branch selection, post-processing) occupies one compute unit per component.  A caller that
+        # keeps several batches in flight can use it to let the next batch's chip-filling phase start (bench.py)
+        self.on_wide_phase_done = None
 
     def forward(self, cloud: Cloud) -> DisjointTreeSkeleton:
         """`cloud` may be a batch of independent clouds (Cloud.collate): every stage below then runs ONCE for all of
@@ -123,6 +127,8 @@ class Skeletonizer:
             graph = nn_graph(medial, radius.clamp(min=self.min_connection_length), K=self.K, seg_off=cloud.seg_off)
         with profiling.stage("components"):
             comps = graph.connected_cugraph_components(minimum_vertices=self.minimum_graph_vertices)
+        if self.on_wide_phase_done is not None:
+            self.on_wide_phase_done()
         with profiling.stage("sssp_sample_tree"):
             res = run_components(comps, medial, radius, cloud.xyz[:, 1].contiguous(), block_threads=self.block_threads)
         with profiling.stage("assemble"):
