@@ -314,6 +314,8 @@ def main():
     ap.add_argument("--points", type=int, default=N_POINTS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the configs[3] / configs[4] single-cloud timings")
+    ap.add_argument("--free-running", action="store_true", help="one GPU: an extra untimed pass with 3 batches in flight and no "
+                    "ordering of their chip-filling phases, reported as `free_running` (profiles/r02_free_running.txt)")
     ap.add_argument("--batch", type=int, default=MAX_BATCH, help="clouds per launch set (Pipeline.process_clouds); 1 = one cloud per call")
     ap.add_argument("--streams", type=int, default=STREAMS, help="batches in flight per GPU (one host thread + HIP stream each)")
     args = ap.parse_args()
@@ -354,7 +356,7 @@ def main():
     #                 clouds differ in cost, a collective per step would make every step as slow as its slowest rank)
     # for the record (one GPU only): the same K steps free-running -- the chip-filling phases of the batches in flight overlap,
     # which fills the bubbles at their host round trips (a few % more throughput) and stretches every kernel's launch bracket
-    S_free = max(1, min(FREE_STREAMS, usable_cores(), max(1, args.steps // 16))) if world == 1 and ORDERED == 1 and args.streams == STREAMS else 0
+    S_free = max(1, min(FREE_STREAMS, usable_cores(), max(1, args.steps // 16))) if world == 1 and ORDERED == 1 and args.free_running else 0
     worker = CloudWorker(device, max(S, S_free), args.points, rank)
 
     def run_steps(total, upload=False):

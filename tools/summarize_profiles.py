@@ -65,6 +65,10 @@ if a and b:
     (out / f"{tag}_config5_fp16.txt").write_text(
         "# python tools/time_fp16.py [5000000 0.01 0.6]    (configs[4]: peach-forest-65, float32 vs half-precision storage; "
         "1 x MI355X, one stream)\n# 1M-point tree, 2 cm voxels:\n" + a + "# 5M-point dense canopy, 1 cm voxels:\n" + b)
+b = body(f"{tag}_free_running.txt")
+if b:
+    (out / f"{tag}_free_running.txt").write_text("# python bench.py --free-running --no-cpu-baseline --no-extras, twice on one box (tools/collect_r2.sh): the default schedule\n"
+                                                 "# (chip-filling phases of the batches in flight take turns) beside the free-running one\n" + b)
 solo = sorted(glob.glob(str(ROOT / "gpurun_out" / "prof_solo" / "*" / "*kernel_stats.csv")), key=os.path.getmtime)
 if solo:
     shutil.copy(solo[-1], out / f"{tag}_kernel_stats_single_stream.csv")
