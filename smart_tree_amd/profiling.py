@@ -114,7 +114,9 @@ def _pmc_traffic(kernel_name: str):
         base = row["kernel"].split("(")[0].split("<")[0].strip().split(" ")[-1]  # "void k_x<..>(..)" -> "k_x"
         if (base.startswith(stem) if family else base == stem):
             n = int(row["launches"] or 0)
-            total += n * (float(row["FETCH_SIZE_KB_per_launch"] or 0) + float(row["WRITE_SIZE_KB_per_launch"] or 0)) * 1024.0
+            # gfx950 correction (MI355X_MICROARCH.md "HBM" + the calibration it asks for, profiles/r02_pmc_calibration.txt):
+            # FETCH_SIZE tallies every 128-byte line at 64 B, for streams and gathers alike -> x2; WRITE_SIZE is exact
+            total += n * (2.0 * float(row["FETCH_SIZE_KB_per_launch"] or 0) + float(row["WRITE_SIZE_KB_per_launch"] or 0)) * 1024.0
             launches += n
     return total / launches if launches else None
 
@@ -165,7 +167,8 @@ def roofline(peak_gbs: float, peak_f32_tflops: float = 157.3, clouds_per_launch:
            "frac": achieved / peak_gbs, "traffic": _scaled_traffic(name, clouds_per_launch), "launches": r["launches"], "avg_us": r["avg_us"],
            "traffic_note": f"HBM bytes per launch (FETCH_SIZE + WRITE_SIZE, two rocprofv3 PMC passes, profiles/*_pmc_summary.csv) "
                            f"measured at {PMC_CLOUDS_PER_LAUNCH} clouds per launch set and scaled linearly to this run's "
-                           f"{clouds_per_launch or PMC_CLOUDS_PER_LAUNCH}; no gfx950 x2 correction (scattered accesses); "
+                           f"{clouds_per_launch or PMC_CLOUDS_PER_LAUNCH}; gfx950 correction: 2 x FETCH_SIZE + WRITE_SIZE (FETCH_SIZE counts a "
+                           "128-byte line as 64 B for streams and gathers alike, WRITE_SIZE is exact: profiles/r02_pmc_calibration.txt); "
                            "a kernel family = launch-weighted mean over its instantiations",
            "algorithmic_bytes_per_launch": r["bytes_per_launch"],
            "note": notes.get(name, "")}
