@@ -36,10 +36,10 @@ VOXEL = 0.02
 WEIGHTS = ROOT / "smart_tree_amd" / "model" / "weights"
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MAX_BATCH = 64  # clouds per launch set  } measured on one MI355X (tools/sweep_batch.sh, profiles/r02_sweep_batch.txt, 384 steps, final kernels):
-STREAMS = 2     # batches in flight      } ordered phases: 2 x 64 = 1.32 ms per cloud, 3 x 64 = 1.33, 3 x 48 = 1.37, 4 x 48 = 1.40;
+STREAMS = 2     # batches in flight      } phases in turns: voxelise .. network 2 x 64 = 1.29 ms per cloud (3 x 64 the same); voxelise .. adjacency 2 x 64 = 1.32;
 FREE_STREAMS = 3  #                       } free-running: 3 x 64 = 1.25-1.27, 3 x 48 = 1.30, 2 x 64 = 1.29, 4 x 32 = 1.29, 4 x 48 = 1.32
 N_SEEDS = 4  # distinct clouds per rank, cycled
-ORDERED = int(os.environ.get("ST_BENCH_ORDERED", "1"))  # 1 (default): voxelise .. adjacency of the batches in flight take turns; 0: free-running; 2: only the conv sequences
+ORDERED = int(os.environ.get("ST_BENCH_ORDERED", "3"))  # 3 (default): voxelise .. network of the batches in flight take turns; 1: voxelise .. adjacency; 0: free-running; 2: only the conv sequences
 
 
 def build_pipeline(device, weights="noble-elevator-58", voxel=VOXEL, fp16=False, blocking="blocks"):
@@ -192,7 +192,7 @@ class CloudWorker:
         # other's launches last longer.  What overlaps with a batch's chip-filling phase is the others' skeleton stage (one
         # compute unit per tree).  `wide` is held from the start of a batch to Skeletonizer.on_wide_phase_done; the event makes
         # the order hold on the GPU as well.
-        ordered = mode == 1 and S > 1
+        ordered = mode in (1, 3) and S > 1
         conv_ordered = mode == 2 and S > 1
         wide = threading.Lock()
 
@@ -240,13 +240,17 @@ class CloudWorker:
                                     held[0] = False
                                     wide.release()
 
-                            self.pipes[w].skeletonizer.on_wide_phase_done = release
+                            if mode == 3:  # half-phase offset: the next batch may start voxelising once this one's network is enqueued
+                                self.pipes[w].model_inference.on_network_done = release
+                            else:
+                                self.pipes[w].skeletonizer.on_wide_phase_done = release
                         try:
                             parts = self.pipes[w].process_clouds(clouds) if batches[i] > 1 else [self.pipes[w].process_cloud(cloud=clouds[0])]
                         finally:
                             if ordered:
                                 release()  # (a batch without a single graph vertex never reaches the hook)
                                 self.pipes[w].skeletonizer.on_wide_phase_done = None
+                                self.pipes[w].model_inference.on_network_done = None
                         self.last = parts[-1]
                         if collect:
                             for k, sk in enumerate(parts):
@@ -356,7 +360,7 @@ def main():
     #                 clouds differ in cost, a collective per step would make every step as slow as its slowest rank)
     # for the record (one GPU only): the same K steps free-running -- the chip-filling phases of the batches in flight overlap,
     # which fills the bubbles at their host round trips (a few % more throughput) and stretches every kernel's launch bracket
-    S_free = max(1, min(FREE_STREAMS, usable_cores(), max(1, args.steps // 16))) if world == 1 and ORDERED == 1 and args.free_running else 0
+    S_free = max(1, min(FREE_STREAMS, usable_cores(), max(1, args.steps // 16))) if world == 1 and ORDERED in (1, 3) and args.free_running else 0
     worker = CloudWorker(device, max(S, S_free), args.points, rank)
 
     def run_steps(total, upload=False):
@@ -468,6 +472,9 @@ def main():
                        "batches_in_flight_per_gpu": S, "host_threads_per_gpu": S, "warmup_steps_run": warm,
                        "schedule": {1: "the chip-filling phases (voxelise .. adjacency) of the batches in flight take turns; a batch's "
                                        "skeleton stage (one compute unit per tree) overlaps with the other batch's chip-filling phase",
+                                    3: "the batches in flight take turns with voxelise .. network (half a phase apart): a batch's searches / "
+                                       "components / adjacency and its skeleton stage (one compute unit per tree) overlap with the other "
+                                       "batch's voxelisation and network, two networks never share the chip",
                                     0: "free-running", 2: "conv sequences take turns"}.get(ORDERED if S > 1 else 0),
                        "single_cloud_latency_ms": None if serial_ms is None else round(serial_ms, 3)},
             "value_incl_host_upload": world * args.steps * args.points / dt_up,

@@ -64,6 +64,9 @@ class ModelInference:
         self.num_workers = num_workers
         self.batch_size = batch_size
         self.model = load_model(model_path, weights_path, self.device, fp16=fp16)
+        # optional callable, invoked at the end of every forward() when the network's last kernel has been enqueued (see
+        # Skeletonizer.on_wide_phase_done: a caller with several batches in flight can schedule their phases with the two hooks)
+        self.on_network_done = None
         if self.verbose:
             print("Model Loaded Succesfully")
 
@@ -88,6 +91,8 @@ class ModelInference:
         masks = vb.mask
         lc = Cloud(xyz=sparse_input.features, rgb=vb.feats[:, 3:6].contiguous(), medial_vector=mv, class_l=cls,
                    seg_off=vb.seg_vox_off)
+        if self.on_network_done is not None:
+            self.on_network_done()
         # the inner-block filter (reference :97-100) is handed on as a pending mask: Pipeline's filter_by_class folds into it
         return MaskedCloud(lc, masks) if return_masked else lc
 
