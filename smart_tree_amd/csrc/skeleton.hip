@@ -115,6 +115,15 @@ __device__ __forceinline__ T ld(const T* p) { return __hip_atomic_load(p, __ATOM
 __device__ __forceinline__ float ld(const float* p) { return __uint_as_float(ld((const unsigned*)p)); }
 // workgroup-scope load: may be served by this CU's L1 / this XCD's L2
 __device__ __forceinline__ unsigned ld_wg(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ int ld_wg(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ float ld_wg(const float* p) { return __uint_as_float(ld_wg((const unsigned*)p)); }
+// Workgroup-scope read-modify-writes.  The selection state of a component (SkPt records, marks) is touched by ONE workgroup
+// per launch: its atomics need not be coherent across the eight XCDs' L2s.  A device-scope atomic is executed on the memory
+// side of the fabric (calibration: 32 bytes of WRITE_SIZE each, ~12 G/s) and every agent-scope load goes there too; at
+// workgroup scope both stay in this XCD's L2.  Visibility to the NEXT launch comes with the kernel boundary.
+__device__ __forceinline__ void wg_or(unsigned* p, unsigned v) { (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void wg_and(unsigned* p, unsigned v) { (void)__hip_atomic_fetch_and(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void wg_max(int* p, int v) { (void)__hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 // workgroup-wide max of a 64-bit key; every thread must call; lds needs SK_MAX_WAVES words
 __device__ __forceinline__ unsigned long long block_max_u64(unsigned long long v, unsigned long long* lds) {
@@ -621,7 +630,7 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
                 if (j < n) {
                     wv = (int)order[j] - base;
                     wtail = !(A.order_init[base + j] > 0.0f);
-                    live = !wtail && ld(&A.pt[base + wv].alloc) > 0.0f;
+                    live = !wtail && ld_wg(&A.pt[base + wv].alloc) > 0.0f;
                     if (live) {
                         const float* pv = A.pts + 3 * (int64_t)(base + wv);
                         wx = pv[0]; wy = pv[1]; wz = pv[2]; wr = A.rad[base + wv];
@@ -701,7 +710,7 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
             SkSelSlot& S = L.slot[wave];
             const int tip = cand_v[my_ent];
             const int node = lane == 0 ? tip : A.anc[(int64_t)(base + tip) * SK_ANC + lane - 1];
-            const bool end = node < 0 || ld(&A.pt[base + node].term) != 0u;
+            const bool end = node < 0 || ld_wg(&A.pt[base + node].term) != 0u;
             const unsigned long long eb = __ballot(end);
             int big = eb == 0ull, len = 0, termv = -1, nrows = 0, ncand = 0, parent = -1;
             float rp = 0.0f;
@@ -714,7 +723,7 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
                 __builtin_amdgcn_wave_barrier();
                 // the parent id is read BEFORE anything is stamped (path.py:128-136); termination -1 reads
                 // branch_ids[-1] = the last vertex (quirk kept)
-                if (lane == 0 && len >= 2) parent = ld(&A.pt[base + (termv < 0 ? n - 1 : termv)].branch);
+                if (lane == 0 && len >= 2) parent = ld_wg(&A.pt[base + (termv < 0 ? n - 1 : termv)].branch);
                 if (lane < len) {
                     const float r = A.rad[base + node];
                     const float* pv = A.pts + 3 * (int64_t)(base + node);
@@ -792,7 +801,7 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
             const int T = pre[SK_WSLOTS];
             // 3. claims (select_path_points, path.py:19-46), point-centric: the candidates of ALL slots are dealt
             //    out over the workgroup; each finds ITS nearest path vertex from LDS -- no atomics but the mark.
-            if (wave < nc && lane < sl_len[wave]) atomicOr(&cmask[L.slot[wave].path[lane]].mark, 1u << wave);
+            if (wave < nc && lane < sl_len[wave]) wg_or(&cmask[L.slot[wave].path[lane]].mark, 1u << wave);
             unsigned cl_bits = 0u;  // bit k: my k-th item was claimed but did not fit cl_list
             int cl_n = 0;
             const int nround = (T + W - 1) / W;
@@ -837,7 +846,7 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
                         if (d2 < bd2) { bd2 = d2; bq = qi; }
                     }
                     if (bd2 < rp * rp && sqrtf(bd2) < S.p[bq].w) {  // path.py:35-40
-                        atomicOr(&cmask[p].mark, 1u << ss[u]);
+                        wg_or(&cmask[p].mark, 1u << ss[u]);
                         if (cl_n < SK_CL_KEEP) cl_list[cl_n][tid] = (unsigned)p | ((unsigned)ss[u] << 28);
                         else cl_bits |= 1u << (k0 + u);
                         cl_n++;
@@ -851,13 +860,13 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
                 const SkSelSlot& S = L.slot[wave];
                 const int len = sl_len[wave], termv = sl_term[wave];
                 unsigned mk = 0u;
-                if (lane < len) mk = ld(&cmask[S.path[lane]].mark);
-                else if (lane == len) mk = ld(&cmask[termv < 0 ? n - 1 : termv].mark);
+                if (lane < len) mk = ld_wg(&cmask[S.path[lane]].mark);
+                else if (lane == len) mk = ld_wg(&cmask[termv < 0 ? n - 1 : termv].mark);
                 const unsigned walkm = wave_or_u(mk);
                 if (lane == 0) sl_walkm[wave] = walkm;
             }
             unsigned etip = 0u;
-            if (wave == 0 && lane < ne) etip = ld(&cmask[ent_v].mark);
+            if (wave == 0 && lane < ne) etip = ld_wg(&cmask[ent_v].mark);
             __syncthreads();
             if (wave == 0) {  // the sequential replay over the entries, lane e holding entry e
                 if (my_slot >= nc) my_slot = -1;
@@ -892,12 +901,12 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
                 const int len = sl_len[wave], id = sl_id[wave];
                 if (lane < len) {
                     const int v = S.path[lane];
-                    atomicAnd(&cmask[v].mark, ~(1u << wave));
+                    wg_and(&cmask[v].mark, ~(1u << wave));
                     if (id != -2) {
                         if (id >= 0) A.path_verts[base + sl_off[wave] + lane] = v;  // (a dropped path shares its offset with the next one)
                         A.pt[base + v].alloc = -1.0f;
                         A.pt[base + v].term = 1u;
-                        if (id >= 0) atomicMax(&A.pt[base + v].branch, id);
+                        if (id >= 0) wg_max(&A.pt[base + v].branch, id);
                         const unsigned q = (unsigned)(pos[v] - win_base);
                         if (q < (unsigned)W) win_live[q] = 0;
                     }
@@ -913,12 +922,12 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
             for (int j = 0; j < kept_n; j++) {
                 const unsigned e = cl_list[j][tid];
                 const int p = (int)(e & 0x0fffffffu), sidx = (int)(e >> 28);
-                atomicAnd(&cmask[p].mark, ~(1u << sidx));
+                wg_and(&cmask[p].mark, ~(1u << sidx));
                 if ((alive >> sidx) & 1u) {
                     const int id = sl_id[sidx];
                     A.pt[base + p].alloc = -1.0f;
                     A.pt[base + p].term = 1u;
-                    if (id >= 0) atomicMax(&A.pt[base + p].branch, id);
+                    if (id >= 0) wg_max(&A.pt[base + p].branch, id);
                     const unsigned q = (unsigned)(pos[p] - win_base);
                     if (q < (unsigned)W) win_live[q] = 0;
                 }
@@ -935,12 +944,12 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
                 const uint32_t t = (uint32_t)(gi - acc);
                 const int row = sk_find_row(S.row_off, sl_nrows[sidx], t);
                 const int p = (int)__float_as_uint(recs[S.row_first[row] + (t - S.row_off[row])].w) - base;
-                atomicAnd(&cmask[p].mark, ~(1u << sidx));
+                wg_and(&cmask[p].mark, ~(1u << sidx));
                 if ((alive >> sidx) & 1u) {
                     const int id = sl_id[sidx];
                     A.pt[base + p].alloc = -1.0f;
                     A.pt[base + p].term = 1u;
-                    if (id >= 0) atomicMax(&A.pt[base + p].branch, id);
+                    if (id >= 0) wg_max(&A.pt[base + p].branch, id);
                     const unsigned q = (unsigned)(pos[p] - win_base);
                     if (q < (unsigned)W) win_live[q] = 0;
                 }
@@ -956,7 +965,7 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
         for (unsigned chunk = 0; len < 0; chunk += blockDim.x) {
             const unsigned j = chunk + tid;
             const int node = sk_ancestor(A, base, far, j);
-            const bool end = node < 0 || ld(&A.pt[base + node].term) != 0u;
+            const bool end = node < 0 || ld_wg(&A.pt[base + node].term) != 0u;
             if (!end) { if (j < SK_LPATH) L.one.lpath[j] = node; else tmp[j] = (unsigned)node; }
             unsigned long long k = end ? ((unsigned long long)(0xffffffffu - j) << 32) | (unsigned)(node + 1) : 0ull;
             k = block_max_u64(k, s_red);
@@ -971,13 +980,13 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
         // coordinates / radii / cell bounding box into LDS for the claim below.
         const bool keep = len >= 2;
         int parent = -1;
-        if (tid == 0 && keep) parent = ld(&A.pt[base + (s_term < 0 ? n - 1 : s_term)].branch);
+        if (tid == 0 && keep) parent = ld_wg(&A.pt[base + (s_term < 0 ? n - 1 : s_term)].branch);
         int* path_out = A.path_verts + base + total;
         const bool fits = len <= SK_LPATH;
         unsigned long long rk = 0;
         for (int qi = tid; qi < len; qi += blockDim.x) {
             const int w = len - 1 - qi;  // walk order -> root side first
-            const int v = w < SK_LPATH ? L.one.lpath[w] : (int)ld(&tmp[w]);
+            const int v = w < SK_LPATH ? L.one.lpath[w] : (int)ld_wg(&tmp[w]);
             path_out[qi] = v;
             const float r = A.rad[base + v];
             const unsigned long long k = (unsigned long long)st_f2ord(r) << 32;
