@@ -25,6 +25,14 @@ import threading
 import time
 from pathlib import Path
 
+# A bench that starts right after another GPU process has exited -- the round-end sequence pytest -> smoke -> bench -- runs in a
+# slow state for its first ~15-20 s on the gpurun boxes (profiles/r02_after_another_process.txt): 2.5-2.9 ms per cloud instead of
+# 1.30, every stage that ends in a count read-back 5-10x longer; an idle probe of such a read-back shows nothing (20 us).
+# HSA_ENABLE_SDMA=0 (host copies by shader kernels) shortens it, waiting it out removes it: the warm-up lasts until the process
+# is MIN_UPTIME seconds old (with either copy path 1.29-1.30 ms per cloud then; the SDMA engines stay on: faster uploads).
+T_PROCESS = time.perf_counter()
+MIN_UPTIME = float(os.environ.get("ST_BENCH_MIN_UPTIME_S", "30"))  # warm-up lasts at least until the process is this old
+
 import numpy as np
 import torch
 
@@ -385,19 +393,24 @@ def main():
     warm = max(args.warmup, sum(plan)) if args.warmup > 0 and plan else 0
     if warm:
         finished.extend(worker.run(plan + plan_batches(warm - sum(plan), S, B), collect=world > 1, streams=S))
-        # ... repeated until two consecutive passes agree to 5 % (at most 6 more passes / 10 s): a process that starts right
+        # ... repeated until two consecutive passes agree to 5 %: a process that starts right
         # after another GPU process has exited runs with inflated host round trips for its first seconds (measured on the
         # gpurun boxes: 3.0 instead of 1.55 ms per cloud, gone a few seconds later).  Warm-up is untimed; the K steps
         # are timed once.
-        prev, t_start = None, time.perf_counter()
-        for _ in range(6):
+        # ... and for at least MIN_UPTIME seconds of process life.  Measured on the gpurun boxes (profiles/
+        # r02_after_another_process.txt): in the round-end sequence pytest -> smoke -> bench the passes of the first ~15-20 s
+        # agree with each other at 2.5-2.9 ms per cloud (the two-passes-agree rule alone stopped there) and then drop to 1.3.
+        prev = None
+        while True:
+            finished.clear()  # (multi-rank: only the last warm-up pass is gathered)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             finished.extend(worker.run(plan, collect=world > 1, streams=S))
             torch.cuda.synchronize()
             cur = time.perf_counter() - t0
             warm += sum(plan)
-            if (prev is not None and abs(cur - prev) <= 0.05 * prev) or time.perf_counter() - t_start > 10.0:
+            uptime = time.perf_counter() - T_PROCESS
+            if (prev is not None and abs(cur - prev) <= 0.05 * prev and uptime >= MIN_UPTIME) or uptime > MIN_UPTIME + 45.0:
                 break
             prev = cur
     gather()
@@ -476,7 +489,8 @@ def main():
                                        "components / adjacency and its skeleton stage (one compute unit per tree) overlap with the other "
                                        "batch's voxelisation and network, two networks never share the chip",
                                     0: "free-running", 2: "conv sequences take turns"}.get(ORDERED if S > 1 else 0),
-                       "single_cloud_latency_ms": None if serial_ms is None else round(serial_ms, 3)},
+                       "single_cloud_latency_ms": None if serial_ms is None else round(serial_ms, 3),
+                       "warmup_until_process_age_s": MIN_UPTIME},
             "value_incl_host_upload": world * args.steps * args.points / dt_up,
             "parity_note": "results are checked against oracle/ (a CPU restatement pinned by goldens that the reference's own "
                            "glue code produced); the semantics of the reference's un-vendored third-party packages (spconv "

@@ -1,4 +1,5 @@
 # GPU box: kernel statistics of one batch of 24 clouds at a time (solo durations), top kernels in us per cloud
+export ST_BENCH_MIN_UPTIME_S=${ST_BENCH_MIN_UPTIME_S:-0}  # developer sweeps: no minimum warm-up time
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_x

@@ -1,4 +1,5 @@
 # GPU box: average duration of the SSSP / select launches of one batch of 24 clouds at a time under different launch shapes
+export ST_BENCH_MIN_UPTIME_S=${ST_BENCH_MIN_UPTIME_S:-0}  # developer sweeps: no minimum warm-up time
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 for p in "6=4" "6=6" "6=8" "6=12" "6=8,8=32"; do

@@ -1,5 +1,6 @@
 # GPU box: what the skeleton stage costs the batched pipeline, and the SSSP launch shape (ST_SKELETON_PARAMS 10 = workgroups,
 # 8 = lanes per frontier vertex, 6 = levels per launch).  ST_DIAG_STAGES=1 runs SSSP only (no branch selection: zero branches).
+export ST_BENCH_MIN_UPTIME_S=${ST_BENCH_MIN_UPTIME_S:-0}  # developer sweeps: no minimum warm-up time
 cd $GRAFT_REPO_ROOT
 run() { # label, env...
   label=$1; shift
