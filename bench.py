@@ -403,6 +403,7 @@ def main():
         prev = None
         while True:
             finished.clear()  # (multi-rank: only the last warm-up pass is gathered)
+            profiling.enable(True)  # the warm-up passes run exactly what the timed pass runs, kernel timers included
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             finished.extend(worker.run(plan, collect=world > 1, streams=S))
@@ -413,6 +414,10 @@ def main():
             if (prev is not None and abs(cur - prev) <= 0.05 * prev and uptime >= MIN_UPTIME) or uptime > MIN_UPTIME + 45.0:
                 break
             prev = cur
+        profiling.enable(False)
+        warm_last_ms = 1e3 * cur / max(sum(plan), 1)
+    else:
+        warm_last_ms = None
     gather()
     fence()
     serial_ms = worker.serial_ms() if warm > 0 else None
@@ -490,7 +495,8 @@ def main():
                                        "batch's voxelisation and network, two networks never share the chip",
                                     0: "free-running", 2: "conv sequences take turns"}.get(ORDERED if S > 1 else 0),
                        "single_cloud_latency_ms": None if serial_ms is None else round(serial_ms, 3),
-                       "warmup_until_process_age_s": MIN_UPTIME},
+                       "warmup_until_process_age_s": MIN_UPTIME,
+                       "last_warmup_pass_ms_per_step": None if warm_last_ms is None else round(warm_last_ms, 3)},
             "value_incl_host_upload": world * args.steps * args.points / dt_up,
             "parity_note": "results are checked against oracle/ (a CPU restatement pinned by goldens that the reference's own "
                            "glue code produced); the semantics of the reference's un-vendored third-party packages (spconv "

@@ -1,9 +1,10 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -x -q 2>&1 | tail -2
-python tools/parity_stress.py 2>&1 | tail -1
-python tools/diag_phases.py 1000000 0.02 0 0 2>&1 | grep "^params\|phases" | cut -c1-330
-python tools/diag_phases.py 5000000 0.01 0.6 3 2>&1 | grep "^params\|phases" | cut -c1-330
-bash tools/run_prof_solo.sh 2>&1 | grep "ms_per_step\|total\|k_sk_select\|k_sk_sssp\|k_sk_claim"
-for i in 1 2; do python bench.py --no-cpu-baseline --no-extras | python -c "
+p() { python -c "
 import json,sys
-d=json.loads(sys.stdin.read()); print('bench: %.3f ms/cloud, single %.2f ms, frac %.3f' % (d['ms_per_step'], d['config']['single_cloud_latency_ms'], d['roofline']['frac']))"; done
+d=json.load(open('$1')); s=d['stage_ms']; print('$2: %.3f ms/cloud, upload-inclusive %.3f, outlier_removal stage %.3f, warm-up clouds %d' % (d['ms_per_step'], 1e9/d['value_incl_host_upload'], s['outlier_removal'], d['config']['warmup_steps_run']))"; }
+timeout -s KILL 600 python bench.py > /tmp/a.json 2>/dev/null; p /tmp/a.json "full (1)"
+timeout -s KILL 600 python bench.py --no-cpu-baseline --no-extras > /tmp/b.json 2>/dev/null; p /tmp/b.json "no baseline / extras (2)"
+timeout -s KILL 600 python bench.py > /tmp/c.json 2>/dev/null; p /tmp/c.json "full (3)"
+timeout -s KILL 600 python bench.py --no-extras > /tmp/d.json 2>/dev/null; p /tmp/d.json "no extras (4)"
+timeout -s KILL 600 python bench.py --no-cpu-baseline > /tmp/e.json 2>/dev/null; p /tmp/e.json "no baseline (5)"
+nproc; uptime
