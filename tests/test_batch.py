@@ -189,3 +189,10 @@ def test_process_clouds_edge_cases(backend):
     tiny = _clouds(backend, sizes=(25, 30))
     parts = pipe.process_clouds([Cloud(c.xyz, c.rgb) for c in tiny])
     assert len(parts) == 2 and all(len(p.skeletons) == 0 for p in parts)
+    # the phase hooks a caller with several batches in flight schedules by (bench.py): once per call, in order, results unchanged
+    calls = []
+    pipe.model_inference.on_network_done = lambda: calls.append("network")
+    pipe.skeletonizer.on_wide_phase_done = lambda: calls.append("wide")
+    (again,) = pipe.process_clouds([Cloud(clouds[0].xyz, clouds[0].rgb)])
+    assert calls == ["network", "wide"] and _signature(again) == _signature(one)
+    pipe.model_inference.on_network_done = pipe.skeletonizer.on_wide_phase_done = None
