@@ -178,6 +178,23 @@ def test_config2_batch_of_million_point_trees_equals_one_at_a_time():
             assert len(one) > 100 and _signature(got) == one
 
 
+@pytest.mark.gpu
+def test_bench_sized_batch_equals_one_at_a_time():
+    """The batch `bench.py` times: 64 x 1M-point clouds (4 distinct trees, cycled) through ONE launch set -- the largest batch
+    the library takes (ST_MAX_SEG) -- gives every cloud the skeleton it gets alone."""
+    dev = torch.device("cuda:0")
+    distinct = []
+    for seed in (0, 1, 2, 3):
+        c = sample_tree_cloud(1_000_000, seed=seed)
+        distinct.append(Cloud(xyz=torch.from_numpy(c["xyz"]).to(dev), rgb=torch.from_numpy(c["rgb"]).to(dev)))
+    pipe = _pipeline(dev, 0.02)
+    serial = [_signature(pipe.process_cloud(cloud=c)) for c in distinct]
+    parts = pipe.process_clouds([distinct[k % 4] for k in range(64)])
+    assert len(parts) == 64
+    for k, got in enumerate(parts):
+        assert len(serial[k % 4]) > 100 and _signature(got) == serial[k % 4]
+
+
 def test_process_clouds_edge_cases(backend):
     """An empty list, a batch of one, and a batch whose clouds give no skeleton at all (too few points for a block)."""
     pipe = _pipeline(backend, 0.04)
