@@ -361,7 +361,11 @@ def main():
     # OpenMP pool spinning on every core beside them only takes cycles from the launch threads (the CPU baseline sets its own)
     torch.set_num_threads(int(os.environ.get("ST_BENCH_TORCH_THREADS", "1")))
 
-    S = max(1, min(args.streams, max(1, usable_cores() // max(world, 1))))
+    # host budget: a worker thread keeps one core busy (measured: 1.92 cores for 2 batches in flight, 1.01 for one) and the HIP
+    # runtime's helper threads, the main thread and the collective's proxy want their share: two cores per worker thread and
+    # one per rank, or fewer batches in flight (one in flight costs 14 % at 64 clouds per batch: 1.47 instead of 1.29 ms per
+    # cloud; a throttled cgroup costs more)
+    S = max(1, min(args.streams, max(1, (usable_cores() - world) // (2 * max(world, 1)))))
     S = max(1, min(S, args.steps // 16), min(S, 3, args.steps // 6))  # see plan_batches
     B = max(1, min(args.batch, 64))
     finished = []  # packed skeletons of this rank, gathered to rank 0 once per timed region (no per-step rendezvous:
@@ -423,11 +427,14 @@ def main():
     serial_ms = worker.serial_ms() if warm > 0 else None
     fence()
     profiling.enable(True)
+    cpu0 = os.times()
     t0 = time.perf_counter()
     run_steps(args.steps)  # returns when every worker has synchronised its streams
     gather()  # inside the timed region: the skeletons of all ranks end up on rank 0
     fence()
     dt = time.perf_counter() - t0
+    cpu1 = os.times()
+    host_cores_used = ((cpu1.user - cpu0.user) + (cpu1.system - cpu0.system)) / max(dt, 1e-9)  # this rank's process
     profiling.enable(False)
     roof = profiling.roofline(HBM_PEAK_GBS, clouds_per_launch=max(plan_batches(args.steps, S, B)))
     stage_ms = profiling.stage_ms(args.steps)
@@ -496,6 +503,7 @@ def main():
                                     0: "free-running", 2: "conv sequences take turns"}.get(ORDERED if S > 1 else 0),
                        "single_cloud_latency_ms": None if serial_ms is None else round(serial_ms, 3),
                        "warmup_until_process_age_s": MIN_UPTIME,
+                       "host_cpu_cores_busy_in_timed_region": round(host_cores_used, 2),
                        "last_warmup_pass_ms_per_step": None if warm_last_ms is None else round(warm_last_ms, 3)},
             "value_incl_host_upload": world * args.steps * args.points / dt_up,
             "parity_note": "results are checked against oracle/ (a CPU restatement pinned by goldens that the reference's own "
