@@ -342,6 +342,14 @@ def main():
     dryrun = os.environ.get("ST_BENCH_DRYRUN") == "1"
     if dryrun:
         local_rank = 0
+    blocking = os.environ.get("ST_BENCH_BLOCKING_SYNC", "1") == "1"
+    if blocking:
+        # host waits block on the completion interrupt instead of spinning (hipDeviceScheduleBlockingSync = 4; must be set
+        # before the device's context exists).  Measured: 0.2 host cores busy instead of 1.93 for two batches in flight, at
+        # 1.297-1.302 instead of 1.288-1.292 ms per cloud -- eight ranks need two cores, not sixteen.
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        assert hip.hipSetDevice(local_rank) == 0 and hip.hipSetDeviceFlags(4) == 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist
@@ -361,11 +369,11 @@ def main():
     # OpenMP pool spinning on every core beside them only takes cycles from the launch threads (the CPU baseline sets its own)
     torch.set_num_threads(int(os.environ.get("ST_BENCH_TORCH_THREADS", "1")))
 
-    # host budget: a worker thread keeps one core busy (measured: 1.92 cores for 2 batches in flight, 1.01 for one) and the HIP
-    # runtime's helper threads, the main thread and the collective's proxy want their share: two cores per worker thread and
-    # one per rank, or fewer batches in flight (one in flight costs 14 % at 64 clouds per batch: 1.47 instead of 1.29 ms per
-    # cloud; a throttled cgroup costs more)
-    S = max(1, min(args.streams, max(1, (usable_cores() - world) // (2 * max(world, 1)))))
+    # host budget: with spinning waits a worker thread keeps one core busy (1.92 cores for 2 batches in flight, 1.01 for one) and
+    # the HIP runtime's helper threads, the main thread and the collective's proxy want their share -- two cores per worker thread
+    # and one per rank, or fewer batches in flight (one in flight costs 14 % at 64 clouds per batch: 1.47 instead of 1.29 ms per
+    # cloud; a throttled cgroup costs more).  With blocking waits (the default) a worker needs a fifth of a core.
+    S = max(1, min(args.streams, max(1, (usable_cores() - world) // ((1 if blocking else 2) * max(world, 1)))))
     S = max(1, min(S, args.steps // 16), min(S, 3, args.steps // 6))  # see plan_batches
     B = max(1, min(args.batch, 64))
     finished = []  # packed skeletons of this rank, gathered to rank 0 once per timed region (no per-step rendezvous:
@@ -504,6 +512,7 @@ def main():
                        "single_cloud_latency_ms": None if serial_ms is None else round(serial_ms, 3),
                        "warmup_until_process_age_s": MIN_UPTIME,
                        "host_cpu_cores_busy_in_timed_region": round(host_cores_used, 2),
+                       "host_waits": "blocking (hipDeviceScheduleBlockingSync)" if blocking else "spinning (HIP default)",
                        "last_warmup_pass_ms_per_step": None if warm_last_ms is None else round(warm_last_ms, 3)},
             "value_incl_host_upload": world * args.steps * args.points / dt_up,
             "parity_note": "results are checked against oracle/ (a CPU restatement pinned by goldens that the reference's own "
