@@ -59,6 +59,7 @@ def build_pipeline(device, weights="noble-elevator-58", voxel=VOXEL, fp16=False,
     mi = ModelInference(f"{weights}_model.pt", WEIGHTS / f"{weights}.npz", voxel_size=voxel, block_size=4, buffer_size=0.4,
                         device=device, fp16=fp16, blocking=blocking)
     sk = Skeletonizer(K=16, min_connection_length=0.02, minimum_graph_vertices=32, device=device)
+    sk.block_threads = int(os.environ.get("ST_BENCH_SELECT_THREADS", "0"))  # developer knob: lanes of the per-tree selection workgroup
     return Pipeline(AugmentationPipeline([CentreCloud()]), mi, sk, repair_skeletons=True, smooth_skeletons=True,
                     smooth_kernel_size=11, prune_skeletons=True, min_skeleton_radius=0.01, min_skeleton_length=0.02,
                     device=device)
