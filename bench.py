@@ -14,6 +14,11 @@ Prints ONE JSON line (rank 0): throughput, the roofline of the dominant kernel m
 launch stream, the aggregate gather-GEMM roofline, and -- at N = 1 -- the CPU baseline (the oracle: a port of the
 reference algorithm; the reference itself is CUDA-only) timed on this host's cores on one full cloud, whose skeleton
 is also compared with the GPU's for the same cloud (`parity_in_run`).
+
+Environment (all optional): ST_BENCH_ORDERED 3 (default: batches in flight take turns with voxelise .. network) / 1 (with the
+whole chip-filling phase) / 0 (free-running); ST_BENCH_MIN_UPTIME_S (30: the warm-up lasts until the process is that old);
+ST_BENCH_BLOCKING_SYNC (1: host waits block instead of spinning); ST_BENCH_TORCH_THREADS (1); ST_BENCH_SELECT_THREADS,
+ST_SKELETON_PARAMS (developer knobs); ST_BENCH_DRYRUN=1 (multi-rank control flow on one GPU over gloo).
 """
 from __future__ import annotations
 
