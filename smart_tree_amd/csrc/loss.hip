@@ -46,7 +46,9 @@ __global__ void __launch_bounds__(LS_BLOCK) k_loss_partial(LsArgs A, double* par
         if (A.mask && !A.mask[i]) continue;
         const float* t = A.targets + 5 * i;
         const float tcf = t[4];
-        const long long tc = (long long)tcf;  // .long(): truncation
+        // .long(): truncation.  A NaN / infinite class id has no defined conversion: it is reported like an id outside the logits
+        const bool tc_ok = tcf > -1.0f && tcf < (float)C;
+        const long long tc = tc_ok ? (long long)tcf : -1ll;
         // class terms (every masked row)
         const float* z = A.class_l + (int64_t)C * i;
         float zmax = z[0];
@@ -56,7 +58,7 @@ __global__ void __launch_bounds__(LS_BLOCK) k_loss_partial(LsArgs A, double* par
         const float lse = logf(se);
         acc[4] += 1.0;
         acc[6] += 1.0;  // a softmax row sums to one
-        if (tc >= 0 && tc < C) {
+        if (tc_ok) {
             const float logpt = (z[tc] - zmax) - lse;  // log_softmax
             const float pt = expf(logpt);
             const float om = 1.0f - pt;

@@ -53,11 +53,16 @@ class Cloud:
         changed = {name: fn(getattr(self, name)) for name in _PER_POINT if getattr(self, name) is not None}
         return replace(self, **changed)
 
-    def filter(self, mask) -> "Cloud":
-        """Boolean-mask or index gather of every per-point field (reference cloud.py:72-95)."""
+    def filter(self, mask, assume_sorted: bool = False) -> "Cloud":
+        """Boolean-mask or index gather of every per-point field (reference cloud.py:72-95).  A batch of clouds (`seg_off`)
+        can only be cut by a selection that keeps the points in order -- a boolean mask, or a strictly increasing index
+        (checked, unless the caller vouches for it with `assume_sorted`): anything else would mix the clouds."""
         mask = mask.to(self.xyz.device)
         if mask.dtype == torch.bool:  # one compaction (one host sync) for all fields instead of one per field
             mask = mask.nonzero().view(-1)
+        elif self.seg_off is not None and not assume_sorted and mask.numel() > 1 and not bool((mask[1:] > mask[:-1]).all()):
+            raise ValueError("Cloud.filter: a batch of clouds (seg_off) needs a boolean mask or a strictly increasing index; "
+                             "split() the batch before reordering / resampling its points")
         out = self._map(lambda t: t.index_select(0, mask))
         if self.seg_off is not None:  # batched: the clouds' new ranges (`mask` must keep the points in order)
             out.seg_off = torch.searchsorted(mask, self.seg_off.to(mask.dtype)).to(torch.int32)
@@ -122,15 +127,16 @@ class Cloud:
         return self.filter(by_voxel[starts])
 
     # -- geometry (these drop every field but xyz/rgb, as the reference does: cloud.py:194-202)
+    #    -- the batch offsets are kept: these ops leave the point order alone)
     def scale(self, factor) -> "Cloud":
-        return Cloud(self.xyz * factor, self.rgb)
+        return Cloud(self.xyz * factor, self.rgb, seg_off=self.seg_off)
 
     def translate(self, offset) -> "Cloud":
-        return Cloud(self.xyz + offset.to(self.xyz.device), self.rgb)
+        return Cloud(self.xyz + offset.to(self.xyz.device), self.rgb, seg_off=self.seg_off)
 
     def rotate(self, rot_mat) -> "Cloud":
         rot_mat = rot_mat.to(device=self.xyz.device, dtype=self.xyz.dtype)
-        return Cloud(self.xyz @ rot_mat, self.rgb)
+        return Cloud(self.xyz @ rot_mat, self.rgb, seg_off=self.seg_off)
 
     @property
     def max_xyz(self) -> torch.Tensor:

@@ -88,7 +88,9 @@ _FUSED_CLASS = {focal_loss: _OUT["focal"], dice_loss: _OUT["dice"]}
 
 def compute_loss(preds, targets, mask=None, radius_loss_fn=None, direction_loss_fn=None, class_loss_fn=None,
                  target_radius_log=True, vector_class=None):
-    """loss.py:7-51.  preds: {"radius" [n,1], "direction" [n,3], "class_l" [n,C]}; targets [n,5] = radius, direction, class."""
+    """loss.py:7-51.  preds: {"radius" [n,1], "direction" [n,3], "class_l" [n,C]}; targets [n,5] = radius, direction, class.
+    The fused dice term one-hot encodes over the C classes of the logits; the reference's `F.one_hot(targets)` infers the width
+    from the largest id PRESENT and raises a shape mismatch for a batch that lacks class C-1 -- here such a batch is evaluated."""
     if radius_loss_fn is L1Loss and direction_loss_fn is cosine_similarity_loss and class_loss_fn in _FUSED_CLASS:
         out = _forward(preds["radius"], preds["direction"], preds["class_l"], targets, mask, vector_class, target_radius_log)
         return {"radius": out[0], "direction": out[1], "class_l": out[_FUSED_CLASS[class_loss_fn]]}
@@ -105,3 +107,23 @@ def compute_loss(preds, targets, mask=None, radius_loss_fn=None, direction_loss_
         t_rad = torch.log(t_rad)
     return {"radius": radius_loss_fn(radius.view(-1), t_rad.view(-1)), "direction": direction_loss_fn(direction, t_dir),
             "class_l": class_loss_fn(class_l, t_class)}
+
+
+@torch.no_grad()
+def evaluate_losses(batches, model, loss_fn, device=None) -> dict:
+    """Forward-only evaluation of collated batches (`model.sparse.batch_collate` items: ((inputs, targets), coords, loss_mask,
+    names)): every batch through the network and `loss_fn(preds, targets, mask)`; returns the mean of each loss term over the
+    batches plus their sum under "total".  This is the part of the reference's validation pass (train.py:61-84) that is a
+    forward computation; the optimiser loop, the logger and the backward pass are out of scope."""
+    from .sparse import sparse_from_batch
+
+    device = torch.device(device) if device is not None else torch.device("cuda")
+    sums, count = {}, 0
+    for (feats, target_feats), coords, mask, _ in batches:
+        preds = model.forward(sparse_from_batch(feats, coords, device=device))
+        for k, v in loss_fn(preds, target_feats.to(device), mask.to(device)).items():
+            sums[k] = sums.get(k, 0.0) + float(v)
+        count += 1
+    out = {k: v / max(count, 1) for k, v in sums.items()}
+    out["total"] = sum(out.values())
+    return out

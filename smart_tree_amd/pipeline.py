@@ -81,6 +81,8 @@ class Pipeline:
         batch = Cloud.collate([Cloud(c.xyz, c.rgb if c.rgb is not None else torch.zeros_like(c.xyz)) for c in clouds])
         with profiling.stage("preprocess"):
             batch = self.preprocessing(batch)
+        if batch.n_seg != len(clouds):  # an augmentation that rebuilt the Cloud without its batch offsets would merge the inputs
+            raise RuntimeError(f"process_clouds: preprocessing returned {batch.n_seg} cloud(s) for a batch of {len(clouds)}")
         lc = self.model_inference.forward(batch).to_device(self.device)
         self.last_labelled_cloud = lc
         with profiling.stage("class_filter"):
@@ -89,6 +91,8 @@ class Pipeline:
         with profiling.stage("post_process"):
             self.post_process(skeleton)
             parts = skeleton.split()  # device post-processing of all clouds, ONE device-to-host copy, per-cloud views
+        if len(parts) != len(clouds):
+            raise RuntimeError(f"process_clouds: {len(parts)} skeleton(s) for a batch of {len(clouds)} clouds")
         if self.view_model_output or self.view_skeletons:
             raise NotImplementedError("viewing needs open3d, which is out of scope of smart_tree_amd")
         return parts

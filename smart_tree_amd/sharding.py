@@ -4,8 +4,9 @@ The reference is single-GPU (`cuda:0` literals everywhere).  Tree clouds are ind
 no shared state, BatchNorm in eval mode -- so a batch of clouds is split round-robin over the
 ranks (one process per GPU) and every rank runs the whole pipeline on its own clouds with no
 data-path collective.  The only communication is the variable-length gather of the finished
-skeletons to rank 0: `all_gather` of the packed sizes, then `all_gather` of the padded payloads
-(KBs per cloud -- xGMI bandwidth is irrelevant; RCCL when the backend is "nccl", gloo in the CPU tests).
+skeletons to rank 0: `all_gather` of the packed sizes (16 bytes per rank: every rank needs the padded
+length), then ONE `gather` of the padded payloads to rank 0 only (KBs per cloud -- xGMI bandwidth is
+irrelevant; RCCL when the backend is "nccl", gloo in the CPU tests).
 """
 from __future__ import annotations
 
@@ -49,9 +50,10 @@ def unpack_skeletons(table: torch.Tensor, geom: torch.Tensor) -> dict:
     return {c: DisjointTreeSkeleton([trees[k] for k in sorted(trees)]) for c, trees in clouds.items()}
 
 
-def gather_skeletons(packed: Sequence, device=None):
+def gather_skeletons(packed: Sequence, device=None, always_collective: bool = False):
     """Every rank passes [(table, geom), ...] for its clouds; rank 0 gets ([table], [geom]) per rank
-    (others get None).  Works on any initialised process group; falls through when not distributed."""
+    (others get None).  Works on any initialised process group; falls through when not distributed (or when the group
+    has one rank, unless `always_collective`: tests/test_sharding.py runs the RCCL calls on a one-rank "nccl" group)."""
     tables = [t for t, _ in packed]
     geoms = [g for _, g in packed]
     # offsets in each table are relative to its own geom block: make them relative to the rank's block
@@ -63,7 +65,7 @@ def gather_skeletons(packed: Sequence, device=None):
         fixed.append(t)
     table = torch.cat(fixed) if fixed else torch.zeros((0, 6), dtype=torch.int64)
     geom = torch.cat(geoms) if geoms else torch.zeros((0, 4), dtype=torch.float32)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not always_collective):
         return [table], [geom]
     world, rank = dist.get_world_size(), dist.get_rank()
     dev = device if device is not None else torch.device("cpu")
@@ -76,10 +78,12 @@ def gather_skeletons(packed: Sequence, device=None):
     pg = torch.zeros((max_pts, 4), dtype=torch.float32, device=dev)
     pt[: table.shape[0]] = table.to(dev)
     pg[: geom.shape[0]] = geom.to(dev)
-    out_t = [torch.zeros_like(pt) for _ in range(world)]
-    out_g = [torch.zeros_like(pg) for _ in range(world)]
-    dist.all_gather(out_t, pt)
-    dist.all_gather(out_g, pg)
+    # one payload per rank (the int64 table bit-cast behind the float32 geometry would save a call; two calls keep the
+    # dtypes honest), received by rank 0 only
+    out_t = [torch.zeros_like(pt) for _ in range(world)] if rank == 0 else None
+    out_g = [torch.zeros_like(pg) for _ in range(world)] if rank == 0 else None
+    dist.gather(pt, gather_list=out_t, dst=0)
+    dist.gather(pg, gather_list=out_g, dst=0)
     if rank != 0:
         return None, None
     return ([out_t[r][: int(all_sizes[r][0])].cpu() for r in range(world)],

@@ -121,7 +121,7 @@ class Skeletonizer:
             medial, radius = medial_points(cloud.xyz, cloud.medial_vector)
             mask = outlier_removal(medial, radius.unsqueeze(1), nb_points=8, seg_off=cloud.seg_off)
             keep = mask.nonzero().view(-1)  # one compaction (one host sync) shared by every field
-            cloud = cloud.filter(keep)
+            cloud = cloud.filter(keep, assume_sorted=True)  # nonzero(): ascending
             medial, radius = medial.index_select(0, keep), radius.index_select(0, keep)
         with profiling.stage("nn_graph"):
             graph = nn_graph(medial, radius.clamp(min=self.min_connection_length), K=self.K, seg_off=cloud.seg_off)

@@ -1,5 +1,6 @@
 """Host-side containers that defer a compaction: MaskedCloud (ModelInference.forward's result) and PaddedGraph
 (nn_graph's result) must read exactly like the eager objects of the reference (cloud.py:72-103, graph.py:15-31)."""
+import pytest
 import torch
 
 from smart_tree_amd.data_types.cloud import Cloud, MaskedCloud
@@ -48,3 +49,20 @@ def test_padded_graph_cuts_the_reference_views():
     assert torch.equal(g.edges, edges[:4]) and torch.equal(g.edge_weights, w[:4])
     moved = g.to_device("cpu")
     assert type(moved) is Graph and torch.equal(moved.edges, edges[:4])
+
+
+def test_batch_offsets_survive_geometry_ops_and_refuse_reordering():
+    """scale / translate / rotate keep `seg_off` (they leave the point order alone); a selection that does not
+    keep the order (RandomDropout's with-replacement gather) raises instead of silently merging the clouds of a batch."""
+    a = Cloud(xyz=torch.rand(50, 3), rgb=torch.rand(50, 3))
+    b = Cloud(xyz=torch.rand(70, 3) + 2.0, rgb=torch.rand(70, 3))
+    batch = Cloud.collate([a, b])
+    for moved in (batch.scale(2.0), batch.translate(torch.tensor([1.0, 0.0, 0.0])), batch.rotate(torch.eye(3))):
+        assert moved.n_seg == 2 and moved.seg_off.tolist() == [0, 50, 120]
+    kept = batch.filter(torch.tensor([3, 10, 60, 119]))
+    assert kept.seg_off.tolist() == [0, 2, 4]
+    with pytest.raises(ValueError, match="strictly increasing"):
+        batch.filter(torch.tensor([3, 3, 60]))
+    with pytest.raises(ValueError, match="strictly increasing"):
+        batch.filter(torch.tensor([60, 3]))
+    assert len(a.filter(torch.tensor([5, 5, 1]))) == 3  # a single cloud may be resampled freely

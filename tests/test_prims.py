@@ -6,12 +6,7 @@ import torch
 from smart_tree_amd import _lib
 
 
-@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 2047, 2048, 2049, 4095, 4096, 4097, 70001,
-                               pytest.param(4_300_003, marks=pytest.mark.gpu),  # > 1024 tiles: the recursive tile-offset scan
-                               pytest.param(51_000_001, marks=pytest.mark.gpu)])  # the cell table of a batched kNN grid
-def test_exclusive_scan(backend, n):
-    if n > 1_000_000 and backend.type == "cpu":
-        pytest.skip("large scans run on the GPU")
+def _check_scan(backend, n):
     L = _lib.lib()
     a = np.random.RandomState(n).randint(0, 7, n).astype(np.int32)
     t = torch.from_numpy(a).to(backend)
@@ -22,6 +17,19 @@ def test_exclusive_scan(backend, n):
     ref = np.cumsum(a) - a
     np.testing.assert_array_equal(out.cpu().numpy()[:n], ref)
     assert int(total.cpu()[0]) == int(a.sum())
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 2047, 2048, 2049, 4095, 4096, 4097, 70001])
+def test_exclusive_scan(backend, n):
+    _check_scan(backend, n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [4_300_003,    # > 1024 tiles: the recursive tile-offset scan
+                               51_000_001])  # the cell table of a batched kNN grid
+def test_exclusive_scan_large(n):
+    assert torch.cuda.is_available()
+    _check_scan(torch.device("cuda:0"), n)
 
 
 @pytest.mark.parametrize("n,bits", [(2, 8), (1000, 5), (1025, 13), (40001, 32)])

@@ -4,6 +4,7 @@ import os
 from pathlib import Path
 import socket
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -82,6 +83,36 @@ def test_gather_world_size_2_gloo():
     for i in range(n_clouds):
         t, g = (torch.from_numpy(a) for a in got[i])
         _same(unpack_skeletons(t, g)[i], _fake_skeleton(i))
+
+
+@pytest.mark.gpu
+def test_rccl_one_rank_group_runs_the_collectives():
+    """No 8-GPU node is available to the builder: the "nccl" (= RCCL) branch at least EXECUTES here -- communicator init on
+    cuda:0, the size all_gather + payload gathers of gather_skeletons on device tensors, and bench.py's all_reduce(MAX) and
+    barrier -- on a one-rank group.  (Scaling itself stays unmeasured until the driver's SCALE run exists.)"""
+    assert torch.cuda.is_available()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        assert dist.get_backend() == "nccl"
+        packed = [pack_skeleton(_fake_skeleton(i), cloud_id=i) for i in range(3)]
+        tables, geoms = gather_skeletons(packed, device=dev, always_collective=True)
+        assert len(tables) == 1 and not tables[0].is_cuda
+        merged = unpack_skeletons(tables[0], geoms[0])
+        for i in range(3):
+            _same(merged[i], _fake_skeleton(i))
+        t = torch.tensor([1.5, 2.5], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        torch.cuda.synchronize()
+        assert t.tolist() == [1.5, 2.5]
+    finally:
+        dist.destroy_process_group()
 
 
 def test_bench_batch_plan():

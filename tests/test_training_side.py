@@ -1,5 +1,5 @@
 """Training / evaluation-side forward path: TreeDataset.process_cloud + batch_collate, the three losses,
-eval_epoch -- HIP path vs oracle/loss_oracle.py and the golden vectors produced by the reference's own loss.py / dataset.py
+evaluate_losses -- HIP path vs oracle/loss_oracle.py and the golden vectors produced by the reference's own loss.py / dataset.py
 (tools/make_goldens.py: loss_case, tree_dataset_case)."""
 import json
 from pathlib import Path
@@ -17,7 +17,6 @@ from smart_tree_amd.dataset.dataset import TreeDataset, voxelize_cloud
 from smart_tree_amd.model import loss as L
 from smart_tree_amd.model.model import Smart_Tree
 from smart_tree_amd.model.sparse import batch_collate
-from smart_tree_amd.model.train import eval_epoch, train_epoch
 from smart_tree_amd.synthetic import sample_tree_cloud
 
 GOLDEN = Path(__file__).parent / "golden"
@@ -130,8 +129,11 @@ def test_loss_edge_cases(backend):
     bad[7, 4] = 2.0  # class id outside the logits: torch's gather raises, so does the kernel
     with pytest.raises(_lib.StError, match="class ids outside"):
         L.compute_loss(preds, t(bad), None, *fns)
-    with pytest.raises(NotImplementedError):
-        train_epoch()
+    for junk in (np.nan, np.inf, -np.inf):  # a non-finite class id is reported the same way (no undefined float -> int cast)
+        bad = targets.copy()
+        bad[3, 4] = junk
+        with pytest.raises(_lib.StError, match="class ids outside"):
+            L.compute_loss(preds, t(bad), None, *fns)
 
 
 def _write_split(tmp_path, clouds):
@@ -218,8 +220,8 @@ def test_augmentations(backend):
     assert abs(pipe(cloud).xyz[:, 1].min().item() - 1.0) < 1e-5
 
 
-def test_eval_epoch_is_forward_plus_losses(backend, tmp_path):
-    """Two labelled clouds through TreeDataset -> batch_collate -> the HIP network -> the fused losses; the tracker's numbers equal
+def test_evaluate_losses_is_forward_plus_losses(backend, tmp_path):
+    """Two labelled clouds through TreeDataset -> batch_collate -> the HIP network -> the fused losses; the mean losses equal
     the float64 oracle network + oracle losses on the same voxels (1e-3: the network's float32 accumulation order)."""
     from test_unet import random_state_dict
 
@@ -230,10 +232,10 @@ def test_eval_epoch_is_forward_plus_losses(backend, tmp_path):
     w = random_state_dict(uo.load_weights(WEIGHTS / "noble-elevator-58.npz"), seed=1)
     net = Smart_Tree(w, device=backend)
     fn = lambda p, t, m: L.compute_loss(p, t, m, L.L1Loss, L.cosine_similarity_loss, L.focal_loss, vector_class=0)
-    tracker = eval_epoch(loader, net, fn, device=backend)
+    got = L.evaluate_losses(loader, net, fn, device=backend)
     (inputs, targets), coords, mask, _ = loader[0]
     ref_preds = uo.OracleNet(w, dtype=torch.float64).forward(inputs.cpu().numpy(), coords.cpu().numpy())
     ref = lo.compute_loss(ref_preds, targets.cpu().numpy(), mask=mask.cpu().numpy(), vector_class=0)
-    np.testing.assert_allclose([tracker.radius_loss, tracker.direction_loss, tracker.class_loss],
+    np.testing.assert_allclose([got["radius"], got["direction"], got["class_l"]],
                                [ref["radius"], ref["direction"], ref["class_l"]], rtol=1e-3)
-    assert np.isclose(tracker.total_loss, tracker.radius_loss + tracker.direction_loss + tracker.class_loss)
+    assert np.isclose(got["total"], got["radius"] + got["direction"] + got["class_l"])
