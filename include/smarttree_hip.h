@@ -208,14 +208,16 @@ int st_voxelize_cloud_seg(const float* xyz, const float* rgb, int64_t n, const i
                           int64_t max_voxels, float* feats, int32_t* coords, uint8_t* mask, int64_t* point_index,
                           int32_t* seg_vox_off, int64_t* n_voxels_host, void* ws, int64_t ws_bytes, void* stream);
 int64_t st_knn_workspace_bytes_seg(int64_t n_dst, int nseg);
+/* cell_mean_mult (with cell_hint < 0): the grid cell is at most this multiple of the MEAN per-query bound (< 0: library
+ * default, 0: no cap); it changes the speed of a search, never its result (test hook, tests/test_skeleton.py) */
 int st_knn_radius_seg(const float* src, int64_t n1, const float* dst, int64_t n2, int K, float r, const float* bound,
                       int bound_mode, float cell_hint, int64_t* idx, float* dist, const int32_t* src_seg_off,
-                      const int32_t* dst_seg_off, int nseg, void* ws, int64_t ws_bytes, void* stream);
+                      const int32_t* dst_seg_off, int nseg, void* ws, int64_t ws_bytes, void* stream, float cell_mean_mult);
 /* replaces: skeleton/filter.py:6-11 (outlier_removal): mask[i] = the query has >= K neighbours inside its bound, i.e.
  *           st_knn_radius_seg(...).idx[:, K-1] != -1 without the neighbour lists (K = 8; workspace as st_knn_radius_seg). */
 int st_radius_count_seg(const float* src, int64_t n1, const float* dst, int64_t n2, int K, float r, const float* bound,
                         int bound_mode, float cell_hint, uint8_t* mask, const int32_t* src_seg_off,
-                        const int32_t* dst_seg_off, int nseg, void* ws, int64_t ws_bytes, void* stream);
+                        const int32_t* dst_seg_off, int nseg, void* ws, int64_t ws_bytes, void* stream, float cell_mean_mult);
 /* components / adjacency straight from the neighbour search (idx / dist [n,K] of st_knn_radius_seg after the caller's radius
  * filter): the edge set is make_edges' (graph.py:52-60: (i, idx) for idx > vertex 0 of i's cloud) without materialising
  * the int64 edge list.  Same labels / CSR as st_connected_components / st_component_csr on st_make_edges_seg's output. */
@@ -237,7 +239,8 @@ int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, const int32_
                                int block_threads, float* dist, int32_t* pred, int32_t* root_local, float* tree_dist,
                                int32_t* branch_parent, int32_t* branch_off, int32_t* branch_len, int32_t* n_branches,
                                int32_t* path_verts, int32_t* branch_of, int64_t* stats_host, void* ws, int64_t ws_bytes,
-                               void* stream);
+                               void* stream, const int64_t* tuning /*NULL = defaults; 16 entries, see csrc/skeleton.hip "Tuning of
+                               one call": per-call strategy / sweep knobs (no process-global state)*/);
 int st_post_process_seg(int n_trees, const int32_t* tree_off, const int32_t* parent, const int32_t* start, const int32_t* len,
                         float* xyz, const float* rad_in, float* rad_out, uint8_t* keep, uint8_t* repaired, uint8_t* smoothed,
                         int32_t* depth_scratch, int do_prune, float min_radius, float min_length, int do_repair,

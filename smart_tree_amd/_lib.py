@@ -78,15 +78,15 @@ SIGNATURES = {
                                              P, c_int, P, P, I64, P]),
     "st_build_strided_rulebook_seg": (c_int, [P, I64, P, P, I64, P, I64, P, P, I64, ctypes.POINTER(ctypes.c_int32), P, P, P, P, P, P]),
     "st_knn_workspace_bytes_seg": (I64, [I64, c_int]),
-    "st_knn_radius_seg": (c_int, [P, I64, P, I64, c_int, c_float, P, c_int, c_float, P, P, P, P, c_int, P, I64, P]),
-    "st_radius_count_seg": (c_int, [P, I64, P, I64, c_int, c_float, P, c_int, c_float, P, P, P, c_int, P, I64, P]),
+    "st_knn_radius_seg": (c_int, [P, I64, P, I64, c_int, c_float, P, c_int, c_float, P, P, P, P, c_int, P, I64, P, c_float]),
+    "st_radius_count_seg": (c_int, [P, I64, P, I64, c_int, c_float, P, c_int, c_float, P, P, P, c_int, P, I64, P, c_float]),
     "st_connected_components_knn": (c_int, [P, I64, c_int, P, P, P, I64, P]),
     "st_component_csr_knn": (c_int, [P, P, I64, c_int, P, P, I64, P, P, P, P, I64, P]),
     "st_make_edges_seg": (c_int, [P, P, I64, c_int, P, P, ctypes.POINTER(I64), P, c_int, P, I64, P]),
     "st_component_layout_seg": (c_int, [P, I64, c_int, P, c_int, P, P, P, P, P, P, P, ctypes.POINTER(I64), ctypes.POINTER(I64), P, I64, P]),
     "st_skeleton_workspace_bytes_seg": (I64, [I64, I64, c_int]),
     "st_skeleton_components_seg": (c_int, [c_int, P, P, P, c_int, I64, P, P, P, P, P, P, c_float, c_int, c_int, P, P, P, P, P, P, P, P,
-                                           P, P, ctypes.POINTER(I64), P, I64, P]),
+                                           P, P, ctypes.POINTER(I64), P, I64, P, ctypes.POINTER(I64)]),
     "st_post_process_seg": (c_int, [c_int, P, P, P, P, P, P, P, P, P, P, P, c_int, c_float, c_float, c_int, c_int, c_int, P, c_int, P]),
     "st_skeleton_components": (c_int, [c_int, P, P, I64, P, P, P, P, P, P, c_float, c_int, c_int, P, P, P, P, P, P, P, P,
                                        P, P, ctypes.POINTER(I64), P, I64, P]),
@@ -118,7 +118,7 @@ NOWAIT_VARIANTS = ("st_make_edges", "st_assemble_branches", "st_make_edges_seg")
 
 class _Bound:
     """The declared entry points as attributes (one ctypes function object each); any other exported symbol
-    (the st_debug_* developer knobs) resolves through the GIL-dropping handle."""
+    resolves through the GIL-dropping handle."""
 
     def __init__(self, cdll):
         self._cdll = cdll
@@ -156,9 +156,6 @@ def lib():
             _LIB = declare(ctypes.CDLL(str(LIB_PATH)))
         else:
             _LIB = declare(ctypes.CDLL(str(LIB_PATH)), ctypes.PyDLL(str(LIB_PATH)))
-        for kv in filter(None, os.environ.get("ST_SKELETON_PARAMS", "").split(",")):  # developer knob, e.g. "3=24,9=3"
-            which, value = kv.split("=")
-            _LIB.st_debug_set_skeleton_param(int(which), int(value))
     return _LIB
 
 

@@ -19,7 +19,8 @@
 
 #define KNN_BLOCK 256
 
-float g_knn_mean_mult = 0.45f;  // (0.45 x the mean radius = the max / 12 cell of a 1M-point tree at 2 cm: that tuning, without the outliers)
+#define KNN_MEAN_MULT 0.45f  // neighbour-search grids: cell <= this x the mean per-query bound (0.45 x the mean radius = the max / 12 cell of a 1M-point
+                             // tree at 2 cm: that tuning, without the outliers); a call may override it (cell_mean_mult >= 0: test hook)
 
 // ------------------------------------------------------------------------------- grid build ---
 __global__ void k_grid_init(StGrid* g) {
@@ -448,7 +449,8 @@ extern "C" int64_t st_knn_workspace_bytes(int64_t n_dst) { return st_knn_workspa
 // for it (indices are positions in the batched dst array).
 extern "C" int st_knn_radius_seg(const float* src, int64_t n1, const float* dst, int64_t n2, int K, float r, const float* bound,
                                  int bound_mode, float cell_hint, int64_t* idx, float* dist, const int32_t* src_seg_off,
-                                 const int32_t* dst_seg_off, int nseg, void* ws, int64_t ws_bytes, void* stream_) {
+                                 const int32_t* dst_seg_off, int nseg, void* ws, int64_t ws_bytes, void* stream_,
+                                 float cell_mean_mult) {
     hipStream_t stream = (hipStream_t)stream_;
     ST_REQUIRE(K == 1 || K == 8 || K == 16, "knn: K must be 1, 8 or 16 (got %d)", K);
     ST_REQUIRE(bound_mode == 0 || bound != nullptr, "knn: bound_mode needs a bound array");
@@ -468,7 +470,7 @@ extern "C" int st_knn_radius_seg(const float* src, int64_t n1, const float* dst,
     }
     const float cell_arg = cell_hint != 0.0f ? cell_hint : (r >= 0.0f ? r : -1.0f);
     ST_TRY(st_grid_build(dst, n2, cell_arg, knn_max_cells(nseg), g, cell_start, recs, sub, sub_bytes, stream, r, bound, n1,
-                         dst_seg_off, nseg, src_seg_off, cell_hint < 0.0f ? g_knn_mean_mult : 0.0f));
+                         dst_seg_off, nseg, src_seg_off, cell_hint < 0.0f ? (cell_mean_mult >= 0.0f ? cell_mean_mult : KNN_MEAN_MULT) : 0.0f));
     dim3 grid((unsigned)st_div_up(n1, KNN_WAVES)), block(KNN_BLOCK);
     const int cell_order = src == dst && n1 == n2 ? 1 : 0;
     if (K == 1)
@@ -489,7 +491,8 @@ extern "C" int st_knn_radius_seg(const float* src, int64_t n1, const float* dst,
 // the neighbour lists.  replaces: skeleton/filter.py:6-11 (outlier_removal's FRNN query + mask arithmetic).
 extern "C" int st_radius_count_seg(const float* src, int64_t n1, const float* dst, int64_t n2, int K, float r, const float* bound,
                                    int bound_mode, float cell_hint, uint8_t* mask, const int32_t* src_seg_off,
-                                   const int32_t* dst_seg_off, int nseg, void* ws, int64_t ws_bytes, void* stream_) {
+                                   const int32_t* dst_seg_off, int nseg, void* ws, int64_t ws_bytes, void* stream_,
+                                   float cell_mean_mult) {
     hipStream_t stream = (hipStream_t)stream_;
     ST_REQUIRE(K == 8, "radius_count: K must be 8 (outlier_removal's nb_points; got %d)", K);
     ST_REQUIRE(bound_mode == 0 || bound != nullptr, "radius_count: bound_mode needs a bound array");
@@ -509,7 +512,7 @@ extern "C" int st_radius_count_seg(const float* src, int64_t n1, const float* ds
     }
     const float cell_arg = cell_hint != 0.0f ? cell_hint : (r >= 0.0f ? r : -1.0f);
     ST_TRY(st_grid_build(dst, n2, cell_arg, knn_max_cells(nseg), g, cell_start, recs, sub, sub_bytes, stream, r, bound, n1,
-                         dst_seg_off, nseg, src_seg_off, cell_hint < 0.0f ? g_knn_mean_mult : 0.0f));
+                         dst_seg_off, nseg, src_seg_off, cell_hint < 0.0f ? (cell_mean_mult >= 0.0f ? cell_mean_mult : KNN_MEAN_MULT) : 0.0f));
     hipLaunchKernelGGL((k_knn<8, true>), dim3((unsigned)st_div_up(n1, KNN_WAVES)), dim3(KNN_BLOCK), 0, stream, src, n1,
                        (const StGrid*)g, (const uint32_t*)cell_start, (const float4*)recs, r, bound, bound_mode,
                        reinterpret_cast<int64_t*>(mask), (float*)nullptr, src_seg_off, nseg, src == dst && n1 == n2 ? 1 : 0);
@@ -521,5 +524,5 @@ extern "C" int st_knn_radius(const float* src, int64_t n1, const float* dst, int
                              int bound_mode, float cell_hint, int64_t* idx, float* dist, void* ws, int64_t ws_bytes,
                              void* stream_) {
     return st_knn_radius_seg(src, n1, dst, n2, K, r, bound, bound_mode, cell_hint, idx, dist, nullptr, nullptr, 1, ws, ws_bytes,
-                             stream_);
+                             stream_, -1.0f);
 }

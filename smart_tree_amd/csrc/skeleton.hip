@@ -37,13 +37,16 @@
 #define SK_ANC 64  // direct ancestors kept per vertex; longer walks hop 64 levels at a time (16 measured slower: every lane
                    // of a 1024-wide chunk hops j/SK_ANC times, so the chunk costs as much as its farthest lane)
 
-// Per-vertex state of the branch selection in ONE 16-byte record: a claimed point is stamped in all four words, and as
-// four separate arrays that was four scattered cache lines per point (rocprofv3 PMC, round 1: 13x the algorithmic bytes).
+// Per-vertex state of the branch selection in ONE 16-byte record: a claimed point is stamped in all three words, and as
+// separate arrays that was one scattered cache line each per point (rocprofv3 PMC, round 1: 13x the algorithmic bytes).
+// The speculation marks of a round are NOT here (rounds 1-2 kept a mark word per point that every candidate of every
+// round set and wiped: 20x the algorithmic bytes in HBM traffic): they live in an LDS table of the few points a round's
+// validation looks at (k_sk_select, "watch table").
 struct SkPt {
     float alloc;    // sample_tree's `distances` (-1 once allocated)
     unsigned term;  // termination set
     int branch;     // branch id of the point (-1: none); copied to `branch_of` when the selection is done
-    unsigned mark;  // speculation marks of k_sk_select (bit s: slot s of the current round would allocate the point)
+    unsigned pad;
 };
 
 struct SkArgs {
@@ -78,6 +81,7 @@ struct SkArgs {
     unsigned* q0;
     unsigned* q1;
     SkPt* pt;         // [m] selection state (see SkPt)
+    float4* pr;       // [m] (x, y, z, radius) of every vertex in one 16-byte record (k_sk_lift_init): one gather instead of two
     unsigned long long* best;  // claim race: (d2 bits << 32) | path position
     unsigned* touched;
     int* anc;         // [m][SK_ANC] direct ancestor table (component-local ids)
@@ -124,6 +128,15 @@ __device__ __forceinline__ float ld_wg(const float* p) { return __uint_as_float(
 __device__ __forceinline__ void wg_or(unsigned* p, unsigned v) { (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void wg_and(unsigned* p, unsigned v) { (void)__hip_atomic_fetch_and(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void wg_max(int* p, int v) { (void)__hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// allocation / termination / branch-id stamp of a point (path.py:112-122,135-136) as ONE store where the branch id is simply
+// written (8 or 16 bytes of the point's record), or an 8-byte store + a max where several slots of a round may stamp it
+__device__ __forceinline__ void sk_stamp(SkPt* pt, int id, bool several) {
+    const unsigned a = __float_as_uint(-1.0f);
+    if (id >= 0 && !several) { *reinterpret_cast<uint4*>(pt) = make_uint4(a, 1u, (unsigned)id, 0u); return; }
+    *reinterpret_cast<uint2*>(pt) = make_uint2(a, 1u);
+    if (id >= 0) wg_max(&pt->branch, id);
+}
 
 // workgroup-wide max of a 64-bit key; every thread must call; lds needs SK_MAX_WAVES words
 __device__ __forceinline__ unsigned long long block_max_u64(unsigned long long v, unsigned long long* lds) {
@@ -276,6 +289,7 @@ __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_sssp_round(SkArgs A, int r
     for (unsigned i = threadIdx.x; i < nloc; i += blockDim.x) qn[lq_base + i] = keep[i];
 }
 
+
 __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_dist_out(SkArgs A) {
     SK_VERTEX_LOOP(v) A.dist[v] = st_ord2f(A.dist_ord[v]);
 }
@@ -377,7 +391,8 @@ __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_lift_init(SkArgs A, const 
         A.pt[v].term = 0u;
         A.pt[v].branch = -1;
         A.best[v] = SK_EMPTY64;
-        A.pt[v].mark = 0u;
+        A.pt[v].pad = 0u;
+        A.pr[v] = make_float4(A.pts[3 * v], A.pts[3 * v + 1], A.pts[3 * v + 2], A.rad[v]);
     }
     if (blockIdx.x == 0)
         for (int c = threadIdx.x; c < A.C; c += blockDim.x) { A.s_done[c] = 0; A.s_nb[c] = 0; A.s_total[c] = 0; A.s_len[c] = 0; A.s_cursor[c] = 0; A.s_wide[c] = 0; }
@@ -499,16 +514,12 @@ __device__ __forceinline__ void sk_finish_branch(const SkArgs& A, int base, int 
         const float d2 = __uint_as_float((unsigned)(pk >> 32));
         const int qi = (int)(pk & 0xffffffffu);
         if (sqrtf(d2) < A.rad[base + (path_in_lds ? path[qi] : ld(&path[qi]))]) {
-            A.pt[base + p].alloc = -1.0f;
-            A.pt[base + p].term = 1u;
-            if (id >= 0) A.pt[base + p].branch = id;
+            sk_stamp(&A.pt[base + p], id, false);
         }
     }
     for (int qi = threadIdx.x; qi < len; qi += blockDim.x) {
         const int v = path_in_lds ? path[qi] : ld(&path[qi]);
-        A.pt[base + v].alloc = -1.0f;
-        A.pt[base + v].term = 1u;
-        if (id >= 0) A.pt[base + v].branch = id;
+        sk_stamp(&A.pt[base + v], id, false);
     }
     __syncthreads();  // stores drained (vmcnt) before anyone re-reads through L2
 }
@@ -561,10 +572,31 @@ __device__ __forceinline__ int sk_find_row(const uint32_t* row_off, int nrows, u
     return lo;
 }
 
+// Watch table of a speculative round (LDS, open addressing): the points whose marks the replay will ask for -- the tips of
+// the round's entries, every slot's walk and the vertex its parent id is read from: at most SK_WENT + SK_WSLOTS x
+// (SK_WPATH + 1) keys, so the table (SK_WT slots) never fills.  A claim of point p by slot s ORs bit s into p's word IF p is
+// watched; nobody ever asks about the other claimed points.
+#define SK_WT 4096
+#define SK_WT_EMPTY 0xffffffffu
+__device__ __forceinline__ unsigned sk_wt_hash(unsigned key) { return (key * 0x9E3779B1u) >> 20; }  // 12 bits
+__device__ __forceinline__ void sk_wt_insert(unsigned* wkey, unsigned* wmask, unsigned key, unsigned bits) {
+    for (unsigned h = sk_wt_hash(key);; h = (h + 1u) & (SK_WT - 1u)) {
+        const unsigned old = atomicCAS(&wkey[h], SK_WT_EMPTY, key);
+        if (old == SK_WT_EMPTY || old == key) { if (bits) atomicOr(&wmask[h], bits); return; }
+    }
+}
+__device__ __forceinline__ int sk_wt_find(const unsigned* wkey, unsigned key) {
+    for (unsigned h = sk_wt_hash(key);; h = (h + 1u) & (SK_WT - 1u)) {
+        const unsigned k = wkey[h];
+        if (k == key) return (int)h;
+        if (k == SK_WT_EMPTY) return -1;
+    }
+}
+
 // select: one workgroup per component.  sample_tree (path.py:49-140) is a sequential greedy loop -- take the
 // farthest unallocated vertex, walk to the skeleton, claim the points within the path's radius -- but
 // branches far apart do not interact, so each ROUND speculates: wavefront s takes the s-th farthest
-// unallocated vertex, walks it and marks (bit s of cmask[].mark) every point its branch would allocate, all
+// unallocated vertex, walks it and marks (bit s of the point's watch-table word) every watched point its branch would allocate, all
 // against the state at the start of the round.  A scan in order then replays the sequential semantics from
 // the marks: a tip already marked by an accepted earlier slot would never have been selected (skipped); a
 // walk (or the vertex the parent id is read from) touched by an accepted earlier slot would have come out
@@ -581,6 +613,7 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
     __shared__ SkSelLds L;
     __shared__ unsigned cl_list[SK_CL_KEEP][1024];  // claimed points of this round, SK_CL_KEEP private entries per thread
     __shared__ uint32_t s_scan[SK_MAX_WAVES + 1];
+    __shared__ unsigned wt_key[SK_WT], wt_mask[SK_WT];  // watch table (see above)
     __shared__ unsigned char win_live[1024];  // candidate window: "still unallocated" flag of order[win_base + lane]
     __shared__ int s_lo[3], s_hi[3];
     __shared__ int s_term;
@@ -599,7 +632,6 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
     const unsigned* order = A.order + base;
     const int* pos = A.pos + base;
     unsigned* tmp = A.q0 + base;
-    SkPt* cmask = A.pt + base;  // .mark: speculation marks (zeroed by k_sk_lift_init, zero again after every round)
     const float4* __restrict__ recs = A.recs;
     const StGrid* g = A.grid;
     const int xoff = A.comp_seg ? A.comp_seg[c] * g->seg_dim0 : 0;  // this cloud's slab of grid cells (batched call)
@@ -632,8 +664,8 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
                     wtail = !(A.order_init[base + j] > 0.0f);
                     live = !wtail && ld_wg(&A.pt[base + wv].alloc) > 0.0f;
                     if (live) {
-                        const float* pv = A.pts + 3 * (int64_t)(base + wv);
-                        wx = pv[0]; wy = pv[1]; wz = pv[2]; wr = A.rad[base + wv];
+                        const float4 q = A.pr[base + wv];
+                        wx = q.x; wy = q.y; wz = q.z; wr = q.w;
                     }
                 } else if (j == n) {
                     wtail = true;
@@ -645,6 +677,7 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
             const bool live = win_live[tid] != 0;
             const unsigned long long lb = __ballot(live), tb = __ballot(wtail);
             if (lane == 0) { w_cnt[wave] = __popcll(lb); w_tail[wave] = tb != 0ull; }
+            for (int i = tid; i < SK_WT; i += W) { wt_key[i] = SK_WT_EMPTY; wt_mask[i] = 0u; }  // this round's watch table
             __syncthreads();
             int before = 0, tot = 0, anytail = 0;
             for (int w = 0; w < nw; w++) { const int k = w_cnt[w]; before += w < wave ? k : 0; tot += k; anytail |= w_tail[w]; }
@@ -683,6 +716,7 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
                 ent_v = cand_v[lane];
                 const float4 e4 = cand_p[lane];
                 ex = e4.x; ey = e4.y; ez = e4.z; er = e4.w * A.prune_factor;
+                if (wave == 0) sk_wt_insert(wt_key, wt_mask, (unsigned)ent_v, 0u);  // the replay asks who claimed this tip
             }
             int shadowed = 0, chosen = 0;
             for (int u = 0; u < ne; u++) {
@@ -724,11 +758,13 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
                 // the parent id is read BEFORE anything is stamped (path.py:128-136); termination -1 reads
                 // branch_ids[-1] = the last vertex (quirk kept)
                 if (lane == 0 && len >= 2) parent = ld_wg(&A.pt[base + (termv < 0 ? n - 1 : termv)].branch);
+                // watched: the walk (marked by its own slot) and the vertex the parent id is read from
+                if (lane < len) sk_wt_insert(wt_key, wt_mask, (unsigned)node, 1u << wave);
+                else if (lane == len) sk_wt_insert(wt_key, wt_mask, (unsigned)(termv < 0 ? n - 1 : termv), 0u);
                 if (lane < len) {
-                    const float r = A.rad[base + node];
-                    const float* pv = A.pts + 3 * (int64_t)(base + node);
-                    const float x = pv[0], y = pv[1], z = pv[2];
-                    S.path[qi] = node; S.p[qi] = make_float4(x, y, z, r);
+                    const float4 q4 = A.pr[base + node];
+                    const float x = q4.x, y = q4.y, z = q4.z, r = q4.w;
+                    S.path[qi] = node; S.p[qi] = q4;
                     const int cx = (int)floorf((x - g->lo[0]) / g->cell), cy = (int)floorf((y - g->lo[1]) / g->cell),
                               cz = (int)floorf((z - g->lo[2]) / g->cell);
                     atomicMax(&S.rk, st_f2ord(r));  // path.py:31
@@ -784,24 +820,26 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
             int pre[SK_WSLOTS + 1];
             pre[0] = 0;
             {
+                // lane k reads slot k's numbers once (one LDS round trip), the scan below takes them out with readlane
+                int cand_l = 0, big_l = 0, ent_l = 0;
+                if (lane < SK_WSLOTS && lane < nc) { cand_l = sl_ncand[lane]; big_l = sl_big[lane]; ent_l = sl_ent[lane]; }
                 bool open = true;
                 int k_cut = nc;
 #pragma unroll
                 for (int k = 0; k < SK_WSLOTS; k++) {
                     int add = 0;
                     if (k < nc && open) {
-                        const int cand_k = __builtin_amdgcn_readfirstlane(sl_ncand[k]), big_k = __builtin_amdgcn_readfirstlane(sl_big[k]);
+                        const int cand_k = __builtin_amdgcn_readlane(cand_l, k), big_k = __builtin_amdgcn_readlane(big_l, k);
                         if (big_k || pre[k] + cand_k > SK_ROUND_ITEMS * W) { open = false; k_cut = k; }
                         else add = cand_k;
                     }
                     pre[k + 1] = pre[k] + add;
                 }
-                if (k_cut < nc) { ne = __builtin_amdgcn_readfirstlane(sl_ent[k_cut]); nc = k_cut; }
+                if (k_cut < nc) { ne = __builtin_amdgcn_readlane(ent_l, k_cut); nc = k_cut; }
             }
             const int T = pre[SK_WSLOTS];
             // 3. claims (select_path_points, path.py:19-46), point-centric: the candidates of ALL slots are dealt
             //    out over the workgroup; each finds ITS nearest path vertex from LDS -- no atomics but the mark.
-            if (wave < nc && lane < sl_len[wave]) wg_or(&cmask[L.slot[wave].path[lane]].mark, 1u << wave);
             unsigned cl_bits = 0u;  // bit k: my k-th item was claimed but did not fit cl_list
             int cl_n = 0;
             const int nround = (T + W - 1) / W;
@@ -835,38 +873,51 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
                     const float rp = sl_rp[ss[u]];
                     float bd2 = __uint_as_float(0x7f800000u);
                     int bq = 0;
-                    for (int qi = 0; qi < len; qi++) {  // ascending: ties keep the first path vertex
-                        const float4 q = S.p[qi];
-                        const float dx = r4[u].x - q.x, dy = r4[u].y - q.y, dz = r4[u].z - q.z;
-                        float d2 = dx * dx;
-                        float tt = dy * dy;
-                        d2 = d2 + tt;
-                        tt = dz * dz;
-                        d2 = d2 + tt;
-                        if (d2 < bd2) { bd2 = d2; bq = qi; }
+                    float bw = 0.0f;
+                    // ascending: ties keep the first path vertex.  Four path vertices per step: their LDS reads are in flight together
+#define SK_NEAREST(q, qi_)                                                                    \
+    {                                                                                          \
+        const float dx = r4[u].x - (q).x, dy = r4[u].y - (q).y, dz = r4[u].z - (q).z;          \
+        float d2 = dx * dx;                                                                    \
+        float tt = dy * dy;                                                                    \
+        d2 = d2 + tt;                                                                          \
+        tt = dz * dz;                                                                          \
+        d2 = d2 + tt;                                                                          \
+        if (d2 < bd2) { bd2 = d2; bq = (qi_); bw = (q).w; }                                    \
+    }
+                    int qi = 0;
+                    for (; qi + 4 <= len; qi += 4) {
+                        const float4 q0 = S.p[qi], q1 = S.p[qi + 1], q2 = S.p[qi + 2], q3 = S.p[qi + 3];
+                        SK_NEAREST(q0, qi) SK_NEAREST(q1, qi + 1) SK_NEAREST(q2, qi + 2) SK_NEAREST(q3, qi + 3)
                     }
-                    if (bd2 < rp * rp && sqrtf(bd2) < S.p[bq].w) {  // path.py:35-40
-                        wg_or(&cmask[p].mark, 1u << ss[u]);
+                    for (; qi < len; qi++) {
+                        const float4 q = S.p[qi];
+                        SK_NEAREST(q, qi)
+                    }
+#undef SK_NEAREST
+                    (void)bq;
+                    if (bd2 < rp * rp && sqrtf(bd2) < bw) {  // path.py:35-40
+                        const int h = sk_wt_find(wt_key, (unsigned)p);
+                        if (h >= 0) atomicOr(&wt_mask[h], 1u << ss[u]);
                         if (cl_n < SK_CL_KEEP) cl_list[cl_n][tid] = (unsigned)p | ((unsigned)ss[u] << 28);
                         else cl_bits |= 1u << (k0 + u);
                         cl_n++;
                     }
                 }
             }
-            __syncthreads();  // all marks are in L2
+            __syncthreads();  // all marks are in the table
             SK_TICK(3);
             // 4. what did the earlier slots touch?  (walk + the vertex the parent id was read from; tip of every entry)
             if (wave < nc) {
                 const SkSelSlot& S = L.slot[wave];
                 const int len = sl_len[wave], termv = sl_term[wave];
                 unsigned mk = 0u;
-                if (lane < len) mk = ld_wg(&cmask[S.path[lane]].mark);
-                else if (lane == len) mk = ld_wg(&cmask[termv < 0 ? n - 1 : termv].mark);
+                if (lane <= len) mk = wt_mask[sk_wt_find(wt_key, (unsigned)(lane < len ? S.path[len - 1 - lane] : (termv < 0 ? n - 1 : termv)))];
                 const unsigned walkm = wave_or_u(mk);
                 if (lane == 0) sl_walkm[wave] = walkm;
             }
             unsigned etip = 0u;
-            if (wave == 0 && lane < ne) etip = ld_wg(&cmask[ent_v].mark);
+            if (wave == 0 && lane < ne) etip = wt_mask[sk_wt_find(wt_key, (unsigned)ent_v)];
             __syncthreads();
             if (wave == 0) {  // the sequential replay over the entries, lane e holding entry e
                 if (my_slot >= nc) my_slot = -1;
@@ -901,12 +952,9 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
                 const int len = sl_len[wave], id = sl_id[wave];
                 if (lane < len) {
                     const int v = S.path[lane];
-                    wg_and(&cmask[v].mark, ~(1u << wave));
                     if (id != -2) {
                         if (id >= 0) A.path_verts[base + sl_off[wave] + lane] = v;  // (a dropped path shares its offset with the next one)
-                        A.pt[base + v].alloc = -1.0f;
-                        A.pt[base + v].term = 1u;
-                        if (id >= 0) wg_max(&A.pt[base + v].branch, id);
+                        sk_stamp(&A.pt[base + v], id, true);
                         const unsigned q = (unsigned)(pos[v] - win_base);
                         if (q < (unsigned)W) win_live[q] = 0;
                     }
@@ -922,12 +970,9 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
             for (int j = 0; j < kept_n; j++) {
                 const unsigned e = cl_list[j][tid];
                 const int p = (int)(e & 0x0fffffffu), sidx = (int)(e >> 28);
-                wg_and(&cmask[p].mark, ~(1u << sidx));
                 if ((alive >> sidx) & 1u) {
                     const int id = sl_id[sidx];
-                    A.pt[base + p].alloc = -1.0f;
-                    A.pt[base + p].term = 1u;
-                    if (id >= 0) wg_max(&A.pt[base + p].branch, id);
+                    sk_stamp(&A.pt[base + p], id, true);
                     const unsigned q = (unsigned)(pos[p] - win_base);
                     if (q < (unsigned)W) win_live[q] = 0;
                 }
@@ -940,16 +985,14 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
 #pragma unroll
                 for (int k2 = 1; k2 < SK_WSLOTS; k2++)
                     if (gi >= pre[k2]) { sidx = k2; acc = pre[k2]; }
+                if (!((alive >> sidx) & 1u)) continue;
                 const SkSelSlot& S = L.slot[sidx];
                 const uint32_t t = (uint32_t)(gi - acc);
                 const int row = sk_find_row(S.row_off, sl_nrows[sidx], t);
                 const int p = (int)__float_as_uint(recs[S.row_first[row] + (t - S.row_off[row])].w) - base;
-                wg_and(&cmask[p].mark, ~(1u << sidx));
-                if ((alive >> sidx) & 1u) {
+                {
                     const int id = sl_id[sidx];
-                    A.pt[base + p].alloc = -1.0f;
-                    A.pt[base + p].term = 1u;
-                    if (id >= 0) wg_max(&A.pt[base + p].branch, id);
+                    sk_stamp(&A.pt[base + p], id, true);
                     const unsigned q = (unsigned)(pos[p] - win_base);
                     if (q < (unsigned)W) win_live[q] = 0;
                 }
@@ -988,12 +1031,12 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
             const int w = len - 1 - qi;  // walk order -> root side first
             const int v = w < SK_LPATH ? L.one.lpath[w] : (int)ld_wg(&tmp[w]);
             path_out[qi] = v;
-            const float r = A.rad[base + v];
+            const float4 q4 = A.pr[base + v];
+            const float r = q4.w;
             const unsigned long long k = (unsigned long long)st_f2ord(r) << 32;
             rk = k > rk ? k : rk;
             if (fits) {
-                const float* pv = A.pts + 3 * (int64_t)(base + v);
-                const float x = pv[0], y = pv[1], z = pv[2];
+                const float x = q4.x, y = q4.y, z = q4.z;
                 L.one.lpx[qi] = x; L.one.lpy[qi] = y; L.one.lpz[qi] = z; L.one.lpr[qi] = r;
                 const int cx = (int)floorf((x - g->lo[0]) / g->cell), cy = (int)floorf((y - g->lo[1]) / g->cell),
                           cz = (int)floorf((z - g->lo[2]) / g->cell);
@@ -1081,18 +1124,14 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
                 if (d2 < bd2) { bd2 = d2; bq = qi; }
             }
             if (bd2 < rp2 && sqrtf(bd2) < L.one.lpr[bq]) {  // path.py:35-40
-                A.pt[base + p].alloc = -1.0f;
-                A.pt[base + p].term = 1u;
-                if (id >= 0) A.pt[base + p].branch = id;
+                sk_stamp(&A.pt[base + p], id, false);
                 const unsigned q = (unsigned)(pos[p] - win_base);
                 if (q < (unsigned)W) win_live[q] = 0;
             }
         }
         for (int qi = tid; qi < len; qi += blockDim.x) {  // path.py:112-113,135
             const int v = L.one.lpath[len - 1 - qi];
-            A.pt[base + v].alloc = -1.0f;
-            A.pt[base + v].term = 1u;
-            if (id >= 0) A.pt[base + v].branch = id;
+            sk_stamp(&A.pt[base + v], id, false);
             const unsigned q = (unsigned)(pos[v] - win_base);
             if (q < (unsigned)W) win_live[q] = 0;
         }
@@ -1157,6 +1196,7 @@ struct SkLayout {
     unsigned *dist_ord, *stamp, *q0, *q1, *touched, *cnt, *s_ntouched, *sort_keys, *order;
     float *s_rp, *order_init;
     SkPt* pt;
+    float4* pr;
     int *s_cursor, *s_wide, *pos;
     char* sort_ws;
     int64_t sort_bytes;
@@ -1178,6 +1218,7 @@ static void sk_layout(StArena& a, int64_t m, int64_t C, SkLayout* s, int nseg = 
     s->q1 = a.take<unsigned>(m + C);
     s->touched = a.take<unsigned>(m);
     s->pt = a.take<SkPt>(m);
+    s->pr = a.take<float4>(m);
     s->best = a.take<unsigned long long>(m);
     s->anc = a.take<int>((int64_t)SK_ANC * m);
     s->comp_of = a.take<int>(m);
@@ -1208,37 +1249,41 @@ static void sk_layout(StArena& a, int64_t m, int64_t C, SkLayout* s, int nseg = 
     s->gws = a.take<char>(s->gws_bytes);
 }
 
-static long long* g_debug_ticks = nullptr;
-static float g_prune_factor = 1.0f;
-static float g_grid_mean_mult = 1.0f;  // claim-grid cell <= this x the mean radius (0: max radius / GRID_DIV alone)
-static int g_sssp_hops = 4, g_sssp_batch = 32, g_sssp_lanes = 64, g_sssp_first = 2, g_sssp_blocks = SK_SSSP_BLOCKS, g_sssp_lcap = SK_LQ;
+// Tuning of one call (st_skeleton_components_seg's `tuning` argument: 16 x int64, entry = ST_TUNE_DEFAULT or NULL array =
+// the default).  Test hook (tests/test_skeleton.py forces every claim strategy and every SSSP form) and sweep aid
+// (tools/); nothing is process-global, so concurrent calls cannot see each other's settings.
+//   0 prune factor (x1000)   1 small_work   2 rounds per select launch   3 select launches per host read-back
+//   4 local_items   5 wave_work   6 SSSP levels per frontier launch   7 frontier launches per read-back   8 lanes per vertex
+//   9 length of the first frontier batch (in batches)   10 frontier workgroups   11 claim-grid cell cap (hundredths of the
+//   mean radius)   13 frontier: 0 = no look before the atomic, else vertices a workgroup relaxes per local level
+//   15 device pointer of 16 int64 phase timers / counters of k_sk_select
+#define ST_TUNE_DEFAULT INT64_MIN
 #define SK_MAX_LAUNCH_BATCH 32
-static int g_small_work = SK_SMALL_WORK, g_iters_per_launch = SK_ITERS_PER_LAUNCH, g_launch_batch = 24, g_local_items = 0, g_wave_work = SK_WAVE_WORK;
-// developer aid / test hook (forces every claim strategy): 0 prune factor (x1000), 1 small_work, 2 rounds per launch,
-// 3 launches per host read-back, 4 local_items, 5 wave_work, 6 SSSP levels per launch, 7 SSSP launches per read-back, 9 length of the first SSSP batch (in batches), 10 SSSP workgroups,
-// 11 / 12 claim-grid / search-grid cell cap in hundredths of the mean radius; a negative `which` restores the defaults
-extern "C" void st_debug_set_skeleton_param(int which, int value) {
-    if (which < 0) {
-        g_prune_factor = 1.0f; g_small_work = SK_SMALL_WORK; g_iters_per_launch = SK_ITERS_PER_LAUNCH; g_launch_batch = 24;
-        g_local_items = 0; g_wave_work = SK_WAVE_WORK; g_sssp_hops = 4; g_sssp_batch = 32; g_sssp_lanes = 64; g_sssp_first = 2;
-        g_sssp_blocks = SK_SSSP_BLOCKS; g_sssp_lcap = SK_LQ; g_grid_mean_mult = 1.0f; g_knn_mean_mult = 0.45f;
+struct SkTuning {
+    float prune_factor = 1.0f, grid_mean_mult = 1.0f;
+    int small_work = SK_SMALL_WORK, iters_per_launch = SK_ITERS_PER_LAUNCH, launch_batch = 24, local_items = 0, wave_work = SK_WAVE_WORK;
+    int sssp_hops = 4, sssp_batch = 32, sssp_lanes = 64, sssp_first = 2, sssp_blocks = SK_SSSP_BLOCKS, sssp_lcap = SK_LQ;
+    bool small_work_set = false, iters_set = false;
+    long long* ticks = nullptr;
+    explicit SkTuning(const int64_t* t) {
+        if (!t) return;
+        auto has = [&](int i) { return t[i] != ST_TUNE_DEFAULT; };
+        if (has(0)) prune_factor = (float)t[0] / 1000.0f;
+        if (has(1)) { small_work = (int)t[1]; small_work_set = true; }
+        if (has(2)) { iters_per_launch = (int)t[2]; iters_set = true; }
+        if (has(3)) launch_batch = t[3] < 1 ? 1 : (t[3] > SK_MAX_LAUNCH_BATCH ? SK_MAX_LAUNCH_BATCH : (int)t[3]);
+        if (has(4)) local_items = (int)t[4];
+        if (has(5)) wave_work = (int)t[5];
+        if (has(6)) sssp_hops = t[6] < 1 ? 1 : (int)t[6];
+        if (has(7)) sssp_batch = t[7] < 1 ? 1 : (t[7] > 64 ? 64 : (int)t[7]);
+        if (has(8)) sssp_lanes = t[8] == 64 ? 64 : (t[8] == 32 ? 32 : 16);
+        if (has(9)) sssp_first = t[9] < 1 ? 1 : (t[9] > 8 ? 8 : (int)t[9]);
+        if (has(10)) sssp_blocks = t[10] < 1 ? 1 : (t[10] > 8192 ? 8192 : (int)t[10]);
+        if (has(11)) grid_mean_mult = (float)t[11] / 100.0f;
+        if (has(13)) sssp_lcap = t[13] == 0 ? -SK_LQ : (t[13] > SK_LQ ? SK_LQ : (int)t[13]);
+        if (has(15)) ticks = (long long*)(intptr_t)t[15];
     }
-    if (which == 0) g_prune_factor = value / 1000.0f;
-    if (which == 1) g_small_work = value;
-    if (which == 2) g_iters_per_launch = value;
-    if (which == 3) g_launch_batch = value < 1 ? 1 : (value > SK_MAX_LAUNCH_BATCH ? SK_MAX_LAUNCH_BATCH : value);
-    if (which == 4) g_local_items = value;
-    if (which == 5) g_wave_work = value;
-    if (which == 6) g_sssp_hops = value < 1 ? 1 : value;
-    if (which == 8) g_sssp_lanes = value == 64 ? 64 : (value == 32 ? 32 : 16);
-    if (which == 7) g_sssp_batch = value < 1 ? 1 : (value > 64 ? 64 : value);
-    if (which == 9) g_sssp_first = value < 1 ? 1 : (value > 8 ? 8 : value);
-    if (which == 13) g_sssp_lcap = value == 0 ? -SK_LQ : (value > SK_LQ ? SK_LQ : value);  // 0: no look before the atomic; else cap  // SSSP: vertices a workgroup relaxes per local level
-    if (which == 11) g_grid_mean_mult = value / 100.0f;
-    if (which == 12) g_knn_mean_mult = value / 100.0f;
-    if (which == 10) g_sssp_blocks = value < 1 ? 1 : (value > 8192 ? 8192 : value);  // workgroups of the SSSP frontier launches
-}
-extern "C" void st_debug_set_ticks(long long* device_ptr) { g_debug_ticks = device_ptr; }
+};
 
 extern "C" int64_t st_skeleton_workspace_bytes_seg(int64_t m, int64_t n_comp, int nseg) {
     StArena a(nullptr, 0);
@@ -1282,7 +1327,7 @@ extern "C" int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, c
                                       float* dist, int32_t* pred, int32_t* root_local, float* tree_dist,
                                       int32_t* branch_parent, int32_t* branch_off, int32_t* branch_len, int32_t* n_branches,
                                       int32_t* path_verts, int32_t* branch_of, int64_t* stats_host, void* ws,
-                                      int64_t ws_bytes, void* stream_) {
+                                      int64_t ws_bytes, void* stream_, const int64_t* tuning) {
     hipStream_t stream = (hipStream_t)stream_;
     const bool time_select = stats_host && stats_host[7] != 0;
     if (stats_host) for (int i = 0; i < 7; i++) stats_host[i] = 0;
@@ -1308,25 +1353,26 @@ extern "C" int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, c
     A.dist = dist; A.pred = pred; A.root_local = root_local; A.tree_dist = tree_dist;
     A.branch_parent = branch_parent; A.branch_off = branch_off; A.branch_len = branch_len; A.n_branches = n_branches;
     A.path_verts = path_verts; A.branch_of = branch_of;
-    A.dist_ord = s.dist_ord; A.stamp = s.stamp; A.q0 = s.q0; A.q1 = s.q1; A.pt = s.pt;
+    A.dist_ord = s.dist_ord; A.stamp = s.stamp; A.q0 = s.q0; A.q1 = s.q1; A.pt = s.pt; A.pr = s.pr;
     A.best = s.best; A.touched = s.touched; A.anc = s.anc; A.cnt = s.cnt;
     A.s_done = s.s_done; A.s_len = s.s_len; A.s_cur_id = s.s_cur_id; A.s_cur_off = s.s_cur_off; A.s_nb = s.s_nb;
     A.s_total = s.s_total; A.s_rp = s.s_rp; A.s_ntouched = s.s_ntouched;
     A.blk_comp = s.blk_comp; A.blk_first = s.blk_first; A.blk_count = s.blk_count;
     A.s_cursor = s.s_cursor; A.s_wide = s.s_wide; A.order = s.order; A.order_init = s.order_init; A.pos = s.pos;
-    A.ticks = g_debug_ticks;
-    A.prune_factor = g_prune_factor; A.small_work = g_small_work; A.iters_per_launch = g_iters_per_launch; A.local_items = g_local_items; A.wave_work = g_wave_work;
+    const SkTuning T(tuning);
+    A.ticks = T.ticks;
+    A.prune_factor = T.prune_factor; A.small_work = T.small_work; A.iters_per_launch = T.iters_per_launch; A.local_items = T.local_items; A.wave_work = T.wave_work;
     // A batch of clouds advances in lockstep: a launch lasts as long as its slowest component, and a component that hands a
     // long path to the chip-wide claim kernel waits for everybody else's rounds.  Fewer hand-overs (the workgroup claims
     // paths up to 16x larger by itself) and shorter launches measured 2.98 -> 2.48 ms of skeleton stage per cloud at 8 clouds
     // per batch (tools/sweep_select.sh, profiles/r02_sweep_select.txt); one cloud alone keeps the round-1 optimum.
     if (nseg > 1) {
-        if (g_small_work == SK_SMALL_WORK) A.small_work = 1 << 22;
-        if (g_iters_per_launch == SK_ITERS_PER_LAUNCH) A.iters_per_launch = 16;
+        if (!T.small_work_set) A.small_work = 1 << 22;
+        if (!T.iters_set) A.iters_per_launch = 16;
     }
 
     const unsigned vg = sk_vgrid(m);
-    const unsigned fg = (unsigned)st_min64(st_div_up(m, SK_WIDE_BLOCK), g_sssp_blocks);
+    const unsigned fg = (unsigned)st_min64(st_div_up(m, SK_WIDE_BLOCK), T.sssp_blocks);
     unsigned h[8];
     int64_t sssp_rounds = 0;
     const bool defer_plateaus = (stages & 1) && (stages & 4) && !(stages & 2);
@@ -1348,9 +1394,9 @@ extern "C" int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, c
         hipLaunchKernelGGL(k_sk_roots, dim3((unsigned)n_comp), dim3((unsigned)block_threads), 0, stream, A);
         for (int r = 0;;) {  // frontier rounds in batches, one counter read-back per batch.  The first batch is twice as long:
             // a tree of a million points needs 65-96 launches, an empty round costs ~4 us, a read-back beside other clouds ~1 ms
-            const int batch = r == 0 ? g_sssp_first * g_sssp_batch : g_sssp_batch;
+            const int batch = r == 0 ? T.sssp_first * T.sssp_batch : T.sssp_batch;
             for (int b = 0; b < batch; b++, r++)
-                hipLaunchKernelGGL(k_sk_sssp_round, dim3(fg), dim3(SK_WIDE_BLOCK), 0, stream, A, r, g_sssp_hops, g_sssp_lanes, g_sssp_lcap);
+                hipLaunchKernelGGL(k_sk_sssp_round, dim3(fg), dim3(SK_WIDE_BLOCK), 0, stream, A, r, T.sssp_hops, T.sssp_lanes, T.sssp_lcap);
             ST_TRY(sk_read(h, s.cnt, sizeof(unsigned) * 8, stream));
             sssp_rounds = r;
             if (h[r % 3] == 0) break;
@@ -1386,7 +1432,7 @@ extern "C" int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, c
         // grid_cell < 0: cell = max(rad) / -grid_cell with the maximum reduced on the device (no host round trip)
         ST_TRY(st_grid_build(pts, m, grid_cell, sk_grid_cells(nseg), s.g, s.cell_start, s.recs, s.gws, s.gws_bytes, stream,
                              grid_cell < 0.0f ? -1.0f : 0.0f, grid_cell < 0.0f ? rad : nullptr, grid_cell < 0.0f ? m : 0,
-                             vert_seg_off, nseg, vert_seg_off, g_grid_mean_mult));
+                             vert_seg_off, nseg, vert_seg_off, T.grid_mean_mult));
         int64_t iters = 0;
         struct EventSet {  // destroyed on every way out of the select loop (early error returns included)
             hipEvent_t e[2 * SK_MAX_LAUNCH_BATCH];
@@ -1421,7 +1467,7 @@ extern "C" int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, c
             bool redo = false;
             // the 1M-point synthetic trees need 10-21 launch pairs (tools/round_counts.py): a first batch of 24 ends them with ONE
             // progress read-back; A/B on one box, 8 clouds in flight: 5.08 ms per cloud against 5.66 with 16 (tools/sweep_batches.sh)
-            for (int batch = g_launch_batch;; batch = batch > 4 ? 4 : batch) {  // launch pairs per counter read-back: a long first
+            for (int batch = T.launch_batch;; batch = batch > 4 ? 4 : batch) {  // launch pairs per counter read-back: a long first
                 // batch, short ones for the stragglers (a finished launch pair still costs its ~10 us of launch latency)
                 for (int b = 0; b < batch; b++, iters++) {
                     if (time_sel) (void)hipEventRecord(ev[2 * b], stream);
@@ -1473,7 +1519,7 @@ extern "C" int st_skeleton_components(int n_comp, const int32_t* comp_off, const
     (void)comp_size_host;
     return st_skeleton_components_seg(n_comp, comp_off, nullptr, nullptr, 1, m, pts, rad, ysurf, row_off, col, wgt, grid_cell,
                                       stages, block_threads, dist, pred, root_local, tree_dist, branch_parent, branch_off,
-                                      branch_len, n_branches, path_verts, branch_of, stats_host, ws, ws_bytes, stream_);
+                                      branch_len, n_branches, path_verts, branch_of, stats_host, ws, ws_bytes, stream_, nullptr);
 }
 
 // Named single-stage entry points: the same call with one stage selected.

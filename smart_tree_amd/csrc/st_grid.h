@@ -45,7 +45,6 @@ __device__ __forceinline__ int64_t st_grid_cell(const StGrid* g, float x, float 
     return ((int64_t)(st_grid_axis(g, x, 0) + seg * g->seg_dim0) * g->dim[1] + st_grid_axis(g, y, 1)) * g->dim[2] + st_grid_axis(g, z, 2);
 }
 
-extern float g_knn_mean_mult;  // neighbour-search grids: cell <= this x the mean per-query bound (0: off); developer knob 12
 int64_t st_grid_ws_bytes(int64_t n, int64_t max_cells);
 // r < 0: the search radius is max(bound[0 .. n_bound)), reduced on the device (no host round trip); cell < 0: the
 // cell size is max(r / -cell, 1e-4).  seg_off / nseg: the clouds of a batched call (pts index space; bound_seg_off the

@@ -21,6 +21,7 @@ def outlier_removal(points: torch.Tensor, radii: torch.Tensor, nb_points: int = 
     # seg_off (additive): `points` holds several independent clouds; neighbours are counted inside a point's own cloud.
     # st_radius_count_seg = the same search, but it only counts and stops at the nb_points-th hit (no neighbour lists).
     from .. import _lib
+    from . import tuning
 
     L = _lib.lib()
     pts = points.contiguous().float()
@@ -30,5 +31,5 @@ def outlier_removal(points: torch.Tensor, radii: torch.Tensor, nb_points: int = 
     ws = _lib.workspace(L.st_knn_workspace_bytes_seg(n, nseg), dev)
     _lib.check(L.st_radius_count_seg(_lib.ptr(pts), n, _lib.ptr(pts), n, nb_points, -1.0, _lib.ptr(bound), BOUND_LT,
                                      -float(SEARCH_CELL_DIV), _lib.ptr(mask), _lib.ptr(seg_off), _lib.ptr(seg_off), nseg,
-                                     _lib.ptr(ws), ws.numel(), _lib.stream(dev)))
+                                     _lib.ptr(ws), ws.numel(), _lib.stream(dev), tuning.knn_cell_mean_mult()))
     return mask.bool()

@@ -14,6 +14,7 @@ from typing import Optional
 import torch
 
 from .. import _lib
+from . import tuning
 from ..data_types.graph import Graph, KnnGraph, PaddedGraph
 
 BOUND_NONE, BOUND_LE, BOUND_LT = 0, 1, 2
@@ -47,7 +48,7 @@ def knn(src: torch.Tensor, dest: torch.Tensor, K: int = 50, r: float = 1.0, grid
     b = bound.contiguous().float() if bound is not None else None
     _lib.check(L.st_knn_radius_seg(_lib.ptr(src), n1, _lib.ptr(dest), n2, K, float(r), _lib.ptr(b), bound_mode, float(cell),
                                    _lib.ptr(idx), _lib.ptr(dist), _lib.ptr(src_seg_off), _lib.ptr(dest_seg_off), nseg,
-                                   _lib.ptr(ws), ws.numel(), _lib.stream(dev)))
+                                   _lib.ptr(ws), ws.numel(), _lib.stream(dev), tuning.knn_cell_mean_mult()))
     return idx, dist, grid
 
 

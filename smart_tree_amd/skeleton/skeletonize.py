@@ -20,6 +20,7 @@ from ..data_types.branch import BranchSkeleton
 from ..data_types.cloud import Cloud
 from ..data_types.tree import DisjointTreeSkeleton, TreeSkeleton
 from .filter import outlier_removal
+from . import tuning
 from .graph import ComponentSet, medial_points, nn_graph
 
 STAGE_SSSP, STAGE_TREE_DISTANCE, STAGE_SAMPLE = 1, 2, 4
@@ -79,7 +80,8 @@ def run_components(comps: ComponentSet, medial_pts: torch.Tensor, radius: torch.
             _lib.ptr(comps.row_off), _lib.ptr(comps.col), _lib.ptr(comps.wgt), -float(GRID_DIV), int(stages),
             int(block_threads), _lib.ptr(res.dist), _lib.ptr(res.pred), _lib.ptr(res.root_local), _lib.ptr(res.tree_dist),
             _lib.ptr(res.branch_parent), _lib.ptr(res.branch_off), _lib.ptr(res.branch_len), _lib.ptr(res.n_branches),
-            _lib.ptr(res.path_verts), _lib.ptr(res.branch_of), stats, _lib.ptr(ws), ws.numel(), _lib.stream(dev)))
+            _lib.ptr(res.path_verts), _lib.ptr(res.branch_of), stats, _lib.ptr(ws), ws.numel(), _lib.stream(dev),
+            tuning.skeleton_array()))
     res.stats = {"sssp_rounds": stats[0], "plateau_rounds": stats[1], "select_launches": stats[2], "lift_levels": stats[3]}
     if stages & STAGE_SAMPLE:  # cloud totals from the select loop's last progress read-back
         res.stats["branches"], res.stats["path_vertices"] = int(stats[6] & 0xFFFFFFFF), int(stats[6] >> 32)

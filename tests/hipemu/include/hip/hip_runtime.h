@@ -380,6 +380,8 @@ template <class T> inline T max(T a, T b) { return a > b ? a : b; }
 #define __hip_atomic_fetch_and(p, v, order, scope) __atomic_fetch_and((p), (v), (order))
 #define __hip_atomic_fetch_max(p, v, order, scope) hipemu_fetch_max((p), (v))
 template <class T> inline T hipemu_fetch_max(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
+#define __hip_atomic_fetch_min(p, v, order, scope) hipemu_fetch_min((p), (v))
+template <class T> inline T hipemu_fetch_min(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
 inline long long wall_clock64() { return 0; }
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 

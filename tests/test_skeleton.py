@@ -163,15 +163,10 @@ def test_components_match_oracle(backend):
 ], ids=["noprune", "prune4", "relaunch", "one", "local", "wide", "mixed", "sssp-rows", "sssp-hops", "sssp-cap"])
 def test_sample_tree_strategies_agree(backend, params):
     """Branch selection has four claim strategies picked by size; each one alone must reproduce the oracle."""
-    from smart_tree_amd import _lib
-    hook = _lib.lib().st_debug_set_skeleton_param
+    from smart_tree_amd.skeleton import tuning
     pts, mv = _tree()
-    try:
-        for k, v in params.items():
-            hook(int(k), int(v))
+    with tuning.override(params):  # per call: the library has no process-global knobs
         assert _compare_components(backend, pts, mv, block_threads=256, cache_key="strategies") >= 2
-    finally:
-        hook(-1, 0)
 
 
 @pytest.mark.parametrize("mults", [(0, 0), (100, 45), (25, 15)], ids=["max-only", "default", "fine"])
@@ -179,17 +174,12 @@ def test_grid_cell_size_is_invisible_with_radius_outliers(backend, mults):
     """The search grids take their cell from the radii (max / DIV, capped at a multiple of the MEAN so that one radius the
     network got wrong does not coarsen every cell -- csrc/st_grid.h).  The cell changes the speed of a search, never its
     result: a cloud with a few 15x radius outliers gives the oracle's graph and skeleton under every setting."""
-    from smart_tree_amd import _lib
-    hook = _lib.lib().st_debug_set_skeleton_param
+    from smart_tree_amd.skeleton import tuning
     pts, mv = _tree()
     mv = mv.copy()
     mv[::97] *= 15.0  # ~1 % of the points with a far-too-large radius
-    try:
-        hook(11, mults[0])
-        hook(12, mults[1])
+    with tuning.override({11: mults[0], tuning.KNN_CELL_MEAN_MULT: mults[1]}):
         assert _compare_components(backend, pts, mv, block_threads=256) >= 2
-    finally:
-        hook(-1, 0)
 
 
 def test_components_with_duplicates_and_plateaus(backend):

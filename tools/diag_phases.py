@@ -13,6 +13,7 @@ from smart_tree_amd import _lib  # noqa: E402
 from smart_tree_amd.data_types.cloud import Cloud  # noqa: E402
 from smart_tree_amd.skeleton import graph as G  # noqa: E402
 from smart_tree_amd.skeleton.filter import outlier_removal  # noqa: E402
+from smart_tree_amd.skeleton import tuning  # noqa: E402
 from smart_tree_amd.skeleton.skeletonize import STAGE_SSSP, run_components  # noqa: E402
 from smart_tree_amd.synthetic import sample_tree_cloud  # noqa: E402
 
@@ -35,11 +36,10 @@ comps = g.connected_cugraph_components(32)
 print(f"{n} points, voxel {voxel}, foliage {fol}: graph vertices {len(bc)}, components {comps.n_components}, largest {comps.comp_size[:4].tolist()}, "
       f"radius quantiles {torch.quantile(radius[:1000000], torch.tensor([0, .5, .9, 1.0], device=dev)).tolist()}")
 L = _lib.lib()
-L.st_debug_set_ticks.argtypes = [ctypes.c_void_p]
-L.st_debug_set_skeleton_param(-1, 0)
+knobs = {}
 for kv in filter(None, params.split(",")):
     k, v = kv.split("=")
-    L.st_debug_set_skeleton_param(int(k), int(v))
+    knobs[int(k)] = int(v)
 ys = bc.xyz[:, 1].contiguous()
 
 
@@ -47,7 +47,8 @@ def timed(**kw):
     for _ in range(3):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        res = run_components(comps, medial, radius, ys, **kw)
+        with tuning.override(knobs):
+            res = run_components(comps, medial, radius, ys, **kw)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
     return dt * 1e3, res
@@ -57,10 +58,9 @@ sssp_ms, _ = timed(stages=STAGE_SSSP)
 ms, res = timed()
 print(f"params [{params}]: SSSP + predecessors {sssp_ms:.2f} ms, with the branch selection {ms:.2f} ms; {res.stats}; branches of the first component {int(res.n_branches[0])}")
 ticks = torch.zeros(16, dtype=torch.int64, device=dev)
-L.st_debug_set_ticks(ticks.data_ptr())
-run_components(comps, medial, radius, ys)
+with tuning.override({**knobs, tuning.TICKS: ticks.data_ptr()}):
+    run_components(comps, medial, radius, ys)
 torch.cuda.synchronize()
-L.st_debug_set_ticks(None)
 t = ticks.cpu().numpy()
 print(f"  phases (us, summed over components): head {t[0]/100:.0f} rank {t[7]/100:.0f} prune {t[1]/100:.0f} walk+rows {t[2]/100:.0f} claim {t[3]/100:.0f} "
       f"validate+commit {t[4]/100:.0f} one-mode {t[5]/100:.0f} local {t[6]/100:.0f} ({t[15]}) | rounds {t[8]} slots {t[13]} commits {t[12]} "

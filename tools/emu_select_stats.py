@@ -19,6 +19,7 @@ from smart_tree_amd import _lib  # noqa: E402
 from smart_tree_amd.data_types.cloud import Cloud  # noqa: E402
 from smart_tree_amd.skeleton import graph as G  # noqa: E402
 from smart_tree_amd.skeleton.filter import outlier_removal  # noqa: E402
+from smart_tree_amd.skeleton import tuning  # noqa: E402
 from smart_tree_amd.skeleton.skeletonize import STAGE_SSSP, run_components  # noqa: E402
 from smart_tree_amd.synthetic import sample_tree_cloud  # noqa: E402
 
@@ -46,16 +47,14 @@ medial, radius = medial[mask], radius[mask]
 g = G.nn_graph(medial, radius.clamp(min=0.02), K=16)
 comps = g.connected_cugraph_components(32)
 print(f"{n} points: graph vertices {len(bc)}, components {comps.n_components}, largest {comps.comp_size[:4].tolist()}", flush=True)
-L.st_debug_set_ticks.argtypes = [ctypes.c_void_p]
-L.st_debug_set_skeleton_param(-1, 0)
+knobs = {}
 for kv in filter(None, params.split(",")):
     k, v = kv.split("=")
-    L.st_debug_set_skeleton_param(int(k), int(v))
+    knobs[int(k)] = int(v)
 ticks = torch.zeros(16, dtype=torch.int64)
-L.st_debug_set_ticks(ticks.data_ptr())
 t0 = time.time()
-res = run_components(comps, medial, radius, bc.xyz[:, 1].contiguous())
-L.st_debug_set_ticks(None)
+with tuning.override({**knobs, tuning.TICKS: ticks.data_ptr()}):
+    res = run_components(comps, medial, radius, bc.xyz[:, 1].contiguous())
 t = ticks.numpy()
 print(f"params [{params}] ({time.time() - t0:.1f} s on the emulator): {res.stats}\n  rounds {t[8]} slots {t[13]} commits {t[12]} one-mode iters {t[9]} "
       f"(path vertices {t[10]}) wide {t[14]} local {t[15]} candidates {t[11]}")
