@@ -128,7 +128,9 @@ def save_skeleton(skeleton, save_location) -> None:
     as_np = lambda t: t.detach().cpu().numpy() if hasattr(t, "detach") else np.asarray(t)
     data = {"tree_id": skeleton._id,
             "skeleton_xyz": np.concatenate([as_np(b.xyz) for b in branches]),
-            "skeleton_radii": np.concatenate([as_np(b.radii) for b in branches])[..., np.newaxis],
+            # `smooth` flattens the radii of the branches it touches to [m] (tree.py:130-134) and leaves the short ones [m,1]:
+            # every branch goes in as [m,1], the layout the reference writes for an unsmoothed tree ([P,1,1] in the file)
+            "skeleton_radii": np.concatenate([as_np(b.radii).reshape(-1, 1) for b in branches])[..., np.newaxis],
             "branch_id": np.asarray([b._id for b in branches]),
             "branch_parent_id": np.asarray([b.parent_id for b in branches]),
             "branch_num_elements": np.asarray([len(b) for b in branches])}

@@ -29,6 +29,19 @@ def _rms(a):
     return float(np.sqrt(np.mean(np.square(a, dtype=np.float64)))) + 1e-30
 
 
+def _record_tolerance(what, err, base, scale):
+    """The measured numbers behind the relaxed fp32 bar (`max(1e-4, 4 x the fp32 oracle's own distance from fp64)`), written
+    where the builder collects them (gpurun_out/ -> profiles/r03_fp32_tolerance.txt) so the relaxation is a documented figure."""
+    out = Path(__file__).resolve().parents[1] / "gpurun_out"
+    try:
+        out.mkdir(exist_ok=True)
+        with open(out / "fp32_tolerance.txt", "a") as f:
+            f.write(f"{what}: max|hip - fp64 oracle| / rms(fp64) = {err:.3e}; max|fp32 oracle - fp64 oracle| / rms = {base:.3e}; "
+                    f"rms(fp64 medial vector) = {scale:.4e}; bar = max(1e-4, 4 x base) = {max(1e-4, 4 * base):.3e}\n")
+    except OSError:
+        pass
+
+
 def _pipeline(dev, voxel):
     mi = ModelInference("unused", WEIGHTS, voxel_size=voxel, block_size=4, buffer_size=0.4, device=dev)
     sk = Skeletonizer(K=16, min_connection_length=0.02, minimum_graph_vertices=32, device=dev)
@@ -61,6 +74,7 @@ def test_config1_million_point_tree_stagewise():
     scale = _rms(mv64[inner])
     err = np.abs(lc.medial_vector.cpu().numpy() - mv64[inner]).max() / scale
     base = np.abs(mv32[inner] - mv64[inner]).max() / scale
+    _record_tolerance("test_config1_million_point_tree_stagewise (noble-elevator-58, %d voxels)" % len(inner), err, base, scale)
     assert err <= max(1e-4, 4 * base), (err, base)
     assert (lc.class_l.cpu().numpy() != cls64[inner]).mean() < 1e-3
     # skeleton + post-processing from the SAME labelled cloud: identical to the oracle
@@ -117,6 +131,46 @@ def test_config3_dense_canopy_properties():
     for tree in sk.skeletons:
         for b in tree.branches.values():
             assert b.parent_id < b._id and b.xyz.shape[0] == b.radii.shape[0] and torch.isfinite(b.xyz).all()
+
+
+def test_config3_style_canopy_against_the_oracle():
+    """configs[3]'s regime at a size the oracle finishes in seconds: 400k points, 60 % foliage, 1 cm voxels, and radius
+    outliers injected into the network's medial vectors (the full-size cloud has a median radius of 6 cm and a maximum of
+    1.0 m: the case that made every claim / search cell too coarse in round 2).  Voxels bit-exact; skeleton + post-processing
+    of the SAME labelled cloud identical to the oracle, branch by branch."""
+    dev = torch.device("cuda:0")
+    c = sample_tree_cloud(400_000, seed=3, foliage_fraction=0.6)
+    pipe = _pipeline(dev, 0.01)
+    pipe.process_cloud(cloud=Cloud(xyz=torch.from_numpy(c["xyz"]).to(dev), rgb=torch.from_numpy(c["rgb"]).to(dev)))
+    xyz = vo.centre_cloud(c["xyz"])
+    ref = vo.voxelize_cloud(xyz, c["rgb"], 0.01)
+    got = voxelize_blocks(torch.from_numpy(xyz).to(dev), torch.from_numpy(c["rgb"]).to(dev), 0.01)
+    np.testing.assert_array_equal(got.coords.cpu().numpy(), ref["coords"])
+    np.testing.assert_array_equal(got.point_index.cpu().numpy(), ref["point"])
+    lc = pipe.last_labelled_cloud
+    np.testing.assert_array_equal(lc.xyz.cpu().numpy(), ref["feats"][ref["mask"], :3])
+    mv = lc.medial_vector.clone()
+    rng = np.random.RandomState(5)
+    hit = torch.from_numpy(rng.choice(len(lc), size=max(len(lc) // 400, 8), replace=False)).to(dev)
+    mv[hit] *= torch.from_numpy(rng.uniform(4.0, 16.0, (len(hit), 1)).astype(np.float32)).to(dev)  # radii up to ~1 m
+    labelled = Cloud(xyz=lc.xyz, rgb=lc.rgb, medial_vector=mv, class_l=lc.class_l)
+    rad = mv.norm(dim=1)
+    assert float(rad.max()) > 8 * float(rad.median())
+    skeleton = pipe.skeletonizer.forward(labelled.filter_by_class(pipe.branch_classes))
+    pipe.post_process(skeleton)
+    trees = po.skeleton_from_labelled(lc.xyz.cpu().numpy(), mv.cpu().numpy(), lc.class_l.cpu().numpy())
+    po.post_process(trees, True, 0.01, 0.02, True, True, 11)
+    assert len(skeleton.skeletons) == len(trees) >= 1
+    n_branches = 0
+    for got_tree, rt in zip(skeleton.skeletons, trees):
+        assert list(got_tree.branches) == list(rt.branches)
+        for k, rb in rt.branches.items():
+            gb = got_tree.branches[k]
+            assert gb.parent_id == rb.parent_id
+            np.testing.assert_array_equal(gb.xyz.numpy(), rb.xyz)
+            np.testing.assert_array_equal(gb.radii.numpy(), rb.radii)
+        n_branches += len(rt.branches)
+    assert n_branches > 20
 
 
 def test_config1_ground_truth_medial_many_components():

@@ -142,3 +142,53 @@ def test_device_smooth_matches_conv1d_same_padding_for_even_kernels(backend, ker
     ob = po.OTree(0, {0: po.OBranch(0, -1, np.zeros((6, 3), np.float32), np.array([1, 2, 4, 8, 16, 32], np.float32))})
     po.smooth(ob, 4)
     np.testing.assert_array_equal(ob.branches[0].radii, np.array([7, 15, 30, 60, 56, 48], np.float32) / 4)
+
+
+# ---- the reference's WHOLE Skeletonizer.forward (tools/make_goldens.py::quirks_case), every SURVEY 8c(4) quirk asserted to fire there:
+# vertex 0's in-edges dropped (graph.py:59), single-vertex paths consumed without a branch (path.py:125-126), the root-reaching
+# path's parent read from branch_ids[-1] (path.py:132), components of 31 / 32 vertices (data_types/graph.py:44-45), size order
+def _quirk_trees(g):
+    for ti in range(int(g["n_trees"])):
+        ids = g[f"tree_{ti}_ids"].tolist()
+        yield ti, ids, g[f"tree_{ti}_parent"].tolist(), [g[f"tree_{ti}_branch_{k}_xyz"] for k in ids], [g[f"tree_{ti}_branch_{k}_radii"] for k in ids]
+
+
+def test_oracle_matches_reference_forward_with_every_quirk():
+    g = np.load(GOLD / "skeleton_quirks.npz")
+    assert int(g["single_vertex_paths"]) >= 1 and 32 in g["component_sizes"] and 31 not in g["component_sizes"]
+    xyz, mv = g["raw_xyz"], g["raw_medial_vector"]
+    ref = so.skeletonize(xyz, mv)
+    np.testing.assert_array_equal(ref.keep_mask, g["keep_mask"])
+    np.testing.assert_array_equal(ref.edges, g["edges"])
+    np.testing.assert_array_equal(ref.weights, g["weights"])
+    assert not (ref.edges[:, 1] == 0).any()  # graph.py:59
+    sizes = np.unique(ref.labels, return_counts=True)[1]
+    assert 31 in sizes  # a 31-vertex component exists in the graph and is dropped
+    assert [len(c.vertex_ids) for c in ref.components] == g["component_sizes"].tolist()
+    medial, radius = (xyz + mv)[ref.keep_mask], _radius(mv)[ref.keep_mask]
+    iterations = 0
+    for (ti, ids, parents, pts, radii), comp in zip(_quirk_trees(g), ref.components):
+        np.testing.assert_array_equal(comp.preds, g[f"tree_{ti}_preds"])  # the stand-in SSSP is the oracle's: pins the renumbering around it
+        np.testing.assert_array_equal(comp.tree_dist, g[f"tree_{ti}_dist"])  # reference pred_graph + second sssp
+        np.testing.assert_array_equal(comp.dist, comp.tree_dist)
+        assert [b.branch_id for b in comp.branches] == ids and [b.parent_id for b in comp.branches] == parents
+        for b, p, r in zip(comp.branches, pts, radii):
+            np.testing.assert_array_equal(medial[comp.vertex_ids][b.verts], p)
+            np.testing.assert_array_equal(radius[comp.vertex_ids][b.verts].reshape(-1, 1), r)
+        iterations += so.sample_tree(medial[comp.vertex_ids], radius[comp.vertex_ids], comp.preds, comp.tree_dist)[2]
+    assert iterations == int(g["iterations"])  # incl. the single-vertex paths that consume points without a branch
+
+
+def test_hip_matches_reference_forward_with_every_quirk(backend):
+    g = np.load(GOLD / "skeleton_quirks.npz")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(backend)
+    sk = Skeletonizer(K=16, min_connection_length=0.02, minimum_graph_vertices=32, device=backend)
+    sk.block_threads = 128 if backend.type == "cpu" else 0
+    out = sk.forward(Cloud(xyz=t(g["raw_xyz"]), medial_vector=t(g["raw_medial_vector"])))
+    assert len(out.skeletons) == int(g["n_trees"])
+    for (ti, ids, parents, pts, radii), tree in zip(_quirk_trees(g), out.skeletons):
+        assert list(tree.branches) == ids
+        assert [b.parent_id for b in tree.branches.values()] == parents
+        for b, p, r in zip(tree.branches.values(), pts, radii):
+            np.testing.assert_array_equal(b.xyz.numpy(), p)
+            np.testing.assert_array_equal(b.radii.numpy(), r)

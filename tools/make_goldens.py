@@ -116,6 +116,117 @@ def install_stubs():
                     torch.from_numpy(vid))
 
     sys.modules["spconv.pytorch.utils"].PointToVoxel = PointToVoxel
+    install_graph_standins()
+
+
+# ------------------------------------------------------------ cugraph / cudf / cupy stand-ins ---
+class FSeries:
+    """The few cudf.Series operations the reference's glue performs (data_types/graph.py:32-51, skeletonize.py:60-63)."""
+
+    def __init__(self, a):
+        self.a = np.asarray(a)
+
+    def unique(self):
+        return FSeries(np.unique(self.a))  # ascending: with labels = smallest member id this is the oracle's canonical order
+
+    def to_pandas(self):
+        return self.a.tolist()
+
+    def __eq__(self, other):
+        return FSeries(self.a == other)
+
+    def count(self):
+        return int(len(self.a))
+
+    @property
+    def values(self):
+        return self.a
+
+    def to_numpy(self):
+        return self.a
+
+    def __array__(self, dtype=None, copy=None):
+        return self.a if dtype is None else self.a.astype(dtype)
+
+    def __len__(self):
+        return len(self.a)
+
+
+class FFrame:
+    def __init__(self, cols=None):
+        self.cols = dict(cols or {})
+
+    def __setitem__(self, k, v):
+        self.cols[k] = np.asarray(v)
+
+    def __getitem__(self, k):
+        if isinstance(k, str):
+            return FSeries(self.cols[k])
+        mask = k.a if isinstance(k, FSeries) else np.asarray(k)
+        return FFrame({c: v[mask] for c, v in self.cols.items()})
+
+    @property
+    def values(self):
+        return np.stack([self.cols[c] for c in self.cols], 1)
+
+
+class FGraph:
+    """cugraph.Graph(directed=False) over an edge list with vertex ids 0 .. max (renumber=False)."""
+
+    def __init__(self, directed=False):
+        self.src = self.dst = np.zeros(0, np.int64)
+        self.w = np.zeros(0, np.float32)
+
+    def from_cudf_edgelist(self, d, edge_attr=None, renumber=False):
+        assert not renumber
+        self.src, self.dst = d.cols["source"].astype(np.int64), d.cols["destination"].astype(np.int64)
+        self.w = d.cols[edge_attr].astype(np.float32)
+
+    def n(self):
+        return int(max(self.src.max(), self.dst.max())) + 1 if len(self.src) else 0
+
+    def nodes(self):
+        return FSeries(np.unique(np.concatenate([self.src, self.dst])))
+
+    def edges(self):
+        return FFrame({"src": self.src, "dst": self.dst})
+
+    def edge_array(self):
+        return np.stack([self.src, self.dst], 1)
+
+
+def install_graph_standins():
+    """cugraph / cudf / cupy are CUDA-only: connected components, sub-graphs and SSSP are served by the oracle's canonical
+    restatements (oracle/skeleton_oracle.c: labels = smallest member, SSSP = least fixed point + smallest tight predecessor),
+    so that the reference's OWN glue around them -- the >= minimum_vertices filter, the size ordering, the vertex-id /
+    edge renumbering of process_subgraph, shortest_paths / pred_graph / the second sssp -- runs unmodified on the CPU."""
+    from oracle import skeleton_oracle as so
+
+    def connected_components(g):
+        n = g.n()
+        return FFrame({"labels": so.cc_labels(n, g.edge_array()), "vertex": np.arange(n, dtype=np.int64)})
+
+    def subgraph(g, vertices):
+        ids = np.asarray(vertices.a if isinstance(vertices, FSeries) else vertices)
+        keep = np.isin(g.src, ids) & np.isin(g.dst, ids)
+        out = FGraph()
+        out.src, out.dst, out.w = g.src[keep], g.dst[keep], g.w[keep]
+        return out
+
+    def sssp(g, source=0):
+        n = g.n()
+        dist, pred = so.sssp(n, g.edge_array(), g.w, int(source))
+        return {"vertex": np.arange(n, dtype=np.int64), "predecessor": pred, "distance": dist}
+
+    def to_pandas_edgelist(g):
+        return {"src": g.src, "dst": g.dst, "weights": g.w}
+
+    cg = sys.modules["cugraph"]
+    cg.Graph, cg.connected_components, cg.subgraph, cg.sssp, cg.to_pandas_edgelist = FGraph, connected_components, subgraph, sssp, to_pandas_edgelist
+    sys.modules["cudf"].DataFrame = FFrame
+    cp = sys.modules["cupy"]
+    cp.asarray = lambda a: np.asarray(a.detach().cpu().numpy() if torch.is_tensor(a) else a)
+    cp.unique = np.unique
 
 
 def reference(module: str):
@@ -182,6 +293,112 @@ def skeleton_case(name: str, xyz: np.ndarray, mv: np.ndarray):
         out[f"post_{k}_radii"] = b.radii.numpy()
     np.savez_compressed(OUT / f"{name}.npz", **out)
     print(name, "points", len(keep), "kept", keep.sum(), "component", len(ids), "branches", len(branches), "after post", len(tree.branches))
+
+
+def quirk_cloud():
+    """A small procedural tree + two isolated twigs whose graph components have exactly 32 and 31 vertices (the reference
+    keeps components with count >= minimum_vertices = 32, data_types/graph.py:44-45)."""
+    from oracle import voxel_oracle as vo
+    from smart_tree_amd.synthetic import sample_tree_cloud
+
+    c = sample_tree_cloud(40_000, seed=5, scale=0.5, max_depth=4)
+    vx = vo.voxelize_cloud(vo.centre_cloud(c["xyz"]), c["rgb"], 0.02)
+    m = vx["mask"]
+    xyz, mv = [vx["feats"][m, :3]], [c["medial_vector"][vx["point"][m]]]
+    rng = np.random.RandomState(3)
+    for count, x0 in ((32, 4.0), (31, -4.0)):  # twig: medial points 5 mm apart on a vertical axis, radius 5 cm
+        t = np.arange(count, dtype=np.float64) * 0.005
+        th = rng.rand(count) * 2 * np.pi
+        radial = np.stack([np.cos(th), np.zeros(count), np.sin(th)], 1)
+        axis = np.stack([np.full(count, x0), 0.3 + t, np.zeros(count)], 1)
+        xyz.append((axis + 0.05 * radial).astype(np.float32))
+        mv.append((-0.05 * radial).astype(np.float32))
+    return np.concatenate(xyz).astype(np.float32), np.concatenate(mv).astype(np.float32)
+
+
+def quirks_case(name: str = "skeleton_quirks"):
+    """The reference's OWN `Skeletonizer.forward` (skeleton/skeletonize.py:31-95), whole, on the CPU: outlier_removal ->
+    nn_graph / make_edges -> Graph.connected_cugraph_components -> per component process_subgraph (vertex ids, Cloud.filter,
+    decompose_cuda_graph + remap_edges, root_idx, shortest_paths, pred_graph, the second sssp, sample_tree) -> TreeSkeleton.
+    Third-party calls go to the stand-ins above; the two torch-CPU roundings that differ from a GPU's (sqrt, documented at
+    _ExactSqrt) are pinned to the correctly rounded value in Cloud.radius and pred_graph's torch.norm.
+    The generator ASSERTS that every quirk SURVEY 8c(4) lists fires in this cloud."""
+    r_cloud = reference("smart_tree.data_types.cloud")
+    r_sk = reference("smart_tree.skeleton.skeletonize")
+    r_sp = reference("smart_tree.skeleton.shortest_path")
+    r_path = reference("smart_tree.skeleton.path")
+    r_graph = reference("smart_tree.skeleton.graph")
+    real_device = torch.device
+    r_path.torch = types.SimpleNamespace(**{k: getattr(torch, k) for k in dir(torch)})
+    r_path.torch.device = lambda *a, **k: real_device("cpu")  # path.py:74,78 hard-code "cuda"
+
+    def exact_norm(t, dim=1):  # correctly rounded sqrt((dx^2 + dy^2) + dz^2): what sqrtf gives on a GPU
+        a = t.numpy()
+        s = ((a[:, 0] * a[:, 0] + a[:, 1] * a[:, 1]) + a[:, 2] * a[:, 2]).astype(np.float32)
+        return torch.from_numpy(np.sqrt(s.astype(np.float64)).astype(np.float32))
+
+    r_sp.torch = types.SimpleNamespace(**{k: getattr(torch, k) for k in dir(torch)})
+    r_sp.torch.norm = exact_norm
+    r_cloud.Cloud.radius = property(lambda self: exact_norm(self.medial_vector))
+    seen = {"paths": [], "dist_pairs": []}
+    real_trace, real_sample = r_path.trace_route, r_sk.sample_tree
+
+    def trace_route(preds, idx, termination_pts):
+        path, term = real_trace(preds, idx, termination_pts)
+        seen["paths"].append((len(path), int(term)))
+        return path, term
+
+    r_path.trace_route = trace_route
+    real_sp = r_sk.shortest_paths
+
+    def shortest_paths(root, edges, w, renumber=True):
+        out = real_sp(root, edges, w, renumber=renumber)
+        seen["first"] = out[2].numpy().copy()
+        return out
+
+    def sample_tree(medial, radius, preds, distances, surface):
+        seen["dist_pairs"].append(bool(np.array_equal(seen["first"], distances.numpy())))  # second SSSP == first, bit for bit
+        seen.setdefault("inputs", []).append((preds.numpy().copy(), distances.numpy().copy()))
+        return real_sample(medial, radius, preds, distances, surface)
+
+    r_sk.shortest_paths, r_sk.sample_tree = shortest_paths, sample_tree
+    xyz, mv = quirk_cloud()
+    t = torch.from_numpy
+    cloud = r_cloud.Cloud(xyz=t(xyz), medial_vector=t(mv))
+    # graph-level facts for the quirk assertions (the same reference calls forward() makes)
+    keep = reference("smart_tree.skeleton.filter").outlier_removal(cloud.medial_pts, cloud.radius.unsqueeze(1), nb_points=8).numpy()
+    kept = cloud.filter(t(keep))
+    idxs, dists, _ = r_graph.knn(kept.medial_pts, kept.medial_pts, K=16, r=float(kept.radius.clamp(min=0.02).max()))
+    idxs[dists > kept.radius.clamp(min=0.02).unsqueeze(1)] = -1
+    edges, weights = r_graph.make_edges(dists, idxs)
+    sk = r_sk.Skeletonizer(K=16, min_connection_length=0.02, minimum_graph_vertices=32, device=real_device("cpu"))
+    result = sk.forward(cloud)
+    r_path.trace_route, r_sk.shortest_paths, r_sk.sample_tree = real_trace, real_sp, real_sample
+    # ---- every quirk fires
+    from oracle import skeleton_oracle as so
+    assert (idxs[1:] == 0).any() and not (edges[:, 1] == 0).any(), "vertex 0 must have in-edges for graph.py:59 to drop"
+    labels = so.cc_labels(int(keep.sum()), edges.numpy())
+    sizes = np.unique(labels, return_counts=True)[1]
+    assert 31 in sizes and 32 in sizes, sizes
+    comp_sizes = [len(p[0]) for p in seen["inputs"]]
+    assert 32 in comp_sizes and 31 not in comp_sizes and comp_sizes == sorted(comp_sizes, reverse=True), comp_sizes
+    assert any(l == 1 for l, _ in seen["paths"]), "no single-vertex path (path.py:125-126)"
+    assert sum(1 for _, term in seen["paths"] if term == -1) == len(result.skeletons), "one root-reaching path per component (path.py:132)"
+    assert all(seen["dist_pairs"]), "second SSSP differs from the first"
+    out = {"raw_xyz": xyz, "raw_medial_vector": mv, "keep_mask": keep, "edges": edges.numpy(), "weights": weights.numpy(),
+           "component_sizes": np.array(comp_sizes, np.int64), "n_trees": np.int64(len(result.skeletons)),
+           "single_vertex_paths": np.int64(sum(1 for l, _ in seen["paths"] if l == 1)),
+           "iterations": np.int64(len(seen["paths"]))}
+    for ti, tree in enumerate(result.skeletons):
+        out[f"tree_{ti}_preds"], out[f"tree_{ti}_dist"] = seen["inputs"][ti]
+        out[f"tree_{ti}_ids"] = np.array(list(tree.branches.keys()), np.int64)
+        out[f"tree_{ti}_parent"] = np.array([b.parent_id for b in tree.branches.values()], np.int64)
+        for k, b in tree.branches.items():
+            out[f"tree_{ti}_branch_{k}_xyz"] = b.xyz.numpy()
+            out[f"tree_{ti}_branch_{k}_radii"] = b.radii.numpy()
+    np.savez_compressed(OUT / f"{name}.npz", **out)
+    print(name, "points", len(keep), "kept", int(keep.sum()), "components", comp_sizes, "branches",
+          [len(tr.branches) for tr in result.skeletons], "iterations", len(seen["paths"]), "single-vertex paths", int(out["single_vertex_paths"]))
 
 
 def blocking_case():
@@ -362,6 +579,7 @@ def main():
     vx = vo.voxelize_cloud(vo.centre_cloud(c["xyz"]), c["rgb"], 0.02)
     m = vx["mask"]
     skeleton_case("skeleton_small_tree", vx["feats"][m, :3], c["medial_vector"][vx["point"][m]])
+    quirks_case()
     blocking_case()
     nearest_tube_case()
     skeleton_file_case()
