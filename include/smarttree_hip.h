@@ -81,20 +81,37 @@ int st_build_strided_rulebook(const int32_t* coords, int64_t n, const unsigned l
 int st_sparse_conv_fwd(const float* x0, int c0, const float* x1, int cin, const int32_t* nbr, int K, int64_t n_out,
                        const float* w, int cout, const float* scale, const float* shift, const float* residual,
                        int relu, float* y, const int32_t* row_order /*[n_out] or NULL: launch order of the output rows (bits 0-27 row, top 4 bits 0 or the parity tag of st_build_strided_rulebook)*/,
-                       void* stream);
+                       void* stream, int64_t nbr_stride /*elements between the rows of nbr; 0 = n_out*/);
 /* same contract; weights pre-permuted to wp[K][cin/16][4][cout][4] = W[k][16c+4kg+s][co]; cin, cout, c0 % 16 == 0.
  * The per-offset [16 x cin].[cin x cout] contraction runs on v_mfma_f32_16x16x4_f32 (exact fp32). */
 int st_sparse_conv_mfma_fwd(const float* x0, int c0, const float* x1, int cin, const int32_t* nbr, int K, int64_t n_out,
                             const float* wp, int cout, const float* scale, const float* shift, const float* residual,
                             int relu, float* y, const int32_t* row_order /*[n_out] or NULL: launch order of the output rows (bits 0-27 row, top 4 bits 0 or the parity tag of st_build_strided_rulebook)*/,
-                       void* stream);
+                            void* stream, int64_t nbr_stride /*0 = n_out*/,
+                            int variant /*0 = the library picks the tile shape by size; else row tiles per wave | (weights through LDS) << 4 (bench aid)*/);
 /* Half-precision storage (BASELINE.json configs[4]; an extension -- the reference's inference, model/model_inference.py:49-100,
  * is float32): in_half && out_half -> x0 / x1 / residual / y are IEEE half, w is the MFMA order as half, Cin, Cout and the
  * concat split multiples of 16, v_mfma_f32_16x16x16_f16 with float32 accumulation; exactly one of them -> the float32
  * kernel with a converting load or store (w [K][cin][cout] float32, no residual, no concat). */
 int st_sparse_conv_f16_fwd(const void* x0, int c0, const void* x1, int cin, const int32_t* nbr, int K, int64_t n_out,
                            const void* w, int cout, const float* scale, const float* shift, const void* residual, int relu,
-                           void* y, int in_half, int out_half, const int32_t* row_order, void* stream);
+                           void* y, int in_half, int out_half, const int32_t* row_order, void* stream, int64_t nbr_stride /*0 = n_out*/);
+
+/* ---- rulebooks without hash probes (csrc/brick.hip) ------------------------------------------------
+ * replaces, for the network's own forward pass, the per-conv hash build of spconv (model/model_blocks.py:57-70,90-101,134-143)
+ * AND the builders above: every level's active set is kept as 8 x 8 x 8 occupancy bricks with popcount ranks, the voxels of a
+ * level are ordered (block, brick Morton code, z, y, x), a neighbour look-up is a table entry + one mask word.  One call builds
+ * every level (sets, submanifold tables, strided / inverse tables, parity order) with the counts on the device and ONE
+ * read-back.  Tables are laid out with row stride caps[level] (pass it as nbr_stride to the convolutions).
+ * st_brick_pyramid_workspace_bytes returns 0 when the structure cannot be sized for the arguments (use the builders above). */
+int64_t st_brick_pyramid_workspace_bytes(int64_t n0, int n_blocks, int coord_bound, int depth, const int64_t* caps);
+int st_brick_pyramid(const int32_t* coords0 /*[n0,4] (batch index, z, y, x), any order*/, int64_t n0, int n_blocks /*batch indices < this*/,
+                     int coord_bound /*z, y, x < this*/, int depth, const int32_t* blk_seg /*[n_blocks] cloud of a batch index or NULL*/,
+                     int nseg, const int64_t* caps /*[depth+1] row capacity per level, caps[0] >= n0*/,
+                     int32_t* order0 /*[n0]: row p of level 0 = input voxel order0[p]*/, int32_t* const* coords_out /*[depth+1] x [caps[l],4]*/,
+                     int32_t* const* subm /*[depth+1] x [27][caps[l]]*/, int32_t* const* down /*[depth] x [27][caps[l+1]]*/,
+                     int32_t* const* up /*[depth] x [27][caps[l]]*/, int32_t* const* up_order /*[depth] x [caps[l] + 16]*/,
+                     int64_t* counts_host /*[depth+1] rows per level*/, void* ws, int64_t ws_bytes, void* stream);
 int st_head_param_floats(void);
 int st_pointwise_mlp_heads(const float* x, int64_t n, const float* params, float* radius, float* direction,
                            float* class_l, float* medial_vector /*nullable*/, int64_t* class_idx /*nullable*/, void* stream);

@@ -50,7 +50,7 @@ __device__ __forceinline__ uint32_t conv_live_offsets(int32_t entry, int K) {
 template <int CIN, int COT, class TIN = float, class TOUT = float>
 __global__ void __launch_bounds__(CONV_BLOCK) k_sparse_conv(const TIN* __restrict__ x0, int c0,
                                                             const TIN* __restrict__ x1, const int32_t* __restrict__ nbr,
-                                                            int K, int64_t n_out, const float* __restrict__ w, int cout,
+                                                            int K, int64_t n_out, int64_t nstride, const float* __restrict__ w, int cout,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
                                                             const float* __restrict__ residual, int relu,
                                                             TOUT* __restrict__ y, const int32_t* __restrict__ row_order) {
@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(CONV_BLOCK) k_sparse_conv(const TIN* __restric
             for (int j = 0; j < G; j++) {
                 const int k = k0 + j;
                 idx[j] = -1;
-                if (k < K && active && ((live >> k) & 1u)) idx[j] = nbr ? nbr[(int64_t)k * n_out + o] : (int)o;
+                if (k < K && active && ((live >> k) & 1u)) idx[j] = nbr ? nbr[(int64_t)k * nstride + o] : (int)o;
             }
 #pragma unroll
             for (int j = 0; j < G; j++)
@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(CONV_BLOCK) k_sparse_conv(const TIN* __restric
     } else
     for (int k = 0; k < K; k++) {
         int idx = -1;
-        if (active && ((live >> k) & 1u)) idx = nbr ? nbr[(int64_t)k * n_out + o] : (int)o;
+        if (active && ((live >> k) & 1u)) idx = nbr ? nbr[(int64_t)k * nstride + o] : (int)o;
         if (idx < 0) continue;
         const float* __restrict__ wk = w + (int64_t)k * CIN * cout + co0;
         if (CIN % 4 == 0) {
@@ -150,12 +150,12 @@ __global__ void __launch_bounds__(CONV_BLOCK) k_sparse_conv(const TIN* __restric
 }
 
 template <int CIN, int COT, class TIN = float, class TOUT = float>
-static int conv_launch(const TIN* x0, int c0, const TIN* x1, const int32_t* nbr, int K, int64_t n_out, const float* w,
+static int conv_launch(const TIN* x0, int c0, const TIN* x1, const int32_t* nbr, int K, int64_t n_out, int64_t nstride, const float* w,
                        int cout, const float* scale, const float* shift, const float* residual, int relu, TOUT* y,
                        hipStream_t stream, const int32_t* row_order = nullptr) {
     int64_t blocks = st_div_up(n_out, CONV_BLOCK) * (cout / COT);
     hipLaunchKernelGGL((k_sparse_conv<CIN, COT, TIN, TOUT>), dim3((unsigned)blocks), dim3(CONV_BLOCK), 0, stream, x0, c0, x1, nbr, K,
-                       n_out, w, cout, scale, shift, residual, relu, y, row_order);
+                       n_out, nstride, w, cout, scale, shift, residual, relu, y, row_order);
     ST_CHECK_LAUNCH();
     return ST_OK;
 }
@@ -181,7 +181,7 @@ typedef float st_v4f __attribute__((ext_vector_type(4)));
 // barrier, loads free to run ahead of the MFMAs).
 template <int CIN, int COUT, int RT, bool LDSW>
 __global__ void __launch_bounds__(MF_BLOCK) k_sparse_conv_mfma(const float* __restrict__ x0, int c0, const float* __restrict__ x1,
-                                                               const int32_t* __restrict__ nbr, int K, int64_t n_out,
+                                                               const int32_t* __restrict__ nbr, int K, int64_t n_out, int64_t nstride,
                                                                const float* __restrict__ wp, const float* __restrict__ scale,
                                                                const float* __restrict__ shift, const float* __restrict__ residual,
                                                                int relu, float* __restrict__ y, const int32_t* __restrict__ row_order) {
@@ -216,7 +216,7 @@ __global__ void __launch_bounds__(MF_BLOCK) k_sparse_conv_mfma(const float* __re
         bool any = false;
 #pragma unroll
         for (int t = 0; t < RT; t++) {
-            idx[t] = orow[t] >= 0 && ((live[t] >> k) & 1u) ? (nbr ? nbr[(int64_t)k * n_out + orow[t]] : (int)orow[t]) : -1;
+            idx[t] = orow[t] >= 0 && ((live[t] >> k) & 1u) ? (nbr ? nbr[(int64_t)k * nstride + orow[t]] : (int)orow[t]) : -1;
             any = any || idx[t] >= 0;
         }
         if (LDSW) __syncthreads();
@@ -267,29 +267,26 @@ __global__ void __launch_bounds__(MF_BLOCK) k_sparse_conv_mfma(const float* __re
     }
 }
 
-static int g_mfma_variant = 0;  // developer knob (st_debug_set_mfma_variant): 0 auto, else RT | (LDSW << 4)
-extern "C" void st_debug_set_mfma_variant(int v) { g_mfma_variant = v; }
-
 template <int CIN, int COUT, int RT, bool LDSW>
-static void conv_launch_mfma_v(const float* x0, int c0, const float* x1, const int32_t* nbr, int K, int64_t n_out, const float* wp,
+static void conv_launch_mfma_v(const float* x0, int c0, const float* x1, const int32_t* nbr, int K, int64_t n_out, int64_t nstride, const float* wp,
                                const float* scale, const float* shift, const float* residual, int relu, float* y,
                                hipStream_t stream, const int32_t* row_order) {
     const int64_t blocks = st_div_up(n_out, (MF_BLOCK / 64) * 16 * RT);
     hipLaunchKernelGGL((k_sparse_conv_mfma<CIN, COUT, RT, LDSW>), dim3((unsigned)blocks), dim3(MF_BLOCK), 0, stream, x0, c0, x1,
-                       nbr, K, n_out, wp, scale, shift, residual, relu, y, row_order);
+                       nbr, K, n_out, nstride, wp, scale, shift, residual, relu, y, row_order);
 }
 
 template <int CIN, int COUT>
-static int conv_launch_mfma(const float* x0, int c0, const float* x1, const int32_t* nbr, int K, int64_t n_out, const float* wp,
+static int conv_launch_mfma(const float* x0, int c0, const float* x1, const int32_t* nbr, int K, int64_t n_out, int64_t nstride, const float* wp,
                             const float* scale, const float* shift, const float* residual, int relu, float* y,
-                            hipStream_t stream, const int32_t* row_order) {
-    int v = g_mfma_variant;
+                            hipStream_t stream, const int32_t* row_order, int variant) {
+    int v = variant;  // 0: by size (below); else RT | (LDSW << 4): tools/bench_conv.py times the variants
     // measured on MI355X (tools/bench_conv.py, profiles/r02_conv_variants_batch8.txt): one row tile per wave with the weights
     // straight from L2 wins while a level has too few rows to fill the chip (one cloud: <= 90k rows below level 0) and for the
     // parity-ordered inverse convs; from ~150k rows on (a batch of clouds, the 5M-point cloud) two row tiles per wave with
     // W_k staged once per workgroup in LDS is 5-20 % faster (B fragments reused, a quarter of the weight traffic from L2)
     if (v == 0) v = (row_order == nullptr && n_out >= 150000) ? 18 : 1;
-#define MFMA_V(RT_, L_) conv_launch_mfma_v<CIN, COUT, RT_, L_>(x0, c0, x1, nbr, K, n_out, wp, scale, shift, residual, relu, y, stream, row_order)
+#define MFMA_V(RT_, L_) conv_launch_mfma_v<CIN, COUT, RT_, L_>(x0, c0, x1, nbr, K, n_out, nstride, wp, scale, shift, residual, relu, y, stream, row_order)
     switch (v) {
         case 1: MFMA_V(1, false); break;
         case 2: MFMA_V(2, false); break;
@@ -309,7 +306,7 @@ static int conv_launch_mfma(const float* x0, int c0, const float* x1, const int3
 // quarter of the matrix instructions.  BatchNorm affine / residual / ReLU in float32, one rounding on the store.
 template <int CIN, int COUT>
 __global__ void __launch_bounds__(MF_BLOCK) k_sparse_conv_mfma_f16(const st_h* __restrict__ x0, int c0, const st_h* __restrict__ x1,
-                                                                   const int32_t* __restrict__ nbr, int K, int64_t n_out,
+                                                                   const int32_t* __restrict__ nbr, int K, int64_t n_out, int64_t nstride,
                                                                    const st_h* __restrict__ wp, const float* __restrict__ scale,
                                                                    const float* __restrict__ shift, const st_h* __restrict__ residual,
                                                                    int relu, st_h* __restrict__ y, const int32_t* __restrict__ row_order) {
@@ -326,7 +323,7 @@ __global__ void __launch_bounds__(MF_BLOCK) k_sparse_conv_mfma_f16(const st_h* _
     const uint32_t live = conv_live_offsets(entry, K);
     for (int k = 0; k < K; k++) {
         const st_v4h* wsrc = reinterpret_cast<const st_v4h*>(wp + (int64_t)k * CIN * COUT);
-        const int idx = orow >= 0 && ((live >> k) & 1u) ? (nbr ? nbr[(int64_t)k * n_out + orow] : (int)orow) : -1;
+        const int idx = orow >= 0 && ((live >> k) & 1u) ? (nbr ? nbr[(int64_t)k * nstride + orow] : (int)orow) : -1;
         if (__ballot(idx >= 0) == 0ull) continue;  // no voxel of this wave has a neighbour at offset k (wave-uniform)
 #pragma unroll
         for (int c = 0; c < NC; c++) {
@@ -368,8 +365,10 @@ __global__ void __launch_bounds__(MF_BLOCK) k_sparse_conv_mfma_f16(const st_h* _
 //                no residual
 extern "C" int st_sparse_conv_f16_fwd(const void* x0, int c0, const void* x1, int cin, const int32_t* nbr, int K, int64_t n_out,
                                       const void* w, int cout, const float* scale, const float* shift, const void* residual,
-                                      int relu, void* y, int in_half, int out_half, const int32_t* row_order, void* stream_) {
+                                      int relu, void* y, int in_half, int out_half, const int32_t* row_order, void* stream_,
+                                      int64_t nbr_stride) {
     hipStream_t stream = (hipStream_t)stream_;
+    const int64_t nstride = nbr_stride > 0 ? nbr_stride : n_out;
     ST_REQUIRE(K >= 1 && (nbr != nullptr || K == 1), "conv: a NULL neighbour table means pointwise (K = 1)");
     ST_REQUIRE(c0 > 0 && c0 <= cin && (c0 == cin || x1 != nullptr), "conv: bad concat split");
     ST_REQUIRE((scale == nullptr) == (shift == nullptr), "conv: scale and shift go together");
@@ -381,7 +380,7 @@ extern "C" int st_sparse_conv_f16_fwd(const void* x0, int c0, const void* x1, in
 #define F16_CASE(CI, CO)                                                                                                        \
     if (cin == CI && cout == CO) {                                                                                              \
         hipLaunchKernelGGL((k_sparse_conv_mfma_f16<CI, CO>), dim3((unsigned)blocks), dim3(MF_BLOCK), 0, stream, (const st_h*)x0, c0, \
-                           (const st_h*)x1, nbr, K, n_out, (const st_h*)w, scale, shift, (const st_h*)residual, relu, (st_h*)y, row_order); \
+                           (const st_h*)x1, nbr, K, n_out, nstride, (const st_h*)w, scale, shift, (const st_h*)residual, relu, (st_h*)y, row_order); \
         ST_CHECK_LAUNCH();                                                                                                      \
         return ST_OK;                                                                                                           \
     }
@@ -400,9 +399,9 @@ extern "C" int st_sparse_conv_f16_fwd(const void* x0, int c0, const void* x1, in
     ST_REQUIRE(cin % 4 == 0 && cout % 4 == 0, "conv(f16): channels must be multiples of 4");
 #define CAST_CASE(CI, CO, COT_)                                                                                                 \
     if (cin == CI && cout == CO) {                                                                                              \
-        if (in_half) return conv_launch<CI, COT_, st_h, float>((const st_h*)x0, c0, (const st_h*)x1, nbr, K, n_out, (const float*)w, \
+        if (in_half) return conv_launch<CI, COT_, st_h, float>((const st_h*)x0, c0, (const st_h*)x1, nbr, K, n_out, nstride, (const float*)w, \
                                                                cout, scale, shift, nullptr, relu, (float*)y, stream, row_order); \
-        return conv_launch<CI, COT_, float, st_h>((const float*)x0, c0, (const float*)x1, nbr, K, n_out, (const float*)w, cout,   \
+        return conv_launch<CI, COT_, float, st_h>((const float*)x0, c0, (const float*)x1, nbr, K, n_out, nstride, (const float*)w, cout,   \
                                                   scale, shift, nullptr, relu, (st_h*)y, stream, row_order);                     \
     }
     CAST_CASE(8, 16, 16)
@@ -418,15 +417,17 @@ extern "C" int st_sparse_conv_f16_fwd(const void* x0, int c0, const void* x1, in
 // Needs Cin, Cout multiples of 16 and a concat split that is a multiple of 16 (or no concat).
 extern "C" int st_sparse_conv_mfma_fwd(const float* x0, int c0, const float* x1, int cin, const int32_t* nbr, int K,
                                        int64_t n_out, const float* wp, int cout, const float* scale, const float* shift,
-                                       const float* residual, int relu, float* y, const int32_t* row_order, void* stream_) {
+                                       const float* residual, int relu, float* y, const int32_t* row_order, void* stream_,
+                                       int64_t nbr_stride, int variant) {
     hipStream_t stream = (hipStream_t)stream_;
+    const int64_t nstride = nbr_stride > 0 ? nbr_stride : n_out;
     ST_REQUIRE(K >= 1 && (nbr != nullptr || K == 1), "conv: a NULL neighbour table means pointwise (K = 1)");
     ST_REQUIRE(c0 > 0 && c0 <= cin && (c0 == cin || x1 != nullptr), "conv: bad concat split");
     ST_REQUIRE((scale == nullptr) == (shift == nullptr), "conv: scale and shift go together");
     ST_REQUIRE(cin % 16 == 0 && cout % 16 == 0 && c0 % 16 == 0, "conv(mfma): channels and concat split must be multiples of 16");
     if (n_out <= 0) return ST_OK;
 #define MFMA_CASE(CI, CO) \
-    if (cin == CI && cout == CO) return conv_launch_mfma<CI, CO>(x0, c0, x1, nbr, K, n_out, wp, scale, shift, residual, relu, y, stream, row_order);
+    if (cin == CI && cout == CO) return conv_launch_mfma<CI, CO>(x0, c0, x1, nbr, K, n_out, nstride, wp, scale, shift, residual, relu, y, stream, row_order, variant);
     MFMA_CASE(16, 16)
     MFMA_CASE(16, 32)
     MFMA_CASE(32, 16)
@@ -440,7 +441,8 @@ extern "C" int st_sparse_conv_mfma_fwd(const float* x0, int c0, const float* x1,
 }
 
 // x = cat(x0[:, :c0], x1[:, :cin-c0]) (x1 may be NULL when c0 == cin); w [K][cin][cout];
-// nbr [K][n_out] or NULL (K must be 1: pointwise); scale/shift/residual may be NULL.
+// nbr [K][n_out] or NULL (K must be 1: pointwise); scale/shift/residual may be NULL.  nbr_stride: elements between the rows of
+// the table (0 = n_out; st_brick_pyramid lays its tables out with the level's capacity as the stride).
 // row_order (may be NULL): a permutation of the output rows (bits 0-27; the top four bits may carry the parity tag
 // described at conv_live_offsets, 0 = none); wave / tile position p works on output row_order[p].
 // Every row is still computed by one lane (or one MFMA tile row) with the same k-ordered arithmetic, so the result
@@ -449,8 +451,10 @@ extern "C" int st_sparse_conv_mfma_fwd(const float* x0, int c0, const float* x1,
 // offsets can have a partner, and the wave-uniform "nobody has offset k" skip then drops the other 19-26.
 extern "C" int st_sparse_conv_fwd(const float* x0, int c0, const float* x1, int cin, const int32_t* nbr, int K,
                                   int64_t n_out, const float* w, int cout, const float* scale, const float* shift,
-                                  const float* residual, int relu, float* y, const int32_t* row_order, void* stream_) {
+                                  const float* residual, int relu, float* y, const int32_t* row_order, void* stream_,
+                                  int64_t nbr_stride) {
     hipStream_t stream = (hipStream_t)stream_;
+    const int64_t nstride = nbr_stride > 0 ? nbr_stride : n_out;
     ST_REQUIRE(K >= 1 && (nbr != nullptr || K == 1), "conv: a NULL neighbour table means pointwise (K = 1)");
     ST_REQUIRE(c0 > 0 && c0 <= cin && (c0 == cin || x1 != nullptr), "conv: bad concat split");
     ST_REQUIRE((scale == nullptr) == (shift == nullptr), "conv: scale and shift go together");
@@ -459,7 +463,7 @@ extern "C" int st_sparse_conv_fwd(const float* x0, int c0, const float* x1, int 
     if (n_out <= 0) return ST_OK;
 #define CONV_CASE(CI, CO, COT_)                                                                                  \
     if (cin == CI && cout == CO)                                                                                 \
-        return conv_launch<CI, COT_>(x0, c0, x1, nbr, K, n_out, w, cout, scale, shift, residual, relu, y, stream, row_order);
+        return conv_launch<CI, COT_>(x0, c0, x1, nbr, K, n_out, nstride, w, cout, scale, shift, residual, relu, y, stream, row_order);
     CONV_CASE(3, 8, 8)
     CONV_CASE(8, 8, 8)
     CONV_CASE(8, 16, 16)

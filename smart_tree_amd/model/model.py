@@ -71,6 +71,7 @@ class Smart_Tree:
                 p = key[: -len(".running_mean")]
                 self.bn[p] = _Affine(sd, p, self.device)
         self.head_params = self._pack_heads(sd).to(self.device)
+        self.use_bricks = True  # rulebooks from occupancy bricks when the input carries `brick_hint` (sparse.py); else hash tables
         self.spatial_order = True  # run the network on Morton-ordered rows (same values; see features()); traces keep input order
         self.trace = None  # set to a dict to record every block's output (input, head{l}, enc{l}, dec{l}, tail{l}): parity tests
 
@@ -148,10 +149,18 @@ class Smart_Tree:
         gathers hit rows that are close in memory and the 16 rows of a matrix-core tile share their live offsets."""
         coords = sparse_input.indices.contiguous()
         feats = sparse_input.features.contiguous().float()
-        order = ops.spatial_order(coords) if self.spatial_order and self.trace is None and coords.shape[0] > 1 else None
-        if order is not None:
-            coords, feats = ops.move_rows(coords, order), ops.move_rows(feats, order)
-        pyr = ops.build_pyramid(coords, self.depth, getattr(sparse_input, "blk_seg", None), getattr(sparse_input, "n_seg", 1))
+        blk_seg, n_seg = getattr(sparse_input, "blk_seg", None), getattr(sparse_input, "n_seg", 1)
+        reorder = self.spatial_order and self.trace is None and coords.shape[0] > 1
+        hint = getattr(sparse_input, "brick_hint", None)
+        bricks = ops.brick_pyramid(coords, self.depth, hint[0], hint[1], blk_seg, n_seg) if reorder and hint and self.use_bricks else None
+        if bricks is not None:  # occupancy bricks: the order and every table from one call, no hash probes, one read-back
+            pyr, order = bricks
+            feats = ops.move_rows(feats, order)
+        else:
+            order = ops.spatial_order(coords) if reorder else None
+            if order is not None:
+                coords, feats = ops.move_rows(coords, order), ops.move_rows(feats, order)
+            pyr = ops.build_pyramid(coords, self.depth, blk_seg, n_seg)
         gate = getattr(self, "conv_gate", None)  # optional context-manager factory around the convolution launches (no host
         #                                            synchronisation inside): a caller with several batches in flight can keep
         #                                            their conv sequences from sharing the chip (bench.py)

@@ -82,8 +82,13 @@ class ModelInference:
             else:
                 vb = SingleTreeInference(cloud, self.voxel_size, self.block_size, self.buffer_size).batch
         # every block of the cloud -- of every cloud of a batch (Cloud.collate) -- in ONE collated batch
+        # blocks mode: batch indices < number of blocks, voxel coordinates < round(block + 2 halos) / voxel (csrc/voxelize.hip
+        # k_vx_block_grid) -- the bounds the network's brick rulebooks are sized from (verified on the device)
+        hint = None
+        if self.blocking == "blocks" and vb.block_centres.shape[0] > 0:
+            hint = (int(vb.block_centres.shape[0]), int(round((self.block_size + 2 * self.buffer_size) / self.voxel_size)) + 2)
         sparse_input = sparse_from_batch(vb.feats[:, :3].contiguous(), vb.coords, device=self.device, blk_seg=vb.blk_seg,
-                                         n_seg=vb.n_seg)
+                                         n_seg=vb.n_seg, brick_hint=hint)
         # radius / direction / class_l come out exactly as model.forward(sparse_input) gives them;
         # exp(radius)*direction and argmax (reference :87-88) are fused into the head kernel
         with profiling.stage("unet"):

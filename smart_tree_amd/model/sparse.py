@@ -20,16 +20,19 @@ class SparseConvTensor:
         self.indice_dict = {}
         self.blk_seg = None  # batched clouds (Cloud.collate): cloud of every batch index coords[:,0] -> per-cloud spatial extents
         self.n_seg = 1
+        # optional host-side bounds (number of batch indices, exclusive bound of z / y / x) from whoever made the voxels:
+        # lets the network build its rulebooks from occupancy bricks (csrc/brick.hip) instead of hash tables
+        self.brick_hint = None
 
     def replace_feature(self, new_features: torch.Tensor) -> "SparseConvTensor":
         out = SparseConvTensor(new_features, self.indices, self.spatial_shape, self.batch_size)
         out.indice_dict = self.indice_dict
-        out.blk_seg, out.n_seg = self.blk_seg, self.n_seg
+        out.blk_seg, out.n_seg, out.brick_hint = self.blk_seg, self.n_seg, self.brick_hint
         return out
 
 
 def sparse_from_batch(features: torch.Tensor, coordinates: torch.Tensor, device, blk_seg: torch.Tensor = None,
-                      n_seg: int = 1) -> SparseConvTensor:
+                      n_seg: int = 1, brick_hint=None) -> SparseConvTensor:
     """Reference sparse.py:9-19, quirks kept on the attributes: spatial_shape = max coordinate (not
     +1) and batch_size = number of voxels.  The kernels derive the true extent from the indices."""
     batch_size = features.shape[0]
@@ -43,6 +46,7 @@ def sparse_from_batch(features: torch.Tensor, coordinates: torch.Tensor, device,
     out = SparseConvTensor(features.contiguous(), coordinates.int().contiguous(), shape, batch_size=batch_size)
     if blk_seg is not None and n_seg > 1:
         out.blk_seg, out.n_seg = blk_seg.to(device).int().contiguous(), n_seg
+    out.brick_hint = brick_hint
     return out
 
 

@@ -110,6 +110,73 @@ def build_pyramid(coords: torch.Tensor, depth: int, blk_seg: Optional[torch.Tens
     return pyr
 
 
+def brick_pyramid(coords: torch.Tensor, depth: int, n_blocks: int, coord_bound: int, blk_seg: Optional[torch.Tensor] = None,
+                  n_seg: int = 1):
+    """The whole pyramid from occupancy bricks + popcount ranks (csrc/brick.hip): no hash probes, no sorts, ONE read-back.
+    Returns (RulebookPyramid, order0) or None when the structure cannot be sized for (n_blocks, coord_bound) -- the caller
+    then takes `build_pyramid`.  Level 0's rows are the input voxels in brick order (row p = input voxel order0[p]); the
+    tables are views with row stride = the level's capacity (`sparse_conv` passes the stride on)."""
+    L = _lib.lib()
+    dev = coords.device
+    n0 = coords.shape[0]
+    if n0 == 0 or n_blocks < 1 or coord_bound < 1:
+        return None
+    if blk_seg is None or blk_seg.numel() == 0:
+        n_seg = 1
+    i32 = dict(dtype=torch.int32, device=dev)
+    for attempt in range(2):
+        # k3 s2 p1: a surface-like set shrinks to ~half per level; isolated odd voxels reach up to 8 outputs each (retry)
+        caps = [n0]
+        for _ in range(depth):
+            caps.append((3 * caps[-1]) // 4 + 4096 if attempt == 0 else 8 * caps[-1] + 4096)
+        c_caps = (ctypes.c_int64 * (depth + 1))(*caps)
+        nbytes = L.st_brick_pyramid_workspace_bytes(n0, int(n_blocks), int(coord_bound), depth, c_caps)
+        if nbytes <= 0 or nbytes > (24 << 30):
+            return None
+        ws = _lib.workspace(nbytes, dev)
+        order0 = torch.empty(n0, **i32)
+        coords_out = [torch.empty((caps[l], 4), **i32) for l in range(depth + 1)]
+        subm = [torch.empty((27, caps[l]), **i32) for l in range(depth + 1)]
+        down = [torch.empty((27, caps[l + 1]), **i32) for l in range(depth)]
+        up = [torch.empty((27, caps[l]), **i32) for l in range(depth)]
+        up_order = [torch.empty(caps[l] + 16, **i32) for l in range(depth)]
+        arr = lambda ts: (ctypes.c_void_p * max(len(ts), 1))(*[t.data_ptr() for t in ts])
+        counts = (ctypes.c_int64 * (depth + 1))()
+        rc = L.st_brick_pyramid(_lib.ptr(coords), n0, int(n_blocks), int(coord_bound), depth, _lib.ptr(blk_seg) if n_seg > 1 else None,
+                                n_seg, c_caps, _lib.ptr(order0), arr(coords_out), arr(subm), arr(down), arr(up), arr(up_order), counts,
+                                _lib.ptr(ws), ws.numel(), _lib.stream(dev))
+        if rc == 0:
+            break
+        if b"outside the declared bounds" in L.st_last_error():
+            return None  # the hint was wrong for this input: hash-table builders
+        if attempt == 1 or b"capacity" not in L.st_last_error():
+            _lib.check(rc)
+    n = [int(counts[l]) for l in range(depth + 1)]
+    pyr = RulebookPyramid()
+    for l in range(depth + 1):
+        pyr.coords.append(coords_out[l][: n[l]])
+        pyr.subm.append(subm[l][:, : n[l]])
+        if l < depth:
+            pyr.down.append(down[l][:, : n[l + 1]])
+            pyr.up.append(up[l][:, : n[l]])
+            pyr.up_order.append(up_order[l][: n[l]])
+    return pyr, order0
+
+
+def _nbr_args(nbr: Optional[torch.Tensor]):
+    """(device pointer, row stride) of a neighbour table [K, n] -- contiguous, or a column slice of a capacity-strided one."""
+    if nbr is None:
+        return None, 0
+    if nbr.ndim != 2 or (nbr.shape[1] > 1 and nbr.stride(1) != 1):
+        raise _lib.StError("neighbour table must be [K, n] with unit column stride")
+    if not nbr.is_cuda and not _lib._ALLOW_HOST_POINTERS:
+        raise _lib.StError("smart_tree_amd kernels need tensors on the GPU (got a CPU tensor); there is no CPU fallback")
+    return nbr.data_ptr(), int(nbr.stride(0)) if nbr.shape[0] > 1 else int(max(nbr.shape[1], 1))
+
+
+MFMA_VARIANT = 0  # bench aid (tools/bench_conv.py): tile shape of the f32 matrix-core kernel, 0 = the library picks by size
+
+
 def spatial_order(coords: torch.Tensor) -> torch.Tensor:
     """[N] int32 permutation: voxels sorted by (batch index, Morton code of z, y, x) (csrc/rulebook.hip st_spatial_order)."""
     L = _lib.lib()
@@ -153,6 +220,7 @@ def sparse_conv(x0: torch.Tensor, w: torch.Tensor, nbr: Optional[torch.Tensor], 
     L = _lib.lib()
     K, cin, cout = w.shape
     c0 = x0.shape[1]
+    nbr_ptr, nbr_stride = _nbr_args(nbr)
     if n_out == 0:  # an empty active set (a cloud without a block of > 20 points): nothing to launch
         return torch.empty((0, cout), dtype=torch.float16 if out_half else torch.float32, device=x0.device)
     in_half = x0.dtype == torch.float16
@@ -167,10 +235,10 @@ def sparse_conv(x0: torch.Tensor, w: torch.Tensor, nbr: Optional[torch.Tensor], 
         nflops = (lambda: 2.0 * (_pair_count(nbr) if nbr is not None else n_out) * cin * cout) if profiling.enabled() else 0
         name = f"k_sparse_conv_mfma_f16<{cin},{cout}>" if both else f"k_sparse_conv<{cin},{cout}> {'h->f' if in_half else 'f->h'}"
         with profiling.kernel(name + ("" if nbr is not None else " k1"), nbytes, nflops):
-            _lib.check(L.st_sparse_conv_f16_fwd(_lib.ptr(x0), c0, _lib.ptr(x1), cin, _lib.ptr(nbr), K, n_out,
+            _lib.check(L.st_sparse_conv_f16_fwd(_lib.ptr(x0), c0, _lib.ptr(x1), cin, nbr_ptr, K, n_out,
                                                 _lib.ptr(wp16 if both else w), cout, _lib.ptr(scale), _lib.ptr(shift),
                                                 _lib.ptr(residual), int(relu), _lib.ptr(y), int(in_half), int(out_half),
-                                                _lib.ptr(row_order), _lib.stream(x0.device)))
+                                                _lib.ptr(row_order), _lib.stream(x0.device), nbr_stride))
         return y
     # 16 -> 16 submanifold convs run on the vector kernel (lane = voxel, weights from scalar registers): with Morton-ordered
     # rows it beats the matrix-core kernel wherever the level fills the chip (67 % against 53 % of the HBM peak at 1.5M rows,
@@ -184,9 +252,9 @@ def sparse_conv(x0: torch.Tensor, w: torch.Tensor, nbr: Optional[torch.Tensor], 
                   + n_out * cout * 4) if profiling.enabled() else 0
         nflops = (lambda: 2.0 * (_pair_count(nbr) if nbr is not None else n_out) * cin * cout) if profiling.enabled() else 0
         with profiling.kernel(f"k_sparse_conv_mfma<{cin},{cout}>" + ("" if nbr is not None else " k1"), nbytes, nflops):
-            _lib.check(L.st_sparse_conv_mfma_fwd(_lib.ptr(x0), c0, _lib.ptr(x1), cin, _lib.ptr(nbr), K, n_out, _lib.ptr(wp), cout,
+            _lib.check(L.st_sparse_conv_mfma_fwd(_lib.ptr(x0), c0, _lib.ptr(x1), cin, nbr_ptr, K, n_out, _lib.ptr(wp), cout,
                                                  _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(residual), int(relu), _lib.ptr(y),
-                                                 _lib.ptr(row_order), _lib.stream(x0.device)))
+                                                 _lib.ptr(row_order), _lib.stream(x0.device), nbr_stride, int(MFMA_VARIANT)))
         return y
     y = torch.empty((n_out, cout), dtype=torch.float32, device=x0.device)
     # algorithmic bytes: P*(Cin*4 + 4) + N*Cout*4 (pointwise: N*(Cin+Cout)*4); the pair count
@@ -195,9 +263,9 @@ def sparse_conv(x0: torch.Tensor, w: torch.Tensor, nbr: Optional[torch.Tensor], 
               + n_out * cout * 4) if profiling.enabled() else 0
     nflops = (lambda: 2.0 * (_pair_count(nbr) if nbr is not None else n_out) * cin * cout) if profiling.enabled() else 0
     with profiling.kernel(f"k_sparse_conv<{cin},{cout}>" + ("" if nbr is not None else " k1"), nbytes, nflops):
-      _lib.check(L.st_sparse_conv_fwd(_lib.ptr(x0), c0, _lib.ptr(x1), cin, _lib.ptr(nbr), K, n_out, _lib.ptr(w), cout,
+      _lib.check(L.st_sparse_conv_fwd(_lib.ptr(x0), c0, _lib.ptr(x1), cin, nbr_ptr, K, n_out, _lib.ptr(w), cout,
                                     _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(residual), int(relu), _lib.ptr(y),
-                                    _lib.ptr(row_order), _lib.stream(x0.device)))
+                                    _lib.ptr(row_order), _lib.stream(x0.device), nbr_stride))
     return y
 
 

@@ -209,3 +209,110 @@ def test_spatial_order_is_invisible(backend):
         b = net.forward(sp)
         for k in a:
             assert torch.equal(a[k], b[k]), (k, fp16)
+
+
+# ---- rulebooks from occupancy bricks (csrc/brick.hip): same sets, same pairs, same network outputs as the hash-table builders ----
+def _hint(coords):
+    return int(coords[:, 0].max()) + 1, int(coords[:, 1:].max()) + 1
+
+
+def _row_map(mine, ref):
+    """perm[i] = row of mine[i] among the oracle's rows (the brick path numbers the rows of a level in brick order)."""
+    key = lambda c: ((c[:, 0].astype(np.int64) * 4096 + c[:, 1]) * 4096 + c[:, 2]) * 4096 + c[:, 3]
+    km, kr = key(mine), key(ref)
+    assert len(np.unique(km)) == len(km) == len(kr)
+    order = np.argsort(kr)
+    pos = np.searchsorted(kr[order], km)
+    assert np.array_equal(kr[order][pos], km), "different voxel sets"
+    return order[pos]
+
+
+def _renumber(table, perm_out, perm_in, n_ref_out):
+    """a brick-order table [27, n] in the oracle's numbering"""
+    out = np.full((27, n_ref_out), -2, np.int64)
+    t = np.where(table >= 0, perm_in[np.clip(table, 0, None)], -1)
+    out[:, perm_out] = t
+    return out
+
+
+@pytest.mark.parametrize("case", ["tree", "isolated-odd", "batch"])
+def test_brick_pyramid_matches_the_oracle(backend, case):
+    """Every level's active set, submanifold table, strided and inverse tables equal the oracle's after renumbering the rows
+    (brick order instead of first appearance); level 0's order0 is the permutation that produces its coordinates."""
+    blk_seg, n_seg = None, 1
+    if case == "tree":
+        coords = _small_batch()["coords"]
+    elif case == "isolated-odd":  # every voxel reaches 8 outputs: the first capacity guess overflows, the call retries
+        g = np.arange(7, dtype=np.int32) * 10 + 5
+        z, y, x = np.meshgrid(g, g, g, indexing="ij")
+        coords = np.stack([np.zeros(z.size, np.int32), z.ravel(), y.ravel(), x.ravel()], axis=1).astype(np.int32)
+        coords = np.repeat(coords, 1, axis=0)
+    else:  # two clouds in one batch: each cloud's coarse sets are clipped to ITS extent
+        a, b = _small_batch(seed=5)["coords"], _small_batch(n=3000, seed=7)["coords"]
+        b = b.copy()
+        b[:, 0] += a[:, 0].max() + 1
+        coords = np.concatenate([a, b]).astype(np.int32)
+        seg = np.concatenate([np.zeros(a[:, 0].max() + 1, np.int32), np.ones(b[:, 0].max() + 1 - (a[:, 0].max() + 1), np.int32)])
+        blk_seg, n_seg = torch.from_numpy(seg).to(backend), 2
+    rng = np.random.RandomState(0)
+    coords = coords[rng.permutation(len(coords))]  # any input order
+    nb, bound = _hint(coords)
+    got = ops.brick_pyramid(torch.from_numpy(coords).to(backend), 3, nb, bound, blk_seg, n_seg)
+    assert got is not None
+    pyr, order0 = got
+    order0 = order0.cpu().numpy()
+    assert sorted(order0.tolist()) == list(range(len(coords)))
+    np.testing.assert_array_equal(pyr.coords[0].cpu().numpy(), coords[order0])
+    if n_seg == 1:
+        ref_levels = [coords]
+        for _ in range(3):
+            ref_levels.append(uo.strided_out_coords(ref_levels[-1]))
+    else:  # the oracle clips a cloud's outputs to that cloud's own extent: level by level per cloud, then concatenated
+        seg_of = seg[coords[:, 0]]
+        per = [[coords[seg_of == s]] for s in range(2)]
+        for s in range(2):
+            for _ in range(3):
+                per[s].append(uo.strided_out_coords(per[s][-1]))
+        ref_levels = [np.concatenate([per[0][l], per[1][l]]) for l in range(4)]
+    perms = []
+    for level in range(4):
+        mine = pyr.coords[level].cpu().numpy()
+        ref = ref_levels[level]
+        perms.append(_row_map(mine, ref))
+        ref_subm = uo.subm_rulebook(ref)
+        np.testing.assert_array_equal(_renumber(pyr.subm[level].cpu().numpy(), perms[level], perms[level], len(ref)), ref_subm)
+    for level in range(3):
+        fine, coarse = ref_levels[level], ref_levels[level + 1]
+        if n_seg == 1:
+            ref_down, ref_up = uo.down_rulebook(coarse, fine), uo.up_rulebook(fine, coarse)
+        else:  # per cloud, rows shifted
+            nf0, nc0 = len(per[0][level]), len(per[0][level + 1])
+            d0, u0 = uo.down_rulebook(per[0][level + 1], per[0][level]), uo.up_rulebook(per[0][level], per[0][level + 1])
+            d1, u1 = uo.down_rulebook(per[1][level + 1], per[1][level]), uo.up_rulebook(per[1][level], per[1][level + 1])
+            ref_down = np.concatenate([d0, np.where(d1 >= 0, d1 + nf0, -1)], axis=1)
+            ref_up = np.concatenate([u0, np.where(u1 >= 0, u1 + nc0, -1)], axis=1)
+        np.testing.assert_array_equal(_renumber(pyr.down[level].cpu().numpy(), perms[level + 1], perms[level], len(coarse)), ref_down)
+        np.testing.assert_array_equal(_renumber(pyr.up[level].cpu().numpy(), perms[level], perms[level + 1], len(fine)), ref_up)
+        tagged = pyr.up_order[level].cpu().numpy()
+        rows = tagged & 0x0FFFFFFF
+        assert sorted(rows.tolist()) == list(range(len(fine)))
+        c = pyr.coords[level].cpu().numpy()[rows]
+        cls = ((c[:, 1] & 1) << 2) | ((c[:, 2] & 1) << 1) | (c[:, 3] & 1)
+        assert (np.diff(cls) >= 0).all()
+        np.testing.assert_array_equal((tagged >> 28) & 0xF, 8 + cls)
+
+
+def test_brick_path_leaves_the_network_outputs_unchanged(backend):
+    """The network on brick rulebooks (rows in brick order, coarse rows numbered differently) == the network on hash-table
+    rulebooks, bit for bit: every output row is computed on its own, in k order, from the rows its table names."""
+    vx = _small_batch(n=5000, seed=9)
+    w = random_state_dict(uo.load_weights(WEIGHTS / "noble-elevator-58.npz"), seed=4)
+    net = Smart_Tree(w, device=backend)
+    plain = sparse_from_batch(torch.from_numpy(vx["feats"][:, :3]), torch.from_numpy(vx["coords"]), backend)
+    hinted = sparse_from_batch(torch.from_numpy(vx["feats"][:, :3]), torch.from_numpy(vx["coords"]), backend, brick_hint=_hint(vx["coords"]))
+    a = net.forward(hinted)
+    b = net.forward(plain)
+    wrong = sparse_from_batch(torch.from_numpy(vx["feats"][:, :3]), torch.from_numpy(vx["coords"]), backend, brick_hint=(1, 8))
+    c = net.forward(wrong)  # a hint the input violates is noticed on the device: the hash-table path takes over
+    for k in a:
+        assert torch.equal(a[k], b[k]) and torch.equal(a[k], c[k]), k
