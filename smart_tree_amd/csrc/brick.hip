@@ -141,7 +141,8 @@ __device__ __forceinline__ void bk_set_bit(const BkLevel& L, int b, int z, int y
     if (!(*half & v)) atomicOr(half, v);  // (a stale read can only send us to the atomic needlessly)
 }
 
-__global__ void __launch_bounds__(BK_BLOCK) k_bk_bits0(const int32_t* coords, int64_t n, BkLevel L) {
+__global__ void __launch_bounds__(BK_BLOCK) k_bk_bits0(const int32_t* coords, int64_t n, BkLevel L, const BkState* st) {
+    if (st->fail & 2u) return;  // a coordinate outside the declared bounds: nothing below may index the tables with it
     const int lim = 8 << L.mb;
     BK_LOOP(i, n) {
         const int4 c = reinterpret_cast<const int4*>(coords)[i];
@@ -168,7 +169,9 @@ __global__ void __launch_bounds__(BK_BLOCK) k_bk_count(BkLevel L) {
 }
 
 // order0[row] = input voxel, coords_sorted[row] = its coordinates
-__global__ void __launch_bounds__(BK_BLOCK) k_bk_order0(const int32_t* coords, int64_t n, BkLevel L, int32_t* order0, int32_t* sorted) {
+__global__ void __launch_bounds__(BK_BLOCK) k_bk_order0(const int32_t* coords, int64_t n, BkLevel L, int32_t* order0, int32_t* sorted,
+                                                        const BkState* st) {
+    if (st->fail & 2u) return;
     BK_LOOP(i, n) {
         const int4 c = reinterpret_cast<const int4*>(coords)[i];
         const int r = bk_lookup(L, c.x, c.y, c.z, c.w);
@@ -181,7 +184,9 @@ __global__ void __launch_bounds__(BK_BLOCK) k_bk_order0(const int32_t* coords, i
 // ---- submanifold neighbour table of a level (rows in the level's order) ------------------------------------------------------
 // A 3 x 3 x 3 neighbourhood meets at most 2 x 2 x 2 bricks: their table entries are fetched once, then per z-plane the
 // (up to four) mask words; the 27 ranks are popcounts.
-__global__ void __launch_bounds__(BK_BLOCK) k_bk_subm(const int32_t* coords, const int64_t* n_dev, int64_t cap, BkLevel L, int32_t* nbr) {
+__global__ void __launch_bounds__(BK_BLOCK) k_bk_subm(const int32_t* coords, const int64_t* n_dev, int64_t cap, BkLevel L, int32_t* nbr,
+                                                      const BkState* st) {
+    if (st->fail & 2u) return;
     const int64_t n = *n_dev < cap ? *n_dev : cap;
     const int lim = 8 << L.mb;
     BK_LOOP(o, n) {
@@ -236,6 +241,7 @@ __global__ void __launch_bounds__(BK_BLOCK) k_bk_subm(const int32_t* coords, con
 template <int PASS>  // 0: flag the bricks, 1: set the bits
 __global__ void __launch_bounds__(BK_BLOCK) k_bk_coarse(const int32_t* coords, const int64_t* n_dev, int64_t cap, BkLevel Lc, const BkState* st,
                                                         int level, const int32_t* blk_seg) {
+    if (st->fail & 2u) return;
     const int64_t n = *n_dev < cap ? *n_dev : cap;
     BK_LOOP(i, n) {
         const int4 c4 = reinterpret_cast<const int4*>(coords)[i];
@@ -261,6 +267,7 @@ __global__ void __launch_bounds__(BK_BLOCK) k_bk_coarse(const int32_t* coords, c
 
 // coordinates of a level enumerated from its masks (rows in the level's order)
 __global__ void __launch_bounds__(BK_BLOCK) k_bk_emit(BkLevel L, int32_t* coords, int64_t cap, BkState* st) {
+    if (st->fail & 2u) return;
     const int64_t ns = *L.n_slots < L.slot_cap ? *L.n_slots : L.slot_cap;
     BK_LOOP(idx, ns * 8) {
         const int64_t s = idx >> 3;
@@ -289,6 +296,7 @@ __global__ void __launch_bounds__(BK_BLOCK) k_bk_updown(const int32_t* coords, c
                                                         int level, const int32_t* blk_seg, const int64_t* m_dev, int64_t cap_c,
                                                         int32_t* nbr_up, int32_t* nbr_down, uint32_t* parity_count) {
     __shared__ uint32_t hist[8];
+    if (st->fail & 2u) return;
     if (threadIdx.x < 8) hist[threadIdx.x] = 0;
     __syncthreads();
     const int64_t n = *n_dev < cap_f ? *n_dev : cap_f;
@@ -320,8 +328,9 @@ __global__ void __launch_bounds__(BK_BLOCK) k_bk_updown(const int32_t* coords, c
 // launch order of the inverse convolution; never changes a result).  count[8] from k_bk_updown, cursor[8] zeroed.
 #define BK_ORDER_BLOCKS 512
 __global__ void __launch_bounds__(BK_BLOCK) k_bk_parity_order(const int32_t* coords, const int64_t* n_dev, int64_t cap, const uint32_t* count,
-                                                              uint32_t* cursor, int32_t* order) {
+                                                              uint32_t* cursor, int32_t* order, const BkState* st) {
     __shared__ uint32_t hist[8], gbase[8], lcur[8];
+    if (st->fail & 2u) return;
     const int64_t n = *n_dev < cap ? *n_dev : cap;
     const int lane = threadIdx.x & 63;
     const int64_t per = (n + gridDim.x - 1) / gridDim.x, chunk = (per + BK_BLOCK - 1) / BK_BLOCK * BK_BLOCK;
@@ -472,13 +481,13 @@ extern "C" int st_brick_pyramid(const int32_t* coords0, int64_t n0, int n_blocks
     // ---- level 0: structure, order, sorted coordinates
     hipLaunchKernelGGL(k_bk_mark0, dim3(bk_grid(n0)), dim3(BK_BLOCK), 0, stream, coords0, n0, L[0], Y.st, blk_seg, nseg, n_blocks);
     ST_TRY(close_flags(0));
-    hipLaunchKernelGGL(k_bk_bits0, dim3(bk_grid(n0)), dim3(BK_BLOCK), 0, stream, coords0, n0, L[0]);
+    hipLaunchKernelGGL(k_bk_bits0, dim3(bk_grid(n0)), dim3(BK_BLOCK), 0, stream, coords0, n0, L[0], (const BkState*)Y.st);
     ST_TRY(close_bits(0));
-    hipLaunchKernelGGL(k_bk_order0, dim3(bk_grid(n0)), dim3(BK_BLOCK), 0, stream, coords0, n0, L[0], order0, coords_out[0]);
+    hipLaunchKernelGGL(k_bk_order0, dim3(bk_grid(n0)), dim3(BK_BLOCK), 0, stream, coords0, n0, L[0], order0, coords_out[0], (const BkState*)Y.st);
     for (int l = 0;; l++) {
         const int64_t cap = caps[l];
         hipLaunchKernelGGL(k_bk_subm, dim3(bk_grid(cap)), dim3(BK_BLOCK), 0, stream, (const int32_t*)coords_out[l], (const int64_t*)L[l].n_vox, cap,
-                           L[l], subm[l]);
+                           L[l], subm[l], (const BkState*)Y.st);
         if (l == depth) break;
         const int64_t cap_c = caps[l + 1];
         hipLaunchKernelGGL((k_bk_coarse<0>), dim3(bk_grid(cap)), dim3(BK_BLOCK), 0, stream, (const int32_t*)coords_out[l], (const int64_t*)L[l].n_vox,
@@ -495,7 +504,7 @@ extern "C" int st_brick_pyramid(const int32_t* coords0, int64_t n0, int n_blocks
                            L[l + 1], (const BkState*)Y.st, l, blk_seg, (const int64_t*)L[l + 1].n_vox, cap_c, up[l], down[l], pc);
         const unsigned og = bk_grid(cap) < BK_ORDER_BLOCKS ? bk_grid(cap) : BK_ORDER_BLOCKS;
         hipLaunchKernelGGL(k_bk_parity_order, dim3(og), dim3(BK_BLOCK), 0, stream, (const int32_t*)coords_out[l], (const int64_t*)L[l].n_vox, cap,
-                           (const uint32_t*)pc, pc + 8, up_order[l]);
+                           (const uint32_t*)pc, pc + 8, up_order[l], (const BkState*)Y.st);
     }
     // the ONE read-back: rows per level + the fail flags
     struct { int64_t counts[2 * (BK_MAX_DEPTH + 1)]; } hc;

@@ -133,6 +133,21 @@ def test_config3_dense_canopy_properties():
             assert b.parent_id < b._id and b.xyz.shape[0] == b.radii.shape[0] and torch.isfinite(b.xyz).all()
 
 
+def test_config1_brick_rulebooks_equal_hash_rulebooks_full_size():
+    """The two rulebook builders (occupancy bricks, csrc/brick.hip; hash tables, csrc/rulebook.hip) number the rows of the
+    coarse levels differently; the labelled cloud of the 1M-point tree (176k voxels, 21 blocks) must come out bit-identical."""
+    dev = torch.device("cuda:0")
+    c = sample_tree_cloud(1_000_000, seed=0)
+    cloud = AugmentationPipeline([CentreCloud()])(Cloud(xyz=torch.from_numpy(c["xyz"]).to(dev), rgb=torch.from_numpy(c["rgb"]).to(dev)))
+    mi = ModelInference("unused", WEIGHTS, voxel_size=0.02, block_size=4, buffer_size=0.4, device=dev)
+    assert mi.model.use_bricks
+    a = mi.forward(cloud)
+    mi.model.use_bricks = False
+    b = mi.forward(cloud)
+    assert len(a) == len(b) > 100_000
+    assert torch.equal(a.xyz, b.xyz) and torch.equal(a.medial_vector, b.medial_vector) and torch.equal(a.class_l, b.class_l)
+
+
 def test_config3_style_canopy_against_the_oracle():
     """configs[3]'s regime at a size the oracle finishes in seconds: 400k points, 60 % foliage, 1 cm voxels, and radius
     outliers injected into the network's medial vectors (the full-size cloud has a median radius of 6 cm and a maximum of
