@@ -87,6 +87,11 @@ def plan_batches(steps: int, streams: int, max_batch: int):
     stream gets the same number of equally sized batches where K allows it)."""
     if steps <= 0:
         return []
+    forced = os.environ.get("ST_BENCH_PLAN")  # developer knob (tools/sweep_r3_plan.sh): explicit batch sizes, e.g. "8,6,4,2"
+    if forced:
+        sizes = [int(v) for v in forced.split(",")]
+        if sum(sizes) == steps:
+            return sizes
     # small batches make poor use of a fourth host thread (the Python side of a batch is ~constant): measured on one MI355X,
     # 20 clouds: 1 / 2 / 3 / 4 in flight = 2.72 / 2.61 / 2.60 / 3.67 ms per cloud; 48 clouds: 2 / 3 / 4 = 1.99 / 1.96 / 2.39
     streams = max(1, min(streams, steps // 16), min(streams, 3, steps // 6))

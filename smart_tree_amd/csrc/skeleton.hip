@@ -110,6 +110,8 @@ struct SkArgs {
     int iters_per_launch;
     int wave_work;       // select: candidate points x path vertices of one speculative branch (beyond: whole workgroup)
     int local_items;     // select: (path vertex, cell row) pairs one workgroup claims path-centric by itself
+    int long_mode;       // select: paths that fit the LDS path buffer but are too much work for the plain point-centric claim are
+                         // claimed by the workgroup itself with chunk-pruned distance tests (below), not handed to k_sk_claim
     long long* ticks;  // optional developer aid: per-phase wall_clock64 sums of k_sk_select (st_debug_set_ticks)
 };
 
@@ -503,6 +505,7 @@ __device__ __forceinline__ bool sk_claim_items(const SkArgs& A, int c, int base,
 #define SK_SMALL_WORK (1 << 18)  // candidate points x path vertices one workgroup takes on itself
 #define SK_ITERS_PER_LAUNCH 32
 #define SK_LPATH 1024
+#define SK_CHUNK 32  // path vertices per bounding box in the long-path claim
 
 // on-path test of the claimed points (path.py:35-40) + allocation / termination / branch-id stamps (:112-122,135-136)
 __device__ __forceinline__ void sk_finish_branch(const SkArgs& A, int base, int len, int id, const int* path, bool path_in_lds,
@@ -614,6 +617,7 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
     __shared__ unsigned cl_list[SK_CL_KEEP][1024];  // claimed points of this round, SK_CL_KEEP private entries per thread
     __shared__ uint32_t s_scan[SK_MAX_WAVES + 1];
     __shared__ unsigned wt_key[SK_WT], wt_mask[SK_WT];  // watch table (see above)
+    __shared__ float cb_lo[3][SK_LPATH / SK_CHUNK], cb_hi[3][SK_LPATH / SK_CHUNK];  // chunk boxes of a long path
     __shared__ unsigned char win_live[1024];  // candidate window: "still unallocated" flag of order[win_base + lane]
     __shared__ int s_lo[3], s_hi[3];
     __shared__ int s_term;
@@ -1080,6 +1084,96 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
         }
         const int cur_off = total;
         if (keep) { nb++; total += len; }
+        // A long path (the trunk, a main limb: hundreds of vertices, tens of thousands of candidates) inside the workgroup, still
+        // point-centric and exact: the path is cut into chunks of SK_CHUNK consecutive vertices with their bounding boxes; a
+        // candidate walks the chunks in path order and skips one whose box is no closer than its best vertex so far (or than the
+        // path radius).  The box distance is evaluated with the SAME float32 operations, in the same order, as the vertex
+        // distance ((dx*dx + dy*dy) + dz*dz): rounding is monotone, so it never exceeds the distance to any vertex inside --
+        // the nearest vertex (ties: the first on the path) is the one the full scan finds.  The rows of grid cells around the
+        // path are taken W at a time.  No hand-over to k_sk_claim, no launch boundary: in a batch of clouds every tree keeps
+        // going at its own pace instead of waiting for the slowest one at every long path.
+        if (fits && !small && A.long_mode) {
+            const int nch = (len + SK_CHUNK - 1) / SK_CHUNK;
+            if (tid < nch) {
+                float lo[3] = {__uint_as_float(0x7f800000u), __uint_as_float(0x7f800000u), __uint_as_float(0x7f800000u)};
+                float hi[3] = {__uint_as_float(0xff800000u), __uint_as_float(0xff800000u), __uint_as_float(0xff800000u)};
+                for (int qi = tid * SK_CHUNK; qi < len && qi < (tid + 1) * SK_CHUNK; qi++) {
+                    const float v[3] = {L.one.lpx[qi], L.one.lpy[qi], L.one.lpz[qi]};
+#pragma unroll
+                    for (int a = 0; a < 3; a++) { lo[a] = v[a] < lo[a] ? v[a] : lo[a]; hi[a] = v[a] > hi[a] ? v[a] : hi[a]; }
+                }
+#pragma unroll
+                for (int a = 0; a < 3; a++) { cb_lo[a][tid] = lo[a]; cb_hi[a][tid] = hi[a]; }
+            }
+            const int x0 = st_max(s_lo[0] - reach, 0), x1 = st_min(s_hi[0] + reach, g->seg_dim0 - 1);
+            const int y0 = st_max(s_lo[1] - reach, 0), y1 = st_min(s_hi[1] + reach, g->dim[1] - 1);
+            const int z0 = st_max(s_lo[2] - reach, 0), z1 = st_min(s_hi[2] + reach, g->dim[2] - 1);
+            const int nx = x1 - x0 + 1, ny = y1 - y0 + 1;
+            const int nrows = (nx > 0 && ny > 0 && z0 <= z1) ? nx * ny : 0;
+            if (A.ticks && tid == 0) { A.ticks[9] += 1; A.ticks[10] += len; A.ticks[15] += 1; }
+            __syncthreads();  // chunk boxes published
+            for (int r0 = 0; r0 < nrows; r0 += W) {
+                const int rr = r0 + tid, nr = nrows - r0 < W ? nrows - r0 : W;
+                uint32_t cnt = 0, first = 0;
+                if (rr < nrows) {
+                    const int64_t row = ((int64_t)(xoff + x0 + rr / ny) * g->dim[1] + (y0 + rr % ny)) * g->dim[2];
+                    first = A.cell_start[row + z0];
+                    cnt = A.cell_start[row + z1 + 1] - first;
+                }
+                uint32_t tot;
+                const uint32_t off = block_exclusive_scan(cnt, s_scan, &tot);  // (its first barrier: the previous rows' tables are dead)
+                if (tid < nr) { L.one.row_off[tid] = off; L.one.row_first[tid] = first; }
+                if (tid == 0) L.one.row_off[nr] = tot;
+                __syncthreads();
+                for (uint32_t t = (uint32_t)tid; t < tot; t += (uint32_t)W) {
+                    const int row = sk_find_row(L.one.row_off, nr, t);
+                    const float4 r4 = recs[L.one.row_first[row] + (t - L.one.row_off[row])];
+                    const int p = (int)__float_as_uint(r4.w) - base;
+                    if (p < 0 || p >= n) continue;  // other component
+                    float bd2 = __uint_as_float(0x7f800000u), bw = 0.0f;
+                    for (int ch = 0; ch < nch; ch++) {
+                        float e[3];
+                        const float pv[3] = {r4.x, r4.y, r4.z};
+#pragma unroll
+                        for (int a = 0; a < 3; a++) {
+                            const float below = cb_lo[a][ch] - pv[a], above = pv[a] - cb_hi[a][ch];
+                            const float m = below > above ? below : above;
+                            e[a] = m > 0.0f ? m : 0.0f;
+                        }
+                        float lb = e[0] * e[0];
+                        float tt = e[1] * e[1];
+                        lb = lb + tt;
+                        tt = e[2] * e[2];
+                        lb = lb + tt;
+                        if (lb >= bd2 || lb >= rp2) continue;  // nothing in this chunk can be strictly nearer / inside the radius
+                        const int q1 = (ch + 1) * SK_CHUNK < len ? (ch + 1) * SK_CHUNK : len;
+                        for (int qi = ch * SK_CHUNK; qi < q1; qi++) {  // ascending: ties keep the first path vertex
+                            const float dx = r4.x - L.one.lpx[qi], dy = r4.y - L.one.lpy[qi], dz = r4.z - L.one.lpz[qi];
+                            float d2 = dx * dx;
+                            float t2 = dy * dy;
+                            d2 = d2 + t2;
+                            t2 = dz * dz;
+                            d2 = d2 + t2;
+                            if (d2 < bd2) { bd2 = d2; bw = L.one.lpr[qi]; }
+                        }
+                    }
+                    if (bd2 < rp2 && sqrtf(bd2) < bw) {  // path.py:35-40
+                        sk_stamp(&A.pt[base + p], id, false);
+                        const unsigned q = (unsigned)(pos[p] - win_base);
+                        if (q < (unsigned)W) win_live[q] = 0;
+                    }
+                }
+            }
+            for (int qi = tid; qi < len; qi += blockDim.x) {  // path.py:112-113,135
+                const int v = L.one.lpath[len - 1 - qi];
+                sk_stamp(&A.pt[base + v], id, false);
+                const unsigned q = (unsigned)(pos[v] - win_base);
+                if (q < (unsigned)W) win_live[q] = 0;
+            }
+            __syncthreads();
+            SK_TICK(6);
+            continue;
+        }
         // too much work point-centric (every candidate against every path vertex)?  Path-centric then: every
         // (path vertex, cell row) pair offers itself to the points of its cells -- here if the path is of moderate
         // length, chip-wide (k_sk_claim) otherwise.
@@ -1256,14 +1350,15 @@ static void sk_layout(StArena& a, int64_t m, int64_t C, SkLayout* s, int nseg = 
 //   4 local_items   5 wave_work   6 SSSP levels per frontier launch   7 frontier launches per read-back   8 lanes per vertex
 //   9 length of the first frontier batch (in batches)   10 frontier workgroups   11 claim-grid cell cap (hundredths of the
 //   mean radius)   13 frontier: 0 = no look before the atomic, else vertices a workgroup relaxes per local level
+//   14 long-path claim inside the workgroup (1, default) or by the local / chip-wide path-centric claims (0)
 //   15 device pointer of 16 int64 phase timers / counters of k_sk_select
 #define ST_TUNE_DEFAULT INT64_MIN
 #define SK_MAX_LAUNCH_BATCH 32
 struct SkTuning {
     float prune_factor = 1.0f, grid_mean_mult = 1.0f;
-    int small_work = SK_SMALL_WORK, iters_per_launch = SK_ITERS_PER_LAUNCH, launch_batch = 24, local_items = 0, wave_work = SK_WAVE_WORK;
+    int small_work = SK_SMALL_WORK, iters_per_launch = SK_ITERS_PER_LAUNCH, launch_batch = 24, local_items = 0, wave_work = SK_WAVE_WORK, long_mode = 1;
     int sssp_hops = 4, sssp_batch = 32, sssp_lanes = 64, sssp_first = 2, sssp_blocks = SK_SSSP_BLOCKS, sssp_lcap = SK_LQ;
-    bool small_work_set = false, iters_set = false;
+    bool small_work_set = false, iters_set = false, long_set = false;
     long long* ticks = nullptr;
     explicit SkTuning(const int64_t* t) {
         if (!t) return;
@@ -1281,6 +1376,7 @@ struct SkTuning {
         if (has(10)) sssp_blocks = t[10] < 1 ? 1 : (t[10] > 8192 ? 8192 : (int)t[10]);
         if (has(11)) grid_mean_mult = (float)t[11] / 100.0f;
         if (has(13)) sssp_lcap = t[13] == 0 ? -SK_LQ : (t[13] > SK_LQ ? SK_LQ : (int)t[13]);
+        if (has(14)) { long_mode = t[14] != 0; long_set = true; }
         if (has(15)) ticks = (long long*)(intptr_t)t[15];
     }
 };
@@ -1361,14 +1457,20 @@ extern "C" int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, c
     A.s_cursor = s.s_cursor; A.s_wide = s.s_wide; A.order = s.order; A.order_init = s.order_init; A.pos = s.pos;
     const SkTuning T(tuning);
     A.ticks = T.ticks;
-    A.prune_factor = T.prune_factor; A.small_work = T.small_work; A.iters_per_launch = T.iters_per_launch; A.local_items = T.local_items; A.wave_work = T.wave_work;
+    A.prune_factor = T.prune_factor; A.small_work = T.small_work; A.iters_per_launch = T.iters_per_launch; A.local_items = T.local_items; A.wave_work = T.wave_work; A.long_mode = T.long_mode;
     // A batch of clouds advances in lockstep: a launch lasts as long as its slowest component, and a component that hands a
     // long path to the chip-wide claim kernel waits for everybody else's rounds.  Fewer hand-overs (the workgroup claims
     // paths up to 16x larger by itself) and shorter launches measured 2.98 -> 2.48 ms of skeleton stage per cloud at 8 clouds
     // per batch (tools/sweep_select.sh, profiles/r02_sweep_select.txt); one cloud alone keeps the round-1 optimum.
+    // Round 3: in a batch the workgroup also claims its long paths itself (chunk-pruned, k_sk_select "long path") and a launch
+    // runs until the tree is done -- no tree waits for another one at a hand-over (profiles/r03_sweep_select.txt: 1.204 -> 1.176 ms
+    // per cloud at 64 clouds per launch set, 2.00 -> 1.95 at 10).  One cloud alone keeps the chip-wide claim for its long paths
+    // (the chip is idle then: 11.2 against 12.0 ms).
     if (nseg > 1) {
-        if (!T.small_work_set) A.small_work = 1 << 22;
-        if (!T.iters_set) A.iters_per_launch = 16;
+        if (!T.small_work_set) A.small_work = 1 << 20;
+        if (!T.iters_set) A.iters_per_launch = 1 << 20;
+    } else if (!T.long_set) {
+        A.long_mode = 0;
     }
 
     const unsigned vg = sk_vgrid(m);

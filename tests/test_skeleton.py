@@ -154,13 +154,15 @@ def test_components_match_oracle(backend):
     {0: 4000},                   # aggressive pruning: wrong guesses stop the replay
     {2: 1, 3: 1},                # one round per launch, host read-back after every launch
     {5: -1},                     # no speculation: the whole workgroup per branch, point-centric
-    {5: -1, 1: -1, 4: 1 << 30},  # ... path-centric inside the workgroup
-    {5: -1, 1: -1, 4: -1},       # ... handed to the chip-wide claim kernel
-    {5: 300, 1: 2000, 4: 200},   # a mix of all of them
+    {5: -1, 1: -1},              # ... every path through the chunk-pruned long-path claim
+    {5: -1, 1: -1, 14: 0, 4: 1 << 30},  # ... path-centric inside the workgroup
+    {5: -1, 1: -1, 14: 0, 4: -1},       # ... handed to the chip-wide claim kernel
+    {5: 300, 1: 2000, 4: 200},   # a mix: speculative slots, plain and long-path claims
+    {5: 300, 1: 2000, 14: 0, 4: 200},   # a mix: slots, plain, local and chip-wide claims
     {6: 1, 8: 16},               # SSSP: one level per launch, 16 lanes per vertex
     {6: 7, 7: 2},                # SSSP: seven levels per launch, read-back every second launch
     {6: 6, 13: 2, 10: 3},        # SSSP: three workgroups, at most two vertices per workgroup and local level (the rest goes back)
-], ids=["noprune", "prune4", "relaunch", "one", "local", "wide", "mixed", "sssp-rows", "sssp-hops", "sssp-cap"])
+], ids=["noprune", "prune4", "relaunch", "one", "long", "local", "wide", "mixed", "mixed-wide", "sssp-rows", "sssp-hops", "sssp-cap"])
 def test_sample_tree_strategies_agree(backend, params):
     """Branch selection has four claim strategies picked by size; each one alone must reproduce the oracle."""
     from smart_tree_amd.skeleton import tuning
