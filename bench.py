@@ -53,6 +53,7 @@ STREAMS = 2     # batches in flight      } phases in turns: voxelise .. network 
 FREE_STREAMS = 3  #                       } free-running: 3 x 64 = 1.25-1.27, 3 x 48 = 1.30, 2 x 64 = 1.29, 4 x 32 = 1.29, 4 x 48 = 1.32
 N_SEEDS = 4  # distinct clouds per rank, cycled
 ORDERED = int(os.environ.get("ST_BENCH_ORDERED", "3"))  # 3 (default): voxelise .. network of the batches in flight take turns; 1: voxelise .. adjacency; 0: free-running; 2: only the conv sequences
+SHORT_RUN_STEPS = 128  # below this a run is one or two rounds of batches: nothing to take turns with, the batches run free (unless ST_BENCH_ORDERED is set)
 
 
 def build_pipeline(device, weights="noble-elevator-58", voxel=VOXEL, fp16=False, blocking="blocks"):
@@ -98,6 +99,12 @@ def plan_batches(steps: int, streams: int, max_batch: int):
     per_round = streams * max_batch
     n_batches = streams * ((steps + per_round - 1) // per_round)
     n_batches = min(n_batches, steps)
+    if n_batches == 2 and steps >= 8 and steps <= max_batch:
+        # a short run is ONE round of two batches: the second one's skeleton stage (one compute unit per tree, ~13 ms whatever
+        # the batch size) is exposed at the end, so it gets the smaller share (20 steps: 12 + 8 measured 1.83 ms per step
+        # against 1.85-1.90 for 10 + 10 / 11 + 9, profiles/r03_sweep_plan.txt)
+        first = (3 * steps + 2) // 5
+        return [first, steps - first]
     base, extra = divmod(steps, n_batches)
     return [base + (1 if i < extra else 0) for i in range(n_batches)]
 
@@ -301,30 +308,49 @@ class CloudWorker:
 
 
 def extra_configs(device):
-    """Single-cloud timings of the other single-GPU configurations of BASELINE.json (untimed region, for the record):
-    configs[3] 5M-point dense canopy at 1 cm, configs[4] peach-forest-65 in half-precision storage mode at 1M / 2 cm."""
+    """The other single-GPU configurations of BASELINE.json (untimed region, for the record), each as a BATCH through
+    Pipeline.process_clouds with the kernel timers on: ms per cloud, the gather / rule-GEMM roofline entry of that batch, and
+    what the skeleton stage did.  configs[3]: 5M-point dense canopy at 1 cm (2 clouds per launch set); configs[4]:
+    peach-forest-65 in half-precision storage mode at 1M / 2 cm (8 clouds per launch set)."""
+    from smart_tree_amd import profiling
     from smart_tree_amd.data_types.cloud import Cloud
     from smart_tree_amd.synthetic import sample_tree_cloud
 
     out = {}
-    for key, n, kw, pk in (("configs[4] peach-forest-65 fp16 storage, 1M pts, 2 cm", 1_000_000, {}, dict(weights="peach-forest-65", fp16=True)),
-                           ("configs[3] dense canopy, 5M pts, 1 cm", 5_000_000, dict(seed=3, foliage_fraction=0.6), dict(voxel=0.01)),
-                           ("configs[3] in the opt-in whole-cloud voxelisation mode (SURVEY 8f.2: no halo copies; NOT the reference's "
-                            "per-block results)", 5_000_000, dict(seed=3, foliage_fraction=0.6), dict(voxel=0.01, blocking="whole"))):
-        c = sample_tree_cloud(n, **({"seed": 0} | kw))
-        cloud = Cloud(xyz=torch.from_numpy(c["xyz"]).to(device), rgb=torch.from_numpy(c["rgb"]).to(device))
+    for key, n, nb, kw, pk in (
+            ("configs[4] peach-forest-65 fp16 storage, 1M pts, 2 cm", 1_000_000, 8, {}, dict(weights="peach-forest-65", fp16=True)),
+            ("configs[3] dense canopy, 5M pts, 1 cm", 5_000_000, 2, dict(seed=3, foliage_fraction=0.6), dict(voxel=0.01)),
+            ("configs[3] in the opt-in whole-cloud voxelisation mode (SURVEY 8f.2: no halo copies; NOT the reference's "
+             "per-block results)", 5_000_000, 2, dict(seed=3, foliage_fraction=0.6), dict(voxel=0.01, blocking="whole"))):
+        clouds = []
+        for b in range(nb):
+            c = sample_tree_cloud(n, seed=kw.get("seed", 0) + b, **{k: v for k, v in kw.items() if k != "seed"})
+            clouds.append(Cloud(xyz=torch.from_numpy(c["xyz"]).to(device), rgb=torch.from_numpy(c["rgb"]).to(device)))
         pipe = build_pipeline(device, **pk)
-        pipe.process_cloud(cloud=cloud)
+        pipe.process_clouds(clouds)
+        pipe.process_clouds(clouds)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        reps = 3
+        reps = 2
         for _ in range(reps):
-            sk = pipe.process_cloud(cloud=cloud)
+            sks = pipe.process_clouds(clouds)
         torch.cuda.synchronize()
-        ms = 1e3 * (time.perf_counter() - t0) / reps
-        out[key] = {"ms_per_cloud": round(ms, 2), "points_per_s": round(n / ms * 1e3), "voxels": int(len(pipe.last_labelled_cloud._base) if hasattr(pipe.last_labelled_cloud, "_base") else len(pipe.last_labelled_cloud)),
-                    "branches": int(sum(len(t.branches) for t in sk.skeletons)), "one cloud at a time": True}
-        del pipe, cloud
+        ms = 1e3 * (time.perf_counter() - t0) / (reps * nb)
+        profiling.enable(True)
+        pipe.process_clouds(clouds)
+        torch.cuda.synchronize()
+        profiling.enable(False)
+        roof = profiling.roofline(HBM_PEAK_GBS) or {}
+        gg = roof.get("gather_gemm") or {}
+        lc = pipe.last_labelled_cloud
+        branches = int(sum(len(t.branches) for sk in sks for t in sk.skeletons))
+        out[key] = {"ms_per_cloud": round(ms, 2), "points_per_s": round(n / ms * 1e3), "clouds_per_launch_set": nb,
+                    "voxels_per_cloud": int((len(lc._base) if hasattr(lc, "_base") else len(lc)) / nb), "branches_per_cloud": branches / nb,
+                    "skeleton_stage": "runs" if branches else "empty (this checkpoint labels no voxel of the synthetic trees as branch: "
+                                                               "the time is voxelise + network + class filter)",
+                    "gather_gemm": {k: gg.get(k) for k in ("hbm_frac", "achieved_GBps", "useful_TFLOPs", "f32_matrix_frac", "total_ms", "launches")},
+                    "stage_ms_per_cloud": profiling.stage_ms(nb)}
+        del pipe, clouds
         torch.cuda.empty_cache()
     return out
 
@@ -336,7 +362,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--points", type=int, default=N_POINTS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the configs[3] / configs[4] single-cloud timings")
+    ap.add_argument("--no-extras", action="store_true", help="skip the configs[3] / configs[4] batches")
     ap.add_argument("--free-running", action="store_true", help="one GPU: an extra untimed pass with 3 batches in flight and no "
                     "ordering of their chip-filling phases, reported as `free_running` (profiles/r02_free_running.txt)")
     ap.add_argument("--batch", type=int, default=MAX_BATCH, help="clouds per launch set (Pipeline.process_clouds); 1 = one cloud per call")
@@ -372,6 +398,9 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     coll_device = torch.device("cpu") if dryrun else device
+    global ORDERED
+    if "ST_BENCH_ORDERED" not in os.environ and args.steps < SHORT_RUN_STEPS:
+        ORDERED = 0  # measured at the driver's --steps 20: 1.83 ms per step free-running against 1.96 in turns (profiles/r03_sweep_plan.txt)
 
     from smart_tree_amd import profiling
     from smart_tree_amd.sharding import gather_skeletons

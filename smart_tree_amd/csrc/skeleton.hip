@@ -85,8 +85,10 @@ struct SkArgs {
     unsigned long long* best;  // claim race: (d2 bits << 32) | path position
     unsigned* touched;
     int* anc;         // [m][SK_ANC] direct ancestor table (component-local ids)
-    // global counters: [0..2] rotating frontier counts, [3] unresolved, [4] plateau progress, [5] components done
+    // global counters: [0..2] rotating frontier counts (tree-distance rounds), [3] unresolved, [4] plateau progress, [5] components done
     unsigned* cnt;
+    unsigned* fcnt;   // [3][SK_FS + 1] SSSP frontier counters per generation: SK_FS shards + the overflow area (see sk_q_reserve)
+    unsigned fseg;    // entries per shard of a frontier queue
     // per-component sample_tree state [C]
     int* s_done;
     int* s_len;
@@ -169,10 +171,29 @@ __device__ __forceinline__ float sk_dist(const float* a, const float* b) {
     for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < A.m; v += (int64_t)gridDim.x * blockDim.x)
 
 // ------------------------------------------------------------------------------- set-up ---
+// SSSP frontier queues.  Every workgroup of a frontier launch appends what it improved to the next frontier with a
+// RETURNING atomicAdd on the queue's counter; on one word those retire at ~90 per microsecond chip-wide
+// (MI355X_MICROARCH.md "dequeue"): the ~2000 workgroups of a batched launch spent 20+ us of a 45 us launch queueing on it
+// (one cloud: 190 workgroups, 2 us).  The queue is therefore cut into SK_FS shards (workgroup b appends to shard b % SK_FS,
+// its own counter, its own segment of `fseg` entries); a reservation that does not fit its segment goes to the overflow
+// area behind the segments (one more counter, room for every vertex), the slots it leaves unused in the segment are
+// filled with SK_Q_HOLE, which readers skip.  A frontier is read as the concatenation shard 0 .. SK_FS-1, overflow.
+#define SK_FS 16
+#define SK_Q_HOLE 0xffffffffu
+// where `n` entries of workgroup-shard `shard` go in queue `q`; fc = the generation's SK_FS + 1 counters
+__device__ __forceinline__ unsigned sk_q_reserve(unsigned* q, unsigned* fc, unsigned seg, unsigned shard, unsigned n) {
+    const unsigned at = atomicAdd(&fc[shard], n);
+    if (at + n <= seg) return shard * seg + at;
+    for (unsigned i = at; i < seg; i++) q[shard * seg + i] = SK_Q_HOLE;  // (at most n - 1 slots, once per shard and launch)
+    return SK_FS * seg + atomicAdd(&fc[SK_FS], n);
+}
+
 __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_init(SkArgs A) {
     const unsigned inf = st_f2ord(__uint_as_float(0x7f800000u));
     SK_VERTEX_LOOP(v) { A.dist_ord[v] = inf; A.stamp[v] = 0u; }
-    if (blockIdx.x == 0 && threadIdx.x < 8) A.cnt[threadIdx.x] = threadIdx.x == 0 ? (unsigned)A.C : 0u;
+    if (blockIdx.x == 0 && threadIdx.x < 8) A.cnt[threadIdx.x] = 0u;
+    if (blockIdx.x == 0)  // round 0's frontier = every component's root, in the overflow area of q0 (k_sk_roots)
+        for (int i = threadIdx.x; i < 3 * (SK_FS + 1); i += blockDim.x) A.fcnt[i] = i == SK_FS ? (unsigned)A.C : 0u;
 }
 
 // one workgroup per component: comp_of[], root = first minimum of the surface y (cloud.py:204-206)
@@ -189,7 +210,7 @@ __global__ void __launch_bounds__(1024) k_sk_roots(SkArgs A) {
     if (threadIdx.x == 0) {
         const int root = n > 0 ? (int)(0xffffffffu - (unsigned)(key & 0xffffffffu)) : 0;
         A.root_local[c] = root;
-        A.q0[c] = (unsigned)(base + root);  // round 0 frontier = every component's root
+        A.q0[(int64_t)SK_FS * A.fseg + c] = (unsigned)(base + root);  // round 0 frontier = every component's root
         if (n > 0) A.dist_ord[base + root] = st_f2ord(0.0f);
     }
 }
@@ -211,14 +232,26 @@ __global__ void __launch_bounds__(1024) k_sk_fill_comp_of(SkArgs A) {
 __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_sssp_round(SkArgs A, int r, int hops, int glanes, int lcap) {
     __shared__ unsigned lq[2][SK_LQ];
     __shared__ unsigned ln[3], lq_base;  // generation h fills lq[h & 1], counted by ln[h % 3]
-    const unsigned count = A.cnt[r % 3];
-    if (blockIdx.x == 0 && threadIdx.x == 0) A.cnt[(r + 2) % 3] = 0u;
-    if (count == 0) return;
+    __shared__ unsigned fpre[SK_FS + 2];  // this launch's frontier: entries in front of each shard / of the overflow area
+    const unsigned* fc_in = A.fcnt + (r % 3) * (SK_FS + 1);
+    unsigned* fc_out = A.fcnt + ((r + 1) % 3) * (SK_FS + 1);
+    if (blockIdx.x == 0 && threadIdx.x <= SK_FS) A.fcnt[((r + 2) % 3) * (SK_FS + 1) + threadIdx.x] = 0u;
+    const unsigned seg = A.fseg, shard = blockIdx.x % SK_FS;
+    if (threadIdx.x == 0) {
+        unsigned run = 0;
+        for (int s_ = 0; s_ <= SK_FS; s_++) {
+            fpre[s_] = run;
+            const unsigned c_ = fc_in[s_];
+            run += s_ < SK_FS && c_ > seg ? seg : c_;  // a shard holds at most `seg` entries (the rest went to the overflow area)
+        }
+        fpre[SK_FS + 1] = run;
+    }
     if (threadIdx.x < 3) ln[threadIdx.x] = 0;
     __syncthreads();
+    const unsigned count = fpre[SK_FS + 1];
+    if (count == 0) return;  // (uniform)
     const unsigned* q = (r & 1) ? A.q1 : A.q0;
     unsigned* qn = (r & 1) ? A.q0 : A.q1;
-    unsigned* cnt_out = &A.cnt[(r + 1) % 3];
     const bool lookfirst = lcap >= 0;
     if (lcap < 0) lcap = -lcap;
     const unsigned round = (unsigned)r + 1u;  // stamp[v] == round: v already sits in the next global frontier
@@ -237,12 +270,16 @@ __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_sssp_round(SkArgs A, int r
             if (o < old) {                                                                                 \
                 const unsigned slot = atomicAdd(out_n, 1u);                                                \
                 if (slot < SK_LQ) (out)[slot] = v;                                                         \
-                else if (atomicExch(&A.stamp[v], round) != round) qn[atomicAdd(cnt_out, 1u)] = v;          \
+                else if (atomicExch(&A.stamp[v], round) != round) qn[sk_q_reserve(qn, fc_out, seg, shard, 1u)] = v; \
             }                                                                                              \
         }                                                                                                  \
     }
     for (unsigned f = gw; f < count; f += tw) {
-        const unsigned u = q[f];
+        int sh = 0;  // the f-th entry of the frontier sits in shard `sh` (SK_FS: the overflow area)
+#pragma unroll
+        for (int s_ = 1; s_ <= SK_FS; s_++) sh = f >= fpre[s_] ? s_ : sh;
+        const unsigned u = q[(int64_t)sh * seg + (f - fpre[sh])];
+        if (u == SK_Q_HOLE) continue;  // (wave-uniform: one vertex per lane group)
         const float du = st_ord2f(A.dist_ord[u]);  // written before this launch
         SK_RELAX(u, du, lq[0], &ln[0]);
     }
@@ -260,7 +297,7 @@ __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_sssp_round(SkArgs A, int r
             // frontier, where the next launch deals it out over all workgroups
             for (unsigned i = lcap + threadIdx.x; i < ncur; i += blockDim.x) {
                 const unsigned v = in[i];
-                if (atomicExch(&A.stamp[v], round) != round) qn[atomicAdd(cnt_out, 1u)] = v;
+                if (atomicExch(&A.stamp[v], round) != round) qn[sk_q_reserve(qn, fc_out, seg, shard, 1u)] = v;
             }
             ncur = (unsigned)lcap;
         }
@@ -286,7 +323,7 @@ __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_sssp_round(SkArgs A, int r
     }
     __syncthreads();
     const unsigned nloc = *keep_n;
-    if (threadIdx.x == 0 && nloc) lq_base = atomicAdd(cnt_out, nloc);
+    if (threadIdx.x == 0 && nloc) lq_base = sk_q_reserve(qn, fc_out, seg, shard, nloc);
     __syncthreads();
     for (unsigned i = threadIdx.x; i < nloc; i += blockDim.x) qn[lq_base + i] = keep[i];
 }
@@ -1308,15 +1345,15 @@ static inline int64_t sk_grid_cells(int nseg) { return SK_GRID_CELLS * (nseg < 1
 static void sk_layout(StArena& a, int64_t m, int64_t C, SkLayout* s, int nseg = 1) {
     s->dist_ord = a.take<unsigned>(m);
     s->stamp = a.take<unsigned>(m);
-    s->q0 = a.take<unsigned>(m + C);
-    s->q1 = a.take<unsigned>(m + C);
+    s->q0 = a.take<unsigned>(2 * (m + C));  // SSSP frontier: SK_FS shard segments + the overflow area (sk_q_reserve)
+    s->q1 = a.take<unsigned>(2 * (m + C));
     s->touched = a.take<unsigned>(m);
     s->pt = a.take<SkPt>(m);
     s->pr = a.take<float4>(m);
     s->best = a.take<unsigned long long>(m);
     s->anc = a.take<int>((int64_t)SK_ANC * m);
     s->comp_of = a.take<int>(m);
-    s->cnt = a.take<unsigned>(8);
+    s->cnt = a.take<unsigned>(8 + 3 * (SK_FS + 1));  // [8] counters, then the frontier counters of three generations
     s->s_done = a.take<int>(C);
     s->s_len = a.take<int>(C);
     s->s_cur_id = a.take<int>(C);
@@ -1450,7 +1487,8 @@ extern "C" int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, c
     A.branch_parent = branch_parent; A.branch_off = branch_off; A.branch_len = branch_len; A.n_branches = n_branches;
     A.path_verts = path_verts; A.branch_of = branch_of;
     A.dist_ord = s.dist_ord; A.stamp = s.stamp; A.q0 = s.q0; A.q1 = s.q1; A.pt = s.pt; A.pr = s.pr;
-    A.best = s.best; A.touched = s.touched; A.anc = s.anc; A.cnt = s.cnt;
+    A.best = s.best; A.touched = s.touched; A.anc = s.anc; A.cnt = s.cnt; A.fcnt = s.cnt + 8;
+    A.fseg = (unsigned)((m + n_comp) / SK_FS > 0 ? (m + n_comp) / SK_FS : 1);
     A.s_done = s.s_done; A.s_len = s.s_len; A.s_cur_id = s.s_cur_id; A.s_cur_off = s.s_cur_off; A.s_nb = s.s_nb;
     A.s_total = s.s_total; A.s_rp = s.s_rp; A.s_ntouched = s.s_ntouched;
     A.blk_comp = s.blk_comp; A.blk_first = s.blk_first; A.blk_count = s.blk_count;
@@ -1475,7 +1513,7 @@ extern "C" int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, c
 
     const unsigned vg = sk_vgrid(m);
     const unsigned fg = (unsigned)st_min64(st_div_up(m, SK_WIDE_BLOCK), T.sssp_blocks);
-    unsigned h[8];
+    unsigned h[8 + 3 * (SK_FS + 1)];
     int64_t sssp_rounds = 0;
     const bool defer_plateaus = (stages & 1) && (stages & 4) && !(stages & 2);
     auto resolve_plateaus = [&](unsigned unresolved) -> int {
@@ -1499,9 +1537,11 @@ extern "C" int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, c
             const int batch = r == 0 ? T.sssp_first * T.sssp_batch : T.sssp_batch;
             for (int b = 0; b < batch; b++, r++)
                 hipLaunchKernelGGL(k_sk_sssp_round, dim3(fg), dim3(SK_WIDE_BLOCK), 0, stream, A, r, T.sssp_hops, T.sssp_lanes, T.sssp_lcap);
-            ST_TRY(sk_read(h, s.cnt, sizeof(unsigned) * 8, stream));
+            ST_TRY(sk_read(h, s.cnt, sizeof(h), stream));
             sssp_rounds = r;
-            if (h[r % 3] == 0) break;
+            unsigned left = 0;  // entries of the frontier the next launch would read
+            for (int i = 0; i <= SK_FS; i++) left |= h[8 + (r % 3) * (SK_FS + 1) + i];
+            if (left == 0) break;
             ST_REQUIRE(r < (1 << 24), "skeleton: SSSP did not converge");
         }
         hipLaunchKernelGGL(k_sk_dist_out, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A);
