@@ -423,11 +423,15 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn(const float* __restrict__ src
 // as coarse -- eight times the candidates -- as one cloud alone.
 static inline int64_t knn_max_cells(int nseg) { return KNN_MAX_CELLS * (nseg < 1 ? 1 : (nseg > 32 ? 32 : nseg)); }
 
+// the cell table st_grid_build will actually use: at most 128 cells per point (its own bound) -- the workspace is sized for
+// that, not for the batch cap (32 x 2^24 cells = 2 GiB of table for any batch of >= 32 clouds, however few points it has)
+static inline int64_t knn_cells(int64_t n2, int nseg) { return st_min64(knn_max_cells(nseg), 128 * (n2 > 0 ? n2 : 1) + 65536); }
+
 static void knn_layout(StArena& a, int64_t n2, int nseg, StGrid** g, uint32_t** cell_start, float4** recs, char** sub, int64_t* sub_bytes) {
     *g = a.take<StGrid>(1);
-    *cell_start = a.take<uint32_t>(knn_max_cells(nseg) + 1);
+    *cell_start = a.take<uint32_t>(knn_cells(n2, nseg) + 1);
     *recs = a.take<float4>(n2);
-    *sub_bytes = st_grid_ws_bytes(n2, knn_max_cells(nseg));
+    *sub_bytes = st_grid_ws_bytes(n2, knn_cells(n2, nseg));
     *sub = a.take<char>(*sub_bytes);
 }
 
@@ -469,7 +473,7 @@ extern "C" int st_knn_radius_seg(const float* src, int64_t n1, const float* dst,
         return ST_ERR_WORKSPACE;
     }
     const float cell_arg = cell_hint != 0.0f ? cell_hint : (r >= 0.0f ? r : -1.0f);
-    ST_TRY(st_grid_build(dst, n2, cell_arg, knn_max_cells(nseg), g, cell_start, recs, sub, sub_bytes, stream, r, bound, n1,
+    ST_TRY(st_grid_build(dst, n2, cell_arg, knn_cells(n2, nseg), g, cell_start, recs, sub, sub_bytes, stream, r, bound, n1,
                          dst_seg_off, nseg, src_seg_off, cell_hint < 0.0f ? (cell_mean_mult >= 0.0f ? cell_mean_mult : KNN_MEAN_MULT) : 0.0f));
     dim3 grid((unsigned)st_div_up(n1, KNN_WAVES)), block(KNN_BLOCK);
     const int cell_order = src == dst && n1 == n2 ? 1 : 0;
@@ -511,7 +515,7 @@ extern "C" int st_radius_count_seg(const float* src, int64_t n1, const float* ds
         return ST_ERR_WORKSPACE;
     }
     const float cell_arg = cell_hint != 0.0f ? cell_hint : (r >= 0.0f ? r : -1.0f);
-    ST_TRY(st_grid_build(dst, n2, cell_arg, knn_max_cells(nseg), g, cell_start, recs, sub, sub_bytes, stream, r, bound, n1,
+    ST_TRY(st_grid_build(dst, n2, cell_arg, knn_cells(n2, nseg), g, cell_start, recs, sub, sub_bytes, stream, r, bound, n1,
                          dst_seg_off, nseg, src_seg_off, cell_hint < 0.0f ? (cell_mean_mult >= 0.0f ? cell_mean_mult : KNN_MEAN_MULT) : 0.0f));
     hipLaunchKernelGGL((k_knn<8, true>), dim3((unsigned)st_div_up(n1, KNN_WAVES)), dim3(KNN_BLOCK), 0, stream, src, n1,
                        (const StGrid*)g, (const uint32_t*)cell_start, (const float4*)recs, r, bound, bound_mode,

@@ -114,7 +114,7 @@ struct SkArgs {
     int local_items;     // select: (path vertex, cell row) pairs one workgroup claims path-centric by itself
     int long_mode;       // select: paths that fit the LDS path buffer but are too much work for the plain point-centric claim are
                          // claimed by the workgroup itself with chunk-pruned distance tests (below), not handed to k_sk_claim
-    long long* ticks;  // optional developer aid: per-phase wall_clock64 sums of k_sk_select (st_debug_set_ticks)
+    long long* ticks;  // optional developer aid: per-phase wall_clock64 sums of k_sk_select (tuning[15])
 };
 
 // agent-scope (L2) accesses for data that the SAME launch wrote earlier (never a stale L1 line)
@@ -1340,7 +1340,9 @@ struct SkLayout {
     int64_t gws_bytes;
 };
 
-static inline int64_t sk_grid_cells(int nseg) { return SK_GRID_CELLS * (nseg < 1 ? 1 : (nseg > 32 ? 32 : nseg)); }
+static inline int64_t sk_grid_cells(int nseg, int64_t m) {  // (st_grid_build uses at most 128 cells per point: size for that)
+    return st_min64(SK_GRID_CELLS * (nseg < 1 ? 1 : (nseg > 32 ? 32 : nseg)), 128 * (m > 0 ? m : 1) + 65536);
+}
 
 static void sk_layout(StArena& a, int64_t m, int64_t C, SkLayout* s, int nseg = 1) {
     s->dist_ord = a.take<unsigned>(m);
@@ -1374,9 +1376,9 @@ static void sk_layout(StArena& a, int64_t m, int64_t C, SkLayout* s, int nseg = 
     s->blk_count = a.take<int>(C);
     s->blk_comp = a.take<int>(C + st_div_up(m, 1024));
     s->g = a.take<StGrid>(1);
-    s->cell_start = a.take<uint32_t>(sk_grid_cells(nseg) + 1);
+    s->cell_start = a.take<uint32_t>(sk_grid_cells(nseg, m) + 1);
     s->recs = a.take<float4>(m);
-    s->gws_bytes = st_grid_ws_bytes(m, sk_grid_cells(nseg));
+    s->gws_bytes = st_grid_ws_bytes(m, sk_grid_cells(nseg, m));
     s->gws = a.take<char>(s->gws_bytes);
 }
 
@@ -1572,7 +1574,7 @@ extern "C" int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, c
         const int nblk = (int)st_min64((int64_t)n_comp + st_div_up(m, 1024), (int64_t)n_comp * SK_MAX_CLAIM_BLOCKS);
         hipLaunchKernelGGL(k_sk_blk_tables, dim3(1), dim3(1024), 0, stream, A, s.blk_comp, s.blk_first, s.blk_count, nblk);
         // grid_cell < 0: cell = max(rad) / -grid_cell with the maximum reduced on the device (no host round trip)
-        ST_TRY(st_grid_build(pts, m, grid_cell, sk_grid_cells(nseg), s.g, s.cell_start, s.recs, s.gws, s.gws_bytes, stream,
+        ST_TRY(st_grid_build(pts, m, grid_cell, sk_grid_cells(nseg, m), s.g, s.cell_start, s.recs, s.gws, s.gws_bytes, stream,
                              grid_cell < 0.0f ? -1.0f : 0.0f, grid_cell < 0.0f ? rad : nullptr, grid_cell < 0.0f ? m : 0,
                              vert_seg_off, nseg, vert_seg_off, T.grid_mean_mult));
         int64_t iters = 0;

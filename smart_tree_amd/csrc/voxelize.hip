@@ -29,7 +29,7 @@ struct VxState {
     int lo[3], hi[3];    // block-id bounding box over ALL clouds of the call
     uint32_t n_blocks;
     uint32_t n_vox;
-    uint32_t overflow;   // bit0: block table, bit1: max_blocks, bit2: hash full
+    uint32_t overflow;   // bit0: block table, bit1: max_blocks, bit2: hash full, bit3: a block's voxel grid exceeds the 16-bit key fields
     int table_cells;     // capacity of the block table per cloud (vx_table_cells)
     uint32_t seg_blk_off[ST_MAX_SEG + 1];  // first block of every cloud
     uint32_t seg_vox_off[ST_MAX_SEG + 1];  // first voxel of every cloud (written by the gather pass)
@@ -276,13 +276,17 @@ __global__ void __launch_bounds__(VX_BLOCK) k_vx_minmax(const float* xyz, int64_
 }
 
 // Per block, once (instead of per point and block): the voxel origin as a float and the grid size roundf((hi - lo) / v).
-__global__ void __launch_bounds__(VX_BLOCK) k_vx_block_grid(const VxState* st, int max_blocks, const unsigned* blk_lo,
+__global__ void __launch_bounds__(VX_BLOCK) k_vx_block_grid(VxState* st, int max_blocks, const unsigned* blk_lo,
                                                             const unsigned* blk_hi, float vs, float* blk_lof, int* blk_grid) {
     const int nb = (int)st_min<uint32_t>(st->n_blocks, (uint32_t)max_blocks);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 3 * nb; i += gridDim.x * blockDim.x) {
         const float lo = st_ord2f(blk_lo[i]), hi = st_ord2f(blk_hi[i]);
         blk_lof[i] = lo;
-        blk_grid[i] = (int)roundf((hi - lo) / vs);
+        const float cells = roundf((hi - lo) / vs);
+        // st_pack_key gives z / y / x 16 bits each: a grid beyond that (whole-cloud mode: 1 mm voxels over 65 m) would alias keys
+        // and merge distinct voxels silently -- flagged, the host call fails with a clear message
+        if (!(cells <= 65535.0f)) atomicOr(&st->overflow, 8u);
+        blk_grid[i] = cells <= 65535.0f ? (int)cells : 65535;
     }
 }
 
@@ -575,7 +579,7 @@ static int vx_voxelize(const float* xyz, const float* rgb, int64_t n, const int3
     hipLaunchKernelGGL(k_vx_minmax, gr, dim3(VX_BLOCK), 0, stream, xyz, n, seg_off, (const VxState*)st, (const int*)table, p, blk_lo,
                        blk_hi);
     hipLaunchKernelGGL(k_vx_block_grid, dim3((unsigned)st_min64(st_div_up(3 * (int64_t)max_blocks, VX_BLOCK), 64)), dim3(VX_BLOCK), 0, stream,
-                       (const VxState*)st, max_blocks, (const unsigned*)blk_lo, (const unsigned*)blk_hi, p.vs, blk_lof, blk_grid);
+                       st, max_blocks, (const unsigned*)blk_lo, (const unsigned*)blk_hi, p.vs, blk_lof, blk_grid);
     hipLaunchKernelGGL((k_vx_pass<0>), gs, dim3(VX_BLOCK), 0, stream, xyz, n, seg_off, st, (const int*)table, p,
                        (const float*)blk_lof, (const int*)blk_grid, slots, (unsigned long long)cap, cnt, win, rec_b,
                        rec_pt, max_voxels);
@@ -596,6 +600,7 @@ static int vx_voxelize(const float* xyz, const float* rgb, int64_t n, const int3
     ST_REQUIRE(!(h.overflow & 1u), "voxelize: the block-id bounding box of a cloud has more than %lld cells (raise max_blocks)",
                (long long)vx_table_cells(max_blocks, nseg));
     ST_REQUIRE(!(h.overflow & 2u), "voxelize: %u blocks exceed max_blocks=%d", h.n_blocks, max_blocks);
+    ST_REQUIRE(!(h.overflow & 8u), "voxelize: a voxel grid spans more than 65535 cells along an axis (voxel size %g): use blocks, or a larger voxel", voxel_size);
     ST_REQUIRE(!(h.overflow & 4u) && (int64_t)h.n_vox <= max_voxels, "voxelize: %u voxels exceed max_voxels=%lld",
                h.n_vox, (long long)max_voxels);
     const int64_t m = h.n_vox;

@@ -224,9 +224,14 @@ class DeviceSkeleton(DisjointTreeSkeleton):
         if self._can_defer("prune"):
             self._ops["prune"] = (float(min_radius), float(min_length))
         else:
-            _ = self.skeletons
+            trees = self.skeletons
             self._host = None
-            super().prune(min_radius, min_length)
+            if self._seg_host is not None:  # a batch: "skeleton 0" (tree.py:164-168) is the first tree OF EVERY CLOUD, as on the device
+                for b in range(len(self._seg_host) - 1):
+                    if self._seg_host[b] < self._seg_host[b + 1] and trees[self._seg_host[b]].branches:
+                        trees[self._seg_host[b]].prune(min_radius=min_radius, min_length=min_length)
+            else:
+                super().prune(min_radius, min_length)
 
     def repair(self) -> None:
         if self._can_defer("repair"):
@@ -320,6 +325,8 @@ class DeviceSkeleton(DisjointTreeSkeleton):
                 if isinstance(t, _PackedTree):
                     tree = _PackedTree.__new__(_PackedTree)
                     tree._lazy = t._lazy
+                    if "_branches" in t.__dict__:  # somebody has read (perhaps edited: host-side prune / repair / smooth) the
+                        tree.__dict__["_branches"] = t.__dict__["_branches"]  # branch objects: the cloud's view keeps them
                 else:
                     tree = TreeSkeleton(local, t.branches)
                 tree._id = local

@@ -213,3 +213,29 @@ def test_process_clouds_edge_cases(backend):
     (again,) = pipe.process_clouds([Cloud(clouds[0].xyz, clouds[0].rgb)])
     assert calls == ["network", "wide"] and _signature(again) == _signature(one)
     pipe.model_inference.on_network_done = pipe.skeletonizer.on_wide_phase_done = None
+
+
+def test_host_side_post_processing_of_a_batch_survives_split(backend):
+    """post-processing called AFTER the skeleton has been materialised (or out of the prune -> repair -> smooth
+    order) runs on the host objects; for a batch `prune` must still mean "skeleton 0 of every cloud" and `split()` must hand
+    out the edited branches, not rebuild them from the packed arrays."""
+    clouds = _clouds(backend, sizes=(3000, 2000), scale=0.35) if backend.type == "cpu" else _clouds(backend, sizes=(40000, 30000), scale=0.8)
+    pipe = _pipeline(backend, 0.04 if backend.type == "cpu" else 0.03)
+
+    def late(sk):  # materialise first: every op below takes the host fallback
+        _ = sk.skeletons
+        sk.smooth(5)
+        sk.prune(min_radius=0.01, min_length=0.05)
+        return sk
+
+    serial = []
+    for c in clouds:
+        lc = pipe.model_inference.forward(pipe.preprocessing(Cloud(c.xyz, c.rgb)))
+        serial.append(_signature(late(pipe.skeletonizer.forward(lc.filter_by_class(pipe.branch_classes)))))
+    batch = pipe.preprocessing(Cloud.collate([Cloud(c.xyz, c.rgb) for c in clouds]))
+    lc = pipe.model_inference.forward(batch)
+    parts = late(pipe.skeletonizer.forward(lc.filter_by_class(pipe.branch_classes))).split()
+    assert len(parts) == len(clouds)
+    for one, got in zip(serial, parts):
+        assert _signature(got) == one
+    assert sum(len(one) for one in serial) > 2

@@ -81,3 +81,16 @@ def test_voxelize_plot_larger_than_the_default_block_table(backend):
     xyz = np.concatenate([a, far, a[:50] + np.array([0.0, 130.0, 0.0], np.float32)])
     out = _compare(xyz, np.zeros_like(xyz), 0.1, backend)
     assert out.block_centres.shape[0] >= 2
+
+
+def test_whole_cloud_grid_beyond_the_key_range_is_refused(backend):
+    """whole-cloud mode turns a cloud's bounding box into ONE voxel grid; the hash key gives each axis 16 bits,
+    so a span of more than 65535 cells (here 70 m at 1 mm) must fail loudly instead of merging distinct voxels."""
+    from smart_tree_amd import _lib
+    from smart_tree_amd.dataset.dataset import voxelize_cloud
+
+    xyz = torch.tensor([[0.0, 0.0, 0.0], [0.5, 0.2, 0.1], [70.0, 1.0, 1.0]], device=backend)
+    with pytest.raises(_lib.StError, match="65535 cells"):
+        voxelize_cloud(xyz, None, 0.001)
+    ok = voxelize_cloud(xyz, None, 0.01)  # 7000 cells: fine
+    assert ok.coords.shape[0] == 2  # (the point ON the maximum face has no cell: PointToVoxel drops c == grid)

@@ -27,7 +27,8 @@ vb = voxelize_blocks(cloud.xyz, cloud.rgb, VOX, seg_off=cloud.seg_off)
 coords0 = vb.coords
 if "--input-order" not in sys.argv:  # as Smart_Tree.features does: Morton-ordered rows (st_spatial_order)
     coords0 = ops.move_rows(coords0, ops.spatial_order(coords0))
-pyr = ops.build_pyramid(coords0, 3, vb.blk_seg, vb.n_seg)
+bricks = None if "--input-order" in sys.argv or "--hash" in sys.argv else ops.brick_pyramid(vb.coords, 3, vb.block_centres.shape[0], int(round(4.8 / VOX)) + 2, vb.blk_seg, vb.n_seg)
+pyr = bricks[0] if bricks is not None else ops.build_pyramid(coords0, 3, vb.blk_seg, vb.n_seg)  # as Smart_Tree.features: brick order when it can
 N = [x.shape[0] for x in pyr.coords]
 print("levels", N)
 def timeit(fn, reps=20):
@@ -53,17 +54,14 @@ for lvl in range(4):
         line = f"L{lvl} {name:5s} {cin:3d}->{cout:3d} N={nout:7d} P={pairs:8d}: VALU {t_valu:7.1f} us ({bytes_/t_valu/1e3:7.1f} GB/s = {bytes_/t_valu/1e3/80:4.1f} %, {flops/t_valu/1e6:6.2f} TF)"
         if cin % 16 == 0 and cout % 16 == 0:
             wp = ops.mfma_weight(w)
-            import ctypes
-            from smart_tree_amd import _lib
-            L = _lib.lib(); L.st_debug_set_mfma_variant.argtypes = [ctypes.c_int]
             ya = ops.sparse_conv(x, w, tbl, nout, row_order=ro)
             for var, tag in [(v, f"v{v}") for v in VARIANTS]:
-                L.st_debug_set_mfma_variant(var)
+                ops.MFMA_VARIANT = var  # passed per call (st_sparse_conv_mfma_fwd's `variant`)
                 t_m = timeit(lambda: ops.sparse_conv(x, w, tbl, nout, wp=wp, row_order=ro))
                 yb = ops.sparse_conv(x, w, tbl, nout, wp=wp, row_order=ro)
                 err = (ya - yb).abs().max().item() / (ya.abs().max().item() + 1e-30)
                 line += f" | mfma[{tag}] {t_m:6.1f} us ({bytes_/t_m/1e3:7.1f} GB/s = {bytes_/t_m/1e3/80:4.1f} % of 8 TB/s) {flops/t_m/1e6:5.1f} TF e={err:.0e}"
-            L.st_debug_set_mfma_variant(0)
+            ops.MFMA_VARIANT = 0
             # half-precision storage (config 5): f16 matrix-core kernel, half the gather bytes
             xh, wph = x.half(), wp.half()
             bytes_h = pairs * (cin * 2 + 4) + nout * cout * 2

@@ -1,4 +1,4 @@
-"""GPU box: phase timing inside k_sk_select (st_debug_set_ticks) for one cloud: python tools/diag_phases.py [n] [voxel] [foliage] [seed] [params "k=v,..."]"""
+"""GPU box: phase timing inside k_sk_select (tuning code 15: a device array of phase timers) for one cloud: python tools/diag_phases.py [n] [voxel] [foliage] [seed] [params "k=v,..."]"""
 import ctypes
 import sys
 import time
