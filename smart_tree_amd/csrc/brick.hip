@@ -15,8 +15,8 @@
 //     neighbours of a voxel sit in at most eight bricks, and neighbouring rows (adjacent lanes) read the same lines.
 //   * the same order is the spatially coherent one the convolutions want (st_spatial_order sorted by Morton code for that:
 //     two radix sorts, 26 launches): here it falls out of the structure -- order0[] is computed, not sorted.
-//   * coarse active sets: every fine voxel flags the bricks / sets the bits of its <= 8 outputs o = (c + 1 - k) / 2 in the
-//     coarse level's structure; the coarse coordinates are then ENUMERATED from the masks.  The coarse rows come out in
+//   * coarse active sets: a stencil on the fine level's bit planes (k_bk_coarse_*: per coarse brick 27 fine-brick look-ups, not
+//     3.4 look-ups per fine voxel); the coarse coordinates are then ENUMERATED from the masks.  The coarse rows come out in
 //     brick order, not in spconv's (hash) or the oracle's (first appearance) order: an internal row numbering -- every
 //     output row of a convolution is computed on its own, so the features of a voxel do not depend on it
 //     (tests/test_unet.py::test_brick_pyramid_*: same sets, same pairs, same network outputs bit for bit).
@@ -237,31 +237,106 @@ __global__ void __launch_bounds__(BK_BLOCK) k_bk_subm(const int32_t* coords, con
     }
 }
 
-// ---- coarse active set of the strided convolution (k3 s2 p1): o = (c + 1 - k) / 2 per axis where even, 0 <= o <= ext / 2 ----
-template <int PASS>  // 0: flag the bricks, 1: set the bits
-__global__ void __launch_bounds__(BK_BLOCK) k_bk_coarse(const int32_t* coords, const int64_t* n_dev, int64_t cap, BkLevel Lc, const BkState* st,
-                                                        int level, const int32_t* blk_seg) {
+// ---- coarse active set of the strided convolution (k3 s2 p1): coarse o is active iff a fine voxel sits at 2o - 1 + k, k in 0..2 per
+// axis, and 0 <= o <= ext / 2.  Computed brick by brick on the MASKS (a stencil on bit planes), not voxel by voxel: a fine
+// voxel offers itself to up to 8 outputs and ~6 fine voxels share an output -- per voxel that was 3.4 look-ups + bit-sets each
+// (27 us per cloud at 24 clouds per launch set); per coarse brick it is 27 fine-brick look-ups for 512 outputs.
+// PASS A: every occupied fine brick fb flags the coarse bricks it can reach: fb >> 1 per axis, and (fb >> 1) + 1 when fb is odd
+// and the brick has a voxel on its last layer of that axis (fine c = 8 fb + 7 -> o = 4 fb + 4).
+__global__ void __launch_bounds__(BK_BLOCK) k_bk_coarse_mark(BkLevel Lf, BkLevel Lc, const BkState* st, int level, const int32_t* blk_seg) {
     if (st->fail & 2u) return;
-    const int64_t n = *n_dev < cap ? *n_dev : cap;
-    BK_LOOP(i, n) {
-        const int4 c4 = reinterpret_cast<const int4*>(coords)[i];
-        const int b = c4.x, c[3] = {c4.y, c4.z, c4.w};
+    const int64_t ns = *Lf.n_slots < Lf.slot_cap ? *Lf.n_slots : Lf.slot_cap;
+    const int nbc = 1 << Lc.mb;
+    BK_LOOP(s, ns) {
+        const BkRec& r = Lf.rec[s];
+        const unsigned t = r.tidx, mc = t & (Lf.mt - 1u);
+        const int b = (int)(t >> (3 * Lf.mb));
+        const int fb[3] = {(int)bk_compact3(mc >> 2), (int)bk_compact3(mc >> 1), (int)bk_compact3(mc)};
         const int* e = st->ext[blk_seg ? blk_seg[b] : 0];
-        int lo[3], hi[3];  // candidate outputs per axis: even c -> c / 2; odd c -> (c - 1) / 2 and (c + 1) / 2 (the latter if inside)
+        unsigned long long all = 0ull;
 #pragma unroll
-        for (int a = 0; a < 3; a++) {
-            const int omax = (e[a] >> level) >> 1;
-            lo[a] = c[a] >> 1;  // floor: c / 2 (even) or (c - 1) / 2 (odd)
-            hi[a] = (c[a] & 1) && lo[a] + 1 <= omax ? lo[a] + 1 : lo[a];
-            if (lo[a] > omax) lo[a] = hi[a] = -1;  // (cannot happen: omax = floor(ext / 2) >= floor(c / 2))
+        for (int w = 0; w < 8; w++) all |= r.mask[w];
+        for (int q = 0; q < 8; q++) {  // q bit 2 / 1 / 0: the next coarse brick along z / y / x
+            const int d[3] = {(q >> 2) & 1, (q >> 1) & 1, q & 1};
+            unsigned long long m = d[0] ? r.mask[7] : all;
+            if (d[1]) m &= 0xff00000000000000ull;
+            if (d[2]) m &= 0x8080808080808080ull;
+            bool ok = m != 0ull;
+            int cb[3];
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                cb[a] = (fb[a] >> 1) + d[a];
+                ok = ok && (!d[a] || (fb[a] & 1)) && cb[a] < nbc && 8 * cb[a] <= ((e[a] >> level) >> 1);
+            }
+            if (ok) Lc.p[(int64_t)b * Lc.mt + bk_morton(cb[0], cb[1], cb[2])] = 1u;
         }
-        if (lo[0] < 0 || lo[1] < 0 || lo[2] < 0) continue;
-        for (int oz = lo[0]; oz <= hi[0]; oz++)
-            for (int oy = lo[1]; oy <= hi[1]; oy++)
-                for (int ox = lo[2]; ox <= hi[2]; ox++) {
-                    if (PASS == 0) Lc.p[bk_tab(Lc, b, oz, oy, ox)] = 1u;
-                    else bk_set_bit(Lc, b, oz, oy, ox);
+    }
+}
+
+// PASS B: one thread per (coarse brick, z word): OR of the three fine z planes 2 oz - 1 .. 2 oz + 1, each a 17 x 17 bit window
+// (fine y, x from 16 cb - 1 to 16 cb + 15: the brick pair 2 cb, 2 cb + 1 and the last row / column of brick 2 cb - 1), then
+// "dilate by one and take every second bit" along x and y, then the clip at the cloud's extent.
+__global__ void __launch_bounds__(BK_BLOCK) k_bk_coarse_stencil(BkLevel Lf, BkLevel Lc, const BkState* st, int level, const int32_t* blk_seg) {
+    if (st->fail & 2u) return;
+    const int64_t ns = *Lc.n_slots < Lc.slot_cap ? *Lc.n_slots : Lc.slot_cap;
+    const int limf = 8 << Lf.mb, nbf = 1 << Lf.mb;
+    BK_LOOP(idx, ns * 8) {
+        const int64_t s = idx >> 3;
+        const int w = (int)(idx & 7);
+        const unsigned t = Lc.rec[s].tidx, mc = t & (Lc.mt - 1u);
+        const int b = (int)(t >> (3 * Lc.mb));
+        const int cb[3] = {(int)bk_compact3(mc >> 2), (int)bk_compact3(mc >> 1), (int)bk_compact3(mc)};
+        const int* e = st->ext[blk_seg ? blk_seg[b] : 0];
+        const int omax[3] = {(e[0] >> level) >> 1, (e[1] >> level) >> 1, (e[2] >> level) >> 1};
+        const int oz = 8 * cb[0] + w;
+        unsigned long long word = 0ull;
+        if (oz <= omax[0]) {
+            unsigned rows[17];
+#pragma unroll
+            for (int r = 0; r < 17; r++) rows[r] = 0u;
+            for (int dz = -1; dz <= 1; dz++) {
+                const int fz = 2 * oz + dz;
+                if (fz < 0 || fz >= limf) continue;
+                const int fbz = fz >> 3, wz = fz & 7;
+                for (int iy = 0; iy < 3; iy++) {
+                    const int fby = 2 * cb[1] - 1 + iy;
+                    if (fby < 0 || fby >= nbf) continue;
+                    for (int ix = 0; ix < 3; ix++) {
+                        const int fbx = 2 * cb[2] - 1 + ix;
+                        if (fbx < 0 || fbx >= nbf) continue;
+                        const int64_t tf = (int64_t)b * Lf.mt + bk_morton(fbz, fby, fbx);
+                        const uint32_t sf = Lf.p[tf];
+                        if (Lf.p[tf + 1] == sf) continue;
+                        const unsigned long long m = Lf.rec[sf].mask[wz];
+                        if (m == 0ull) continue;
+                        for (int yy = iy == 0 ? 7 : 0; yy < 8; yy++) {
+                            const unsigned rb = (unsigned)(m >> (8 * yy)) & 0xffu;
+                            const int r = iy == 0 ? 0 : (iy == 1 ? 1 + yy : 9 + yy);
+                            rows[r] |= ix == 0 ? (rb >> 7) : (ix == 1 ? rb << 1 : rb << 9);
+                        }
+                    }
                 }
+            }
+            unsigned c8[17];
+#pragma unroll
+            for (int r = 0; r < 17; r++) {
+                unsigned x = rows[r] | (rows[r] >> 1) | (rows[r] >> 2);  // bit 2 ox: any of columns 2 ox, 2 ox + 1, 2 ox + 2
+                x &= 0x5555u;
+                x = (x | (x >> 1)) & 0x3333u;
+                x = (x | (x >> 2)) & 0x0f0fu;
+                x = (x | (x >> 4)) & 0x00ffu;
+                c8[r] = x;
+            }
+            unsigned xclip = 0xffu;  // coarse x beyond the extent
+            if (8 * cb[2] + 7 > omax[2]) xclip = omax[2] >= 8 * cb[2] ? (0xffu >> (7 - (omax[2] - 8 * cb[2]))) : 0u;
+#pragma unroll
+            for (int oy = 0; oy < 8; oy++) {
+                if (8 * cb[1] + oy > omax[1]) break;
+                const unsigned rb = (c8[2 * oy] | c8[2 * oy + 1] | c8[2 * oy + 2]) & xclip;
+                word |= (unsigned long long)rb << (8 * oy);
+            }
+        }
+        Lc.rec[s].mask[w] = word;
     }
 }
 
@@ -307,6 +382,13 @@ __global__ void __launch_bounds__(BK_BLOCK) k_bk_updown(const int32_t* coords, c
         const int* e = st->ext[blk_seg ? blk_seg[b] : 0];
         const int omax[3] = {(e[0] >> level) >> 1, (e[1] >> level) >> 1, (e[2] >> level) >> 1};
         atomicAdd(&hist[bk_parity_class(c[0], c[1], c[2])], 1u);
+        // a fine voxel reaches at most 2 x 2 x 2 outputs (o = c >> 1, and o + 1 when c is odd), nearly always in ONE coarse brick:
+        // the brick's table entry and the mask word of a z plane are fetched when they change, not once per offset
+        int64_t t_have = -1;
+        int slot = -1, w_have = -1;
+        unsigned bs = 0u, cu = 0u;
+        unsigned long long mw = 0ull;
+        const int limc = 8 << Lc.mb;
 #pragma unroll
         for (int kz = 0; kz < 3; kz++)
 #pragma unroll
@@ -314,8 +396,25 @@ __global__ void __launch_bounds__(BK_BLOCK) k_bk_updown(const int32_t* coords, c
                 const int k = kz * 9 + j;
                 const int nz = c[0] + 1 - kz, ny = c[1] + 1 - j / 3, nx = c[2] + 1 - j % 3;
                 int r = -1;
-                if (!((nz | ny | nx) & 1) && nz >= 0 && ny >= 0 && nx >= 0 && (nz >> 1) <= omax[0] && (ny >> 1) <= omax[1] && (nx >> 1) <= omax[2])
-                    r = bk_lookup(Lc, b, nz >> 1, ny >> 1, nx >> 1);
+                if (!((nz | ny | nx) & 1) && nz >= 0 && ny >= 0 && nx >= 0 && (nz >> 1) <= omax[0] && (ny >> 1) <= omax[1] && (nx >> 1) <= omax[2]) {
+                    const int oz = nz >> 1, oy = ny >> 1, ox = nx >> 1;
+                    if (oz < limc && oy < limc && ox < limc) {
+                        const int64_t tc = bk_tab(Lc, b, oz, oy, ox);
+                        if (tc != t_have) {
+                            t_have = tc;
+                            w_have = -1;
+                            const uint32_t sc = Lc.p[tc];
+                            slot = Lc.p[tc + 1] != sc ? (int)sc : -1;
+                            bs = slot >= 0 ? Lc.base[slot] : 0u;
+                        }
+                        if (slot >= 0) {
+                            const int wz = oz & 7;
+                            if (wz != w_have) { w_have = wz; const BkRec& rc = Lc.rec[slot]; mw = rc.mask[wz]; cu = bs + bk_cum(rc, wz); }
+                            const int bit = ((oy & 7) << 3) | (ox & 7);
+                            if ((mw >> bit) & 1ull) r = (int)(cu + (unsigned)__popcll(mw & ((1ull << bit) - 1ull)));
+                        }
+                    }
+                }
                 nbr_up[(int64_t)k * cap_f + i] = r;
                 if (r >= 0 && r < m) nbr_down[(int64_t)k * cap_c + r] = (int32_t)i;
             }
@@ -490,11 +589,10 @@ extern "C" int st_brick_pyramid(const int32_t* coords0, int64_t n0, int n_blocks
                            L[l], subm[l], (const BkState*)Y.st);
         if (l == depth) break;
         const int64_t cap_c = caps[l + 1];
-        hipLaunchKernelGGL((k_bk_coarse<0>), dim3(bk_grid(cap)), dim3(BK_BLOCK), 0, stream, (const int32_t*)coords_out[l], (const int64_t*)L[l].n_vox,
-                           cap, L[l + 1], (const BkState*)Y.st, l, blk_seg);
+        hipLaunchKernelGGL(k_bk_coarse_mark, dim3(bk_grid(L[l].slot_cap)), dim3(BK_BLOCK), 0, stream, L[l], L[l + 1], (const BkState*)Y.st, l, blk_seg);
         ST_TRY(close_flags(l + 1));
-        hipLaunchKernelGGL((k_bk_coarse<1>), dim3(bk_grid(cap)), dim3(BK_BLOCK), 0, stream, (const int32_t*)coords_out[l], (const int64_t*)L[l].n_vox,
-                           cap, L[l + 1], (const BkState*)Y.st, l, blk_seg);
+        hipLaunchKernelGGL(k_bk_coarse_stencil, dim3(bk_grid(L[l + 1].slot_cap * 8)), dim3(BK_BLOCK), 0, stream, L[l], L[l + 1], (const BkState*)Y.st, l,
+                           blk_seg);
         ST_TRY(close_bits(l + 1));
         hipLaunchKernelGGL(k_bk_emit, dim3(bk_grid(L[l + 1].slot_cap * 8)), dim3(BK_BLOCK), 0, stream, L[l + 1], coords_out[l + 1], cap_c, Y.st);
         (void)hipMemsetAsync(down[l], 0xff, 27 * cap_c * sizeof(int32_t), stream);
