@@ -21,3 +21,8 @@ cd $R
 rm -f gpurun_out/prof_${tag}/*/*kernel_trace.csv gpurun_out/prof_${tag}_steps20/*/*kernel_trace.csv gpurun_out/prof_solo/*/*kernel_trace.csv gpurun_out/pmc_*/*/*kernel_trace.csv
 python tools/time_single.py > gpurun_out/${tag}_single.txt 2>&1
 ls gpurun_out/prof_${tag}/*/ gpurun_out/prof_${tag}_steps20/*/ gpurun_out/prof_solo/*/ gpurun_out/pmc_fetch/*/ gpurun_out/pmc_write/*/ 2>&1 | tail -20
+# the multi-rank control flow on ONE GPU (two gloo ranks, both on cuda:0): sharding, the size all_gather + payload gather, all_reduce, barrier
+ST_BENCH_DRYRUN=1 ST_BENCH_MIN_UPTIME_S=5 timeout -s KILL 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 16 --warmup 2 > gpurun_out/${tag}_dryrun_2ranks.json 2> gpurun_out/${tag}_dryrun_2ranks.err
+tail -c 200 gpurun_out/${tag}_dryrun_2ranks.json; echo
+timeout -s KILL 600 python tools/parity_stress.py 300 > gpurun_out/${tag}_parity_stress.txt 2>&1
+tail -2 gpurun_out/${tag}_parity_stress.txt
