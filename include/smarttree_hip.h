@@ -237,7 +237,13 @@ int st_radius_count_seg(const float* src, int64_t n1, const float* dst, int64_t 
                         const int32_t* dst_seg_off, int nseg, void* ws, int64_t ws_bytes, void* stream, float cell_mean_mult);
 /* components / adjacency straight from the neighbour search (idx / dist [n,K] of st_knn_radius_seg after the caller's radius
  * filter): the edge set is make_edges' (graph.py:52-60: (i, idx) for idx > vertex 0 of i's cloud) without materialising
- * the int64 edge list.  Same labels / CSR as st_connected_components / st_component_csr on st_make_edges_seg's output. */
+ * the int64 edge list.  Same labels as st_connected_components on st_make_edges_seg's output; the CSR holds the same
+ * (neighbour, weight) pairs per row as st_component_csr's, but every pair ONCE: a mutual pair (v in kNN(u), u in kNN(v)) is two
+ * edges of the list and two entries per row there, one here (the reference's cugraph graph is undirected, one edge per pair).
+ * Row layout: valid forward neighbours in table order, then the reverse-only ones.  With a workspace smaller than
+ * st_component_csr_knn_workspace_bytes (st_component_csr_workspace_bytes is the minimum) or a K that is not a power of two
+ * <= 64 the call builds st_component_csr's rows. */
+int64_t st_component_csr_knn_workspace_bytes(int64_t m, int64_t n, int K);
 int st_connected_components_knn(const int64_t* idx, int64_t n, int K, const int32_t* first_of /*[n] first vertex of the
                                 vertex's cloud; NULL = one cloud*/, int32_t* labels, void* ws, int64_t ws_bytes, void* stream);
 int st_component_csr_knn(const int64_t* idx, const float* dist, int64_t n, int K, const int32_t* first_of,

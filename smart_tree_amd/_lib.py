@@ -85,6 +85,7 @@ SIGNATURES = {
     "st_radius_count_seg": (c_int, [P, I64, P, I64, c_int, c_float, P, c_int, c_float, P, P, P, c_int, P, I64, P, c_float]),
     "st_connected_components_knn": (c_int, [P, I64, c_int, P, P, P, I64, P]),
     "st_component_csr_knn": (c_int, [P, P, I64, c_int, P, P, I64, P, P, P, P, I64, P]),
+    "st_component_csr_knn_workspace_bytes": (I64, [I64, I64, c_int]),
     "st_make_edges_seg": (c_int, [P, P, I64, c_int, P, P, ctypes.POINTER(I64), P, c_int, P, I64, P]),
     "st_component_layout_seg": (c_int, [P, I64, c_int, P, c_int, P, P, P, P, P, P, P, ctypes.POINTER(I64), ctypes.POINTER(I64), P, I64, P]),
     "st_skeleton_workspace_bytes_seg": (I64, [I64, I64, c_int]),
@@ -110,7 +111,7 @@ ENQUEUE_ONLY = frozenset({
     "st_connected_components", "st_component_csr", "st_post_process", "st_knn_radius", "st_brick_pyramid_workspace_bytes",
     "st_centre_cloud_seg", "st_voxelize_workspace_bytes_seg", "st_build_strided_rulebook_seg", "st_knn_workspace_bytes_seg",
     "st_knn_radius_seg", "st_skeleton_workspace_bytes_seg", "st_post_process_seg", "st_radius_count_seg",
-    "st_voxelize_cloud_workspace_bytes", "st_loss_workspace_bytes", "st_spatial_order_workspace_bytes", "st_spatial_order", "st_connected_components_knn", "st_component_csr_knn", "st_move_rows",
+    "st_voxelize_cloud_workspace_bytes", "st_loss_workspace_bytes", "st_spatial_order_workspace_bytes", "st_spatial_order", "st_connected_components_knn", "st_component_csr_knn", "st_component_csr_knn_workspace_bytes", "st_move_rows",
 })
 
 

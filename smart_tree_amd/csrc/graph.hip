@@ -618,10 +618,103 @@ __global__ void __launch_bounds__(GR_BLOCK) k_csr_fill(GrEdges G, int64_t E, con
     }
 }
 
+// ---- adjacency straight from the neighbour tables, WITHOUT the duplicate of a mutual pair (round 3) ----
+// In a kNN graph most pairs are mutual (v in kNN(u) and u in kNN(v)); the edge-list build above stores such a pair twice in
+// both rows (the reference's cugraph graph is undirected and keeps one edge per pair).  Here row(x) = the valid forward
+// neighbours of x, in table order, followed by the "reverse-only" ones (w lists x, x does not list w):
+//   * forward entries need no atomics at all: their count is a ballot over the K lanes of the source's table row and their
+//     slot is row_off[x] + rank;
+//   * only a reverse-only edge costs a scattered atomic (count) and a returning one (fill) -- about one edge in five;
+//   * whether u -> v is mutual is ONE 8K-byte read of v's table row (K = 16: a 128-byte line), done in the count pass; the
+//     fill pass gets the renumbered target and the flag back as one int32 per edge.
+// The same set of (neighbour, weight) pairs per row as the edge-list build, each pair once (d(u,v) is computed from the same
+// squares on either side, so the two copies of a mutual pair carry the same float): distances, predecessors and the tree
+// distance do not change, the SSSP relaxes ~40 % fewer entries.
+#define CSRK_MUTUAL 0x40000000
+struct __attribute__((aligned(16))) GrI64x2 { int64_t x, y; };  // one 16-byte load of two table entries
+template <int K>
+__global__ void __launch_bounds__(GR_BLOCK) k_csrk_count(const int64_t* __restrict__ idx, int64_t n, const int* __restrict__ first_of,
+                                                         const int* __restrict__ new_id, uint32_t* deg, uint32_t* fwdc,
+                                                         int32_t* __restrict__ tgt) {
+    const int64_t E = n * K;
+    const int lane = threadIdx.x & 63;
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x - lane); base < E; base += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = base + lane;
+        const int64_t i = e / K;
+        int x = -1, y = -1;
+        bool mutual = false;
+        if (e < E) {
+            x = new_id[i];  // (the K lanes of a source read one word)
+            const int64_t j = idx[e], first = first_of ? first_of[i] : 0;
+            if (x >= 0 && j > first && j != i) {
+                y = new_id[j];
+                if (y >= 0 && i > first) {  // does j list i?  (that entry is valid by the same rule: i > first, i != j, both kept)
+                    const int64_t* row = idx + j * K;
+                    if (K % 2 == 0) {
+#pragma unroll
+                        for (int k = 0; k < K; k += 2) {
+                            const GrI64x2 r = *reinterpret_cast<const GrI64x2*>(row + k);
+                            mutual = mutual || r.x == i || r.y == i;
+                        }
+                    } else {
+                        for (int k = 0; k < K; k++) mutual = mutual || row[k] == i;
+                    }
+                }
+            }
+        }
+        const bool fwd = y >= 0;
+        const unsigned long long fb = __ballot(fwd);
+        if (e < E) tgt[e] = fwd ? (y | (mutual ? CSRK_MUTUAL : 0)) : -1;
+        if (fwd && !mutual) atomicAdd(&deg[y], 1u);  // reverse-only entry of row y
+        if ((lane % K) == 0 && x >= 0) {  // leader of the table row (every kept vertex has exactly one): its forward entries at once
+            const unsigned cnt = (unsigned)__popcll(K == 64 ? fb : (fb >> lane) & ((1ull << (K & 63)) - 1ull));
+            fwdc[x] = cnt;
+            if (cnt) atomicAdd(&deg[x], cnt);
+        }
+    }
+}
+template <int K>
+__global__ void __launch_bounds__(GR_BLOCK) k_csrk_fill(const int64_t n, const float* __restrict__ dist, const int* __restrict__ new_id,
+                                                        const int32_t* __restrict__ tgt, const uint32_t* __restrict__ row_off,
+                                                        uint32_t* cursor, uint32_t* __restrict__ col, float* __restrict__ wgt) {
+    const int64_t E = n * K;
+    const int lane = threadIdx.x & 63;
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x - lane); base < E; base += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = base + lane;
+        const int32_t t = e < E ? tgt[e] : -1;
+        const bool fwd = t >= 0;
+        const unsigned long long fb = __ballot(fwd);
+        if (!fwd) continue;
+        const int x = new_id[e / K], y = t & ~CSRK_MUTUAL;
+        const float we = dist[e];
+        const int k = lane % K;
+        const unsigned long long mine = K == 64 ? fb : (fb >> (lane - k)) & ((1ull << (K & 63)) - 1ull);
+        const uint32_t pa = row_off[x] + (uint32_t)__popcll(mine & ((1ull << k) - 1ull));
+        col[pa] = (uint32_t)y; wgt[pa] = we;
+        if (!(t & CSRK_MUTUAL)) {
+            const uint32_t pb = atomicAdd(&cursor[y], 1u);
+            col[pb] = (uint32_t)x; wgt[pb] = we;
+        }
+    }
+}
+__global__ void __launch_bounds__(GR_BLOCK) k_csrk_cursor(const uint32_t* __restrict__ row_off, const uint32_t* __restrict__ fwdc, int64_t m,
+                                                          uint32_t* __restrict__ cursor) {
+    GR_LOOP(v, m) cursor[v] = row_off[v] + fwdc[v];
+}
+
 extern "C" int64_t st_component_csr_workspace_bytes(int64_t m) {
     StArena a(nullptr, 0);
     a.take<uint32_t>(m + 1);
     a.take<char>(st_scan_ws_bytes(m + 1));
+    return a.used;
+}
+// the table form (st_component_csr_knn) also keeps a forward count per vertex and one int32 per table entry
+extern "C" int64_t st_component_csr_knn_workspace_bytes(int64_t m, int64_t n, int K) {
+    StArena a(nullptr, 0);
+    a.take<uint32_t>(m + 1);
+    a.take<char>(st_scan_ws_bytes(m + 1));
+    a.take<uint32_t>(m + 1);
+    a.take<int32_t>(n * (int64_t)(K > 0 ? K : 1));
     return a.used;
 }
 
@@ -636,11 +729,45 @@ extern "C" int st_component_csr(const int64_t* edges, const float* w, int64_t E,
     return csr_run(G, E, new_id, m, row_off, col, wgt, ws, ws_bytes, stream_);
 }
 
-// The same adjacency straight from the neighbour search (idx / dist [n,K]); col / wgt capacity 2 * n * K.
+// The same adjacency straight from the neighbour search (idx / dist [n,K]); col / wgt capacity 2 * n * K.  Every
+// (neighbour, weight) pair of a row ONCE (see k_csrk_count above): forward neighbours in table order, then the reverse-only
+// ones in unspecified order.  Workspace: st_component_csr_knn_workspace_bytes; with the smaller st_component_csr_workspace_bytes
+// (or a K that is not a power of two <= 64) the call falls back to the edge-list build, which keeps both copies of a mutual pair.
+template <int K>
+static void csrk_launch(const int64_t* idx, const float* dist, int64_t n, const int32_t* first_of, const int32_t* new_id, int64_t m,
+                        uint32_t* row_off, uint32_t* col, float* wgt, uint32_t* cursor, uint32_t* fwdc, int32_t* tgt, char* sw, int64_t sb,
+                        hipStream_t stream, int* rc) {
+    const int64_t E = n * K;
+    (void)hipMemsetAsync(row_off, 0, (m + 1) * sizeof(uint32_t), stream);
+    hipLaunchKernelGGL((k_csrk_count<K>), dim3(gr_grid(E)), dim3(GR_BLOCK), 0, stream, idx, n, first_of, new_id, row_off, fwdc, tgt);
+    *rc = st_exclusive_scan_u32(row_off, row_off, m + 1, nullptr, sw, sb, stream);
+    if (*rc != ST_OK) return;
+    hipLaunchKernelGGL(k_csrk_cursor, dim3(gr_grid(m)), dim3(GR_BLOCK), 0, stream, (const uint32_t*)row_off, (const uint32_t*)fwdc, m, cursor);
+    hipLaunchKernelGGL((k_csrk_fill<K>), dim3(gr_grid(E)), dim3(GR_BLOCK), 0, stream, n, dist, new_id, (const int32_t*)tgt,
+                       (const uint32_t*)row_off, cursor, col, wgt);
+}
 extern "C" int st_component_csr_knn(const int64_t* idx, const float* dist, int64_t n, int K, const int32_t* first_of,
                                     const int32_t* new_id, int64_t m, uint32_t* row_off, uint32_t* col, float* wgt, void* ws,
                                     int64_t ws_bytes, void* stream_) {
     ST_REQUIRE(K >= 1, "csr(knn): K must be positive");
+    hipStream_t stream = (hipStream_t)stream_;
+    if (m > 0 && n > 0 && gr_shift_of(K) >= 0 && K <= 64 && ws_bytes >= st_component_csr_knn_workspace_bytes(m, n, K)) {
+        ST_REQUIRE(m < CSRK_MUTUAL, "csr(knn): too many vertices");
+        StArena a(ws, ws_bytes);
+        uint32_t* cursor = a.take<uint32_t>(m + 1);
+        const int64_t sb = st_scan_ws_bytes(m + 1);
+        char* sw = a.take<char>(sb);
+        uint32_t* fwdc = a.take<uint32_t>(m + 1);
+        int32_t* tgt = a.take<int32_t>(n * (int64_t)K);
+        if (!cursor || !sw || !fwdc || !tgt) { st_set_error("component_csr(knn): workspace too small"); return ST_ERR_WORKSPACE; }
+        int rc = ST_OK;
+#define CSRK_CASE(K_) case K_: csrk_launch<K_>(idx, dist, n, first_of, new_id, m, row_off, col, wgt, cursor, fwdc, tgt, sw, sb, stream, &rc); break;
+        switch (K) { CSRK_CASE(1) CSRK_CASE(2) CSRK_CASE(4) CSRK_CASE(8) CSRK_CASE(16) CSRK_CASE(32) CSRK_CASE(64) }
+#undef CSRK_CASE
+        if (rc != ST_OK) return rc;
+        ST_CHECK_LAUNCH();
+        return ST_OK;
+    }
     GrEdges G = {nullptr, nullptr, idx, dist, K, gr_shift_of(K), first_of};
     return csr_run(G, n * (int64_t)K, new_id, m, row_off, col, wgt, ws, ws_bytes, stream_);
 }

@@ -1397,7 +1397,7 @@ struct SkTuning {
     float prune_factor = 1.0f, grid_mean_mult = 1.0f;
     int small_work = SK_SMALL_WORK, iters_per_launch = SK_ITERS_PER_LAUNCH, launch_batch = 24, local_items = 0, wave_work = SK_WAVE_WORK, long_mode = 1;
     int sssp_hops = 4, sssp_batch = 32, sssp_lanes = 64, sssp_first = 2, sssp_blocks = SK_SSSP_BLOCKS, sssp_lcap = SK_LQ;
-    bool small_work_set = false, iters_set = false, long_set = false;
+    bool small_work_set = false, iters_set = false, long_set = false, launch_set = false;
     long long* ticks = nullptr;
     explicit SkTuning(const int64_t* t) {
         if (!t) return;
@@ -1405,7 +1405,7 @@ struct SkTuning {
         if (has(0)) prune_factor = (float)t[0] / 1000.0f;
         if (has(1)) { small_work = (int)t[1]; small_work_set = true; }
         if (has(2)) { iters_per_launch = (int)t[2]; iters_set = true; }
-        if (has(3)) launch_batch = t[3] < 1 ? 1 : (t[3] > SK_MAX_LAUNCH_BATCH ? SK_MAX_LAUNCH_BATCH : (int)t[3]);
+        if (has(3)) { launch_batch = t[3] < 1 ? 1 : (t[3] > SK_MAX_LAUNCH_BATCH ? SK_MAX_LAUNCH_BATCH : (int)t[3]); launch_set = true; }
         if (has(4)) local_items = (int)t[4];
         if (has(5)) wave_work = (int)t[5];
         if (has(6)) sssp_hops = t[6] < 1 ? 1 : (int)t[6];
@@ -1506,9 +1506,14 @@ extern "C" int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, c
     // runs until the tree is done -- no tree waits for another one at a hand-over (profiles/r03_sweep_select.txt: 1.204 -> 1.176 ms
     // per cloud at 64 clouds per launch set, 2.00 -> 1.95 at 10).  One cloud alone keeps the chip-wide claim for its long paths
     // (the chip is idle then: 11.2 against 12.0 ms).
+    int first_launches = T.launch_batch;
     if (nseg > 1) {
         if (!T.small_work_set) A.small_work = 1 << 20;
         if (!T.iters_set) A.iters_per_launch = 1 << 20;
+        // ... so ONE launch pair normally ends every tree (a path too long for the workgroup's LDS still goes to k_sk_claim and
+        // costs another pair): the 23 further pairs of the first batch were empty launches, ~19 us each = 0.45 ms at the end of
+        // every launch set (kernel trace of a 24-cloud batch, round 3)
+        if (!T.launch_set && A.long_mode && A.iters_per_launch >= (1 << 20)) first_launches = 1;
     } else if (!T.long_set) {
         A.long_mode = 0;
     }
@@ -1611,7 +1616,7 @@ extern "C" int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, c
             bool redo = false;
             // the 1M-point synthetic trees need 10-21 launch pairs (tools/round_counts.py): a first batch of 24 ends them with ONE
             // progress read-back; A/B on one box, 8 clouds in flight: 5.08 ms per cloud against 5.66 with 16 (tools/sweep_batches.sh)
-            for (int batch = T.launch_batch;; batch = batch > 4 ? 4 : batch) {  // launch pairs per counter read-back: a long first
+            for (int batch = first_launches;; batch = batch > 4 ? 4 : batch) {  // launch pairs per counter read-back: a long first
                 // batch, short ones for the stragglers (a finished launch pair still costs its ~10 us of launch latency)
                 for (int b = 0; b < batch; b++, iters++) {
                     if (time_sel) (void)hipEventRecord(ev[2 * b], stream);

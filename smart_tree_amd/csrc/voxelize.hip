@@ -6,8 +6,8 @@
 //   batch_collate                        smart_tree/model/sparse.py:40-61
 // with one device-resident pass over the cloud: block histogram -> kept blocks (count > min,
 // lexicographic order) -> per-block bounding boxes over halo members -> hash insert with
-// atomicMin(point index) (deterministic "first point wins") -> ordered compaction by
-// (block, representative point index), which is exactly the order a sequential voxeliser emits.
+// atomicMin(point index) (deterministic "first point wins") -> the occupied slots ARE the voxels: streamed out of the table
+// and put in (block, representative point index) order, which is exactly the order a sequential voxeliser emits.
 // All float arithmetic that decides an integer (block id, membership, voxel coordinate, grid
 // size, inner mask) is float32 in the same operation order as the oracle (oracle/voxel_oracle.py).
 #include "st_common.h"
@@ -352,69 +352,66 @@ __device__ __forceinline__ int vx_find(const VxSlot* slots, unsigned long long c
     return -1;
 }
 
-// pass 0: insert (key -> min point index); pass 1: count the voxels a point won and remember WHICH of its blocks
-// (bit j of win[i] = the j-th block vx_for_each_block visits; at most 27); pass 2: emit winners from that mask -- no
-// second round of hash look-ups.
-template <int PASS>
-__global__ void __launch_bounds__(VX_BLOCK) k_vx_pass(const float* xyz, int64_t n, const int* seg_off, VxState* st,
-                                                      const int* table, VxParams p, const float* blk_lof,
-                                                      const int* blk_grid, VxSlot* slots,
-                                                      unsigned long long cap, uint32_t* cnt_or_off, uint32_t* win,
-                                                      uint32_t* rec_b, uint32_t* rec_pt, int64_t max_voxels) {
+// Insert pass: key (block, voxel) -> min point index ("first point wins", deterministic), one look-up per block membership.
+// The voxels are then read off the TABLE, not off the points (round 3): every occupied slot is one voxel and holds its
+// representative, so k_vx_emit streams the slots once (16 bytes each, coalesced) instead of sending every point that raced for
+// a voxel back into the table (one more random probe for a quarter of the 2.6 memberships per point), scanning a count per point
+// and walking the points a third time.  Emission order is the table's; the (block, representative) order of a sequential
+// voxeliser comes from the two radix sorts in vx_voxelize.
+__global__ void __launch_bounds__(VX_BLOCK) k_vx_insert(const float* xyz, int64_t n, const int* seg_off, VxState* st,
+                                                        const int* table, VxParams p, const float* blk_lof,
+                                                        const int* blk_grid, VxSlot* slots, unsigned long long cap) {
     int d[3];
     if (!vx_dims(st, d)) return;
     const int seg = blockIdx.y;
     const int* tab = table + (int64_t)seg * (d[0] * d[1] * d[2]);
     const int64_t i0 = seg_off ? seg_off[seg] : 0, i1 = seg_off ? seg_off[seg + 1] : n;
-    if (PASS == 2) {  // one lane per point: only the winners (one point in nine) have anything to do
-        for (int64_t i = i0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < i1; i += (int64_t)gridDim.x * blockDim.x) {
-            const uint32_t won = win[i];
-            if (won == 0u) continue;
-            const float pt[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
-            const uint32_t off = cnt_or_off[i];
-            uint32_t mine = 0;
-            int j = 0;
-            vx_for_each_block(pt, st, d, tab, p, [&](int b) {
-                const uint32_t bit = 1u << j++;
-                if (!(won & bit)) return;
-                if ((int64_t)(off + mine) < max_voxels) {
-                    rec_b[off + mine] = (uint32_t)b;
-                    rec_pt[off + mine] = (uint32_t)i;
-                }
-                mine++;
-            });
-        }
-        return;
-    }
-    // a table that filled up (the host's capacity guess was too small: it retries with a larger one): pass 1 has nothing to
-    // do, and pass 0 stops inserting as soon as it sees the flag (checked where a probe sequence gets long, below)
-    if (PASS == 1 && (st->overflow & 4u)) return;
+    // a table that filled up (the host's capacity guess was too small: it retries with a larger one): stop inserting as soon as
+    // the flag is seen (checked where a probe sequence gets long, vx_insert_min)
     vx_stream_points(xyz, n, i0, i1, [&](int64_t i, float x, float y, float z) {
         const float pt[3] = {x, y, z};
-        uint32_t mine = 0, won = 0u;
-        // pass 0 leaves in win[i] the blocks in which point i raced for a voxel; pass 1 checks only those (a point that
-        // found an earlier point in the slot cannot be the smallest index of that voxel): ~1 membership in 4 is looked up again
-        const uint32_t cand = PASS == 1 ? win[i] : 0u;
-        if (PASS == 1 && cand == 0u) { cnt_or_off[i] = 0u; return; }
-        int j = 0;
         vx_for_each_block(pt, st, d, tab, p, [&](int b) {
-            const uint32_t bit = 1u << j++;
-            if (PASS == 1 && !(cand & bit)) return;
             int c[3];
             if (!vx_coord(pt, b, blk_lof, blk_grid, p.vs, p.vs_inv, c)) return;
-            unsigned long long key = st_pack_key(b, c[2], c[1], c[0]);
-            if (PASS == 0) {
-                const int r = vx_insert_min(slots, cap, key, (unsigned)i, &st->overflow);
-                if (r == 0) atomicOr(&st->overflow, 4u);
-                if (r == 2) won |= bit;
-            } else if (vx_find(slots, cap, key) == (int)i) {
-                won |= bit;
-                mine++;
-            }
+            if (vx_insert_min(slots, cap, st_pack_key(b, c[2], c[1], c[0]), (unsigned)i, &st->overflow) == 0) atomicOr(&st->overflow, 4u);
         });
-        if (PASS == 1) cnt_or_off[i] = mine;
-        win[i] = won;
     });
+}
+
+// every occupied slot -> one record (representative point, block).  A workgroup stages the records of a tile of VX_EMIT_TILE
+// slots in LDS and reserves their place with ONE returning atomic on the voxel counter: returning atomics on one word retire at
+// ~90 per microsecond chip-wide, so a reservation per wavefront (262 k of them for a 16 M-slot table) made this pass 3 ms long.
+#define VX_EMIT_TILE 4096
+__global__ void __launch_bounds__(VX_BLOCK) k_vx_emit(const VxSlot* __restrict__ slots, unsigned long long cap, VxState* st,
+                                                      uint32_t* __restrict__ rec_b, uint32_t* __restrict__ rec_pt, int64_t max_voxels) {
+    __shared__ uint32_t l_pt[VX_EMIT_TILE], l_b[VX_EMIT_TILE];
+    __shared__ unsigned l_n, l_base;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long ntile = (cap + VX_EMIT_TILE - 1) / VX_EMIT_TILE;
+    for (unsigned long long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        if (threadIdx.x == 0) l_n = 0u;
+        __syncthreads();
+#pragma unroll 4
+        for (int k = 0; k < VX_EMIT_TILE / VX_BLOCK; k++) {
+            const unsigned long long s = tile * VX_EMIT_TILE + (unsigned long long)k * VX_BLOCK + threadIdx.x;
+            VxRaw seen = {ST_EMPTY_KEY, 0ull};
+            if (s < cap) seen = *reinterpret_cast<const VxRaw*>(&slots[s]);
+            const bool occ = seen.x != ST_EMPTY_KEY;
+            const unsigned long long ob = __ballot(occ);
+            if (ob == 0ull) continue;  // (wave-uniform)
+            unsigned at = 0;
+            if (lane == 0) at = atomicAdd(&l_n, (unsigned)__popcll(ob));
+            at = __shfl(at, 0) + (unsigned)__popcll(ob & ((1ull << lane) - 1ull));
+            if (occ) { l_pt[at] = (uint32_t)(seen.y & 0xffffffffull); l_b[at] = (uint32_t)(seen.x >> 48); }
+        }
+        __syncthreads();
+        const unsigned cnt = l_n;
+        if (threadIdx.x == 0 && cnt) l_base = atomicAdd(&st->n_vox, cnt);
+        __syncthreads();
+        for (unsigned i = threadIdx.x; i < cnt; i += VX_BLOCK)
+            if ((int64_t)l_base + i < max_voxels) { rec_pt[l_base + i] = l_pt[i]; rec_b[l_base + i] = l_b[i]; }
+        __syncthreads();
+    }
 }
 
 __global__ void __launch_bounds__(VX_BLOCK) k_vx_iota(uint32_t* v, int64_t n) {
@@ -430,7 +427,7 @@ __global__ void __launch_bounds__(VX_BLOCK) k_vx_gather(const float* xyz, const 
                                                         const int32_t* blk_seg, VxState* st) {
     for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += (int64_t)gridDim.x * blockDim.x) {
         int b = (int)sorted_b[j];
-        int64_t i = rec_pt[order[j]];
+        int64_t i = order ? rec_pt[order[j]] : rec_pt[j];
         float pt[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
         int c[3];
         vx_coord(pt, b, blk_lof, blk_grid, p.vs, p.vs_inv, c);
@@ -580,16 +577,10 @@ static int vx_voxelize(const float* xyz, const float* rgb, int64_t n, const int3
                        blk_hi);
     hipLaunchKernelGGL(k_vx_block_grid, dim3((unsigned)st_min64(st_div_up(3 * (int64_t)max_blocks, VX_BLOCK), 64)), dim3(VX_BLOCK), 0, stream,
                        st, max_blocks, (const unsigned*)blk_lo, (const unsigned*)blk_hi, p.vs, blk_lof, blk_grid);
-    hipLaunchKernelGGL((k_vx_pass<0>), gs, dim3(VX_BLOCK), 0, stream, xyz, n, seg_off, st, (const int*)table, p,
-                       (const float*)blk_lof, (const int*)blk_grid, slots, (unsigned long long)cap, cnt, win, rec_b,
-                       rec_pt, max_voxels);
-    hipLaunchKernelGGL((k_vx_pass<1>), gs, dim3(VX_BLOCK), 0, stream, xyz, n, seg_off, st, (const int*)table, p,
-                       (const float*)blk_lof, (const int*)blk_grid, slots, (unsigned long long)cap, cnt, win, rec_b,
-                       rec_pt, max_voxels);
-    ST_TRY(st_exclusive_scan_u32(cnt, cnt, n, &st->n_vox, sub, sub_bytes, stream));
-    hipLaunchKernelGGL((k_vx_pass<2>), g1, dim3(VX_BLOCK), 0, stream, xyz, n, seg_off, st, (const int*)table, p,
-                       (const float*)blk_lof, (const int*)blk_grid, slots, (unsigned long long)cap, cnt, win, rec_b,
-                       rec_pt, max_voxels);
+    hipLaunchKernelGGL(k_vx_insert, gs, dim3(VX_BLOCK), 0, stream, xyz, n, seg_off, st, (const int*)table, p, (const float*)blk_lof,
+                       (const int*)blk_grid, slots, (unsigned long long)cap);
+    hipLaunchKernelGGL(k_vx_emit, dim3((unsigned)st_min64(st_div_up(cap, VX_EMIT_TILE), 4096)), dim3(VX_BLOCK), 0, stream,
+                       (const VxSlot*)slots, (unsigned long long)cap, st, rec_b, rec_pt, max_voxels);
     if (nseg > 1) hipLaunchKernelGGL(k_vx_seg_vox_init, dim3(1), dim3(128), 0, stream, st, nseg, (const uint32_t*)&st->n_vox);
     ST_CHECK_LAUNCH();
 
@@ -607,13 +598,15 @@ static int vx_voxelize(const float* xyz, const float* rgb, int64_t n, const int3
     *n_voxels_out = m;
     *n_blocks_out = h.n_blocks;
     if (m > 0) {
-        // stable sort by block id: records are already ascending in point index
-        int bits = 1;
+        // the order of a sequential voxeliser: by block, inside a block by representative point index (ascending = order of first
+        // appearance).  Two stable radix sorts of the (representative, block) records: by point index, then by block id.
+        int bits = 1, pbits = 1;
         while ((1u << bits) < h.n_blocks) bits++;
-        hipLaunchKernelGGL(k_vx_iota, dim3(vx_grid(m)), dim3(VX_BLOCK), 0, stream, order, m);
-        ST_TRY(st_radix_sort_pairs_u32(rec_b, order, m, bits, sub, sub_bytes, stream));
+        while ((1ll << pbits) < n) pbits++;
+        ST_TRY(st_radix_sort_pairs_u32(rec_pt, rec_b, m, pbits, sub, sub_bytes, stream));
+        ST_TRY(st_radix_sort_pairs_u32(rec_b, rec_pt, m, bits, sub, sub_bytes, stream));
         hipLaunchKernelGGL(k_vx_gather, dim3(vx_grid(m)), dim3(VX_BLOCK), 0, stream, xyz, rgb, m, (const uint32_t*)rec_b,
-                           (const uint32_t*)order, (const uint32_t*)rec_pt, (const float*)block_centres, p,
+                           (const uint32_t*)nullptr, (const uint32_t*)rec_pt, (const float*)block_centres, p,
                            (const float*)blk_lof, (const int*)blk_grid, feats, coords, mask, point_index,
                            (const int32_t*)(nseg > 1 ? blk_seg : nullptr), st);
     }

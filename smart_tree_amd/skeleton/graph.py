@@ -178,7 +178,7 @@ def connected_components(graph: Graph, minimum_vertices: int = 0) -> ComponentSe
     C, m = nc.value, nk.value
     row_off, col, wgt = i32(m + 1), i32(2 * E), torch.empty((max(2 * E, 1),), dtype=torch.float32, device=dev)
     if m > 0:
-        ws = _lib.workspace(L.st_component_csr_workspace_bytes(m), dev)
+        ws = _lib.workspace(L.st_component_csr_knn_workspace_bytes(m, n, K) if from_knn else L.st_component_csr_workspace_bytes(m), dev)
         if from_knn:
             _lib.check(L.st_component_csr_knn(_lib.ptr(idxs), _lib.ptr(dists), n, K, _lib.ptr(first_of),
                                               _lib.ptr(new_id), m, _lib.ptr(row_off), _lib.ptr(col), _lib.ptr(wgt), _lib.ptr(ws),

@@ -384,6 +384,7 @@ template <class T> inline T hipemu_fetch_max(T* p, T v) { T o = *p; if (v > o) *
 template <class T> inline T hipemu_fetch_min(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
 inline long long wall_clock64() { return 0; }
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __builtin_amdgcn_s_sleep(x) ((void)0)
 
 // ---- atomics (fibers never run concurrently, plain RMW is exact) -------------------------
 template <class T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }

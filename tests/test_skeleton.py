@@ -345,10 +345,17 @@ def test_components_from_knn_tables_equal_components_from_the_edge_list(backend)
         _ = b.padded  # materialise the edge list first: the edge-list path
         cb = b.connected_cugraph_components(minimum_vertices=8)
         assert ca.n_components == cb.n_components > 1
-        for name in ("comp_size", "comp_off", "vert_order", "new_id", "labels", "row_off"):
+        for name in ("comp_size", "comp_off", "vert_order", "new_id", "labels"):
             assert torch.equal(getattr(ca, name).cpu(), getattr(cb, name).cpu()), name
-        ro = ca.row_off.cpu().numpy().astype(np.int64)
-        for v in range(0, len(ro) - 1, 7):  # rows as multisets (the order inside a row is unspecified)
-            ra = sorted(zip(ca.col[ro[v]: ro[v + 1]].cpu().tolist(), ca.wgt[ro[v]: ro[v + 1]].cpu().tolist()))
-            rb = sorted(zip(cb.col[ro[v]: ro[v + 1]].cpu().tolist(), cb.wgt[ro[v]: ro[v + 1]].cpu().tolist()))
-            assert ra == rb
+        # adjacency: the table form keeps every (neighbour, weight) pair of a row ONCE, the edge-list form keeps both copies of
+        # a mutual pair -- the same sets, and the table form's rows have no duplicates (the order inside a row is unspecified)
+        roa, rob = ca.row_off.cpu().numpy().astype(np.int64), cb.row_off.cpu().numpy().astype(np.int64)
+        assert len(roa) == len(rob)
+        cola, wa, colb, wb = ca.col.cpu().tolist(), ca.wgt.cpu().tolist(), cb.col.cpu().tolist(), cb.wgt.cpu().tolist()
+        shorter = 0
+        for v in range(len(roa) - 1):
+            ra = sorted(zip(cola[roa[v]: roa[v + 1]], wa[roa[v]: roa[v + 1]]))
+            rb = sorted(set(zip(colb[rob[v]: rob[v + 1]], wb[rob[v]: rob[v + 1]])))
+            assert ra == rb, v
+            shorter += (rob[v + 1] - rob[v]) - (roa[v + 1] - roa[v])
+        assert shorter > 0  # mutual pairs exist in a kNN graph
