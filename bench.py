@@ -455,6 +455,7 @@ def main():
         prev = None
         while True:
             finished.clear()  # (multi-rank: only the last warm-up pass is gathered)
+            profiling.family_mode(True)
             profiling.enable(True)  # the warm-up passes run exactly what the timed pass runs, kernel timers included
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -474,6 +475,10 @@ def main():
     fence()
     serial_ms = worker.serial_ms() if warm > 0 else None
     fence()
+    # kernel timers of the timed region: the convolutions of a forward pass are bracketed ONCE as a family (a pair of events
+    # around each of the 26 launches cost ~10 us apiece between kernels that otherwise run back to back); the per-class table
+    # comes from the solo pass below
+    profiling.family_mode(True)
     profiling.enable(True)
     cpu0 = os.times()
     t0 = time.perf_counter()
@@ -516,6 +521,7 @@ def main():
     # the kernels of the batches in flight share the chip, which inflates every bracket)
     roof_solo = None
     if world == 1:
+        profiling.family_mode(False)  # every launch bracketed: the per-class table
         profiling.enable(True)
         worker.run([min(B, max(args.steps, 1))], collect=False, streams=1)
         torch.cuda.synchronize()

@@ -17,6 +17,7 @@ import numpy as np
 import torch
 
 from . import sparse_ops as ops
+from .. import profiling
 
 BN_EPS = 1e-4  # attribute stored in the checkpoints (model.py:23 would default to 1e-5)
 
@@ -164,7 +165,7 @@ class Smart_Tree:
         gate = getattr(self, "conv_gate", None)  # optional context-manager factory around the convolution launches (no host
         #                                            synchronisation inside): a caller with several batches in flight can keep
         #                                            their conv sequences from sharing the chip (bench.py)
-        with (gate() if gate is not None else contextlib.nullcontext()):
+        with (gate() if gate is not None else contextlib.nullcontext()), profiling.kernel_family("k_sparse_conv* (one forward pass)"):
             x = self._conv("input_conv.sequence.0", feats, None, feats.shape[0], bn="input_conv.sequence.1", relu=True)
             self._record("input", x)
             x = self._ublock("UNet", x, pyr, 0)

@@ -31,6 +31,7 @@ def enable(flag: bool) -> None:
         _stages.clear()
         _kernels.clear()
         _external.clear()
+        _families.clear()
 
 
 def enabled() -> bool:
@@ -56,6 +57,11 @@ def kernel(name: str, algorithmic_bytes, flops=0):
     if not _enabled:
         yield
         return
+    pending = getattr(_tls, "pending", None)
+    if pending is not None:  # inside a kernel_family block in family mode: counted, not bracketed
+        pending.append((algorithmic_bytes, flops))
+        yield
+        return
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     try:
@@ -66,6 +72,36 @@ def kernel(name: str, algorithmic_bytes, flops=0):
 
 
 _external = defaultdict(list)  # name -> [(total_ms, launches, bytes_thunk)] measured by the library itself
+
+# Family mode: a pair of events around every launch costs the GPU ~10 us between two kernels of a back-to-back sequence
+# (measured: 26 convolutions of a forward pass = 0.28 ms per launch set, 3 % of the chip-filling phase of an 8-cloud batch).
+# With family_mode(True) the launches inside a `kernel_family(...)` block are NOT bracketed one by one: the block is, once, and
+# every `kernel(...)` inside it only hands over its byte / flop counts.  The block's duration is then the sum of its launches'
+# durations plus their (sub-microsecond) hand-overs -- what the roofline prices a kernel family with anyway.
+_family = False
+_families = defaultdict(list)  # name -> [(start, end, [(bytes, flops), ...])]
+_tls = __import__("threading").local()  # the open block of THIS host thread (bench.py runs one thread per stream)
+
+
+def family_mode(flag: bool) -> None:
+    global _family
+    _family = bool(flag)
+
+
+@contextmanager
+def kernel_family(name: str):
+    if not (_enabled and _family):
+        yield
+        return
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    _tls.pending = []
+    try:
+        yield
+    finally:
+        b.record()
+        items, _tls.pending = _tls.pending, None
+        _families[name].append((a, b, items))
 
 
 def add_kernel_time(name: str, total_ms: float, launches: int, total_bytes) -> None:
@@ -88,6 +124,13 @@ def kernel_table():
         nflops = [float(r[3]() if callable(r[3]) else r[3]) for r in recs]
         rows[name] = {"launches": len(recs), "total_ms": sum(ms), "avg_us": 1e3 * sum(ms) / len(ms),
                       "bytes_per_launch": sum(nbytes) / len(recs), "flops_per_launch": sum(nflops) / len(recs)}
+    val = lambda t: float(t() if callable(t) else t)
+    for name, recs in _families.items():
+        launches = sum(len(r[2]) for r in recs)
+        total = sum(r[0].elapsed_time(r[1]) for r in recs)
+        rows[name] = {"launches": launches, "total_ms": total, "avg_us": 1e3 * total / max(launches, 1),
+                      "bytes_per_launch": sum(val(i[0]) for r in recs for i in r[2]) / max(launches, 1),
+                      "flops_per_launch": sum(val(i[1]) for r in recs for i in r[2]) / max(launches, 1)}
     for name, recs in _external.items():
         launches = sum(r[1] for r in recs)
         total = sum(r[0] for r in recs)
@@ -159,9 +202,11 @@ def roofline(peak_gbs: float, peak_f32_tflops: float = 157.3, clouds_per_launch:
                        "component runs speculative rounds (each of its 16 wavefronts walks one candidate tip; ~25 us of dependent "
                        "accesses and barriers per round, 3-4 branches accepted per round); bytes = path*24 + claimed*16 + "
                        "8*vertices per tree, divided over its launches; a batch of clouds runs its components side by side",
-        CONV: "gather / rule-GEMM / scatter: every instantiation of the two sparse-conv templates (per-class table in "
-              "all_kernels); launches of the batches in flight share the chip, so a launch's bracket in the timed region is "
-              "several times its solo duration -- roofline_solo has the same entry for one batch alone on the GPU",
+        CONV: "gather / rule-GEMM / scatter: every instantiation of the two sparse-conv templates.  In the timed region the "
+              "convolutions of a forward pass are bracketed ONCE (HIP events before the first and after the last launch: a pair "
+              "per launch costs ~10 us between kernels that otherwise run back to back), avg_us = bracket / launches; launches "
+              "of the batches in flight share the chip, so a bracket in the timed region is longer than solo -- roofline_solo "
+              "has the same entry for one batch alone on the GPU with every launch bracketed (per-class table in all_kernels)",
     }
     out = {"kernel": name, "bound": "latency" if latency_bound else "hbm", "achieved": achieved, "peak": peak_gbs, "unit": "GB/s",
            "frac": achieved / peak_gbs, "traffic": _scaled_traffic(name, clouds_per_launch), "launches": r["launches"], "avg_us": r["avg_us"],
