@@ -88,7 +88,16 @@ int st_sparse_conv_mfma_fwd(const float* x0, int c0, const float* x1, int cin, c
                             const float* wp, int cout, const float* scale, const float* shift, const float* residual,
                             int relu, float* y, const int32_t* row_order /*[n_out] or NULL: launch order of the output rows (bits 0-27 row, top 4 bits 0 or the parity tag of st_build_strided_rulebook)*/,
                             void* stream, int64_t nbr_stride /*0 = n_out*/,
-                            int variant /*0 = the library picks the tile shape by size; else row tiles per wave | (weights through LDS) << 4 (bench aid)*/);
+                            int variant /*0 = the library picks the tile shape by size;
+ else row tiles per wave | (weights through LDS) << 4 (bench aid)*/);
+/* The same contraction on the bf16 matrix pipe at float32 accuracy: every float32 operand is cut into three bf16 pieces that sum
+ * to it exactly and six of the nine piece products are issued (csrc/sparse_conv.hip "split-bf16 rule-GEMM").  Features stay float32;
+ * wq = the weights as three bf16 planes in operand order [K][Cin/32][3][4][Cout][8] (smart_tree_amd/model/sparse_ops.py b3_weight).
+ * Cin % 32 == 0, Cout % 16 == 0, c0 % 8 == 0.  variant: 0 = row tiles per wavefront by size, 1 / 2 = forced.
+ * replaces: the same spconv calls as st_sparse_conv_fwd (model_blocks.py:57-70,90-101,134-143) on the 32- and 64-channel levels */
+int st_sparse_conv_b3_fwd(const float* x0, int c0, const float* x1, int cin, const int32_t* nbr, int K, int64_t n_out, const void* wq,
+                          int cout, const float* scale, const float* shift, const float* residual, int relu, float* y,
+                          const int32_t* row_order, void* stream, int64_t nbr_stride, int variant);
 /* Half-precision storage (BASELINE.json configs[4]; an extension -- the reference's inference, model/model_inference.py:49-100,
  * is float32): in_half && out_half -> x0 / x1 / residual / y are IEEE half, w is the MFMA order as half, Cin, Cout and the
  * concat split multiples of 16, v_mfma_f32_16x16x16_f16 with float32 accumulation; exactly one of them -> the float32

@@ -45,6 +45,7 @@ SIGNATURES = {
     "st_build_strided_rulebook": (c_int, [P, I64, P, P, I64, P, I64, P, P, I64, ctypes.POINTER(ctypes.c_int32), P, P, P, P]),
     "st_sparse_conv_fwd": (c_int, [P, c_int, P, c_int, P, c_int, I64, P, c_int, P, P, P, c_int, P, P, P, I64]),
     "st_sparse_conv_mfma_fwd": (c_int, [P, c_int, P, c_int, P, c_int, I64, P, c_int, P, P, P, c_int, P, P, P, I64, c_int]),
+    "st_sparse_conv_b3_fwd": (c_int, [P, c_int, P, c_int, P, c_int, I64, P, c_int, P, P, P, c_int, P, P, P, I64, c_int]),
     "st_sparse_conv_f16_fwd": (c_int, [P, c_int, P, c_int, P, c_int, I64, P, c_int, P, P, P, c_int, P, c_int, c_int, P, P, I64]),
     "st_brick_pyramid_workspace_bytes": (I64, [I64, c_int, c_int, c_int, ctypes.POINTER(I64)]),
     "st_brick_pyramid": (c_int, [P, I64, c_int, c_int, c_int, P, c_int, ctypes.POINTER(I64), P, ctypes.POINTER(P), ctypes.POINTER(P),
@@ -107,7 +108,7 @@ ENQUEUE_ONLY = frozenset({
     "st_make_edges_workspace_bytes", "st_connected_components_workspace_bytes", "st_component_layout_workspace_bytes",
     "st_component_csr_workspace_bytes", "st_assemble_workspace_bytes", "st_skeleton_workspace_bytes",
     "st_build_coord_hash", "st_build_subm_rulebook", "st_build_strided_rulebook", "st_sparse_conv_fwd",
-    "st_sparse_conv_mfma_fwd", "st_sparse_conv_f16_fwd", "st_pointwise_mlp_heads", "st_medial_points", "st_centre_cloud",
+    "st_sparse_conv_mfma_fwd", "st_sparse_conv_b3_fwd", "st_sparse_conv_f16_fwd", "st_pointwise_mlp_heads", "st_medial_points", "st_centre_cloud",
     "st_connected_components", "st_component_csr", "st_post_process", "st_knn_radius", "st_brick_pyramid_workspace_bytes",
     "st_centre_cloud_seg", "st_voxelize_workspace_bytes_seg", "st_build_strided_rulebook_seg", "st_knn_workspace_bytes_seg",
     "st_knn_radius_seg", "st_skeleton_workspace_bytes_seg", "st_post_process_seg", "st_radius_count_seg",

@@ -299,6 +299,170 @@ static int conv_launch_mfma(const float* x0, int c0, const float* x1, const int3
     return ST_OK;
 }
 
+// ------------------------------------------------------------- split-bf16 rule-GEMM (round 3) ---
+// The f32 matrix instruction runs at the vector rate (v_mfma_f32_16x16x4_f32: 32 cycles for 2048 flops), and the 32- and
+// 64-channel levels keep that pipe 49-68 % busy.  Here the SAME float32 features and weights are contracted on the bf16 pipe
+// (v_mfma_f32_16x16x32_bf16: ~17 cycles for 16384 flops) without giving up float32 accuracy: a float32 is cut into three bf16
+// pieces by TRUNCATION -- hi = the upper 16 bits, mid = the upper 16 bits of a - hi, lo = those of a - hi - mid -- which splits
+// its 24-bit significand into 8 + 8 + 8 bits, so a = hi + mid + lo EXACTLY.  A product a*b is the sum of nine bf16 products
+// (each exact in float32); the six largest are issued -- hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid -- and the three that are
+// dropped (mid*lo, lo*mid, lo*lo) are below 2^-24 of |a*b|: the result differs from a float32 FMA chain by rounding-order noise
+// only (measured against the float64 oracle: the same 5e-7 as the f32 matrix-core kernel).  Six instructions of the 15x faster
+// kind per 32 channels instead of eight of the slow kind: 2.5x less matrix-pipe time; the split costs ~44 vector instructions
+// per eight gathered channels and row tile, amortised over the Cout / 16 column tiles.  Features stay float32 in memory: no new
+// tensor format, every other kernel is untouched.  Weights: host-side split into the same three planes, operand order
+//   wq[k][c][plane][g][co][e] = piece `plane` of W[k][32c + 8g + e][co]   (bf16, a 16-byte vector per (k, c, plane, g, co))
+// lane (i = l & 15, g = l >> 4) feeds channels 32c + 8g .. +7 of row i (A: two float4 loads) and of output column i (B).
+typedef __bf16 st_bf8 __attribute__((ext_vector_type(8)));
+struct StB3 { uint4 h, m, l; };
+// (upper halves of a1, a0) packed as two bf16: v_perm_b32 {a1.b3, a1.b2, a0.b3, a0.b2}
+__device__ __forceinline__ unsigned b3_pack_hi(unsigned u0, unsigned u1) { return __builtin_amdgcn_perm(u1, u0, 0x07060302u); }
+__device__ __forceinline__ void b3_split_pair(float a0, float a1, unsigned* h, unsigned* m, unsigned* l) {
+    const unsigned u0 = __float_as_uint(a0), u1 = __float_as_uint(a1);
+    *h = b3_pack_hi(u0, u1);
+    const float r0 = a0 - __uint_as_float(u0 & 0xffff0000u), r1 = a1 - __uint_as_float(u1 & 0xffff0000u);  // exact
+    const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+    *m = b3_pack_hi(v0, v1);
+    const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);  // exact
+    *l = b3_pack_hi(__float_as_uint(s0), __float_as_uint(s1));
+}
+__device__ __forceinline__ StB3 b3_split8(float4 a, float4 b) {
+    StB3 o;
+    b3_split_pair(a.x, a.y, &o.h.x, &o.m.x, &o.l.x);
+    b3_split_pair(a.z, a.w, &o.h.y, &o.m.y, &o.l.y);
+    b3_split_pair(b.x, b.y, &o.h.z, &o.m.z, &o.l.z);
+    b3_split_pair(b.z, b.w, &o.h.w, &o.m.w, &o.l.w);
+    return o;
+}
+__device__ __forceinline__ st_bf8 b3_bf8(uint4 v) { return __builtin_bit_cast(st_bf8, v); }
+
+template <int CIN, int COUT, int RT>
+__global__ void __launch_bounds__(MF_BLOCK) k_sparse_conv_mfma_b3(const float* __restrict__ x0, int c0, const float* __restrict__ x1,
+                                                                  const int32_t* __restrict__ nbr, int K, int64_t n_out, int64_t nstride,
+                                                                  const uint4* __restrict__ wq, const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift, const float* __restrict__ residual,
+                                                                  int relu, float* __restrict__ y, const int32_t* __restrict__ row_order) {
+    constexpr int CT = COUT / 16, NC = CIN / 32, WK = NC * 3 * 4 * COUT;  // 16-byte vectors of one offset's weights
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i16 = lane & 15, g = lane >> 4;
+    const int64_t obase = ((int64_t)blockIdx.x * (MF_BLOCK / 64) + wave) * (16 * RT);
+    const int c1 = CIN - c0;
+    st_v4f acc[RT][CT];
+#pragma unroll
+    for (int t = 0; t < RT; t++)
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) acc[t][ct] = st_v4f{0.0f, 0.0f, 0.0f, 0.0f};
+    int64_t orow[RT];
+    uint32_t live[RT];
+#pragma unroll
+    for (int t = 0; t < RT; t++) {
+        const int64_t pos = obase + t * 16 + i16;
+        const int32_t entry = pos < n_out && row_order ? row_order[pos] : 0;
+        orow[t] = pos < n_out ? (row_order ? (int64_t)(entry & CONV_ROW_MASK) : pos) : -1;
+        live[t] = conv_live_offsets(entry, K);
+    }
+    for (int k = 0; k < K; k++) {
+        int idx[RT];
+        bool any = false;
+#pragma unroll
+        for (int t = 0; t < RT; t++) {
+            idx[t] = orow[t] >= 0 && ((live[t] >> k) & 1u) ? (nbr ? nbr[(int64_t)k * nstride + orow[t]] : (int)orow[t]) : -1;
+            any = any || idx[t] >= 0;
+        }
+        if (__ballot(any) == 0ull) continue;  // no voxel of this wave has a neighbour at offset k (wave-uniform)
+        // B fragments straight from the L2-resident planes (staging an offset's planes in LDS once per workgroup, two barriers per
+        // offset, measured no faster at 16 clouds per launch set and 1.5x slower for the parity-ordered inverse convs)
+        const uint4* wk = wq + (int64_t)k * WK;
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const int ci = 32 * c + 8 * g;
+            StB3 a[RT];
+#pragma unroll
+            for (int t = 0; t < RT; t++) {
+                float4 lo4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), hi4 = lo4;
+                if (idx[t] >= 0) {
+                    const float* row = ci < c0 ? x0 + (int64_t)idx[t] * c0 + ci : x1 + (int64_t)idx[t] * c1 + (ci - c0);
+                    lo4 = *reinterpret_cast<const float4*>(row);
+                    hi4 = *reinterpret_cast<const float4*>(row + 4);
+                }
+                a[t] = b3_split8(lo4, hi4);
+            }
+#pragma unroll
+            for (int ct = 0; ct < CT; ct++) {
+                const uint4* wc = wk + ((int64_t)(c * 3) * 4 + g) * COUT + ct * 16 + i16;  // plane stride = 4 * COUT
+                const st_bf8 bh = b3_bf8(wc[0]), bm = b3_bf8(wc[4 * COUT]), bl = b3_bf8(wc[8 * COUT]);
+#pragma unroll
+                for (int t = 0; t < RT; t++) {
+                    const st_bf8 ah = b3_bf8(a[t].h), am = b3_bf8(a[t].m), al = b3_bf8(a[t].l);
+                    st_v4f d = acc[t][ct];
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, d, 0, 0, 0);
+                    acc[t][ct] = d;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++) {
+        const int ch = ct * 16 + i16;
+        const float sc = scale ? scale[ch] : 1.0f, sh = scale ? shift[ch] : 0.0f;
+#pragma unroll
+        for (int t = 0; t < RT; t++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int64_t pos = obase + t * 16 + g * 4 + r;
+                if (pos >= n_out) continue;
+                const int64_t o = row_order ? (int64_t)(row_order[pos] & CONV_ROW_MASK) : pos;
+                float v = acc[t][ct][r];
+                if (scale) v = fmaf(v, sc, sh);
+                if (residual) v += residual[o * COUT + ch];
+                if (relu) v = v > 0.0f ? v : 0.0f;
+                y[o * COUT + ch] = v;
+            }
+    }
+}
+
+// Same contract as st_sparse_conv_mfma_fwd with the weights as three bf16 planes (see above; smart_tree_amd/model/sparse_ops.py
+// b3_weight).  Needs Cin % 32 == 0, Cout % 16 == 0 and a concat split that is a multiple of 8.  variant: 0 = by size, 1 / 2 = row
+// tiles per wavefront.
+extern "C" int st_sparse_conv_b3_fwd(const float* x0, int c0, const float* x1, int cin, const int32_t* nbr, int K, int64_t n_out,
+                                     const void* wq, int cout, const float* scale, const float* shift, const float* residual,
+                                     int relu, float* y, const int32_t* row_order, void* stream_, int64_t nbr_stride, int variant) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const int64_t nstride = nbr_stride > 0 ? nbr_stride : n_out;
+    ST_REQUIRE(K >= 1 && (nbr != nullptr || K == 1), "conv: a NULL neighbour table means pointwise (K = 1)");
+    ST_REQUIRE(c0 > 0 && c0 <= cin && (c0 == cin || x1 != nullptr), "conv: bad concat split");
+    ST_REQUIRE((scale == nullptr) == (shift == nullptr), "conv: scale and shift go together");
+    ST_REQUIRE(cin % 32 == 0 && cout % 16 == 0 && c0 % 8 == 0, "conv(b3): Cin % 32, Cout % 16 and a concat split % 8 are required");
+    if (n_out <= 0) return ST_OK;
+    // measured on MI355X (tools/bench_conv.py at 1 / 4 / 16 clouds per launch set, profiles/r03_conv_layers_b3.txt): two row tiles per
+    // wavefront (each B fragment feeds two tiles) win from ~56k rows on, for the parity-ordered inverse convs from ~300k; below, one
+    // tile per wavefront gives the chip twice the wavefronts.  Both compute a row with the same instruction sequence: same bits.
+    const int rt = variant == 1 || variant == 2 ? variant : (n_out >= (row_order == nullptr ? 56000 : 300000) ? 2 : 1);
+#define B3_LAUNCH(CI, CO, RT_)                                                                                                          \
+    hipLaunchKernelGGL((k_sparse_conv_mfma_b3<CI, CO, RT_>), dim3((unsigned)st_div_up(n_out, (MF_BLOCK / 64) * 16 * RT_)), dim3(MF_BLOCK), 0, \
+                       stream, x0, c0, x1, nbr, K, n_out, nstride, (const uint4*)wq, scale, shift, residual, relu, y, row_order)
+#define B3_CASE(CI, CO)                                                  \
+    if (cin == CI && cout == CO) {                                       \
+        if (rt == 2) B3_LAUNCH(CI, CO, 2); else B3_LAUNCH(CI, CO, 1);    \
+        ST_CHECK_LAUNCH();                                               \
+        return ST_OK;                                                    \
+    }
+    B3_CASE(32, 16)
+    B3_CASE(32, 32)
+    B3_CASE(32, 64)
+    B3_CASE(64, 32)
+    B3_CASE(64, 64)
+#undef B3_CASE
+#undef B3_LAUNCH
+    st_set_error("conv(b3): no kernel instance for cin=%d cout=%d", cin, cout);
+    return ST_ERR_INVALID;
+}
+
 // fp16 rule-GEMM (config 5): features and weights in half precision, v_mfma_f32_16x16x16_f16 with float32
 // accumulation.  The operand layout is the f32 kernel's with four channels per lane and ONE instruction per
 // 16-channel chunk: lane (i = l & 15, kg = l >> 4) feeds channels 16c + 4kg .. +3 of row i (A, an 8-byte load) and of

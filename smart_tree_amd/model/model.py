@@ -60,12 +60,16 @@ class Smart_Tree:
         self.use_mfma = True
         self.fp16 = bool(fp16)
         self.wp16: Dict[str, torch.Tensor] = {}
+        self.wq: Dict[str, torch.Tensor] = {}  # three bf16 planes for the split-bf16 kernel (Cin % 32 == 0: the 32- / 64-channel levels)
+        self.use_b3 = True
         for key, t in sd.items():
             if key.endswith(".weight") and t.ndim == 5 and "_head." not in key:
                 name = key[: -len(".weight")]
                 self.w[name] = _conv_weight(t).to(self.device)
                 if self.w[name].shape[1] % 16 == 0 and self.w[name].shape[2] % 16 == 0:
                     self.wp[name] = ops.mfma_weight(self.w[name])
+                    if self.w[name].shape[1] % 32 == 0:
+                        self.wq[name] = ops.b3_weight(self.w[name])
                     if self.fp16:
                         self.wp16[name] = self.wp[name].half()
             elif key.endswith(".running_mean") and "_head." not in key:
@@ -112,7 +116,8 @@ class Smart_Tree:
         return ops.sparse_conv(x, self.w[name], nbr, n_out, x1=x1, scale=a.scale if a else None,
                                shift=a.shift if a else None, residual=residual, relu=relu,
                                wp=self.wp.get(name) if self.use_mfma else None, out_half=out_half,
-                               wp16=self.wp16.get(name), row_order=row_order)
+                               wp16=self.wp16.get(name), row_order=row_order,
+                               wq=self.wq.get(name) if self.use_mfma and self.use_b3 and not self.fp16 else None)
 
     def _res_block(self, prefix, x, nbr, x1=None):
         """ResBlock.forward (model_blocks.py:149-156); x1 != None is the Tail on cat(skip, decoded)."""

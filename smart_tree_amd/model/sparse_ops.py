@@ -174,6 +174,7 @@ def _nbr_args(nbr: Optional[torch.Tensor]):
     return nbr.data_ptr(), int(nbr.stride(0)) if nbr.shape[0] > 1 else int(max(nbr.shape[1], 1))
 
 
+B3_VARIANT = 0  # bench aid: row tiles per wavefront of the split-bf16 kernel (0 = by size)
 MFMA_VARIANT = 0  # bench aid (tools/bench_conv.py): tile shape of the f32 matrix-core kernel, 0 = the library picks by size
 
 
@@ -208,13 +209,38 @@ def mfma_eligible(cin: int, cout: int, c0: int) -> bool:
     return cin % 16 == 0 and cout % 16 == 0 and c0 % 16 == 0
 
 
+def b3_eligible(cin: int, cout: int, c0: int) -> bool:
+    """The split-bf16 matrix-core kernel (st_sparse_conv_b3_fwd): 32-channel chunks, 16-channel column tiles."""
+    return cin % 32 == 0 and cout % 16 == 0 and c0 % 8 == 0 and (cin, cout) in ((32, 16), (32, 32), (32, 64), (64, 32), (64, 64))
+
+
+def b3_weight(w: torch.Tensor) -> torch.Tensor:
+    """[K, Cin, Cout] float32 -> three bf16 planes in operand order wq[K][Cin/32][3][4][Cout][8] (int16 bit patterns):
+    piece p of W[k][32c + 8g + e][co], where hi = the upper 16 bits of the float, mid = those of w - hi, lo = those of
+    w - hi - mid -- truncating splits, so hi + mid + lo == w exactly (csrc/sparse_conv.hip "split-bf16 rule-GEMM")."""
+    K, cin, cout = w.shape
+    w = w.detach().to(torch.float32).contiguous()
+    mask = torch.tensor(-65536, dtype=torch.int32, device=w.device)  # 0xffff0000
+    planes, r = [], w
+    for _ in range(3):
+        top = (r.view(torch.int32) & mask).view(torch.float32)
+        planes.append((r.view(torch.int32) >> 16).to(torch.int16))  # the upper 16 bits (arithmetic shift keeps the bit pattern)
+        r = r - top  # exact
+    q = torch.stack(planes, 0)  # [3, K, Cin, Cout]
+    q = q.reshape(3, K, cin // 32, 4, 8, cout).permute(1, 2, 0, 3, 5, 4).contiguous()  # [K, c, plane, g, co, e]
+    return q
+
+
 def sparse_conv(x0: torch.Tensor, w: torch.Tensor, nbr: Optional[torch.Tensor], n_out: int,
                 x1: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None,
                 shift: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
                 relu: bool = False, wp: Optional[torch.Tensor] = None, out_half: bool = False,
-                wp16: Optional[torch.Tensor] = None, row_order: Optional[torch.Tensor] = None) -> torch.Tensor:
+                wp16: Optional[torch.Tensor] = None, row_order: Optional[torch.Tensor] = None,
+                wq: Optional[torch.Tensor] = None) -> torch.Tensor:
     """y = act(bn(sum_k W_k . cat(x0, x1)[nbr[k]]) + residual); w is [K, Cin, Cout].
     wp (optional): the same weights in MFMA order -> the matrix-core kernel is used.
+    wq (optional, b3_weight(w)): the weights as three bf16 planes -> the split-bf16 matrix-core kernel (float32 accuracy on the
+    bf16 pipe) where the shape is eligible (b3_eligible); takes precedence over wp.
     row_order (optional, [n_out] int32): launch order of the output rows (never changes the result).
     Half-precision storage mode: a float16 x0 and / or out_half select st_sparse_conv_f16_fwd (wp16 = wp as half)."""
     L = _lib.lib()
@@ -245,6 +271,16 @@ def sparse_conv(x0: torch.Tensor, w: torch.Tensor, nbr: Optional[torch.Tensor], 
     # profiles/r02_conv_layers_batch16.txt).  At EVERY size, not only the large ones: the two kernels round differently in
     # the last bit (the matrix core does not evaluate a k-ordered fmaf chain exactly), and a cloud must get the same values
     # alone and inside a batch (tests/test_batch.py).
+    if wq is not None and b3_eligible(cin, cout, c0):
+        y = torch.empty((n_out, cout), dtype=torch.float32, device=x0.device)
+        nbytes = (lambda: (_pair_count(nbr) if nbr is not None else n_out) * (cin * 4 + (4 if nbr is not None else 0))
+                  + n_out * cout * 4) if profiling.enabled() else 0
+        nflops = (lambda: 2.0 * (_pair_count(nbr) if nbr is not None else n_out) * cin * cout) if profiling.enabled() else 0
+        with profiling.kernel(f"k_sparse_conv_mfma_b3<{cin},{cout}>" + ("" if nbr is not None else " k1"), nbytes, nflops):
+            _lib.check(L.st_sparse_conv_b3_fwd(_lib.ptr(x0), c0, _lib.ptr(x1), cin, nbr_ptr, K, n_out, _lib.ptr(wq), cout,
+                                               _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(residual), int(relu), _lib.ptr(y),
+                                               _lib.ptr(row_order), _lib.stream(x0.device), nbr_stride, int(B3_VARIANT)))
+        return y
     big_16 = cin == 16 and cout == 16 and nbr is not None and row_order is None and x1 is None
     if wp is not None and mfma_eligible(cin, cout, c0) and not big_16:
         y = torch.empty((n_out, cout), dtype=torch.float32, device=x0.device)

@@ -356,6 +356,54 @@ inline hipemu_v4f __builtin_amdgcn_mfma_f32_16x16x16f16(hipemu_v4h a, hipemu_v4h
     return c;
 }
 
+// v_mfma_f32_16x16x32_bf16 (gfx950): lane (i = l & 15, g = l >> 4) holds eight bf16 of A row i / B column i: k = 8g + e.
+// Products of two bf16 are exact in float32; added in k order (tests compare with a float64 oracle under a tolerance).
+typedef __bf16 hipemu_bf8 __attribute__((ext_vector_type(8)));
+inline hipemu_v4f __builtin_amdgcn_mfma_f32_16x16x32_bf16(hipemu_bf8 a, hipemu_bf8 b, hipemu_v4f c, int, int, int) {
+    uint64_t aw[2], bw[2];
+    memcpy(aw, &a, 16);
+    memcpy(bw, &b, 16);
+    // (a WaveView points into the scheduler's snapshot, which the next exchange overwrites: copy the first half out)
+    uint64_t a0[64], b0[64];
+    unsigned lane;
+    {
+        auto v0 = hipemu::wave_exchange(aw[0], bw[0]);
+        lane = v0.lane;
+        for (unsigned l = 0; l < 64; l++) { a0[l] = v0.lo(l); b0[l] = v0.hi(l); }
+    }
+    auto v1 = hipemu::wave_exchange(aw[1], bw[1]);
+    auto bf_at = [](uint64_t word, unsigned e) {
+        const uint32_t bits = (uint32_t)((word >> (16 * e)) & 0xffffu) << 16;
+        float f;
+        memcpy(&f, &bits, 4);
+        return f;
+    };
+    unsigned col = lane & 15;
+    for (int reg = 0; reg < 4; reg++) {
+        unsigned row = (lane >> 4) * 4 + reg;
+        float acc = c[reg];
+        for (unsigned k = 0; k < 32; k++) {
+            const unsigned g = k / 8, e = k % 8;
+            const float av = e < 4 ? bf_at(a0[g * 16 + row], e) : bf_at(v1.lo(g * 16 + row), e - 4);
+            const float bv = e < 4 ? bf_at(b0[g * 16 + col], e) : bf_at(v1.hi(g * 16 + col), e - 4);
+            acc = fmaf(av, bv, acc);
+        }
+        c[reg] = acc;
+    }
+    return c;
+}
+// v_perm_b32: byte i of the result = byte sel[i] of the 8-byte value {s0 (bytes 4-7), s1 (bytes 0-3)}; 0x0c = 0x00
+inline unsigned __builtin_amdgcn_perm(unsigned s0, unsigned s1, unsigned sel) {
+    const uint64_t v = ((uint64_t)s0 << 32) | (uint64_t)s1;
+    unsigned r = 0;
+    for (int i = 0; i < 4; i++) {
+        const unsigned b = (sel >> (8 * i)) & 0xffu;
+        const unsigned byte = b < 8u ? (unsigned)((v >> (8 * b)) & 0xffu) : 0u;
+        r |= byte << (8 * i);
+    }
+    return r;
+}
+
 // ---- bit / math helpers ----------------------------------------------------------------
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __popc(unsigned x) { return __builtin_popcount(x); }

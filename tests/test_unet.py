@@ -316,3 +316,40 @@ def test_brick_path_leaves_the_network_outputs_unchanged(backend):
     c = net.forward(wrong)  # a hint the input violates is noticed on the device: the hash-table path takes over
     for k in a:
         assert torch.equal(a[k], b[k]) and torch.equal(a[k], c[k]), k
+
+
+# ---- split-bf16 rule-GEMM (csrc/sparse_conv.hip k_sparse_conv_mfma_b3): float32 accuracy on the bf16 matrix pipe ----
+@pytest.mark.parametrize("cin,cout,c0", [(32, 16, 16), (32, 32, 32), (32, 64, 32), (64, 32, 32), (64, 64, 64)])
+@pytest.mark.parametrize("variant", [1, 2])
+def test_split_bf16_conv_has_float32_accuracy(backend, cin, cout, c0, variant):
+    """Every float32 operand = three bf16 pieces that sum to it exactly; six of the nine piece products are issued.  The result
+    must be as close to the float64 contraction as the float32 matrix-core kernel's (rounding-order noise), with concat,
+    BatchNorm affine, residual, ReLU and a row order."""
+    rng = np.random.RandomState(cin * 100 + cout + variant)
+    n, n_in, K = 613, 580, 27
+    nbr = rng.randint(0, n_in, size=(K, n)).astype(np.int32)
+    nbr[rng.rand(K, n) < 0.4] = -1
+    x = (rng.randn(n_in, cin) * np.exp(rng.uniform(-6, 6, size=(n_in, 1)))).astype(np.float32)  # rows of very different scale
+    w = (rng.randn(K, cin, cout) * 0.05).astype(np.float32)
+    scale, shift = rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.randn(cout).astype(np.float32)
+    res = rng.randn(n, cout).astype(np.float32)
+    order = rng.permutation(n).astype(np.int32)
+    ref = np.zeros((n, cout))
+    for k in range(K):
+        hit = nbr[k] >= 0
+        ref[hit] += x[nbr[k][hit]].astype(np.float64) @ w[k].astype(np.float64)
+    ref = np.maximum(ref * scale.astype(np.float64) + shift.astype(np.float64) + res.astype(np.float64), 0.0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(backend)
+    x0, x1 = (t(x[:, :c0]), t(x[:, c0:])) if c0 < cin else (t(x), None)
+    args = dict(x1=x1, scale=t(scale), shift=t(shift), residual=t(res), relu=True, row_order=t(order))
+    ops.B3_VARIANT = variant
+    try:
+        got = ops.sparse_conv(x0, t(w), t(nbr), n, wq=ops.b3_weight(t(w)), **args).cpu().numpy().astype(np.float64)
+    finally:
+        ops.B3_VARIANT = 0
+    f32 = ops.sparse_conv(x0, t(w), t(nbr), n, wp=ops.mfma_weight(t(w)) if ops.mfma_eligible(cin, cout, c0) else None, **args)
+    f32 = f32.cpu().numpy().astype(np.float64)
+    # per row: rows differ in scale by e^12, so the error is measured against each row's own magnitude
+    mag = np.abs(ref).max(axis=1, keepdims=True) + np.abs(shift).max() + 1e-30
+    e_b3, e_f32 = (np.abs(got - ref) / mag).max(), (np.abs(f32 - ref) / mag).max()
+    assert e_b3 < 1e-5 and e_b3 < 4 * e_f32 + 2e-7, (e_b3, e_f32)

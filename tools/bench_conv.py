@@ -18,6 +18,7 @@ VOX = float(sys.argv[2]) if len(sys.argv) > 2 else 0.02
 FOL = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
 BATCH = int(sys.argv[4]) if len(sys.argv) > 4 else 1  # clouds per launch set (Cloud.collate): the batched pipeline's sizes
 VARIANTS = [int(v) for v in sys.argv[5].split(",")] if len(sys.argv) > 5 else [1]
+B3_VARIANTS = [int(v) for v in sys.argv[6].split(",")] if len(sys.argv) > 6 and not sys.argv[6].startswith("--") else [1, 2]
 clouds = []
 for b in range(BATCH):
     c = sample_tree_cloud(NPTS, seed=(3 if FOL else 0) + b, **({"foliage_fraction": FOL} if FOL else {}))
@@ -62,6 +63,16 @@ for lvl in range(4):
                 err = (ya - yb).abs().max().item() / (ya.abs().max().item() + 1e-30)
                 line += f" | mfma[{tag}] {t_m:6.1f} us ({bytes_/t_m/1e3:7.1f} GB/s = {bytes_/t_m/1e3/80:4.1f} % of 8 TB/s) {flops/t_m/1e6:5.1f} TF e={err:.0e}"
             ops.MFMA_VARIANT = 0
+            if ops.b3_eligible(cin, cout, cin):  # split-bf16 matrix-core kernel (float32 features, bf16 pipe), 1 / 2 row tiles per wave
+                wq = ops.b3_weight(w)
+                y64 = None
+                for var in B3_VARIANTS:
+                    ops.B3_VARIANT = var
+                    t_b = timeit(lambda: ops.sparse_conv(x, w, tbl, nout, wq=wq, row_order=ro))
+                    yq = ops.sparse_conv(x, w, tbl, nout, wq=wq, row_order=ro)
+                    errq = (ya - yq).abs().max().item() / (ya.abs().max().item() + 1e-30)
+                    line += f" | b3[rt{var}] {t_b:6.1f} us ({bytes_/t_b/1e3:7.1f} GB/s = {bytes_/t_b/1e3/80:4.1f} %) {flops/t_b/1e6:5.1f} TF e={errq:.0e}"
+                ops.B3_VARIANT = 0
             # half-precision storage (config 5): f16 matrix-core kernel, half the gather bytes
             xh, wph = x.half(), wp.half()
             bytes_h = pairs * (cin * 2 + 4) + nout * cout * 2
