@@ -426,6 +426,94 @@ __global__ void __launch_bounds__(MF_BLOCK) k_sparse_conv_mfma_b3(const float* _
     }
 }
 
+// Sixteen input channels (the submanifold and strided convs of level 1): a 32-deep instruction takes TWO kernel offsets at once --
+// lanes g = 0, 1 feed channels 8g .. +7 of the row at offset 2j, lanes g = 2, 3 those of the row at offset 2j + 1, and the B operand
+// stacks W_{2j} on W_{2j+1} (zeros behind an odd last offset): wq[j][plane][g][co][e] = piece of W[2j + (g >> 1)][8 (g & 1) + e][co].
+template <int COUT, int RT>
+__global__ void __launch_bounds__(MF_BLOCK) k_sparse_conv_mfma_b3_c16(const float* __restrict__ x, const int32_t* __restrict__ nbr, int K,
+                                                                      int64_t n_out, int64_t nstride, const uint4* __restrict__ wq,
+                                                                      const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                      const float* __restrict__ residual, int relu, float* __restrict__ y,
+                                                                      const int32_t* __restrict__ row_order) {
+    constexpr int CT = COUT / 16, WK = 3 * 4 * COUT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i16 = lane & 15, g = lane >> 4;
+    const int64_t obase = ((int64_t)blockIdx.x * (MF_BLOCK / 64) + wave) * (16 * RT);
+    st_v4f acc[RT][CT];
+#pragma unroll
+    for (int t = 0; t < RT; t++)
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) acc[t][ct] = st_v4f{0.0f, 0.0f, 0.0f, 0.0f};
+    int64_t orow[RT];
+    uint32_t live[RT];
+#pragma unroll
+    for (int t = 0; t < RT; t++) {
+        const int64_t pos = obase + t * 16 + i16;
+        const int32_t entry = pos < n_out && row_order ? row_order[pos] : 0;
+        orow[t] = pos < n_out ? (row_order ? (int64_t)(entry & CONV_ROW_MASK) : pos) : -1;
+        live[t] = conv_live_offsets(entry, K);
+    }
+    const int ch = 8 * (g & 1);
+    for (int j = 0; 2 * j < K; j++) {
+        const int k = 2 * j + (g >> 1);  // this lane's offset of the pair
+        int idx[RT];
+        bool any = false;
+#pragma unroll
+        for (int t = 0; t < RT; t++) {
+            idx[t] = k < K && orow[t] >= 0 && ((live[t] >> k) & 1u) ? (nbr ? nbr[(int64_t)k * nstride + orow[t]] : (int)orow[t]) : -1;
+            any = any || idx[t] >= 0;
+        }
+        if (__ballot(any) == 0ull) continue;  // neither offset of the pair has a neighbour in this wave (wave-uniform)
+        StB3 a[RT];
+#pragma unroll
+        for (int t = 0; t < RT; t++) {
+            float4 lo4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), hi4 = lo4;
+            if (idx[t] >= 0) {
+                const float* row = x + (int64_t)idx[t] * 16 + ch;
+                lo4 = *reinterpret_cast<const float4*>(row);
+                hi4 = *reinterpret_cast<const float4*>(row + 4);
+            }
+            a[t] = b3_split8(lo4, hi4);
+        }
+        const uint4* wk = wq + (int64_t)j * WK;
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) {
+            const uint4* wc = wk + (int64_t)g * COUT + ct * 16 + i16;  // plane stride = 4 * COUT
+            const st_bf8 bh = b3_bf8(wc[0]), bm = b3_bf8(wc[4 * COUT]), bl = b3_bf8(wc[8 * COUT]);
+#pragma unroll
+            for (int t = 0; t < RT; t++) {
+                const st_bf8 ah = b3_bf8(a[t].h), am = b3_bf8(a[t].m), al = b3_bf8(a[t].l);
+                st_v4f d = acc[t][ct];
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, d, 0, 0, 0);
+                acc[t][ct] = d;
+            }
+        }
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++) {
+        const int co = ct * 16 + i16;
+        const float sc = scale ? scale[co] : 1.0f, sh = scale ? shift[co] : 0.0f;
+#pragma unroll
+        for (int t = 0; t < RT; t++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int64_t pos = obase + t * 16 + g * 4 + r;
+                if (pos >= n_out) continue;
+                const int64_t o = row_order ? (int64_t)(row_order[pos] & CONV_ROW_MASK) : pos;
+                float v = acc[t][ct][r];
+                if (scale) v = fmaf(v, sc, sh);
+                if (residual) v += residual[o * COUT + co];
+                if (relu) v = v > 0.0f ? v : 0.0f;
+                y[o * COUT + co] = v;
+            }
+    }
+}
+
 // Same contract as st_sparse_conv_mfma_fwd with the weights as three bf16 planes (see above; smart_tree_amd/model/sparse_ops.py
 // b3_weight).  Needs Cin % 32 == 0, Cout % 16 == 0 and a concat split that is a multiple of 8.  variant: 0 = by size, 1 / 2 = row
 // tiles per wavefront.
@@ -437,8 +525,21 @@ extern "C" int st_sparse_conv_b3_fwd(const float* x0, int c0, const float* x1, i
     ST_REQUIRE(K >= 1 && (nbr != nullptr || K == 1), "conv: a NULL neighbour table means pointwise (K = 1)");
     ST_REQUIRE(c0 > 0 && c0 <= cin && (c0 == cin || x1 != nullptr), "conv: bad concat split");
     ST_REQUIRE((scale == nullptr) == (shift == nullptr), "conv: scale and shift go together");
-    ST_REQUIRE(cin % 32 == 0 && cout % 16 == 0 && c0 % 8 == 0, "conv(b3): Cin % 32, Cout % 16 and a concat split % 8 are required");
+    ST_REQUIRE((cin % 32 == 0 || (cin == 16 && c0 == cin)) && cout % 16 == 0 && c0 % 8 == 0,
+               "conv(b3): Cin % 32 (or Cin = 16 without concat), Cout % 16 and a concat split % 8 are required");
     if (n_out <= 0) return ST_OK;
+    if (cin == 16) {  // two kernel offsets per instruction; wq = b3_weight's pair layout [ceil(K/2)][3][4][Cout][8]
+        const int rt16 = variant == 1 || variant == 2 ? variant : (n_out >= (row_order == nullptr ? 56000 : 300000) ? 2 : 1);
+#define B3_LAUNCH16(CO, RT_)                                                                                                            \
+    hipLaunchKernelGGL((k_sparse_conv_mfma_b3_c16<CO, RT_>), dim3((unsigned)st_div_up(n_out, (MF_BLOCK / 64) * 16 * RT_)), dim3(MF_BLOCK), 0, \
+                       stream, x0, nbr, K, n_out, nstride, (const uint4*)wq, scale, shift, residual, relu, y, row_order)
+        if (cout == 16) { if (rt16 == 2) B3_LAUNCH16(16, 2); else B3_LAUNCH16(16, 1); }
+        else if (cout == 32) { if (rt16 == 2) B3_LAUNCH16(32, 2); else B3_LAUNCH16(32, 1); }
+        else { st_set_error("conv(b3): no kernel instance for cin=16 cout=%d", cout); return ST_ERR_INVALID; }
+#undef B3_LAUNCH16
+        ST_CHECK_LAUNCH();
+        return ST_OK;
+    }
     // measured on MI355X (tools/bench_conv.py at 1 / 4 / 16 clouds per launch set, profiles/r03_conv_layers_b3.txt): two row tiles per
     // wavefront (each B fragment feeds two tiles) win from ~56k rows on, for the parity-ordered inverse convs from ~300k; below, one
     // tile per wavefront gives the chip twice the wavefronts.  Both compute a row with the same instruction sequence: same bits.

@@ -68,7 +68,7 @@ class Smart_Tree:
                 self.w[name] = _conv_weight(t).to(self.device)
                 if self.w[name].shape[1] % 16 == 0 and self.w[name].shape[2] % 16 == 0:
                     self.wp[name] = ops.mfma_weight(self.w[name])
-                    if self.w[name].shape[1] % 32 == 0:
+                    if self.w[name].shape[1] % 32 == 0 or (self.w[name].shape[0] == 27 and ops.b3_eligible(*self.w[name].shape[1:], self.w[name].shape[1])):
                         self.wq[name] = ops.b3_weight(self.w[name])
                     if self.fp16:
                         self.wp16[name] = self.wp[name].half()

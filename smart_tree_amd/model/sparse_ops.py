@@ -210,16 +210,27 @@ def mfma_eligible(cin: int, cout: int, c0: int) -> bool:
 
 
 def b3_eligible(cin: int, cout: int, c0: int) -> bool:
-    """The split-bf16 matrix-core kernel (st_sparse_conv_b3_fwd): 32-channel chunks, 16-channel column tiles."""
+    """The split-bf16 matrix-core kernel (st_sparse_conv_b3_fwd): 32-channel chunks (16 input channels: two kernel offsets per
+    chunk, no concat), 16-channel column tiles."""
+    if cin == 16:
+        return c0 == 16 and cout in (16, 32)
     return cin % 32 == 0 and cout % 16 == 0 and c0 % 8 == 0 and (cin, cout) in ((32, 16), (32, 32), (32, 64), (64, 32), (64, 64))
 
 
 def b3_weight(w: torch.Tensor) -> torch.Tensor:
-    """[K, Cin, Cout] float32 -> three bf16 planes in operand order wq[K][Cin/32][3][4][Cout][8] (int16 bit patterns):
-    piece p of W[k][32c + 8g + e][co], where hi = the upper 16 bits of the float, mid = those of w - hi, lo = those of
-    w - hi - mid -- truncating splits, so hi + mid + lo == w exactly (csrc/sparse_conv.hip "split-bf16 rule-GEMM")."""
+    """[K, Cin, Cout] float32 -> three bf16 planes in operand order (int16 bit patterns):
+    Cin % 32 == 0: wq[K][Cin/32][3][4][Cout][8] = piece p of W[k][32c + 8g + e][co];
+    Cin == 16:     wq[ceil(K/2)][3][4][Cout][8] = piece p of W[2j + (g >> 1)][8 (g & 1) + e][co] (two offsets per 32-deep chunk, zeros
+                   behind an odd last offset).
+    hi = the upper 16 bits of the float, mid = those of w - hi, lo = those of w - hi - mid -- truncating splits, so
+    hi + mid + lo == w exactly (csrc/sparse_conv.hip "split-bf16 rule-GEMM")."""
     K, cin, cout = w.shape
     w = w.detach().to(torch.float32).contiguous()
+    if cin == 16:  # pairs of offsets stacked along the channel axis
+        if K % 2:
+            w = torch.cat([w, torch.zeros((1, cin, cout), dtype=w.dtype, device=w.device)], 0)
+        w = w.reshape((K + 1) // 2, 32, cout)
+        K, cin = w.shape[0], 32
     mask = torch.tensor(-65536, dtype=torch.int32, device=w.device)  # 0xffff0000
     planes, r = [], w
     for _ in range(3):

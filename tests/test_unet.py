@@ -319,7 +319,7 @@ def test_brick_path_leaves_the_network_outputs_unchanged(backend):
 
 
 # ---- split-bf16 rule-GEMM (csrc/sparse_conv.hip k_sparse_conv_mfma_b3): float32 accuracy on the bf16 matrix pipe ----
-@pytest.mark.parametrize("cin,cout,c0", [(32, 16, 16), (32, 32, 32), (32, 64, 32), (64, 32, 32), (64, 64, 64)])
+@pytest.mark.parametrize("cin,cout,c0", [(16, 16, 16), (16, 32, 16), (32, 16, 16), (32, 32, 32), (32, 64, 32), (64, 32, 32), (64, 64, 64)])
 @pytest.mark.parametrize("variant", [1, 2])
 def test_split_bf16_conv_has_float32_accuracy(backend, cin, cout, c0, variant):
     """Every float32 operand = three bf16 pieces that sum to it exactly; six of the nine piece products are issued.  The result

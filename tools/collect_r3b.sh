@@ -13,3 +13,5 @@ echo "== seed $S params [$P]" >> $O
 python tools/diag_phases.py 1000000 0.02 0 $S "$P" 2>&1 | grep -E "^params|phases" | cut -c1-420 >> $O
 done
 done
+# per-layer table of every sparse-conv kernel at 16 clouds per launch set (f32 vector / f32 matrix / split-bf16 matrix / f16)
+python tools/bench_conv.py 1000000 0.02 0 16 1,18 2>&1 | grep -v amdgpu.ids > gpurun_out/r03_conv_layers_batch16.txt
