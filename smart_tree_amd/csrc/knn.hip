@@ -222,6 +222,7 @@ int st_grid_build(const float* pts, int64_t n, float cell, int64_t max_cells, St
 //      slot -- the K nearest come out sorted by (d2, index) without a sort.  If the list fills up it is cut
 //      back to its K smallest the same way and the scan goes on.
 #define KNN_WAVES (KNN_BLOCK / 64)
+#define KNN_MASK_WORDS 64  // candidate -> row by popcount over start marks while a row chunk holds <= 64 * 64 candidates (else: binary search)
 #define KNN_CAP 128  // keys per query held in LDS between cuts: a cut happens when a chunk of 64 might not fit any more
 
 __device__ __forceinline__ uint32_t knn_wave_scan(uint32_t v, int lane) {  // inclusive
@@ -293,6 +294,7 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn(const float* __restrict__ src
                                                    int64_t* __restrict__ idx_out, float* __restrict__ dist_out,
                                                    const int* __restrict__ seg_off, int nseg, int cell_order) {
     __shared__ uint32_t s_roff[KNN_WAVES][65], s_rfirst[KNN_WAVES][64];
+    __shared__ unsigned long long s_rmask[KNN_WAVES][KNN_MASK_WORDS];  // bit p of word w: a (non-empty) row's candidates start at 64 w + p
     __shared__ __attribute__((aligned(16))) unsigned long long s_keys[KNN_WAVES][KNN_CAP];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int64_t i = (int64_t)blockIdx.x * KNN_WAVES + wave;
@@ -311,6 +313,7 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn(const float* __restrict__ src
     }
     uint32_t* roff = s_roff[wave];
     uint32_t* rfirst = s_rfirst[wave];
+    unsigned long long* rmask = s_rmask[wave];
     unsigned long long* keys = s_keys[wave];
     const int seg = st_seg_find(seg_off, nseg, i);  // wave-uniform: one query per wavefront
     if (r < 0.0f) r = g->seg_r[seg];  // radius reduced on the device (st_knn_radius with r < 0): max(bound) over the query's cloud
@@ -362,19 +365,38 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn(const float* __restrict__ src
         }
         const uint32_t incl = knn_wave_scan(cnt, lane);
         const int total = (int)__shfl(incl, 63);
-        const int nr = st_min(nrows - rbase, 64);  // wave-uniform: a 3 x 3 neighbourhood is searched in four steps, not six
-        __builtin_amdgcn_wave_barrier();  // the previous chunk's reads of roff / rfirst are done
-        roff[lane] = incl - cnt;
-        rfirst[lane] = first;
-        if (lane == 63) roff[64] = incl;
+        // The rows of the chunk, EMPTY ONES DROPPED, in LDS (first candidate's number, first record); candidate t belongs to the last
+        // row that starts at or before it.  Found by counting start marks: every row sets one bit (its first candidate's number) in a
+        // mask of the chunk's candidates, and the 64 candidates [cb, cb + 64) read ONE mask word -- rows before cb + marks at or
+        // below the lane.  (A binary search over the row offsets per candidate was six dependent LDS reads; it stays for a chunk
+        // with more candidates than the mask holds.)
+        const unsigned long long nonempty = __ballot(cnt != 0u);
+        const int nr = __popcll(nonempty);  // wave-uniform
+        const int slot = __popcll(nonempty & ((1ull << lane) - 1ull));
+        const bool marks = total <= 64 * KNN_MASK_WORDS;
+        __builtin_amdgcn_wave_barrier();  // the previous chunk's reads of roff / rfirst / rmask are done
+        if (marks)
+            for (int w = lane; w < (total + 63) / 64; w += 64) rmask[w] = 0ull;
+        if (cnt != 0u) { roff[slot] = incl - cnt; rfirst[slot] = first; }
+        if (lane == 63) roff[nr] = incl;
         __builtin_amdgcn_wave_barrier();
+        if (marks && cnt != 0u) atomicOr(&rmask[(incl - cnt) >> 6], 1ull << ((incl - cnt) & 63u));
+        __builtin_amdgcn_wave_barrier();
+        int rows_before = 0;  // non-empty rows that start before cb (wave-uniform)
         for (int cb = 0; cb < total && !(COUNT && nkeys >= K); cb += 64) {
             const int t = cb + lane;
             bool ok = false;
             unsigned long long key = 0ull;
+            const unsigned long long starts = marks ? rmask[cb >> 6] : 0ull;  // (one word for the whole wavefront: a broadcast)
             if (t < total) {
-                int lo = 0, hi = nr;  // row with roff[row] <= t < roff[row + 1] (rows past the chunk's last one hold no candidates)
-                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (roff[mid] <= (uint32_t)t) lo = mid; else hi = mid; }
+                int lo;
+                if (marks) {
+                    lo = rows_before + __popcll(starts & (~0ull >> (63 - lane))) - 1;
+                } else {
+                    lo = 0;
+                    int hi = nr;  // row with roff[row] <= t < roff[row + 1]
+                    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (roff[mid] <= (uint32_t)t) lo = mid; else hi = mid; }
+                }
                 const float4 q = recs[rfirst[lo] + ((uint32_t)t - roff[lo])];
                 const float dx = px - q.x, dy = py - q.y, dz = pz - q.z;
                 float d2 = dx * dx;
@@ -393,6 +415,7 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn(const float* __restrict__ src
                 nkeys = knn_cut<K>(keys, nkeys, lane);
                 if (nkeys == K) thr = keys[K - 1];
             }
+            rows_before += __popcll(starts);
         }
     }
     if (COUNT) {

@@ -11,7 +11,7 @@ CSRC = ROOT / "smart_tree_amd" / "csrc"
 OUT = HERE / "_build"
 LIB = OUT / "libsmarttree_emu.so"
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
-FLAGS = ["-x", "c++", "-std=c++17", "-O1", "-g", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+FLAGS = ["-x", "c++", "-std=c++17", "-O2", "-g", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function", "-Wno-unknown-attributes", "-Wno-unused-value"]
 
 

@@ -74,7 +74,7 @@ struct Fiber {
     ucontext_t ctx;
     int state;
     dim3 tid;
-    uint64_t deposit[2];
+    uint64_t deposit[4];
 };
 
 struct Runtime {
@@ -85,7 +85,7 @@ struct Runtime {
     dim3 bid, bdim, gdim;
     std::function<void()> body;
     // snapshot of the last resolved wave op, per wave
-    std::vector<uint64_t> snap;      // [nwaves][64][2]
+    std::vector<uint64_t> snap;      // [nwaves][64][4]
     std::vector<uint64_t> snap_mask; // [nwaves]
     static constexpr size_t kStack = 256 * 1024;
 };
@@ -124,7 +124,7 @@ inline void run_block(unsigned nthreads) {
     if (r.fibers.size() < nthreads) r.fibers.resize(nthreads);
     if (r.stacks.size() < (size_t)nthreads * Runtime::kStack) r.stacks.resize((size_t)nthreads * Runtime::kStack);
     unsigned nwaves = (nthreads + 63) / 64;
-    r.snap.assign((size_t)nwaves * 64 * 2, 0);
+    r.snap.assign((size_t)nwaves * 64 * 4, 0);
     r.snap_mask.assign(nwaves, 0);
     for (unsigned t = 0; t < nthreads; t++) {
         Fiber& f = r.fibers[t];
@@ -177,8 +177,7 @@ inline void run_block(unsigned nthreads) {
                 if (f.state != AT_WAVEOP) continue;
                 unsigned lane = t - lo;
                 mask |= 1ull << lane;
-                r.snap[((size_t)w * 64 + lane) * 2] = f.deposit[0];
-                r.snap[((size_t)w * 64 + lane) * 2 + 1] = f.deposit[1];
+                for (int d = 0; d < 4; d++) r.snap[((size_t)w * 64 + lane) * 4 + d] = f.deposit[d];
                 f.state = READY;
             }
             r.snap_mask[w] = mask;
@@ -210,23 +209,26 @@ inline void launch(dim3 grid, dim3 block, F&& body) {
         }
 }
 
-// wave rendezvous: deposit two 64-bit words, get everyone's words back
+// wave rendezvous: deposit up to four 64-bit words, get everyone's words back
 struct WaveView {
     const uint64_t* data;
     uint64_t mask;
     unsigned lane;
-    uint64_t lo(unsigned l) const { return data[l * 2]; }
-    uint64_t hi(unsigned l) const { return data[l * 2 + 1]; }
+    uint64_t lo(unsigned l) const { return data[l * 4]; }
+    uint64_t hi(unsigned l) const { return data[l * 4 + 1]; }
+    uint64_t word(unsigned l, unsigned d) const { return data[l * 4 + d]; }
 };
 
-inline WaveView wave_exchange(uint64_t a, uint64_t b = 0) {
+inline WaveView wave_exchange(uint64_t a, uint64_t b = 0, uint64_t c = 0, uint64_t d = 0) {
     Runtime& r = rt();
     Fiber* f = r.cur;
     f->deposit[0] = a;
     f->deposit[1] = b;
+    f->deposit[2] = c;
+    f->deposit[3] = d;
     yield_to_sched(AT_WAVEOP);
     unsigned t = f->tid.x, w = t / 64;
-    return WaveView{r.snap.data() + (size_t)w * 64 * 2, r.snap_mask[w], t % 64};
+    return WaveView{r.snap.data() + (size_t)w * 64 * 4, r.snap_mask[w], t % 64};
 }
 
 template <class T>
@@ -363,30 +365,20 @@ inline hipemu_v4f __builtin_amdgcn_mfma_f32_16x16x32_bf16(hipemu_bf8 a, hipemu_b
     uint64_t aw[2], bw[2];
     memcpy(aw, &a, 16);
     memcpy(bw, &b, 16);
-    // (a WaveView points into the scheduler's snapshot, which the next exchange overwrites: copy the first half out)
-    uint64_t a0[64], b0[64];
-    unsigned lane;
-    {
-        auto v0 = hipemu::wave_exchange(aw[0], bw[0]);
-        lane = v0.lane;
-        for (unsigned l = 0; l < 64; l++) { a0[l] = v0.lo(l); b0[l] = v0.hi(l); }
-    }
-    auto v1 = hipemu::wave_exchange(aw[1], bw[1]);
+    auto v = hipemu::wave_exchange(aw[0], aw[1], bw[0], bw[1]);  // words 0-1: A elements 0-3 / 4-7, words 2-3: B
     auto bf_at = [](uint64_t word, unsigned e) {
         const uint32_t bits = (uint32_t)((word >> (16 * e)) & 0xffffu) << 16;
         float f;
         memcpy(&f, &bits, 4);
         return f;
     };
-    unsigned col = lane & 15;
+    unsigned col = v.lane & 15;
     for (int reg = 0; reg < 4; reg++) {
-        unsigned row = (lane >> 4) * 4 + reg;
+        unsigned row = (v.lane >> 4) * 4 + reg;
         float acc = c[reg];
         for (unsigned k = 0; k < 32; k++) {
             const unsigned g = k / 8, e = k % 8;
-            const float av = e < 4 ? bf_at(a0[g * 16 + row], e) : bf_at(v1.lo(g * 16 + row), e - 4);
-            const float bv = e < 4 ? bf_at(b0[g * 16 + col], e) : bf_at(v1.hi(g * 16 + col), e - 4);
-            acc = fmaf(av, bv, acc);
+            acc = fmaf(bf_at(v.word(g * 16 + row, e / 4), e % 4), bf_at(v.word(g * 16 + col, 2 + e / 4), e % 4), acc);
         }
         c[reg] = acc;
     }

@@ -127,6 +127,8 @@ def _signature(sk):
 
 def _pipeline(device, voxel):
     mi = ModelInference("unused", WEIGHTS, voxel_size=voxel, block_size=4, buffer_size=0.4, device=device)
+    if device.type == "cpu":  # end-to-end on the sanitizer build: the vector kernels (the matrix-core kernels cost a fiber rendezvous
+        mi.model.use_mfma = False  # per instruction there; they have their own tests in test_unet.py, and batch == single holds for either)
     sk = Skeletonizer(K=16, min_connection_length=0.02, minimum_graph_vertices=32, device=device)
     sk.block_threads = 128 if device.type == "cpu" else 0
     return Pipeline(AugmentationPipeline([CentreCloud()]), mi, sk, repair_skeletons=True, smooth_skeletons=True,

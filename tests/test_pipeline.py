@@ -21,6 +21,8 @@ WEIGHTS = ROOT / "smart_tree_amd" / "model" / "weights" / "noble-elevator-58.npz
 
 def _pipeline(device, voxel=0.03, **kw):
     mi = ModelInference("unused_model.pt", WEIGHTS, voxel_size=voxel, block_size=4, buffer_size=0.4, device=device)
+    if device.type == "cpu":  # end-to-end on the sanitizer build: the vector kernels (the matrix-core kernels cost a fiber rendezvous
+        mi.model.use_mfma = False  # per instruction there and have their own tests in test_unet.py)
     sk = Skeletonizer(K=16, min_connection_length=0.02, minimum_graph_vertices=32, device=device)
     sk.block_threads = 128 if device.type == "cpu" else 0
     return Pipeline(AugmentationPipeline([CentreCloud()]), mi, sk, device=device, **kw)

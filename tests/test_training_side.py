@@ -231,6 +231,7 @@ def test_evaluate_losses_is_forward_plus_losses(backend, tmp_path):
     loader = [batch_collate([ds[0], ds[1]])]
     w = random_state_dict(uo.load_weights(WEIGHTS / "noble-elevator-58.npz"), seed=1)
     net = Smart_Tree(w, device=backend)
+    net.use_mfma = backend.type != "cpu"  # (sanitizer build: the vector kernels; the matrix-core kernels have their tests in test_unet.py)
     fn = lambda p, t, m: L.compute_loss(p, t, m, L.L1Loss, L.cosine_similarity_loss, L.focal_loss, vector_class=0)
     got = L.evaluate_losses(loader, net, fn, device=backend)
     (inputs, targets), coords, mask, _ = loader[0]

@@ -18,6 +18,6 @@ def load(c):
 m, v = load('MfmaUtil'), load('VALUBusy')
 print('kernel, launches, MfmaUtil %, VALUBusy %   (per-dispatch values averaged; 16 clouds per launch)')
 for k in sorted(m, key=lambda k: -sum(m[k])):
-    if 'sparse_conv' in k or 'k_knn' in k or 'k_vx_pass' in k or 'k_sk_select' in k:
+    if 'sparse_conv' in k or 'k_knn' in k or 'k_vx_insert' in k or 'k_sk_select' in k:
         print('%-46s %4d  %6.1f  %6.1f' % (k[:46], len(m[k]), sum(m[k]) / len(m[k]), sum(v.get(k, [0])) / max(len(v.get(k, [0])), 1)))
 P
