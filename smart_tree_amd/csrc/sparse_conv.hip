@@ -623,6 +623,152 @@ __global__ void __launch_bounds__(MF_BLOCK) k_sparse_conv_mfma_f16(const st_h* _
     }
 }
 
+// The same on gfx950's 32-deep instruction (v_mfma_f32_16x16x32_f16, twice the rate per instruction of the 16-deep one) for
+// Cin % 32 == 0, with one or two row tiles per wavefront: lane (i, g) feeds channels 32c + 8g .. +7 of row i (ONE 16-byte load) and
+// of output column i; weights in the order wp[k][c][g][co][e] = W[k][32c + 8g + e][co] (half; sparse_ops.mfma_weight32).
+typedef _Float16 st_v8h __attribute__((ext_vector_type(8)));
+template <int CIN, int COUT, int RT>
+__global__ void __launch_bounds__(MF_BLOCK) k_sparse_conv_mfma_f16x(const st_h* __restrict__ x0, int c0, const st_h* __restrict__ x1,
+                                                                    const int32_t* __restrict__ nbr, int K, int64_t n_out, int64_t nstride,
+                                                                    const st_v8h* __restrict__ wp, const float* __restrict__ scale,
+                                                                    const float* __restrict__ shift, const st_h* __restrict__ residual,
+                                                                    int relu, st_h* __restrict__ y, const int32_t* __restrict__ row_order) {
+    constexpr int CT = COUT / 16, NC = CIN / 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i16 = lane & 15, g = lane >> 4;
+    const int64_t obase = ((int64_t)blockIdx.x * (MF_BLOCK / 64) + wave) * (16 * RT);
+    const int c1 = CIN - c0;
+    st_v4f acc[RT][CT];
+#pragma unroll
+    for (int t = 0; t < RT; t++)
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) acc[t][ct] = st_v4f{0.0f, 0.0f, 0.0f, 0.0f};
+    int64_t orow[RT];
+    uint32_t live[RT];
+#pragma unroll
+    for (int t = 0; t < RT; t++) {
+        const int64_t pos = obase + t * 16 + i16;
+        const int32_t entry = pos < n_out && row_order ? row_order[pos] : 0;
+        orow[t] = pos < n_out ? (row_order ? (int64_t)(entry & CONV_ROW_MASK) : pos) : -1;
+        live[t] = conv_live_offsets(entry, K);
+    }
+    for (int k = 0; k < K; k++) {
+        int idx[RT];
+        bool any = false;
+#pragma unroll
+        for (int t = 0; t < RT; t++) {
+            idx[t] = orow[t] >= 0 && ((live[t] >> k) & 1u) ? (nbr ? nbr[(int64_t)k * nstride + orow[t]] : (int)orow[t]) : -1;
+            any = any || idx[t] >= 0;
+        }
+        if (__ballot(any) == 0ull) continue;  // no voxel of this wave has a neighbour at offset k (wave-uniform)
+        const st_v8h* wk = wp + (int64_t)k * NC * 4 * COUT;
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const int ci = 32 * c + 8 * g;
+            st_v8h a[RT];
+#pragma unroll
+            for (int t = 0; t < RT; t++) {
+                a[t] = st_v8h{(st_h)0.0f, (st_h)0.0f, (st_h)0.0f, (st_h)0.0f, (st_h)0.0f, (st_h)0.0f, (st_h)0.0f, (st_h)0.0f};
+                if (idx[t] >= 0) {
+                    const st_h* row = ci < c0 ? x0 + (int64_t)idx[t] * c0 + ci : x1 + (int64_t)idx[t] * c1 + (ci - c0);
+                    a[t] = *reinterpret_cast<const st_v8h*>(row);
+                }
+            }
+#pragma unroll
+            for (int ct = 0; ct < CT; ct++) {
+                const st_v8h b = wk[((int64_t)c * 4 + g) * COUT + ct * 16 + i16];
+#pragma unroll
+                for (int t = 0; t < RT; t++) acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[t], b, acc[t][ct], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++) {
+        const int ch = ct * 16 + i16;
+        const float sc = scale ? scale[ch] : 1.0f, sh = scale ? shift[ch] : 0.0f;
+#pragma unroll
+        for (int t = 0; t < RT; t++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int64_t pos = obase + t * 16 + g * 4 + r;
+                if (pos >= n_out) continue;
+                const int64_t o = row_order ? (int64_t)(row_order[pos] & CONV_ROW_MASK) : pos;
+                float v = acc[t][ct][r];
+                if (scale) v = fmaf(v, sc, sh);
+                if (residual) v += (float)residual[o * COUT + ch];
+                if (relu) v = v > 0.0f ? v : 0.0f;
+                y[o * COUT + ch] = (st_h)v;
+            }
+    }
+}
+
+// ... and for 16 input channels two kernel offsets per instruction (lanes g = 0, 1: the row at offset 2j, g = 2, 3: at 2j + 1; B stacks
+// W_2j on W_2j+1, zeros behind an odd last offset: mfma_weight16_half lays the pairs out as 32-channel chunks).
+template <int COUT, int RT>
+__global__ void __launch_bounds__(MF_BLOCK) k_sparse_conv_mfma_f16x_c16(const st_h* __restrict__ x, const int32_t* __restrict__ nbr, int K,
+                                                                        int64_t n_out, int64_t nstride, const st_v8h* __restrict__ wp,
+                                                                        const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                        const st_h* __restrict__ residual, int relu, st_h* __restrict__ y,
+                                                                        const int32_t* __restrict__ row_order) {
+    constexpr int CT = COUT / 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i16 = lane & 15, g = lane >> 4;
+    const int64_t obase = ((int64_t)blockIdx.x * (MF_BLOCK / 64) + wave) * (16 * RT);
+    st_v4f acc[RT][CT];
+#pragma unroll
+    for (int t = 0; t < RT; t++)
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) acc[t][ct] = st_v4f{0.0f, 0.0f, 0.0f, 0.0f};
+    int64_t orow[RT];
+    uint32_t live[RT];
+#pragma unroll
+    for (int t = 0; t < RT; t++) {
+        const int64_t pos = obase + t * 16 + i16;
+        const int32_t entry = pos < n_out && row_order ? row_order[pos] : 0;
+        orow[t] = pos < n_out ? (row_order ? (int64_t)(entry & CONV_ROW_MASK) : pos) : -1;
+        live[t] = conv_live_offsets(entry, K);
+    }
+    const int ch = 8 * (g & 1);
+    for (int j = 0; 2 * j < K; j++) {
+        const int k = 2 * j + (g >> 1);  // this lane's offset of the pair
+        bool any = false;
+        st_v8h a[RT];
+#pragma unroll
+        for (int t = 0; t < RT; t++) {
+            const int idx = k < K && orow[t] >= 0 && ((live[t] >> k) & 1u) ? (nbr ? nbr[(int64_t)k * nstride + orow[t]] : (int)orow[t]) : -1;
+            any = any || idx >= 0;
+            a[t] = st_v8h{(st_h)0.0f, (st_h)0.0f, (st_h)0.0f, (st_h)0.0f, (st_h)0.0f, (st_h)0.0f, (st_h)0.0f, (st_h)0.0f};
+            if (idx >= 0) a[t] = *reinterpret_cast<const st_v8h*>(x + (int64_t)idx * 16 + ch);
+        }
+        if (__ballot(any) == 0ull) continue;  // neither offset of the pair has a neighbour in this wave (wave-uniform)
+        const st_v8h* wk = wp + (int64_t)j * 4 * COUT;
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) {
+            const st_v8h b = wk[(int64_t)g * COUT + ct * 16 + i16];
+#pragma unroll
+            for (int t = 0; t < RT; t++) acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[t], b, acc[t][ct], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++) {
+        const int co = ct * 16 + i16;
+        const float sc = scale ? scale[co] : 1.0f, sh = scale ? shift[co] : 0.0f;
+#pragma unroll
+        for (int t = 0; t < RT; t++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int64_t pos = obase + t * 16 + g * 4 + r;
+                if (pos >= n_out) continue;
+                const int64_t o = row_order ? (int64_t)(row_order[pos] & CONV_ROW_MASK) : pos;
+                float v = acc[t][ct][r];
+                if (scale) v = fmaf(v, sc, sh);
+                if (residual) v += (float)residual[o * COUT + co];
+                if (relu) v = v > 0.0f ? v : 0.0f;
+                y[o * COUT + co] = (st_h)v;
+            }
+    }
+}
+
 // Half-precision storage variants of the two calls above (config 5).  in_half / out_half say which side is fp16:
 //   both      -> the f16 matrix-core kernel; weights = the MFMA order as half, residual half, channels % 16 == 0
 //   exactly one -> the float32 kernel with a converting load or store (the 8 -> 16 "down" and 16 -> 8 "up" convs
@@ -641,6 +787,39 @@ extern "C" int st_sparse_conv_f16_fwd(const void* x0, int c0, const void* x1, in
     if (n_out <= 0) return ST_OK;
     if (in_half && out_half) {
         ST_REQUIRE(cin % 16 == 0 && cout % 16 == 0 && c0 % 16 == 0, "conv(f16): channels and concat split must be multiples of 16");
+        if (cin == 16 && c0 == cin && (cout == 16 || cout == 32)) {  // two kernel offsets per 32-deep instruction (weights: mfma_weight16_half)
+            const int rt16 = n_out >= (row_order == nullptr ? 56000 : 300000) ? 2 : 1;
+#define F16C_LAUNCH(CO, RT_)                                                                                                                  \
+    hipLaunchKernelGGL((k_sparse_conv_mfma_f16x_c16<CO, RT_>), dim3((unsigned)st_div_up(n_out, (MF_BLOCK / 64) * 16 * RT_)), dim3(MF_BLOCK), 0, \
+                       stream, (const st_h*)x0, nbr, K, n_out, nstride, (const st_v8h*)w, scale, shift, (const st_h*)residual, relu, (st_h*)y, row_order)
+            if (cout == 16) { if (rt16 == 2) F16C_LAUNCH(16, 2); else F16C_LAUNCH(16, 1); }
+            else { if (rt16 == 2) F16C_LAUNCH(32, 2); else F16C_LAUNCH(32, 1); }
+#undef F16C_LAUNCH
+            ST_CHECK_LAUNCH();
+            return ST_OK;
+        }
+        if (cin % 32 == 0) {  // 32-deep instruction; weights in the 32-channel operand order (mfma_weight32)
+            const int rt = n_out >= (row_order == nullptr ? 56000 : 300000) ? 2 : 1;
+#define F16X_LAUNCH(CI, CO, RT_)                                                                                                          \
+    hipLaunchKernelGGL((k_sparse_conv_mfma_f16x<CI, CO, RT_>), dim3((unsigned)st_div_up(n_out, (MF_BLOCK / 64) * 16 * RT_)), dim3(MF_BLOCK), 0, \
+                       stream, (const st_h*)x0, c0, (const st_h*)x1, nbr, K, n_out, nstride, (const st_v8h*)w, scale, shift,               \
+                       (const st_h*)residual, relu, (st_h*)y, row_order)
+#define F16X_CASE(CI, CO)                                                    \
+    if (cin == CI && cout == CO) {                                           \
+        if (rt == 2) F16X_LAUNCH(CI, CO, 2); else F16X_LAUNCH(CI, CO, 1);    \
+        ST_CHECK_LAUNCH();                                                   \
+        return ST_OK;                                                        \
+    }
+            F16X_CASE(32, 16)
+            F16X_CASE(32, 32)
+            F16X_CASE(32, 64)
+            F16X_CASE(64, 32)
+            F16X_CASE(64, 64)
+#undef F16X_CASE
+#undef F16X_LAUNCH
+            st_set_error("conv(f16): no kernel instance for cin=%d cout=%d", cin, cout);
+            return ST_ERR_INVALID;
+        }
         const int64_t blocks = st_div_up(n_out, (MF_BLOCK / 64) * 16);
 #define F16_CASE(CI, CO)                                                                                                        \
     if (cin == CI && cout == CO) {                                                                                              \

@@ -71,7 +71,7 @@ class Smart_Tree:
                     if self.w[name].shape[1] % 32 == 0 or (self.w[name].shape[0] == 27 and ops.b3_eligible(*self.w[name].shape[1:], self.w[name].shape[1])):
                         self.wq[name] = ops.b3_weight(self.w[name])
                     if self.fp16:
-                        self.wp16[name] = self.wp[name].half()
+                        self.wp16[name] = ops.mfma_weight16_half(self.w[name])
             elif key.endswith(".running_mean") and "_head." not in key:
                 p = key[: -len(".running_mean")]
                 self.bn[p] = _Affine(sd, p, self.device)

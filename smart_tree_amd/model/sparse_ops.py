@@ -205,6 +205,27 @@ def mfma_weight(w: torch.Tensor) -> torch.Tensor:
     return w.reshape(K, cin // 16, 4, 4, cout).permute(0, 1, 2, 4, 3).contiguous()
 
 
+def mfma_weight32(w: torch.Tensor) -> torch.Tensor:
+    """[K, Cin, Cout] (Cin % 32 == 0) -> the 32-deep operand order wp[K][Cin/32][4][Cout][8] = W[k][32c + 8g + e][co]: what
+    st_sparse_conv_f16_fwd expects (as half) for Cin % 32 == 0; 16-channel inputs keep mfma_weight's order."""
+    K, cin, cout = w.shape
+    return w.reshape(K, cin // 32, 4, 8, cout).permute(0, 1, 2, 4, 3).contiguous()
+
+
+def mfma_weight16_half(w: torch.Tensor) -> torch.Tensor:
+    """The half-precision matrix-core weights of a conv in the order its kernel reads them: 32-channel chunks (mfma_weight32);
+    16 input channels with 16 / 32 outputs: pairs of kernel offsets stacked into 32-channel chunks (zeros behind an odd last
+    offset); anything else: mfma_weight's 16-channel order."""
+    K, cin, cout = w.shape
+    if cin % 32 == 0:
+        return mfma_weight32(w).half()
+    if cin == 16 and cout in (16, 32):
+        if K % 2:
+            w = torch.cat([w, torch.zeros((1, cin, cout), dtype=w.dtype, device=w.device)], 0)
+        return mfma_weight32(w.reshape((K + 1) // 2, 32, cout)).half()
+    return mfma_weight(w).half()
+
+
 def mfma_eligible(cin: int, cout: int, c0: int) -> bool:
     return cin % 16 == 0 and cout % 16 == 0 and c0 % 16 == 0
 

@@ -384,6 +384,31 @@ inline hipemu_v4f __builtin_amdgcn_mfma_f32_16x16x32_bf16(hipemu_bf8 a, hipemu_b
     }
     return c;
 }
+// v_mfma_f32_16x16x32_f16 (gfx950): as the bf16 form, eight halves per lane.
+typedef _Float16 hipemu_v8h __attribute__((ext_vector_type(8)));
+inline hipemu_v4f __builtin_amdgcn_mfma_f32_16x16x32_f16(hipemu_v8h a, hipemu_v8h b, hipemu_v4f c, int, int, int) {
+    uint64_t aw[2], bw[2];
+    memcpy(aw, &a, 16);
+    memcpy(bw, &b, 16);
+    auto v = hipemu::wave_exchange(aw[0], aw[1], bw[0], bw[1]);
+    auto half_at = [](uint64_t word, unsigned e) {
+        uint16_t h = (uint16_t)(word >> (16 * e));
+        _Float16 f;
+        memcpy(&f, &h, 2);
+        return (float)f;
+    };
+    unsigned col = v.lane & 15;
+    for (int reg = 0; reg < 4; reg++) {
+        unsigned row = (v.lane >> 4) * 4 + reg;
+        float acc = c[reg];
+        for (unsigned k = 0; k < 32; k++) {
+            const unsigned g = k / 8, e = k % 8;
+            acc = fmaf(half_at(v.word(g * 16 + row, e / 4), e % 4), half_at(v.word(g * 16 + col, 2 + e / 4), e % 4), acc);
+        }
+        c[reg] = acc;
+    }
+    return c;
+}
 // v_perm_b32: byte i of the result = byte sel[i] of the 8-byte value {s0 (bytes 4-7), s1 (bytes 0-3)}; 0x0c = 0x00
 inline unsigned __builtin_amdgcn_perm(unsigned s0, unsigned s1, unsigned sel) {
     const uint64_t v = ((uint64_t)s0 << 32) | (uint64_t)s1;

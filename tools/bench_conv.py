@@ -74,7 +74,7 @@ for lvl in range(4):
                     line += f" | b3[rt{var}] {t_b:6.1f} us ({bytes_/t_b/1e3:7.1f} GB/s = {bytes_/t_b/1e3/80:4.1f} %) {flops/t_b/1e6:5.1f} TF e={errq:.0e}"
                 ops.B3_VARIANT = 0
             # half-precision storage (config 5): f16 matrix-core kernel, half the gather bytes
-            xh, wph = x.half(), wp.half()
+            xh, wph = x.half(), ops.mfma_weight16_half(w)
             bytes_h = pairs * (cin * 2 + 4) + nout * cout * 2
             t_h = timeit(lambda: ops.sparse_conv(xh, w, tbl, nout, out_half=True, wp16=wph, row_order=ro))
             yh = ops.sparse_conv(xh, w, tbl, nout, out_half=True, wp16=wph, row_order=ro).float()
