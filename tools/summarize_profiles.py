@@ -10,10 +10,11 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 out = ROOT / "profiles"
 out.mkdir(exist_ok=True)
 
-bench = ROOT / "gpurun_out" / f"{tag}_bench.json"
-if bench.exists():
-    line = [l for l in bench.read_text().splitlines() if l.startswith("{")][-1]
-    (out / f"{tag}_bench.json").write_text(json.dumps(json.loads(line), indent=1) + "\n")
+for name in (f"{tag}_bench.json", f"{tag}_bench_steps20.json"):  # the default command's line and the driver's (--steps 20)
+    bench = ROOT / "gpurun_out" / name
+    if bench.exists():
+        line = [l for l in bench.read_text().splitlines() if l.startswith("{")][-1]
+        (out / name).write_text(json.dumps(json.loads(line), indent=1) + "\n")
 
 stats = sorted(glob.glob(str(ROOT / "gpurun_out" / f"prof_{tag}" / "*" / "*kernel_stats.csv")), key=os.path.getmtime)
 if stats:
