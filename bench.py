@@ -483,13 +483,15 @@ def main():
     import gc
     gc.collect()
     gc.disable()  # a short run is ONE pass of ~33 ms: a collection of the launch threads' garbage inside it is a millisecond
-    cpu0 = os.times()
-    t0 = time.perf_counter()
-    run_steps(args.steps)  # returns when every worker has synchronised its streams
-    gather()  # inside the timed region: the skeletons of all ranks end up on rank 0
-    fence()
-    dt = time.perf_counter() - t0
-    gc.enable()
+    try:
+        cpu0 = os.times()
+        t0 = time.perf_counter()
+        run_steps(args.steps)  # returns when every worker has synchronised its streams
+        gather()  # inside the timed region: the skeletons of all ranks end up on rank 0
+        fence()
+        dt = time.perf_counter() - t0
+    finally:
+        gc.enable()
     cpu1 = os.times()
     host_cores_used = ((cpu1.user - cpu0.user) + (cpu1.system - cpu0.system)) / max(dt, 1e-9)  # this rank's process
     profiling.enable(False)
