@@ -359,3 +359,39 @@ def test_components_from_knn_tables_equal_components_from_the_edge_list(backend)
             assert ra == rb, v
             shorter += (rob[v + 1] - rob[v]) - (roa[v + 1] - roa[v])
         assert shorter > 0  # mutual pairs exist in a kNN graph
+
+
+def test_csr_from_tables_falls_back_to_the_edge_list_rows_without_the_larger_workspace(backend):
+    """st_component_csr_knn with only st_component_csr_workspace_bytes of scratch (or a K that is not a power of two) builds
+    st_component_csr's rows -- both copies of a mutual pair -- instead of failing (include/smarttree_hip.h)."""
+    from smart_tree_amd import _lib
+    from smart_tree_amd.skeleton import graph as G
+
+    rng = np.random.RandomState(11)
+    pts = (rng.rand(700, 3) * [0.4, 1.5, 0.4]).astype(np.float32)
+    rad = (0.05 + 0.1 * rng.rand(len(pts))).astype(np.float32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(backend)
+    g = G.nn_graph(t(pts), t(rad), K=16)
+    comps = g.connected_cugraph_components(minimum_vertices=8)  # the deduplicated rows (full workspace)
+    L = _lib.lib()
+    n, K, m = len(pts), 16, comps.vert_order.shape[0]
+    idxs, dists = g.idxs.contiguous(), g.dists.contiguous()
+    row_off = torch.empty(m + 1, dtype=torch.int32, device=backend)
+    col = torch.empty(2 * n * K, dtype=torch.int32, device=backend)
+    wgt = torch.empty(2 * n * K, dtype=torch.float32, device=backend)
+    ws = _lib.workspace(L.st_component_csr_workspace_bytes(m), backend)  # the SMALL workspace
+    assert ws.numel() < L.st_component_csr_knn_workspace_bytes(m, n, K)
+    _lib.check(L.st_component_csr_knn(_lib.ptr(idxs), _lib.ptr(dists), n, K, None, _lib.ptr(comps.new_id.contiguous()), m,
+                                      _lib.ptr(row_off), _lib.ptr(col), _lib.ptr(wgt), _lib.ptr(ws), ws.numel(), _lib.stream(backend)))
+    if backend.type == "cuda":
+        torch.cuda.synchronize()
+    ro_full, ro_dedup = row_off.cpu().numpy().astype(np.int64), comps.row_off.cpu().numpy().astype(np.int64)
+    cf, wf = col.cpu().tolist(), wgt.cpu().tolist()
+    cd, wd = comps.col.cpu().tolist(), comps.wgt.cpu().tolist()
+    longer = 0
+    for v in range(m):
+        full = sorted(zip(cf[ro_full[v]: ro_full[v + 1]], wf[ro_full[v]: ro_full[v + 1]]))
+        dedup = sorted(zip(cd[ro_dedup[v]: ro_dedup[v + 1]], wd[ro_dedup[v]: ro_dedup[v + 1]]))
+        assert sorted(set(full)) == dedup, v
+        longer += len(full) - len(dedup)
+    assert longer > 0  # the fallback keeps both copies of the mutual pairs
