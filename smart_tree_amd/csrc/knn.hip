@@ -288,7 +288,7 @@ __device__ __forceinline__ int knn_cut(unsigned long long* keys, int n, int lane
 // outlier_removal (filter.py:6-11: all nb_points slots filled).  No key list, no ranking, and the scan stops at the K-th hit;
 // idx_out is then a byte mask [n1].  The predicates are the search's own, so the mask equals idx[:, K-1] != -1.
 template <int K, bool COUNT = false>
-__global__ void __launch_bounds__(KNN_BLOCK) k_knn(const float* __restrict__ src, int64_t n1, const StGrid* __restrict__ g,
+__global__ void __launch_bounds__(KNN_BLOCK, 8) k_knn(const float* __restrict__ src, int64_t n1, const StGrid* __restrict__ g,
                                                    const uint32_t* __restrict__ cell_start, const float4* __restrict__ recs,
                                                    float r, const float* __restrict__ bound, int mode,
                                                    int64_t* __restrict__ idx_out, float* __restrict__ dist_out,
