@@ -16,24 +16,7 @@ void st_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* st_last_error(void) { return g_err; }
-// ST_SYNC_POLL=1 (developer knob): poll an event with sched_yield() instead of hipStreamSynchronize -- A/B for the
-// question whether blocking waits of several host threads get in each other's way inside the runtime.
-#ifndef ST_HIPEMU
-#include <sched.h>
-#endif
-void st_stream_wait(hipStream_t stream) {
-#ifndef ST_HIPEMU
-    static const bool poll = [] { const char* e = getenv("ST_SYNC_POLL"); return e && e[0] == '1'; }();
-    if (poll) {
-        static thread_local hipEvent_t ev = nullptr;
-        if (!ev) (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-        (void)hipEventRecord(ev, stream);
-        while (hipEventQuery(ev) == hipErrorNotReady) sched_yield();
-        return;
-    }
-#endif
-    (void)hipStreamSynchronize(stream);
-}
+void st_stream_wait(hipStream_t stream) { (void)hipStreamSynchronize(stream); }
 
 extern "C" int st_version(void) { return 100; }
 
