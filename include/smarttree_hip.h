@@ -99,9 +99,17 @@ int st_sparse_conv_b3_fwd(const float* x0, int c0, const float* x1, int cin, con
                           int cout, const float* scale, const float* shift, const float* residual, int relu, float* y,
                           const int32_t* row_order, void* stream, int64_t nbr_stride, int variant);
 /* Half-precision storage (BASELINE.json configs[4]; an extension -- the reference's inference, model/model_inference.py:49-100,
- * is float32): in_half && out_half -> x0 / x1 / residual / y are IEEE half, w is the MFMA order as half, Cin, Cout and the
- * concat split multiples of 16, v_mfma_f32_16x16x16_f16 with float32 accumulation; exactly one of them -> the float32
- * kernel with a converting load or store (w [K][cin][cout] float32, no residual, no concat). */
+ * is float32): in_half && out_half -> x0 / x1 / residual / y are IEEE half, Cin, Cout and the concat split multiples of 16,
+ * matrix cores with float32 accumulation; exactly one of them -> the float32 kernel with a converting load or store
+ * (w [K][cin][cout] float32, no residual, no concat).
+ * WEIGHT LAYOUT of the in_half && out_half form (half elements; smart_tree_amd/model/sparse_ops.py mfma_weight16_half builds it)
+ * depends on the channel counts -- a buffer in another order gives wrong results, the call cannot tell:
+ *   Cin % 32 == 0                      wp[K][Cin/32][4][Cout][8]      = W[k][32c + 8g + e][co]   (v_mfma_f32_16x16x32_f16)
+ *   Cin == 16 and Cout in {16, 32}     pairs of kernel offsets stacked into 32-channel chunks: W' = W padded with a zero offset to
+ *                                      an even K, viewed as [K/2][32][Cout], then the order above (K/2 chunks of 32 channels)
+ *   otherwise (Cin % 16 == 0)          wp[K][Cin/16][4][Cout][4]      = W[k][16c + 4g + s][co]   (v_mfma_f32_16x16x16_f16)
+ * st_sparse_conv_b3_fwd's wq follows the first two rules with three bf16 planes per chunk ([..][3][4][Cout][8]): Cin == 16 uses
+ * the stacked-pair chunks as well (sparse_ops.py b3_weight). */
 int st_sparse_conv_f16_fwd(const void* x0, int c0, const void* x1, int cin, const int32_t* nbr, int K, int64_t n_out,
                            const void* w, int cout, const float* scale, const float* shift, const void* residual, int relu,
                            void* y, int in_half, int out_half, const int32_t* row_order, void* stream, int64_t nbr_stride /*0 = n_out*/);

@@ -142,7 +142,7 @@ __device__ __forceinline__ void bk_set_bit(const BkLevel& L, int b, int z, int y
 }
 
 __global__ void __launch_bounds__(BK_BLOCK) k_bk_bits0(const int32_t* coords, int64_t n, BkLevel L, const BkState* st) {
-    if (st->fail & 2u) return;  // a coordinate outside the declared bounds: nothing below may index the tables with it
+    if (st->fail) return;  // a coordinate outside the declared bounds or a level over its capacity (slots >= slot_cap): nothing below may index the tables
     const int lim = 8 << L.mb;
     BK_LOOP(i, n) {
         const int4 c = reinterpret_cast<const int4*>(coords)[i];
@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(BK_BLOCK) k_bk_count(BkLevel L) {
 // order0[row] = input voxel, coords_sorted[row] = its coordinates
 __global__ void __launch_bounds__(BK_BLOCK) k_bk_order0(const int32_t* coords, int64_t n, BkLevel L, int32_t* order0, int32_t* sorted,
                                                         const BkState* st) {
-    if (st->fail & 2u) return;
+    if (st->fail) return;
     BK_LOOP(i, n) {
         const int4 c = reinterpret_cast<const int4*>(coords)[i];
         const int r = bk_lookup(L, c.x, c.y, c.z, c.w);
@@ -186,7 +186,7 @@ __global__ void __launch_bounds__(BK_BLOCK) k_bk_order0(const int32_t* coords, i
 // (up to four) mask words; the 27 ranks are popcounts.
 __global__ void __launch_bounds__(BK_BLOCK) k_bk_subm(const int32_t* coords, const int64_t* n_dev, int64_t cap, BkLevel L, int32_t* nbr,
                                                       const BkState* st) {
-    if (st->fail & 2u) return;
+    if (st->fail) return;
     const int64_t n = *n_dev < cap ? *n_dev : cap;
     const int lim = 8 << L.mb;
     BK_LOOP(o, n) {
@@ -244,7 +244,7 @@ __global__ void __launch_bounds__(BK_BLOCK) k_bk_subm(const int32_t* coords, con
 // PASS A: every occupied fine brick fb flags the coarse bricks it can reach: fb >> 1 per axis, and (fb >> 1) + 1 when fb is odd
 // and the brick has a voxel on its last layer of that axis (fine c = 8 fb + 7 -> o = 4 fb + 4).
 __global__ void __launch_bounds__(BK_BLOCK) k_bk_coarse_mark(BkLevel Lf, BkLevel Lc, const BkState* st, int level, const int32_t* blk_seg) {
-    if (st->fail & 2u) return;
+    if (st->fail) return;
     const int64_t ns = *Lf.n_slots < Lf.slot_cap ? *Lf.n_slots : Lf.slot_cap;
     const int nbc = 1 << Lc.mb;
     BK_LOOP(s, ns) {
@@ -277,7 +277,7 @@ __global__ void __launch_bounds__(BK_BLOCK) k_bk_coarse_mark(BkLevel Lf, BkLevel
 // (fine y, x from 16 cb - 1 to 16 cb + 15: the brick pair 2 cb, 2 cb + 1 and the last row / column of brick 2 cb - 1), then
 // "dilate by one and take every second bit" along x and y, then the clip at the cloud's extent.
 __global__ void __launch_bounds__(BK_BLOCK) k_bk_coarse_stencil(BkLevel Lf, BkLevel Lc, const BkState* st, int level, const int32_t* blk_seg) {
-    if (st->fail & 2u) return;
+    if (st->fail) return;
     const int64_t ns = *Lc.n_slots < Lc.slot_cap ? *Lc.n_slots : Lc.slot_cap;
     const int limf = 8 << Lf.mb, nbf = 1 << Lf.mb;
     BK_LOOP(idx, ns * 8) {
@@ -342,7 +342,7 @@ __global__ void __launch_bounds__(BK_BLOCK) k_bk_coarse_stencil(BkLevel Lf, BkLe
 
 // coordinates of a level enumerated from its masks (rows in the level's order)
 __global__ void __launch_bounds__(BK_BLOCK) k_bk_emit(BkLevel L, int32_t* coords, int64_t cap, BkState* st) {
-    if (st->fail & 2u) return;
+    if (st->fail) return;
     const int64_t ns = *L.n_slots < L.slot_cap ? *L.n_slots : L.slot_cap;
     BK_LOOP(idx, ns * 8) {
         const int64_t s = idx >> 3;
@@ -371,7 +371,7 @@ __global__ void __launch_bounds__(BK_BLOCK) k_bk_updown(const int32_t* coords, c
                                                         int level, const int32_t* blk_seg, const int64_t* m_dev, int64_t cap_c,
                                                         int32_t* nbr_up, int32_t* nbr_down, uint32_t* parity_count) {
     __shared__ uint32_t hist[8];
-    if (st->fail & 2u) return;
+    if (st->fail) return;
     if (threadIdx.x < 8) hist[threadIdx.x] = 0;
     __syncthreads();
     const int64_t n = *n_dev < cap_f ? *n_dev : cap_f;
@@ -429,7 +429,7 @@ __global__ void __launch_bounds__(BK_BLOCK) k_bk_updown(const int32_t* coords, c
 __global__ void __launch_bounds__(BK_BLOCK) k_bk_parity_order(const int32_t* coords, const int64_t* n_dev, int64_t cap, const uint32_t* count,
                                                               uint32_t* cursor, int32_t* order, const BkState* st) {
     __shared__ uint32_t hist[8], gbase[8], lcur[8];
-    if (st->fail & 2u) return;
+    if (st->fail) return;
     const int64_t n = *n_dev < cap ? *n_dev : cap;
     const int lane = threadIdx.x & 63;
     const int64_t per = (n + gridDim.x - 1) / gridDim.x, chunk = (per + BK_BLOCK - 1) / BK_BLOCK * BK_BLOCK;

@@ -37,18 +37,6 @@
 #define SK_ANC 64  // direct ancestors kept per vertex; longer walks hop 64 levels at a time (16 measured slower: every lane
                    // of a 1024-wide chunk hops j/SK_ANC times, so the chunk costs as much as its farthest lane)
 
-// Per-vertex state of the branch selection in ONE 16-byte record: a claimed point is stamped in all three words, and as
-// separate arrays that was one scattered cache line each per point (rocprofv3 PMC, round 1: 13x the algorithmic bytes).
-// The speculation marks of a round are NOT here (rounds 1-2 kept a mark word per point that every candidate of every
-// round set and wiped: 20x the algorithmic bytes in HBM traffic): they live in an LDS table of the few points a round's
-// validation looks at (k_sk_select, "watch table").
-struct SkPt {
-    float alloc;    // sample_tree's `distances` (-1 once allocated)
-    unsigned term;  // termination set
-    int branch;     // branch id of the point (-1: none); copied to `branch_of` when the selection is done
-    unsigned pad;
-};
-
 struct SkArgs {
     int C;
     int64_t m;
@@ -80,7 +68,7 @@ struct SkArgs {
     unsigned* stamp;  // SSSP: queued-in-round marker; preds: resolution round; tree distance: visited
     unsigned* q0;
     unsigned* q1;
-    SkPt* pt;         // [m] selection state (see SkPt)
+    unsigned* term_bits;  // sample_tree's termination set, one bit per vertex; component c owns the words from (comp_off[c] >> 5) + c
     float4* pr;       // [m] (x, y, z, radius) of every vertex in one 16-byte record (k_sk_lift_init): one gather instead of two
     unsigned long long* best;  // claim race: (d2 bits << 32) | path position
     unsigned* touched;
@@ -102,7 +90,6 @@ struct SkArgs {
     int* s_wide;     // this launch's path is long: the chip-wide claim kernel handles it
     const unsigned* order;  // [m] vertices of each component by distance descending (ties: index ascending)
     const float* order_init;  // [m] initial distance of order[j] (<= 0 marks the tail of never-selectable vertices)
-    const int* pos;           // [m] inverse of `order`, component-local position
     // claim grid: workgroup b works for component blk_comp[b], as slice (b - blk_first[c]) of blk_count[c]
     const int* blk_comp;
     const int* blk_first;
@@ -112,6 +99,7 @@ struct SkArgs {
     int iters_per_launch;
     int wave_work;       // select: candidate points x path vertices of one speculative branch (beyond: whole workgroup)
     int local_items;     // select: (path vertex, cell row) pairs one workgroup claims path-centric by itself
+    int late_cand;       // select: candidate points the replay wavefront evaluates by itself (more: the round ends at that entry)
     int long_mode;       // select: paths that fit the LDS path buffer but are too much work for the plain point-centric claim are
                          // claimed by the workgroup itself with chunk-pruned distance tests (below), not handed to k_sk_claim
     long long* ticks;  // optional developer aid: per-phase wall_clock64 sums of k_sk_select (tuning[15])
@@ -125,22 +113,13 @@ __device__ __forceinline__ float ld(const float* p) { return __uint_as_float(ld(
 __device__ __forceinline__ unsigned ld_wg(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ int ld_wg(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ float ld_wg(const float* p) { return __uint_as_float(ld_wg((const unsigned*)p)); }
-// Workgroup-scope read-modify-writes.  The selection state of a component (SkPt records, marks) is touched by ONE workgroup
+// Workgroup-scope read-modify-writes.  The selection state of a component (termination bits, branch ids) is touched by ONE workgroup
 // per launch: its atomics need not be coherent across the eight XCDs' L2s.  A device-scope atomic is executed on the memory
 // side of the fabric (calibration: 32 bytes of WRITE_SIZE each, ~12 G/s) and every agent-scope load goes there too; at
 // workgroup scope both stay in this XCD's L2.  Visibility to the NEXT launch comes with the kernel boundary.
 __device__ __forceinline__ void wg_or(unsigned* p, unsigned v) { (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void wg_and(unsigned* p, unsigned v) { (void)__hip_atomic_fetch_and(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void wg_max(int* p, int v) { (void)__hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-
-// allocation / termination / branch-id stamp of a point (path.py:112-122,135-136) as ONE store where the branch id is simply
-// written (8 or 16 bytes of the point's record), or an 8-byte store + a max where several slots of a round may stamp it
-__device__ __forceinline__ void sk_stamp(SkPt* pt, int id, bool several) {
-    const unsigned a = __float_as_uint(-1.0f);
-    if (id >= 0 && !several) { *reinterpret_cast<uint4*>(pt) = make_uint4(a, 1u, (unsigned)id, 0u); return; }
-    *reinterpret_cast<uint2*>(pt) = make_uint2(a, 1u);
-    if (id >= 0) wg_max(&pt->branch, id);
-}
 
 // workgroup-wide max of a 64-bit key; every thread must call; lds needs SK_MAX_WAVES words
 __device__ __forceinline__ unsigned long long block_max_u64(unsigned long long v, unsigned long long* lds) {
@@ -422,35 +401,32 @@ __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_td_round(SkArgs A, int r) 
 }
 
 // ----------------------------------------------------------------------------- sample_tree ---
-__global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_lift_init(SkArgs A, const float* distances) {
+__global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_lift_init(SkArgs A) {
     SK_VERTEX_LOOP(v) {
-        const int p = A.pred[v];
-        A.anc[v * SK_ANC] = p;
-        A.pt[v].alloc = p > 0 ? distances[v] : -1.0f;  // path.py:71-72
-        A.pt[v].term = 0u;
-        A.pt[v].branch = -1;
+        A.anc[v * SK_ANC] = A.pred[v];
+        A.branch_of[v] = -1;
         A.best[v] = SK_EMPTY64;
-        A.pt[v].pad = 0u;
         A.pr[v] = make_float4(A.pts[3 * v], A.pts[3 * v + 1], A.pts[3 * v + 2], A.rad[v]);
     }
     if (blockIdx.x == 0)
         for (int c = threadIdx.x; c < A.C; c += blockDim.x) { A.s_done[c] = 0; A.s_nb[c] = 0; A.s_total[c] = 0; A.s_len[c] = 0; A.s_cursor[c] = 0; A.s_wide[c] = 0; }
 }
 
-// sort keys: distance descending (masked vertices, alloc = -1, go last); second pass groups by component
-__global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_sort_keys(SkArgs A, uint32_t* keys, uint32_t* vals, int pass) {
+// sample_tree's initial `distances` (path.py:71-72): vertices whose predecessor is not > 0 are never selectable
+__device__ __forceinline__ float sk_initial_distance(const SkArgs& A, const float* distances, int64_t v) {
+    return A.pred[v] > 0 ? distances[v] : -1.0f;
+}
+
+// sort keys: distance descending (masked vertices, -1, go last); second pass groups by component
+__global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_sort_keys(SkArgs A, const float* distances, uint32_t* keys, uint32_t* vals, int pass) {
     SK_VERTEX_LOOP(v) {
-        if (pass == 0) { keys[v] = ~st_f2ord(A.pt[v].alloc); vals[v] = (uint32_t)v; }
+        if (pass == 0) { keys[v] = ~st_f2ord(sk_initial_distance(A, distances, v)); vals[v] = (uint32_t)v; }
         else keys[v] = (uint32_t)A.comp_of[vals[v]];
     }
 }
 
-__global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_order_init(SkArgs A, float* order_init, int* pos) {
-    SK_VERTEX_LOOP(j) {
-        const unsigned v = A.order[j];
-        order_init[j] = A.pt[v].alloc;
-        pos[v] = (int)(j - A.comp_off[A.comp_of[v]]);
-    }
+__global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_order_init(SkArgs A, const float* distances, float* order_init) {
+    SK_VERTEX_LOOP(j) order_init[j] = sk_initial_distance(A, distances, A.order[j]);
 }
 
 // Ancestor table: anc[v*SK_ANC + k] = (k+1)-th ancestor of v (component-local id, -1 past the root).
@@ -534,60 +510,90 @@ __device__ __forceinline__ bool sk_claim_items(const SkArgs& A, int c, int base,
     return false;
 }
 
-// select: one workgroup per component, up to SK_ITERS_PER_LAUNCH branches per launch.  Per branch:
-// advance the cursor over the distance-sorted vertices to the farthest unallocated one (path.py:92 --
-// nothing is ever re-scanned), trace its route through the ancestor table, record the branch; a
-// short path is claimed and finished right here (state, path and touched list stay in LDS), a long
-// one is left to the chip-wide k_sk_claim and finished at the head of the next launch.
-#define SK_SMALL_WORK (1 << 18)  // candidate points x path vertices one workgroup takes on itself
+// ------------------------------------------------------------------------------ select ---
+// sample_tree (path.py:49-140) is a sequential greedy loop: take the farthest unallocated vertex, walk towards the root
+// until an allocated ("terminated") vertex, claim the points within the path's radii, repeat.  Two facts make it parallel:
+//   (1) the claims of a branch are a pure function of its PATH (select_path_points, path.py:19-46: geometry only), and a
+//       path is the first `len` ancestors of its tip -- state enters only through `len` (where the walk meets the
+//       termination set), through "is the tip still unallocated" and through the parent id read at the walk's end;
+//   (2) branches far apart do not touch each other's walks.
+// So one workgroup per component runs the loop literally -- one wavefront REPLAYS it in order against the termination set,
+// kept as a bitmap in LDS -- and the expensive part, the claims, comes from a cache that the whole workgroup fills
+// speculatively: each round the first SK_ENT unallocated vertices of the distance order are looked at, up to one per
+// wavefront (those not predicted to be swallowed by an earlier one) is walked against the state at the start of the
+// round, and the candidates of all those paths are dealt over the workgroup (each finds its nearest path vertex in LDS).
+// The replay then takes the entries in order: dead (claimed meanwhile) -> skip; cached path still the true path (none of
+// its vertices terminated since) -> commit the cached claims; otherwise (walk cut short by an earlier branch of this
+// round, or no cache entry: a tip predicted to be swallowed that survived) the replay wavefront evaluates the branch
+// itself on the spot when it is small, or ends the round there (the entry then heads the next round, where a path too
+// long or too heavy for one wavefront is worked on by the whole workgroup).  Whatever the speculation guessed, the
+// result is the sequential loop's: the cache is only ever used for the path the loop would have walked.
+#define SK_SMALL_WORK (1 << 18)  // candidate points x path vertices one workgroup takes on point-centric, unpruned
 #define SK_ITERS_PER_LAUNCH 32
 #define SK_LPATH 1024
 #define SK_CHUNK 32  // path vertices per bounding box in the long-path claim
 
-// on-path test of the claimed points (path.py:35-40) + allocation / termination / branch-id stamps (:112-122,135-136)
-__device__ __forceinline__ void sk_finish_branch(const SkArgs& A, int base, int len, int id, const int* path, bool path_in_lds,
-                                                 const unsigned* touched, bool touched_in_lds, unsigned nt) {
+// The termination set of a component (sample_tree's `termination_pts`; `distances == -1` is the same set plus the vertices
+// masked at the start, which sit at the tail of the distance order and are never looked at): one bit per vertex.  In LDS
+// while the workgroup runs (loaded from / flushed to the component's words of A.term_bits at the launch boundaries), in
+// global memory for a component too large for the LDS words.
+#define SK_BM_WORDS 8192  // 262,144 vertices
+struct SkBm {
+    unsigned* lds;
+    unsigned* glb;
+    bool in_lds;
+};
+__device__ __forceinline__ bool bm_test(const SkBm& B, int v) {
+    const unsigned w = B.in_lds ? B.lds[v >> 5] : ld_wg(&B.glb[v >> 5]);
+    return (w >> (v & 31)) & 1u;
+}
+__device__ __forceinline__ void bm_set(const SkBm& B, int v) {
+    if (B.in_lds) atomicOr(&B.lds[v >> 5], 1u << (v & 31));
+    else wg_or(&B.glb[v >> 5], 1u << (v & 31));
+}
+// allocation / termination / branch-id stamp of a point (path.py:112-122,135-136).  branch_ids keeps the LAST writer; ids
+// grow with the order of the loop, so "last" is a max -- commutative, which lets the lanes of a commit race.
+__device__ __forceinline__ void sk_mark(const SkArgs& A, const SkBm& B, int base, int p, int id) {
+    bm_set(B, p);
+    if (id >= 0) wg_max(&A.branch_of[base + p], id);
+}
+
+// on-path test of the points a chip-wide claim touched (path.py:35-40) + their stamps
+__device__ __forceinline__ void sk_finish_branch(const SkArgs& A, const SkBm& B, int base, int len, int id, const int* path,
+                                                 bool path_in_lds, const unsigned* touched, bool touched_in_lds, unsigned nt) {
     for (unsigned t = threadIdx.x; t < nt; t += blockDim.x) {
         const int p = (int)(touched_in_lds ? touched[t] : ld(&touched[t]));
         const unsigned long long pk = ld(&A.best[base + p]);
         A.best[base + p] = SK_EMPTY64;
         const float d2 = __uint_as_float((unsigned)(pk >> 32));
         const int qi = (int)(pk & 0xffffffffu);
-        if (sqrtf(d2) < A.rad[base + (path_in_lds ? path[qi] : ld(&path[qi]))]) {
-            sk_stamp(&A.pt[base + p], id, false);
-        }
+        if (sqrtf(d2) < A.rad[base + (path_in_lds ? path[qi] : ld(&path[qi]))]) sk_mark(A, B, base, p, id);
     }
-    for (int qi = threadIdx.x; qi < len; qi += blockDim.x) {
-        const int v = path_in_lds ? path[qi] : ld(&path[qi]);
-        sk_stamp(&A.pt[base + v], id, false);
-    }
-    __syncthreads();  // stores drained (vmcnt) before anyone re-reads through L2
+    for (int qi = threadIdx.x; qi < len; qi += blockDim.x) sk_mark(A, B, base, path_in_lds ? path[qi] : ld(&path[qi]), id);
+    __syncthreads();
 }
 
 #define SK_TICK(i) do { if (A.ticks && tid == 0) { const long long now_ = wall_clock64(); tk[i] += now_ - t_last; t_last = now_; } } while (0)
 #define SK_TICK_FLUSH() do { if (A.ticks && tid == 0) for (int i_ = 0; i_ < 8; i_++) A.ticks[i_] += tk[i_]; } while (0)
 
 // ---- wavefront helpers (all 64 lanes must call) ----
-__device__ __forceinline__ float wave_readlane_f(float v, int src) { return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), src)); }
-__device__ __forceinline__ int wave_min_i(int v) { for (int d = 32; d > 0; d >>= 1) { const int o = __shfl_xor(v, d); v = o < v ? o : v; } return v; }
-__device__ __forceinline__ int wave_max_i(int v) { for (int d = 32; d > 0; d >>= 1) { const int o = __shfl_xor(v, d); v = o > v ? o : v; } return v; }
-__device__ __forceinline__ unsigned wave_max_u(unsigned v) { for (int d = 32; d > 0; d >>= 1) { const unsigned o = __shfl_xor(v, d); v = o > v ? o : v; } return v; }
-__device__ __forceinline__ unsigned wave_or_u(unsigned v) { for (int d = 32; d > 0; d >>= 1) v |= __shfl_xor(v, d); return v; }
 __device__ __forceinline__ unsigned wave_incl_scan_u(unsigned v, int lane) {
     for (int d = 1; d < 64; d <<= 1) { const unsigned o = __shfl_up(v, (unsigned)d); if (lane >= d) v += o; }
     return v;
 }
 
 // LDS of k_sk_select.  Two modes share the space: `one` = a single branch worked on by the whole workgroup
-// (paths up to SK_LPATH vertices), `slot[]` = one speculative branch per wavefront (short paths).
-#define SK_WSLOTS 16   // = SK_MAX_WAVES
-#define SK_WENT 32     // window entries looked at per round (those predicted to be swallowed get no slot)
-#define SK_WPATH 64    // a speculative walk is ONE row of the ancestor table
-#define SK_WROWS 256   // (x, y) cell rows around a speculative path: up to four per lane
-#define SK_WAVE_WORK (1 << 20)  // candidate points x path vertices per speculative branch
+// (paths up to SK_LPATH vertices), `slot[]` = one cached branch per wavefront (short paths) + one for the replay's own.
+#define SK_NSLOT 16    // = SK_MAX_WAVES: cached evaluations per round
+#define SK_LATE SK_NSLOT  // index of the slot the replay wavefront evaluates into
+#define SK_ENT 256     // unallocated vertices of the distance order a round looks at
+#define SK_WPATH 64    // a cached walk is ONE row of the ancestor table
+#define SK_WROWS 256   // (x, y) cell rows around a cached path: up to four per lane
+#define SK_WAVE_WORK (1 << 20)  // candidate points x path vertices per cached branch
 #define SK_WAVE_CAND 16384
 #define SK_ROUND_ITEMS 32       // candidates per thread and round
-#define SK_CL_KEEP 4            // claimed points a thread remembers in LDS; further ones are found again through a bit mask
+#define SK_CL_CAP 512           // claimed points a cache entry holds (more: the whole workgroup evaluates the entry)
+#define SK_LATE_CAND 1024       // candidates the replay wavefront takes on by itself
 struct SkSelOne {
     int lpath[SK_LPATH];
     float lpx[SK_LPATH], lpy[SK_LPATH], lpz[SK_LPATH], lpr[SK_LPATH];
@@ -602,7 +608,7 @@ struct SkSelSlot {
 };
 union SkSelLds {
     SkSelOne one;
-    SkSelSlot slot[SK_WSLOTS];
+    SkSelSlot slot[SK_NSLOT + 1];
 };
 
 // row r with row_off[r] <= t < row_off[r+1]
@@ -612,129 +618,212 @@ __device__ __forceinline__ int sk_find_row(const uint32_t* row_off, int nrows, u
     return lo;
 }
 
-// Watch table of a speculative round (LDS, open addressing): the points whose marks the replay will ask for -- the tips of
-// the round's entries, every slot's walk and the vertex its parent id is read from: at most SK_WENT + SK_WSLOTS x
-// (SK_WPATH + 1) keys, so the table (SK_WT slots) never fills.  A claim of point p by slot s ORs bit s into p's word IF p is
-// watched; nobody ever asks about the other claimed points.
-#define SK_WT 4096
-#define SK_WT_EMPTY 0xffffffffu
-__device__ __forceinline__ unsigned sk_wt_hash(unsigned key) { return (key * 0x9E3779B1u) >> 20; }  // 12 bits
-__device__ __forceinline__ void sk_wt_insert(unsigned* wkey, unsigned* wmask, unsigned key, unsigned bits) {
-    for (unsigned h = sk_wt_hash(key);; h = (h + 1u) & (SK_WT - 1u)) {
-        const unsigned old = atomicCAS(&wkey[h], SK_WT_EMPTY, key);
-        if (old == SK_WT_EMPTY || old == key) { if (bits) atomicOr(&wmask[h], bits); return; }
+// what a walk leaves behind for the claim pass / the replay (LDS, one set per slot)
+struct SkSlotInfo {
+    int len, term, parent, nrows, ncand, big;
+    float rp;
+};
+
+// One wavefront walks `tip` against the termination set as it is NOW (trace_route, path.py:9-16: lane j inspects the j-th
+// ancestor; the first terminated one, or the step past the root, ends the walk), then gathers position / radius of its
+// path into slot S, the (x, y) rows of grid cells around it and how many candidate points they hold.  All 64 lanes call.
+// The parent id is the value at the time of the walk: for a cached walk that is the start of the round (the replay corrects
+// it from tv_hit), for the replay's own evaluation it is final (the caller fences this wavefront's stamps first).
+__device__ __forceinline__ SkSlotInfo sk_walk(const SkArgs& A, const SkBm& B, SkSelSlot& S, int base, int n, int tip, int xoff,
+                                              int W, int lane) {
+    const StGrid* g = A.grid;
+    SkSlotInfo I;
+    const int node = lane == 0 ? tip : A.anc[(int64_t)(base + tip) * SK_ANC + lane - 1];
+    const bool end = node < 0 || bm_test(B, node);
+    const unsigned long long eb = __ballot(end);
+    I.big = eb == 0ull;
+    I.len = 0; I.term = -1; I.nrows = 0; I.ncand = 0; I.parent = -1; I.rp = 0.0f;
+    if (I.big) return I;
+    const int len = __ffsll(eb) - 1;
+    I.len = len;
+    I.term = __shfl(node, len);
+    const int qi = len - 1 - lane;  // walk order -> root side first
+    if (lane < 3) { S.lo[lane] = 0x7fffffff; S.hi[lane] = (int)0x80000000; }
+    if (lane == 3) S.rk = 0u;
+    __builtin_amdgcn_wave_barrier();
+    // the parent id is read BEFORE anything is stamped (path.py:128-136); termination -1 reads branch_ids[-1] = the last
+    // vertex (quirk kept)
+    if (len >= 2) {
+        // (uniform address: one request; agent scope = read where the stamps' atomics act, never a stale line of this CU's L1)
+        I.parent = ld(&A.branch_of[base + (I.term < 0 ? n - 1 : I.term)]);
     }
-}
-__device__ __forceinline__ int sk_wt_find(const unsigned* wkey, unsigned key) {
-    for (unsigned h = sk_wt_hash(key);; h = (h + 1u) & (SK_WT - 1u)) {
-        const unsigned k = wkey[h];
-        if (k == key) return (int)h;
-        if (k == SK_WT_EMPTY) return -1;
+    if (lane < len) {
+        const float4 q4 = A.pr[base + node];
+        S.path[qi] = node; S.p[qi] = q4;
+        const int cx = (int)floorf((q4.x - g->lo[0]) / g->cell), cy = (int)floorf((q4.y - g->lo[1]) / g->cell),
+                  cz = (int)floorf((q4.z - g->lo[2]) / g->cell);
+        atomicMax(&S.rk, st_f2ord(q4.w));  // path.py:31
+        atomicMin(&S.lo[0], cx); atomicMin(&S.lo[1], cy); atomicMin(&S.lo[2], cz);
+        atomicMax(&S.hi[0], cx); atomicMax(&S.hi[1], cy); atomicMax(&S.hi[2], cz);
     }
+    __builtin_amdgcn_wave_barrier();
+    const float rp = st_ord2f(S.rk);
+    I.rp = rp;
+    int reach = rp > 0.0f ? (int)ceilf(rp / g->cell) : 0;
+    if (reach < 1) reach = 1;
+    const int x0 = st_max(S.lo[0] - reach, 0), x1 = st_min(S.hi[0] + reach, g->seg_dim0 - 1);
+    const int y0 = st_max(S.lo[1] - reach, 0), y1 = st_min(S.hi[1] + reach, g->dim[1] - 1);
+    const int z0 = st_max(S.lo[2] - reach, 0), z1 = st_min(S.hi[2] + reach, g->dim[2] - 1);
+    const int nx = x1 - x0 + 1, ny = y1 - y0 + 1;
+    const int nrows = (nx > 0 && ny > 0 && z0 <= z1) ? nx * ny : 0;
+    I.nrows = nrows;
+    I.big = nrows > SK_WROWS;
+    if (I.big) return I;
+    uint32_t cnt[SK_WROWS / 64], first[SK_WROWS / 64];
+#pragma unroll
+    for (int ch = 0; ch < SK_WROWS / 64; ch++) {  // all loads first, then the scans
+        const int rr = ch * 64 + lane;
+        cnt[ch] = 0u; first[ch] = 0u;
+        if (rr < nrows) {
+            const int64_t row = ((int64_t)(xoff + x0 + rr / ny) * g->dim[1] + (y0 + rr % ny)) * g->dim[2];
+            first[ch] = A.cell_start[row + z0];
+            cnt[ch] = A.cell_start[row + z1 + 1] - first[ch];
+        }
+    }
+    uint32_t run = 0u;
+#pragma unroll
+    for (int ch = 0; ch < SK_WROWS / 64; ch++) {
+        if (ch * 64 >= nrows) break;  // wave-uniform
+        const uint32_t inc = wave_incl_scan_u(cnt[ch], lane);
+        const int rr = ch * 64 + lane;
+        if (rr < nrows) { S.row_off[rr] = run + inc - cnt[ch]; S.row_first[rr] = first[ch]; }
+        run += __shfl(inc, 63);
+    }
+    I.ncand = (int)run;
+    if (lane == 0) S.row_off[nrows] = run;
+    __builtin_amdgcn_wave_barrier();
+    I.big = I.ncand > SK_WAVE_CAND || I.ncand > SK_ROUND_ITEMS * W || (int64_t)I.ncand * len > A.wave_work;
+    return I;
 }
 
-// select: one workgroup per component.  sample_tree (path.py:49-140) is a sequential greedy loop -- take the
-// farthest unallocated vertex, walk to the skeleton, claim the points within the path's radius -- but
-// branches far apart do not interact, so each ROUND speculates: wavefront s takes the s-th farthest
-// unallocated vertex, walks it and marks (bit s of the point's watch-table word) every watched point its branch would allocate, all
-// against the state at the start of the round.  A scan in order then replays the sequential semantics from
-// the marks: a tip already marked by an accepted earlier slot would never have been selected (skipped); a
-// walk (or the vertex the parent id is read from) touched by an accepted earlier slot would have come out
-// differently -- the round stops there and the rest is retried next round; everything else is exactly what the
-// sequential loop produces and is committed (ids / offsets by prefix over the accepted slots;
-// branch_of = max id = last writer).  Slot 0 is always accepted, so every round makes progress.  A path
-// too long for one wavefront is worked on by the whole workgroup (`one` mode); one too long even for that
-// is handed to the chip-wide k_sk_claim and finished at the head of the next launch.
+// nearest path vertex of one candidate point (select_path_points, path.py:19-46): ascending scan, ties keep the first path
+// vertex; four path vertices per step so that their LDS reads are in flight together.  Returns "claimed".
+__device__ __forceinline__ bool sk_on_path(const SkSelSlot& S, int len, float rp, const float4& r4) {
+    float bd2 = __uint_as_float(0x7f800000u), bw = 0.0f;
+#define SK_NEAREST(q)                                                              \
+    {                                                                              \
+        const float dx = r4.x - (q).x, dy = r4.y - (q).y, dz = r4.z - (q).z;       \
+        float d2 = dx * dx;                                                        \
+        float tt = dy * dy;                                                        \
+        d2 = d2 + tt;                                                              \
+        tt = dz * dz;                                                              \
+        d2 = d2 + tt;                                                              \
+        if (d2 < bd2) { bd2 = d2; bw = (q).w; }                                    \
+    }
+    int qi = 0;
+    for (; qi + 4 <= len; qi += 4) {
+        const float4 q0 = S.p[qi], q1 = S.p[qi + 1], q2 = S.p[qi + 2], q3 = S.p[qi + 3];
+        SK_NEAREST(q0) SK_NEAREST(q1) SK_NEAREST(q2) SK_NEAREST(q3)
+    }
+    for (; qi < len; qi++) {
+        const float4 q = S.p[qi];
+        SK_NEAREST(q)
+    }
+#undef SK_NEAREST
+    return bd2 < rp * rp && sqrtf(bd2) < bw;  // path.py:35-40
+}
+
 __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
     long long t_last = A.ticks ? wall_clock64() : 0;
     __shared__ long long tk[8];  // phase timers (developer aid), touched by thread 0 only
     if (A.ticks && threadIdx.x == 0) for (int i_ = 0; i_ < 8; i_++) tk[i_] = 0;
     __shared__ unsigned long long s_red[SK_MAX_WAVES];
     __shared__ SkSelLds L;
-    __shared__ unsigned cl_list[SK_CL_KEEP][1024];  // claimed points of this round, SK_CL_KEEP private entries per thread
+    __shared__ unsigned bm_words[SK_BM_WORDS];           // termination set (see SkBm)
+    __shared__ unsigned cl[SK_NSLOT][SK_CL_CAP], cl_n[SK_NSLOT];  // the claimed points of every cached branch
     __shared__ uint32_t s_scan[SK_MAX_WAVES + 1];
-    __shared__ unsigned wt_key[SK_WT], wt_mask[SK_WT];  // watch table (see above)
     __shared__ float cb_lo[3][SK_LPATH / SK_CHUNK], cb_hi[3][SK_LPATH / SK_CHUNK];  // chunk boxes of a long path
-    __shared__ unsigned char win_live[1024];  // candidate window: "still unallocated" flag of order[win_base + lane]
     __shared__ int s_lo[3], s_hi[3];
     __shared__ int s_term;
-    __shared__ int w_cnt[SK_WSLOTS], w_tail[SK_WSLOTS], cand_v[SK_WENT];  // the round's entries: first live window vertices
-    __shared__ float4 cand_p[SK_WENT];
-    __shared__ int sl_ent[SK_WSLOTS], s_nb2, s_tot2;
-    __shared__ unsigned s_alive;
-    __shared__ int sl_len[SK_WSLOTS], sl_term[SK_WSLOTS], sl_parent[SK_WSLOTS], sl_nrows[SK_WSLOTS], sl_ncand[SK_WSLOTS],
-        sl_big[SK_WSLOTS], sl_id[SK_WSLOTS], sl_off[SK_WSLOTS];
-    __shared__ float sl_rp[SK_WSLOTS];
-    __shared__ unsigned sl_walkm[SK_WSLOTS];
+    __shared__ int w_cnt[SK_MAX_WAVES], w_tail[SK_MAX_WAVES];
+    __shared__ int ent_v[SK_ENT];            // the round's entries: the first unallocated vertices of the window, in order
+    __shared__ float4 ent_p[SK_ENT];         // ... their position and radius
+    __shared__ signed char ent_slot[SK_ENT];  // ... their cache slot (-1: none)
+    __shared__ int slot_ent[SK_NSLOT], s_nc, s_ne, s_nb2, s_tot2;
+    __shared__ SkSlotInfo sl[SK_NSLOT + 1];
+    __shared__ int tvs[SK_NSLOT];        // the vertex each cached branch reads its parent id from (-2: none)
+    __shared__ unsigned tv_hit[SK_NSLOT];  // bit s: cached branch s stamps that vertex
     const int c = blockIdx.x, tid = threadIdx.x, W = (int)blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nw = (W + 63) >> 6;
     if (A.s_done[c]) return;
     const int base = A.comp_off[c], n = A.comp_off[c + 1] - base;
     const unsigned* order = A.order + base;
-    const int* pos = A.pos + base;
     unsigned* tmp = A.q0 + base;
     const float4* __restrict__ recs = A.recs;
     const StGrid* g = A.grid;
     const int xoff = A.comp_seg ? A.comp_seg[c] * g->seg_dim0 : 0;  // this cloud's slab of grid cells (batched call)
+    // the termination set: this component's words of A.term_bits ((base >> 5) + c: no two components share a word)
+    SkBm B;
+    B.lds = bm_words;
+    B.glb = A.term_bits + (base >> 5) + c;
+    const int nwords = (n + 31) >> 5;
+    B.in_lds = nwords <= SK_BM_WORDS;
+    if (B.in_lds) for (int i = tid; i < nwords; i += W) bm_words[i] = B.glb[i];
+    __syncthreads();
+#define SK_FLUSH_BM()                                                             \
+    do {                                                                          \
+        __syncthreads();                                                          \
+        if (B.in_lds) for (int i_ = tid; i_ < nwords; i_ += W) B.glb[i_] = bm_words[i_]; \
+    } while (0)
     // a long path left over from the previous launch: k_sk_claim filled `touched`
     {
         const int plen = A.s_len[c];
         if (plen > 0)
-            sk_finish_branch(A, base, plen, A.s_cur_id[c], A.path_verts + base + A.s_cur_off[c], false, A.touched + base, false,
+            sk_finish_branch(A, B, base, plen, A.s_cur_id[c], A.path_verts + base + A.s_cur_off[c], false, A.touched + base, false,
                              A.s_ntouched[c]);
     }
     SK_TICK(0);
     int win_base = A.s_cursor[c], total = A.s_total[c], nb = A.s_nb[c];  // per-component state lives in registers
     int wv = -1;         // my window entry: component-local vertex, -1 = none
-    float wx = 0.0f, wy = 0.0f, wz = 0.0f, wr = 0.0f;  // ... its position and radius (for step 1b)
+    float4 wq = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // ... its position and radius
     bool wtail = false;  // my entry marks the end of the selectable vertices (initial distance <= 0, or end of the list)
     bool need_fill = true;
+    const int nslot_max = nw < SK_NSLOT ? nw : SK_NSLOT;
     for (int iter = 0; iter < A.iters_per_launch; iter++) {
-        // 1. the farthest unallocated vertices (path.py:92) = the first live entries of the distance-sorted order.
-        //    A window of W entries is held in registers / LDS; its flags are cleared as points get allocated, so
-        //    finding the next tips costs no global access until the window is used up.
-        int nc = 0, ne = 0;
+        // 1. the round's entries = the first unallocated vertices of the distance-sorted order (path.py:92: the farthest
+        //    unallocated vertex is the first of them).  A window of W order positions is held in registers; liveness is a
+        //    bit test, so finding the entries costs no global access until the window is used up.
+        int ne = 0;
         bool exhausted = false;
         for (;;) {
             if (need_fill) {
                 const int j = win_base + tid;
                 wv = -1; wtail = false;
-                bool live = false;
                 if (j < n) {
                     wv = (int)order[j] - base;
                     wtail = !(A.order_init[base + j] > 0.0f);
-                    live = !wtail && ld_wg(&A.pt[base + wv].alloc) > 0.0f;
-                    if (live) {
-                        const float4 q = A.pr[base + wv];
-                        wx = q.x; wy = q.y; wz = q.z; wr = q.w;
-                    }
+                    if (!wtail) wq = A.pr[base + wv];
                 } else if (j == n) {
                     wtail = true;
                 }
-                win_live[tid] = live ? 1 : 0;
                 need_fill = false;
-                __syncthreads();
             }
-            const bool live = win_live[tid] != 0;
+            const bool live = wv >= 0 && !wtail && !bm_test(B, wv);
             const unsigned long long lb = __ballot(live), tb = __ballot(wtail);
+            __syncthreads();  // (w_cnt of the previous pass has been read)
             if (lane == 0) { w_cnt[wave] = __popcll(lb); w_tail[wave] = tb != 0ull; }
-            for (int i = tid; i < SK_WT; i += W) { wt_key[i] = SK_WT_EMPTY; wt_mask[i] = 0u; }  // this round's watch table
             __syncthreads();
             int before = 0, tot = 0, anytail = 0;
             for (int w = 0; w < nw; w++) { const int k = w_cnt[w]; before += w < wave ? k : 0; tot += k; anytail |= w_tail[w]; }
             if (tot == 0) {
                 if (anytail) { exhausted = true; break; }
                 win_base += W; need_fill = true;  // nothing left in this window
-                __syncthreads();
                 continue;
             }
             const int rank = before + __popcll(lb & ((1ull << lane) - 1ull));
-            if (live && rank < SK_WENT) { cand_v[rank] = wv; cand_p[rank] = make_float4(wx, wy, wz, wr); }
-            ne = tot < SK_WENT ? tot : SK_WENT;
+            if (live && rank < SK_ENT) { ent_v[rank] = wv; ent_p[rank] = wq; }
+            ne = tot < SK_ENT ? tot : SK_ENT;
+            if (tid < SK_NSLOT) { cl_n[tid] = 0u; tv_hit[tid] = 0u; tvs[tid] = -2; }
             __syncthreads();
             break;
         }
         if (exhausted) {  // path.py:94-95 (uniform)
+            SK_FLUSH_BM();
             if (tid == 0) {
                 A.s_done[c] = 1; A.s_len[c] = 0; A.s_wide[c] = 0; A.n_branches[c] = nb; A.s_nb[c] = nb; A.s_total[c] = total;
                 atomicAdd(&A.cnt[6], (unsigned)nb);     // cloud totals: branches and path vertices arrive with the progress
@@ -745,129 +834,78 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
             return;
         }
         SK_TICK(7);
-        // 1b. which entries get a wavefront?  A tip within the radius of an earlier chosen tip will almost surely
-        //     be swallowed by that branch: it gets no slot (if the guess is wrong the replay below simply stops
-        //     there).  Every wavefront runs this little greedy pass itself -- no barrier, no LDS.
-        int my_slot = -1;  // lane e < ne: slot of entry e (-1: none)
-        int my_ent = 0;    // the entry this wavefront speculates on (wave < nc)
-        int ent_v = -1;
-        {
-            float ex = 0.0f, ey = 0.0f, ez = 0.0f, er = 0.0f;
-            if (lane < ne) {
-                ent_v = cand_v[lane];
-                const float4 e4 = cand_p[lane];
-                ex = e4.x; ey = e4.y; ez = e4.z; er = e4.w * A.prune_factor;
-                if (wave == 0) sk_wt_insert(wt_key, wt_mask, (unsigned)ent_v, 0u);  // the replay asks who claimed this tip
+        // 2. which entries get a cache slot?  A tip within the radius of an earlier chosen tip will almost surely be
+        //    swallowed by that branch: it gets none (if the guess is wrong the replay evaluates it itself).  The round's
+        //    entries end where the slots run out.  One wavefront; entry e = 64 g + lane.
+        if (wave == 0) {
+            float4 ep[SK_ENT / 64];
+            bool avail[SK_ENT / 64];
+            int mine[SK_ENT / 64];
+#pragma unroll
+            for (int gq = 0; gq < SK_ENT / 64; gq++) {
+                const int e = gq * 64 + lane;
+                avail[gq] = e < ne;
+                mine[gq] = -1;
+                ep[gq] = avail[gq] ? ent_p[e] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             }
-            int shadowed = 0, chosen = 0;
-            for (int u = 0; u < ne; u++) {
-                if (__builtin_amdgcn_readlane(shadowed, u)) continue;
-                if (chosen == nw) { ne = u; break; }  // out of wavefronts: the round ends before this entry
+            int chosen = 0, cut = ne;
+            for (;;) {
+                int first = -1;
+#pragma unroll
+                for (int gq = 0; gq < SK_ENT / 64; gq++) {
+                    const unsigned long long bal = __ballot(avail[gq]);
+                    if (first < 0 && bal) first = gq * 64 + __ffsll(bal) - 1;
+                }
+                if (first < 0) break;
+                if (chosen == nslot_max) { cut = first; break; }  // out of wavefronts: the round ends before this entry
+                const float4 u = ent_p[first];
+                const float ur = u.w * A.prune_factor;
+#pragma unroll
+                for (int gq = 0; gq < SK_ENT / 64; gq++) {
+                    const int e = gq * 64 + lane;
+                    if (e == first) { avail[gq] = false; mine[gq] = chosen; }
+                    else if (avail[gq] && e > first) {
+                        const float dx = ep[gq].x - u.x, dy = ep[gq].y - u.y, dz = ep[gq].z - u.z;
+                        if (dx * dx + dy * dy + dz * dz < ur * ur) avail[gq] = false;
+                    }
+                }
+                if (lane == 0) slot_ent[chosen] = first;
                 chosen++;
-                const float ux = wave_readlane_f(ex, u), uy = wave_readlane_f(ey, u), uz = wave_readlane_f(ez, u),
-                            ur = wave_readlane_f(er, u);
-                const float dx = ex - ux, dy = ey - uy, dz = ez - uz;
-                if (lane > u && dx * dx + dy * dy + dz * dz < ur * ur) shadowed = 1;
             }
-            const unsigned long long cb = __ballot(lane < ne && !shadowed);
-            nc = __popcll(cb);
-            if (lane < ne && !shadowed) my_slot = __popcll(cb & ((1ull << lane) - 1ull));
-            unsigned long long rest = cb;
-            for (int k = 0; k < wave && rest; k++) rest &= rest - 1ull;
-            my_ent = rest ? __ffsll(rest) - 1 : 0;
+#pragma unroll
+            for (int gq = 0; gq < SK_ENT / 64; gq++) {
+                const int e = gq * 64 + lane;
+                if (e < SK_ENT) ent_slot[e] = (signed char)mine[gq];
+            }
+            if (lane == 0) { s_nc = chosen; s_ne = cut; }
         }
+        __syncthreads();
+        int nc = s_nc;
+        ne = s_ne;
         SK_TICK(1);
-        // 2. speculative walks: wavefront s traces its entry through ONE ancestor-table row (trace_route,
-        //    path.py:9-16: lane j inspects the j-th ancestor; the first allocated one, or the step past the root,
-        //    ends the walk), then gathers radius / position of its path, the (x, y) rows of grid cells around it
-        //    and how many candidate points they hold.
+        // 3. cached walks: wavefront s traces its entry through ONE ancestor-table row against the state at the start of
+        //    the round.
         if (wave < nc) {
-            SkSelSlot& S = L.slot[wave];
-            const int tip = cand_v[my_ent];
-            const int node = lane == 0 ? tip : A.anc[(int64_t)(base + tip) * SK_ANC + lane - 1];
-            const bool end = node < 0 || ld_wg(&A.pt[base + node].term) != 0u;
-            const unsigned long long eb = __ballot(end);
-            int big = eb == 0ull, len = 0, termv = -1, nrows = 0, ncand = 0, parent = -1;
-            float rp = 0.0f;
-            if (!big) {
-                len = __ffsll(eb) - 1;
-                termv = __shfl(node, len);
-                const int qi = len - 1 - lane;  // walk order -> root side first
-                if (lane < 3) { S.lo[lane] = 0x7fffffff; S.hi[lane] = (int)0x80000000; }
-                if (lane == 3) S.rk = 0u;
-                __builtin_amdgcn_wave_barrier();
-                // the parent id is read BEFORE anything is stamped (path.py:128-136); termination -1 reads
-                // branch_ids[-1] = the last vertex (quirk kept)
-                if (lane == 0 && len >= 2) parent = ld_wg(&A.pt[base + (termv < 0 ? n - 1 : termv)].branch);
-                // watched: the walk (marked by its own slot) and the vertex the parent id is read from
-                if (lane < len) sk_wt_insert(wt_key, wt_mask, (unsigned)node, 1u << wave);
-                else if (lane == len) sk_wt_insert(wt_key, wt_mask, (unsigned)(termv < 0 ? n - 1 : termv), 0u);
-                if (lane < len) {
-                    const float4 q4 = A.pr[base + node];
-                    const float x = q4.x, y = q4.y, z = q4.z, r = q4.w;
-                    S.path[qi] = node; S.p[qi] = q4;
-                    const int cx = (int)floorf((x - g->lo[0]) / g->cell), cy = (int)floorf((y - g->lo[1]) / g->cell),
-                              cz = (int)floorf((z - g->lo[2]) / g->cell);
-                    atomicMax(&S.rk, st_f2ord(r));  // path.py:31
-                    atomicMin(&S.lo[0], cx); atomicMin(&S.lo[1], cy); atomicMin(&S.lo[2], cz);
-                    atomicMax(&S.hi[0], cx); atomicMax(&S.hi[1], cy); atomicMax(&S.hi[2], cz);
-                }
-                __builtin_amdgcn_wave_barrier();
-                rp = st_ord2f(S.rk);
-                int reach = rp > 0.0f ? (int)ceilf(rp / g->cell) : 0;
-                if (reach < 1) reach = 1;
-                const int x0 = st_max(S.lo[0] - reach, 0), x1 = st_min(S.hi[0] + reach, g->seg_dim0 - 1);
-                const int y0 = st_max(S.lo[1] - reach, 0), y1 = st_min(S.hi[1] + reach, g->dim[1] - 1);
-                const int z0 = st_max(S.lo[2] - reach, 0), z1 = st_min(S.hi[2] + reach, g->dim[2] - 1);
-                const int nx = x1 - x0 + 1, ny = y1 - y0 + 1;
-                nrows = (nx > 0 && ny > 0 && z0 <= z1) ? nx * ny : 0;
-                big = nrows > SK_WROWS;
-                if (!big) {
-                    uint32_t cnt[SK_WROWS / 64], first[SK_WROWS / 64];
-#pragma unroll
-                    for (int ch = 0; ch < SK_WROWS / 64; ch++) {  // all loads first, then the scans
-                        const int rr = ch * 64 + lane;
-                        cnt[ch] = 0u; first[ch] = 0u;
-                        if (rr < nrows) {
-                            const int64_t row = ((int64_t)(xoff + x0 + rr / ny) * g->dim[1] + (y0 + rr % ny)) * g->dim[2];
-                            first[ch] = A.cell_start[row + z0];
-                            cnt[ch] = A.cell_start[row + z1 + 1] - first[ch];
-                        }
-                    }
-                    uint32_t run = 0u;
-#pragma unroll
-                    for (int ch = 0; ch < SK_WROWS / 64; ch++) {
-                        if (ch * 64 >= nrows) break;  // wave-uniform
-                        const uint32_t inc = wave_incl_scan_u(cnt[ch], lane);
-                        const int rr = ch * 64 + lane;
-                        if (rr < nrows) { S.row_off[rr] = run + inc - cnt[ch]; S.row_first[rr] = first[ch]; }
-                        run += __shfl(inc, 63);
-                    }
-                    ncand = (int)run;
-                    if (lane == 0) S.row_off[nrows] = (uint32_t)ncand;
-                    big = ncand > SK_WAVE_CAND || ncand > SK_ROUND_ITEMS * W || (int64_t)ncand * len > A.wave_work;
-                }
-            }
+            const SkSlotInfo I = sk_walk(A, B, L.slot[wave], base, n, ent_v[slot_ent[wave]], xoff, W, lane);
             if (lane == 0) {
-                sl_len[wave] = len; sl_term[wave] = termv; sl_parent[wave] = parent; sl_nrows[wave] = nrows; sl_ncand[wave] = ncand;
-                sl_big[wave] = big; sl_rp[wave] = rp; sl_ent[wave] = my_ent;
+                sl[wave] = I;
+                tvs[wave] = (!I.big && I.len >= 2) ? (I.term < 0 ? n - 1 : I.term) : -2;
             }
         }
         __syncthreads();
         SK_TICK(2);
-        if (!sl_big[0]) {
-            // slots after the first oversized one (or past the per-round item budget) wait for a later round.
+        if (!sl[0].big) {
+            // slots after the first oversized one (or past the per-round item budget) are not evaluated this round.
             // pre[k] = candidates of the slots before k: workgroup-uniform, so it lives in scalar registers.
-            int pre[SK_WSLOTS + 1];
+            int pre[SK_NSLOT + 1];
             pre[0] = 0;
             {
-                // lane k reads slot k's numbers once (one LDS round trip), the scan below takes them out with readlane
-                int cand_l = 0, big_l = 0, ent_l = 0;
-                if (lane < SK_WSLOTS && lane < nc) { cand_l = sl_ncand[lane]; big_l = sl_big[lane]; ent_l = sl_ent[lane]; }
+                int cand_l = 0, big_l = 0;
+                if (lane < SK_NSLOT && lane < nc) { cand_l = sl[lane].ncand; big_l = sl[lane].big; }
                 bool open = true;
                 int k_cut = nc;
 #pragma unroll
-                for (int k = 0; k < SK_WSLOTS; k++) {
+                for (int k = 0; k < SK_NSLOT; k++) {
                     int add = 0;
                     if (k < nc && open) {
                         const int cand_k = __builtin_amdgcn_readlane(cand_l, k), big_k = __builtin_amdgcn_readlane(big_l, k);
@@ -876,13 +914,19 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
                     }
                     pre[k + 1] = pre[k] + add;
                 }
-                if (k_cut < nc) { ne = __builtin_amdgcn_readlane(ent_l, k_cut); nc = k_cut; }
+                nc = k_cut;  // slots [nc, s_nc) have no cache entry (the replay ends the round at a big one)
             }
-            const int T = pre[SK_WSLOTS];
-            // 3. claims (select_path_points, path.py:19-46), point-centric: the candidates of ALL slots are dealt
-            //    out over the workgroup; each finds ITS nearest path vertex from LDS -- no atomics but the mark.
-            unsigned cl_bits = 0u;  // bit k: my k-th item was claimed but did not fit cl_list
-            int cl_n = 0;
+            const int T = pre[SK_NSLOT];
+            // 4. claims of the cached paths (select_path_points, path.py:19-46), point-centric: the candidates of ALL slots
+            //    are dealt out over the workgroup; each finds ITS nearest path vertex from LDS.  A claimed point joins its
+            //    slot's list; if it is the vertex a (later) slot reads its parent id from, that slot learns who stamps it.
+            for (int idx = tid; idx < nc * SK_WPATH; idx += W) {  // ... the paths stamp their own vertices, too
+                const int s_ = idx / SK_WPATH, q_ = idx % SK_WPATH;
+                if (q_ < sl[s_].len && sl[s_].len >= 2) {
+                    const int v = L.slot[s_].path[q_];
+                    for (int k = 0; k < nc; k++) if (tvs[k] == v) atomicOr(&tv_hit[k], 1u << s_);
+                }
+            }
             const int nround = (T + W - 1) / W;
             for (int k0 = 0; k0 < nround; k0 += 4) {
                 float4 r4[4];
@@ -895,11 +939,11 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
                     if (k0 + u < nround && gi < T) {
                         int sidx = 0, acc = 0;
 #pragma unroll
-                        for (int k = 1; k < SK_WSLOTS; k++)
+                        for (int k = 1; k < SK_NSLOT; k++)
                             if (gi >= pre[k]) { sidx = k; acc = pre[k]; }  // pre[] is non-decreasing and ends at T > gi
                         const SkSelSlot& S = L.slot[sidx];
                         const uint32_t t = (uint32_t)(gi - acc);
-                        const int row = sk_find_row(S.row_off, sl_nrows[sidx], t);
+                        const int row = sk_find_row(S.row_off, sl[sidx].nrows, t);
                         r4[u] = recs[S.row_first[row] + (t - S.row_off[row])];
                         ss[u] = sidx;
                     }
@@ -909,147 +953,142 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
                     if (ss[u] < 0) continue;
                     const int p = (int)__float_as_uint(r4[u].w) - base;
                     if (p < 0 || p >= n) continue;  // other component
-                    const SkSelSlot& S = L.slot[ss[u]];
-                    const int len = sl_len[ss[u]];
-                    const float rp = sl_rp[ss[u]];
-                    float bd2 = __uint_as_float(0x7f800000u);
-                    int bq = 0;
-                    float bw = 0.0f;
-                    // ascending: ties keep the first path vertex.  Four path vertices per step: their LDS reads are in flight together
-#define SK_NEAREST(q, qi_)                                                                    \
-    {                                                                                          \
-        const float dx = r4[u].x - (q).x, dy = r4[u].y - (q).y, dz = r4[u].z - (q).z;          \
-        float d2 = dx * dx;                                                                    \
-        float tt = dy * dy;                                                                    \
-        d2 = d2 + tt;                                                                          \
-        tt = dz * dz;                                                                          \
-        d2 = d2 + tt;                                                                          \
-        if (d2 < bd2) { bd2 = d2; bq = (qi_); bw = (q).w; }                                    \
-    }
-                    int qi = 0;
-                    for (; qi + 4 <= len; qi += 4) {
-                        const float4 q0 = S.p[qi], q1 = S.p[qi + 1], q2 = S.p[qi + 2], q3 = S.p[qi + 3];
-                        SK_NEAREST(q0, qi) SK_NEAREST(q1, qi + 1) SK_NEAREST(q2, qi + 2) SK_NEAREST(q3, qi + 3)
-                    }
-                    for (; qi < len; qi++) {
-                        const float4 q = S.p[qi];
-                        SK_NEAREST(q, qi)
-                    }
-#undef SK_NEAREST
-                    (void)bq;
-                    if (bd2 < rp * rp && sqrtf(bd2) < bw) {  // path.py:35-40
-                        const int h = sk_wt_find(wt_key, (unsigned)p);
-                        if (h >= 0) atomicOr(&wt_mask[h], 1u << ss[u]);
-                        if (cl_n < SK_CL_KEEP) cl_list[cl_n][tid] = (unsigned)p | ((unsigned)ss[u] << 28);
-                        else cl_bits |= 1u << (k0 + u);
-                        cl_n++;
-                    }
+                    if (!sk_on_path(L.slot[ss[u]], sl[ss[u]].len, sl[ss[u]].rp, r4[u])) continue;
+                    const unsigned at = atomicAdd(&cl_n[ss[u]], 1u);
+                    if (at < SK_CL_CAP) cl[ss[u]][at] = (unsigned)p;
+                    if (sl[ss[u]].len >= 2)
+                        for (int k = 0; k < nc; k++) if (tvs[k] == p) atomicOr(&tv_hit[k], 1u << ss[u]);
                 }
             }
-            __syncthreads();  // all marks are in the table
+            __syncthreads();  // every list is complete
             SK_TICK(3);
-            // 4. what did the earlier slots touch?  (walk + the vertex the parent id was read from; tip of every entry)
-            if (wave < nc) {
-                const SkSelSlot& S = L.slot[wave];
-                const int len = sl_len[wave], termv = sl_term[wave];
-                unsigned mk = 0u;
-                if (lane <= len) mk = wt_mask[sk_wt_find(wt_key, (unsigned)(lane < len ? S.path[len - 1 - lane] : (termv < 0 ? n - 1 : termv)))];
-                const unsigned walkm = wave_or_u(mk);
-                if (lane == 0) sl_walkm[wave] = walkm;
-            }
-            unsigned etip = 0u;
-            if (wave == 0 && lane < ne) etip = wt_mask[sk_wt_find(wt_key, (unsigned)ent_v)];
-            __syncthreads();
-            if (wave == 0) {  // the sequential replay over the entries, lane e holding entry e
-                if (my_slot >= nc) my_slot = -1;
-                const unsigned walkm = my_slot >= 0 ? sl_walkm[my_slot] : 0u;
-                const int mylen = my_slot >= 0 ? sl_len[my_slot] : 0;
-                unsigned alive = 0u;
-                int nb2 = nb, tot2 = total, commits = 0, my_id = -2, my_off = 0;
-                for (int e = 0; e < ne; e++) {
-                    if ((unsigned)__builtin_amdgcn_readlane((int)etip, e) & alive) continue;  // never selected
-                    const int sl = __builtin_amdgcn_readlane(my_slot, e);
-                    if (sl < 0) break;                                                         // guessed wrong: it lives
-                    if ((unsigned)__builtin_amdgcn_readlane((int)walkm, e) & alive) break;     // depends on an accepted slot
-                    alive |= 1u << sl;
-                    const int l = __builtin_amdgcn_readlane(mylen, e);
-                    const bool keep = l >= 2;  // path.py:125-126: shorter paths still consume their points
-                    if (lane == e) { my_id = keep ? nb2 : -1; my_off = tot2; }
-                    if (keep) { nb2++; tot2 += l; }
-                    commits++;
-                }
-                if (my_slot >= 0) { sl_id[my_slot] = my_id; sl_off[my_slot] = my_off; }
-                if (lane == 0) {
-                    s_alive = alive; s_nb2 = nb2; s_tot2 = tot2;
-                    if (A.ticks) { A.ticks[8] += 1; A.ticks[12] += commits; A.ticks[13] += nc; A.ticks[11] += T; }
-                }
-            }
-            __syncthreads();
-            const unsigned alive = s_alive;
-            nb = s_nb2; total = s_tot2;
-            // 5. commit the accepted slots (path.py:112-136), wipe every mark
-            if (wave < nc) {
-                const SkSelSlot& S = L.slot[wave];
-                const int len = sl_len[wave], id = sl_id[wave];
-                if (lane < len) {
-                    const int v = S.path[lane];
-                    if (id != -2) {
-                        if (id >= 0) A.path_verts[base + sl_off[wave] + lane] = v;  // (a dropped path shares its offset with the next one)
-                        sk_stamp(&A.pt[base + v], id, true);
-                        const unsigned q = (unsigned)(pos[v] - win_base);
-                        if (q < (unsigned)W) win_live[q] = 0;
-                    }
-                }
-                if (lane == 0 && id >= 0) {
-                    A.branch_parent[base + id] = sl_parent[wave];
-                    A.branch_off[base + id] = sl_off[wave];
-                    A.branch_len[base + id] = len;
-                    if (A.ticks) A.ticks[10] += len;
-                }
-            }
-            const int kept_n = cl_n < SK_CL_KEEP ? cl_n : SK_CL_KEEP;
-            for (int j = 0; j < kept_n; j++) {
-                const unsigned e = cl_list[j][tid];
-                const int p = (int)(e & 0x0fffffffu), sidx = (int)(e >> 28);
-                if ((alive >> sidx) & 1u) {
-                    const int id = sl_id[sidx];
-                    sk_stamp(&A.pt[base + p], id, true);
-                    const unsigned q = (unsigned)(pos[p] - win_base);
-                    if (q < (unsigned)W) win_live[q] = 0;
-                }
-            }
-            while (cl_bits) {  // the overflow: find the point again
-                const int k = __ffs(cl_bits) - 1;
-                cl_bits &= cl_bits - 1u;
-                const int gi = k * W + tid;
-                int sidx = 0, acc = 0;
+        }
+        if (!sl[0].big && cl_n[0] <= SK_CL_CAP) {
+            // 5. the replay: ONE wavefront runs the sequential loop over the round's entries.
+            if (wave == 0) {
+                int ev[SK_ENT / 64];
 #pragma unroll
-                for (int k2 = 1; k2 < SK_WSLOTS; k2++)
-                    if (gi >= pre[k2]) { sidx = k2; acc = pre[k2]; }
-                if (!((alive >> sidx) & 1u)) continue;
-                const SkSelSlot& S = L.slot[sidx];
-                const uint32_t t = (uint32_t)(gi - acc);
-                const int row = sk_find_row(S.row_off, sl_nrows[sidx], t);
-                const int p = (int)__float_as_uint(recs[S.row_first[row] + (t - S.row_off[row])].w) - base;
-                {
-                    const int id = sl_id[sidx];
-                    sk_stamp(&A.pt[base + p], id, true);
-                    const unsigned q = (unsigned)(pos[p] - win_base);
-                    if (q < (unsigned)W) win_live[q] = 0;
+                for (int gq = 0; gq < SK_ENT / 64; gq++) {
+                    const int e = gq * 64 + lane;
+                    ev[gq] = e < ne ? ent_v[e] : -1;
+                }
+                int cur = 0, commits = 0, lates = 0;
+                for (;;) {
+                    __builtin_amdgcn_wave_barrier();  // (the stamps of the previous step are in the bitmap)
+                    int first = -1;  // the first entry at or after `cur` that is still unallocated: the loop's next tip
+#pragma unroll
+                    for (int gq = 0; gq < SK_ENT / 64; gq++) {
+                        const int e = gq * 64 + lane;
+                        const bool lv = ev[gq] >= 0 && e >= cur && !bm_test(B, ev[gq]);
+                        const unsigned long long bal = __ballot(lv);
+                        if (first < 0 && bal) first = gq * 64 + __ffsll(bal) - 1;
+                    }
+                    if (first < 0) { if (A.ticks && lane == 0) A.ticks[16] += 1; break; }
+                    const int s = (int)ent_slot[first];
+                    const int tip = ent_v[first];
+                    bool done = false;
+                    if (s >= 0 && s < nc) {
+                        // the cached path is the true path iff none of its vertices has been terminated since its walk
+                        const SkSelSlot& S = L.slot[s];
+                        const int len = sl[s].len;
+                        const bool hit = lane < len && bm_test(B, S.path[lane]);
+                        if (__ballot(hit) == 0ull && cl_n[s] <= SK_CL_CAP) {
+                            const bool keep = len >= 2;  // path.py:125-126: shorter paths still consume their points
+                            const int id = keep ? nb : -1;
+                            if (lane < len) {
+                                const int v = S.path[lane];
+                                if (keep) A.path_verts[base + total + lane] = v;
+                                sk_mark(A, B, base, v, id);
+                            }
+                            const unsigned cn = cl_n[s];
+                            for (unsigned i = lane; i < cn; i += 64) sk_mark(A, B, base, (int)cl[s][i], id);
+                            if (keep) {
+                                if (lane == 0) {
+                                    A.branch_parent[base + nb] = sl[s].parent;
+                                    A.branch_off[base + nb] = total;
+                                    A.branch_len[base + nb] = len;
+                                }
+                                // whose parent id did this branch just become?  (branch_ids keeps the last writer)
+                                if (lane < SK_NSLOT && ((tv_hit[lane] >> s) & 1u)) sl[lane].parent = id;
+                                nb++; total += len;
+                            }
+                            done = true;
+                            commits++;
+                        }
+                    } else if (s >= nc) {
+                        if (A.ticks && lane == 0) A.ticks[17] += 1;
+                        break;  // a slot the round did not evaluate (oversized, or past the item budget): it heads the next round
+                    }
+                    if (!done) {
+                        // no cache entry (a tip predicted to be swallowed that survived), or the walk has been cut short by a
+                        // branch of this round: this wavefront evaluates the branch itself against the state as it is now --
+                        // unless it is too long / too heavy, then the round ends here.
+                        SkSelSlot& S = L.slot[SK_LATE];
+                        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // this wavefront's stamps have reached the L2
+                        const SkSlotInfo I = sk_walk(A, B, S, base, n, tip, xoff, W, lane);
+                        if (I.big || I.ncand > A.late_cand || (int64_t)I.ncand * I.len > 16 * (int64_t)A.late_cand) {
+                            if (A.ticks && lane == 0) A.ticks[18 + (I.big ? 0 : 1)] += 1;
+                            break;
+                        }
+                        const bool keep = I.len >= 2;
+                        const int id = keep ? nb : -1;
+                        for (int t0 = 0; t0 < I.ncand; t0 += 256) {
+                            float4 r4[4];
+#pragma unroll
+                            for (int u = 0; u < 4; u++) {
+                                const int t = t0 + u * 64 + lane;
+                                r4[u] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xffffffffu));
+                                if (t < I.ncand) {
+                                    const int row = sk_find_row(S.row_off, I.nrows, (uint32_t)t);
+                                    r4[u] = recs[S.row_first[row] + ((uint32_t)t - S.row_off[row])];
+                                }
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; u++) {
+                                if (t0 + u * 64 + lane >= I.ncand) continue;
+                                const int p = (int)__float_as_uint(r4[u].w) - base;
+                                if (p < 0 || p >= n) continue;  // other component
+                                if (!sk_on_path(S, I.len, I.rp, r4[u])) continue;
+                                sk_mark(A, B, base, p, id);
+                                if (keep) for (int k = 0; k < nc; k++) if (tvs[k] == p) sl[k].parent = id;
+                            }
+                        }
+                        if (lane < I.len) {
+                            const int v = S.path[lane];
+                            if (keep) A.path_verts[base + total + lane] = v;
+                            sk_mark(A, B, base, v, id);
+                            if (keep) for (int k = 0; k < nc; k++) if (tvs[k] == v) sl[k].parent = id;
+                        }
+                        if (keep) {
+                            if (lane == 0) {
+                                A.branch_parent[base + nb] = I.parent;
+                                A.branch_off[base + nb] = total;
+                                A.branch_len[base + nb] = I.len;
+                            }
+                            nb++; total += I.len;
+                        }
+                        lates++;
+                    }
+                    cur = first + 1;
+                }
+                if (lane == 0) {
+                    s_nb2 = nb; s_tot2 = total;
+                    if (A.ticks) { A.ticks[8] += 1; A.ticks[12] += commits; A.ticks[13] += nc; A.ticks[11] += lates; }
                 }
             }
-            __syncthreads();  // (also: LDS of this round is dead)
+            __syncthreads();
+            nb = s_nb2; total = s_tot2;
             SK_TICK(4);
             continue;
         }
-        // ---- `one` mode: candidate 0 needs the whole workgroup ----
-        const int far = cand_v[0];
+        // ---- `one` mode: entry 0 needs the whole workgroup ----
+        const int far = ent_v[0];
         __syncthreads();  // slot data is dead; its space is reused below
         int len = -1;
         for (unsigned chunk = 0; len < 0; chunk += blockDim.x) {
             const unsigned j = chunk + tid;
             const int node = sk_ancestor(A, base, far, j);
-            const bool end = node < 0 || ld_wg(&A.pt[base + node].term) != 0u;
+            const bool end = node < 0 || bm_test(B, node);
             if (!end) { if (j < SK_LPATH) L.one.lpath[j] = node; else tmp[j] = (unsigned)node; }
             unsigned long long k = end ? ((unsigned long long)(0xffffffffu - j) << 32) | (unsigned)(node + 1) : 0ull;
             k = block_max_u64(k, s_red);
@@ -1064,7 +1103,7 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
         // coordinates / radii / cell bounding box into LDS for the claim below.
         const bool keep = len >= 2;
         int parent = -1;
-        if (tid == 0 && keep) parent = ld_wg(&A.pt[base + (s_term < 0 ? n - 1 : s_term)].branch);
+        if (tid == 0 && keep) parent = ld(&A.branch_of[base + (s_term < 0 ? n - 1 : s_term)]);
         int* path_out = A.path_verts + base + total;
         const bool fits = len <= SK_LPATH;
         unsigned long long rk = 0;
@@ -1194,19 +1233,10 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
                             if (d2 < bd2) { bd2 = d2; bw = L.one.lpr[qi]; }
                         }
                     }
-                    if (bd2 < rp2 && sqrtf(bd2) < bw) {  // path.py:35-40
-                        sk_stamp(&A.pt[base + p], id, false);
-                        const unsigned q = (unsigned)(pos[p] - win_base);
-                        if (q < (unsigned)W) win_live[q] = 0;
-                    }
+                    if (bd2 < rp2 && sqrtf(bd2) < bw) sk_mark(A, B, base, p, id);  // path.py:35-40
                 }
             }
-            for (int qi = tid; qi < len; qi += blockDim.x) {  // path.py:112-113,135
-                const int v = L.one.lpath[len - 1 - qi];
-                sk_stamp(&A.pt[base + v], id, false);
-                const unsigned q = (unsigned)(pos[v] - win_base);
-                if (q < (unsigned)W) win_live[q] = 0;
-            }
+            for (int qi = tid; qi < len; qi += blockDim.x) sk_mark(A, B, base, L.one.lpath[len - 1 - qi], id);  // path.py:112-113,135
             __syncthreads();
             SK_TICK(6);
             continue;
@@ -1224,13 +1254,13 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
             unsigned* lq_ctl = (unsigned*)L.one.lpz;
             const bool in_lds = sk_claim_items(A, c, base, n, len, rp, path_out, false, 0, 1, lq, &lq_ctl[0], &lq_ctl[1], true);
             __syncthreads();
-            sk_finish_branch(A, base, len, id, path_out, false, in_lds ? lq : A.touched + base, in_lds,
+            sk_finish_branch(A, B, base, len, id, path_out, false, in_lds ? lq : A.touched + base, in_lds,
                              in_lds ? lq_ctl[0] : ld(&A.s_ntouched[c]));
-            need_fill = true;  // the window flags are rebuilt from the allocation state
             SK_TICK(6);
             continue;
         }
         if (!small) {  // hand the path to k_sk_claim; its points are finished at the next launch (uniform)
+            SK_FLUSH_BM();
             if (tid == 0) {
                 A.s_len[c] = len; A.s_rp[c] = rp; A.s_ntouched[c] = 0u; A.s_cur_off[c] = cur_off; A.s_cur_id[c] = id;
                 A.s_wide[c] = 1; A.s_cursor[c] = win_base; A.s_total[c] = total; A.s_nb[c] = nb;
@@ -1254,28 +1284,16 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
                 d2 = d2 + tt;
                 if (d2 < bd2) { bd2 = d2; bq = qi; }
             }
-            if (bd2 < rp2 && sqrtf(bd2) < L.one.lpr[bq]) {  // path.py:35-40
-                sk_stamp(&A.pt[base + p], id, false);
-                const unsigned q = (unsigned)(pos[p] - win_base);
-                if (q < (unsigned)W) win_live[q] = 0;
-            }
+            if (bd2 < rp2 && sqrtf(bd2) < L.one.lpr[bq]) sk_mark(A, B, base, p, id);  // path.py:35-40
         }
-        for (int qi = tid; qi < len; qi += blockDim.x) {  // path.py:112-113,135
-            const int v = L.one.lpath[len - 1 - qi];
-            sk_stamp(&A.pt[base + v], id, false);
-            const unsigned q = (unsigned)(pos[v] - win_base);
-            if (q < (unsigned)W) win_live[q] = 0;
-        }
+        for (int qi = tid; qi < len; qi += blockDim.x) sk_mark(A, B, base, L.one.lpath[len - 1 - qi], id);  // path.py:112-113,135
         __syncthreads();
         SK_TICK(5);
     }
+    SK_FLUSH_BM();
     if (tid == 0) { A.s_len[c] = 0; A.s_wide[c] = 0; A.s_cursor[c] = win_base; A.s_total[c] = total; A.s_nb[c] = nb; }
     SK_TICK_FLUSH();
-}
-
-// the selection is done: branch ids of the points -> the caller's array
-__global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_branch_out(SkArgs A) {
-    SK_VERTEX_LOOP(v) A.branch_of[v] = A.pt[v].branch;
+#undef SK_FLUSH_BM
 }
 
 __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_claim(SkArgs A) {
@@ -1326,9 +1344,9 @@ __global__ void __launch_bounds__(1024) k_sk_blk_tables(SkArgs A, int* blk_comp,
 struct SkLayout {
     unsigned *dist_ord, *stamp, *q0, *q1, *touched, *cnt, *s_ntouched, *sort_keys, *order;
     float *s_rp, *order_init;
-    SkPt* pt;
+    unsigned* term_bits;
     float4* pr;
-    int *s_cursor, *s_wide, *pos;
+    int *s_cursor, *s_wide;
     char* sort_ws;
     int64_t sort_bytes;
     unsigned long long* best;
@@ -1344,13 +1362,19 @@ static inline int64_t sk_grid_cells(int nseg, int64_t m) {  // (st_grid_build us
     return st_min64(SK_GRID_CELLS * (nseg < 1 ? 1 : (nseg > 32 ? 32 : nseg)), 128 * (m > 0 ? m : 1) + 65536);
 }
 
+// frontier queue geometry, in one place: SK_FS shard segments of sk_fseg entries + an overflow area with room for every entry
+static inline int64_t sk_fseg(int64_t m, int64_t C) { return (m + C) / SK_FS > 0 ? (m + C) / SK_FS : 1; }
+static inline int64_t sk_queue_words(int64_t m, int64_t C) { return SK_FS * sk_fseg(m, C) + (m + C); }
+// termination bits: component c owns the words from (comp_off[c] >> 5) + c, ceil(size / 32) of them
+static inline int64_t sk_term_words(int64_t m, int64_t C) { return m / 32 + C + 2; }
+
 static void sk_layout(StArena& a, int64_t m, int64_t C, SkLayout* s, int nseg = 1) {
     s->dist_ord = a.take<unsigned>(m);
     s->stamp = a.take<unsigned>(m);
-    s->q0 = a.take<unsigned>(2 * (m + C));  // SSSP frontier: SK_FS shard segments + the overflow area (sk_q_reserve)
-    s->q1 = a.take<unsigned>(2 * (m + C));
+    s->q0 = a.take<unsigned>(sk_queue_words(m, C));  // SSSP frontier: SK_FS shard segments + the overflow area (sk_q_reserve)
+    s->q1 = a.take<unsigned>(sk_queue_words(m, C));
     s->touched = a.take<unsigned>(m);
-    s->pt = a.take<SkPt>(m);
+    s->term_bits = a.take<unsigned>(sk_term_words(m, C));
     s->pr = a.take<float4>(m);
     s->best = a.take<unsigned long long>(m);
     s->anc = a.take<int>((int64_t)SK_ANC * m);
@@ -1369,7 +1393,6 @@ static void sk_layout(StArena& a, int64_t m, int64_t C, SkLayout* s, int nseg = 
     s->sort_keys = a.take<unsigned>(m);
     s->order = a.take<unsigned>(m);
     s->order_init = a.take<float>(m);
-    s->pos = a.take<int>(m);
     s->sort_bytes = st_sort_ws_bytes(m);
     s->sort_ws = a.take<char>(s->sort_bytes);
     s->blk_first = a.take<int>(C);
@@ -1388,14 +1411,16 @@ static void sk_layout(StArena& a, int64_t m, int64_t C, SkLayout* s, int nseg = 
 //   0 prune factor (x1000)   1 small_work   2 rounds per select launch   3 select launches per host read-back
 //   4 local_items   5 wave_work   6 SSSP levels per frontier launch   7 frontier launches per read-back   8 lanes per vertex
 //   9 length of the first frontier batch (in batches)   10 frontier workgroups   11 claim-grid cell cap (hundredths of the
-//   mean radius)   13 frontier: 0 = no look before the atomic, else vertices a workgroup relaxes per local level
+//   mean radius)   12 candidates the selection's replay wavefront evaluates by itself (-1: none, every such entry ends its round)
+//   13 frontier: 0 = no look before the atomic, else vertices a workgroup relaxes per local level
 //   14 long-path claim inside the workgroup (1, default) or by the local / chip-wide path-centric claims (0)
-//   15 device pointer of 16 int64 phase timers / counters of k_sk_select
+//   15 device pointer of 32 int64 phase timers / counters of k_sk_select
 #define ST_TUNE_DEFAULT INT64_MIN
 #define SK_MAX_LAUNCH_BATCH 32
 struct SkTuning {
     float prune_factor = 1.0f, grid_mean_mult = 1.0f;
-    int small_work = SK_SMALL_WORK, iters_per_launch = SK_ITERS_PER_LAUNCH, launch_batch = 24, local_items = 0, wave_work = SK_WAVE_WORK, long_mode = 1;
+    int small_work = SK_SMALL_WORK, iters_per_launch = SK_ITERS_PER_LAUNCH, launch_batch = 24, local_items = 0, wave_work = SK_WAVE_WORK, long_mode = 1,
+        late_cand = SK_LATE_CAND;
     int sssp_hops = 4, sssp_batch = 32, sssp_lanes = 64, sssp_first = 2, sssp_blocks = SK_SSSP_BLOCKS, sssp_lcap = SK_LQ;
     bool small_work_set = false, iters_set = false, long_set = false, launch_set = false;
     long long* ticks = nullptr;
@@ -1414,6 +1439,7 @@ struct SkTuning {
         if (has(9)) sssp_first = t[9] < 1 ? 1 : (t[9] > 8 ? 8 : (int)t[9]);
         if (has(10)) sssp_blocks = t[10] < 1 ? 1 : (t[10] > 8192 ? 8192 : (int)t[10]);
         if (has(11)) grid_mean_mult = (float)t[11] / 100.0f;
+        if (has(12)) late_cand = t[12] < 0 ? -1 : (int)t[12];
         if (has(13)) sssp_lcap = t[13] == 0 ? -SK_LQ : (t[13] > SK_LQ ? SK_LQ : (int)t[13]);
         if (has(14)) { long_mode = t[14] != 0; long_set = true; }
         if (has(15)) ticks = (long long*)(intptr_t)t[15];
@@ -1488,16 +1514,16 @@ extern "C" int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, c
     A.dist = dist; A.pred = pred; A.root_local = root_local; A.tree_dist = tree_dist;
     A.branch_parent = branch_parent; A.branch_off = branch_off; A.branch_len = branch_len; A.n_branches = n_branches;
     A.path_verts = path_verts; A.branch_of = branch_of;
-    A.dist_ord = s.dist_ord; A.stamp = s.stamp; A.q0 = s.q0; A.q1 = s.q1; A.pt = s.pt; A.pr = s.pr;
+    A.dist_ord = s.dist_ord; A.stamp = s.stamp; A.q0 = s.q0; A.q1 = s.q1; A.term_bits = s.term_bits; A.pr = s.pr;
     A.best = s.best; A.touched = s.touched; A.anc = s.anc; A.cnt = s.cnt; A.fcnt = s.cnt + 8;
-    A.fseg = (unsigned)((m + n_comp) / SK_FS > 0 ? (m + n_comp) / SK_FS : 1);
+    A.fseg = (unsigned)sk_fseg(m, n_comp);
     A.s_done = s.s_done; A.s_len = s.s_len; A.s_cur_id = s.s_cur_id; A.s_cur_off = s.s_cur_off; A.s_nb = s.s_nb;
     A.s_total = s.s_total; A.s_rp = s.s_rp; A.s_ntouched = s.s_ntouched;
     A.blk_comp = s.blk_comp; A.blk_first = s.blk_first; A.blk_count = s.blk_count;
-    A.s_cursor = s.s_cursor; A.s_wide = s.s_wide; A.order = s.order; A.order_init = s.order_init; A.pos = s.pos;
+    A.s_cursor = s.s_cursor; A.s_wide = s.s_wide; A.order = s.order; A.order_init = s.order_init;
     const SkTuning T(tuning);
     A.ticks = T.ticks;
-    A.prune_factor = T.prune_factor; A.small_work = T.small_work; A.iters_per_launch = T.iters_per_launch; A.local_items = T.local_items; A.wave_work = T.wave_work; A.long_mode = T.long_mode;
+    A.prune_factor = T.prune_factor; A.small_work = T.small_work; A.iters_per_launch = T.iters_per_launch; A.local_items = T.local_items; A.wave_work = T.wave_work; A.long_mode = T.long_mode; A.late_cand = T.late_cand;
     // A batch of clouds advances in lockstep: a launch lasts as long as its slowest component, and a component that hands a
     // long path to the chip-wide claim kernel waits for everybody else's rounds.  Fewer hand-overs (the workgroup claims
     // paths up to 16x larger by itself) and shorter launches measured 2.98 -> 2.48 ms of skeleton stage per cloud at 8 clouds
@@ -1597,20 +1623,21 @@ extern "C" int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, c
         bool plateaus_pending = defer_plateaus;
         for (;;) {  // second pass only if the deferred check found plateau vertices: predecessors completed, selection redone
             (void)hipMemsetAsync(&s.cnt[5], 0, 3 * sizeof(unsigned), stream);  // finished components, branches, path vertices
-            hipLaunchKernelGGL(k_sk_lift_init, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A,
-                               (const float*)((stages & 2) ? tree_dist : dist));
+            const float* distances = (stages & 2) ? tree_dist : dist;
+            (void)hipMemsetAsync(s.term_bits, 0, sk_term_words(m, n_comp) * sizeof(unsigned), stream);
+            hipLaunchKernelGGL(k_sk_lift_init, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A);
             for (int span = 1; span < SK_ANC; span *= 2)  // direct ancestor table by doubling
                 hipLaunchKernelGGL(k_sk_anc_pass, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A, span);
             // order the vertices of every component by distance, once: the per-branch argmax becomes a cursor
-            hipLaunchKernelGGL(k_sk_sort_keys, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A, s.sort_keys, s.order, 0);
+            hipLaunchKernelGGL(k_sk_sort_keys, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A, distances, s.sort_keys, s.order, 0);
             ST_TRY(st_radix_sort_pairs_u32(s.sort_keys, s.order, m, 32, s.sort_ws, s.sort_bytes, stream));
             if (n_comp > 1) {
                 int bits = 1;
                 while ((1ll << bits) < n_comp) bits++;
-                hipLaunchKernelGGL(k_sk_sort_keys, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A, s.sort_keys, s.order, 1);
+                hipLaunchKernelGGL(k_sk_sort_keys, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A, distances, s.sort_keys, s.order, 1);
                 ST_TRY(st_radix_sort_pairs_u32(s.sort_keys, s.order, m, bits, s.sort_ws, s.sort_bytes, stream));
             }
-            hipLaunchKernelGGL(k_sk_order_init, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A, s.order_init, s.pos);
+            hipLaunchKernelGGL(k_sk_order_init, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A, distances, s.order_init);
             iters = 0;
             select_ms = 0.0;
             bool redo = false;
@@ -1638,10 +1665,7 @@ extern "C" int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, c
                 if (h[5] >= (unsigned)n_comp) break;
                 ST_REQUIRE(iters <= m + 64 && iters < (1 << 26), "skeleton: sample_tree did not terminate");
             }
-            if (!redo) {
-                hipLaunchKernelGGL(k_sk_branch_out, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A);
-                break;
-            }
+            if (!redo) break;
             // plateau vertices left unresolved: redo the predecessor pass with its resolved / unresolved marks, then the plateaus
             (void)hipMemsetAsync(&s.cnt[3], 0, sizeof(unsigned), stream);
             hipLaunchKernelGGL(k_sk_preds, dim3((unsigned)st_min64(st_div_up(m * SK_PRED_LANES, SK_WIDE_BLOCK), 8192)), dim3(SK_WIDE_BLOCK), 0, stream, A);

@@ -125,21 +125,32 @@ def brick_pyramid(coords: torch.Tensor, depth: int, n_blocks: int, coord_bound: 
         n_seg = 1
     i32 = dict(dtype=torch.int32, device=dev)
     for attempt in range(2):
-        # k3 s2 p1: a surface-like set shrinks to ~half per level; isolated odd voxels reach up to 8 outputs each (retry)
+        # k3 s2 p1: a surface-like set shrinks to ~half per level.  Isolated voxels reach up to 8 outputs each and thin lines
+        # ~1.1 per fine voxel: the retry sizes every level for 8x the level below, clamped by what the declared geometry can
+        # hold (blocks x cells of the level's grid); tables of that size that do not fit a budget (27 x 4 bytes x three tables
+        # per row) are not attempted -- the caller then takes the hash-table builders (build_pyramid), which size themselves
+        # level by level from exact counts.
         caps = [n0]
-        for _ in range(depth):
-            caps.append((3 * caps[-1]) // 4 + 4096 if attempt == 0 else 8 * caps[-1] + 4096)
+        for l in range(depth):
+            side = -(-int(coord_bound) // (2 << l)) + 1  # ceil(bound / 2^(l+1)) (+1: padding 1 reaches one cell further)
+            geom = int(n_blocks) * side ** 3
+            caps.append((3 * caps[-1]) // 4 + 4096 if attempt == 0 else min(8 * caps[-1] + 4096, geom))
+        if attempt == 1 and sum(caps) * 27 * 4 * 3 > (16 << 30):
+            return None
         c_caps = (ctypes.c_int64 * (depth + 1))(*caps)
         nbytes = L.st_brick_pyramid_workspace_bytes(n0, int(n_blocks), int(coord_bound), depth, c_caps)
         if nbytes <= 0 or nbytes > (24 << 30):
             return None
-        ws = _lib.workspace(nbytes, dev)
-        order0 = torch.empty(n0, **i32)
-        coords_out = [torch.empty((caps[l], 4), **i32) for l in range(depth + 1)]
-        subm = [torch.empty((27, caps[l]), **i32) for l in range(depth + 1)]
-        down = [torch.empty((27, caps[l + 1]), **i32) for l in range(depth)]
-        up = [torch.empty((27, caps[l]), **i32) for l in range(depth)]
-        up_order = [torch.empty(caps[l] + 16, **i32) for l in range(depth)]
+        try:
+            ws = _lib.workspace(nbytes, dev)
+            order0 = torch.empty(n0, **i32)
+            coords_out = [torch.empty((caps[l], 4), **i32) for l in range(depth + 1)]
+            subm = [torch.empty((27, caps[l]), **i32) for l in range(depth + 1)]
+            down = [torch.empty((27, caps[l + 1]), **i32) for l in range(depth)]
+            up = [torch.empty((27, caps[l]), **i32) for l in range(depth)]
+            up_order = [torch.empty(caps[l] + 16, **i32) for l in range(depth)]
+        except torch.OutOfMemoryError:
+            return None
         arr = lambda ts: (ctypes.c_void_p * max(len(ts), 1))(*[t.data_ptr() for t in ts])
         counts = (ctypes.c_int64 * (depth + 1))()
         rc = L.st_brick_pyramid(_lib.ptr(coords), n0, int(n_blocks), int(coord_bound), depth, _lib.ptr(blk_seg) if n_seg > 1 else None,
@@ -149,8 +160,11 @@ def brick_pyramid(coords: torch.Tensor, depth: int, n_blocks: int, coord_bound: 
             break
         if b"outside the declared bounds" in L.st_last_error():
             return None  # the hint was wrong for this input: hash-table builders
-        if attempt == 1 or b"capacity" not in L.st_last_error():
+        if b"capacity" not in L.st_last_error():
             _lib.check(rc)
+        if attempt == 1:
+            return None  # still over capacity: hash-table builders
+        del ws, order0, coords_out, subm, down, up, up_order
     n = [int(counts[l]) for l in range(depth + 1)]
     pyr = RulebookPyramid()
     for l in range(depth + 1):
@@ -274,7 +288,7 @@ def sparse_conv(x0: torch.Tensor, w: torch.Tensor, nbr: Optional[torch.Tensor], 
     wq (optional, b3_weight(w)): the weights as three bf16 planes -> the split-bf16 matrix-core kernel (float32 accuracy on the
     bf16 pipe) where the shape is eligible (b3_eligible); takes precedence over wp.
     row_order (optional, [n_out] int32): launch order of the output rows (never changes the result).
-    Half-precision storage mode: a float16 x0 and / or out_half select st_sparse_conv_f16_fwd (wp16 = wp as half)."""
+    Half-precision storage mode: a float16 x0 and / or out_half select st_sparse_conv_f16_fwd (wp16 = mfma_weight16_half(w): the layout depends on Cin / Cout, see include/smarttree_hip.h)."""
     L = _lib.lib()
     K, cin, cout = w.shape
     c0 = x0.shape[1]

@@ -57,11 +57,12 @@ def timed(**kw):
 sssp_ms, _ = timed(stages=STAGE_SSSP)
 ms, res = timed()
 print(f"params [{params}]: SSSP + predecessors {sssp_ms:.2f} ms, with the branch selection {ms:.2f} ms; {res.stats}; branches of the first component {int(res.n_branches[0])}")
-ticks = torch.zeros(16, dtype=torch.int64, device=dev)
+ticks = torch.zeros(32, dtype=torch.int64, device=dev)
 with tuning.override({**knobs, tuning.TICKS: ticks.data_ptr()}):
     run_components(comps, medial, radius, ys)
 torch.cuda.synchronize()
 t = ticks.cpu().numpy()
 print(f"  phases (us, summed over components): head {t[0]/100:.0f} rank {t[7]/100:.0f} prune {t[1]/100:.0f} walk+rows {t[2]/100:.0f} claim {t[3]/100:.0f} "
-      f"validate+commit {t[4]/100:.0f} one-mode {t[5]/100:.0f} local {t[6]/100:.0f} ({t[15]}) | rounds {t[8]} slots {t[13]} commits {t[12]} "
-      f"one-mode iters {t[9]} (path vertices {t[10]}) wide {t[14]} cand {t[11]}")
+      f"replay {t[4]/100:.0f} one-mode {t[5]/100:.0f} local {t[6]/100:.0f} ({t[15]}) | rounds {t[8]} cached slots {t[13]} cached commits {t[12]} "
+      f"evaluated by the replay {t[11]} | one-mode iters {t[9]} (path vertices {t[10]}) wide {t[14]}\n"
+      f"  rounds ended by: entries used up {t[16]}, a slot without a cache entry {t[17]}, an entry too long for the replay {t[18]}, too heavy {t[19]}")

@@ -51,10 +51,11 @@ knobs = {}
 for kv in filter(None, params.split(",")):
     k, v = kv.split("=")
     knobs[int(k)] = int(v)
-ticks = torch.zeros(16, dtype=torch.int64)
+ticks = torch.zeros(32, dtype=torch.int64)
 t0 = time.time()
 with tuning.override({**knobs, tuning.TICKS: ticks.data_ptr()}):
     res = run_components(comps, medial, radius, bc.xyz[:, 1].contiguous())
 t = ticks.numpy()
-print(f"params [{params}] ({time.time() - t0:.1f} s on the emulator): {res.stats}\n  rounds {t[8]} slots {t[13]} commits {t[12]} one-mode iters {t[9]} "
-      f"(path vertices {t[10]}) wide {t[14]} local {t[15]} candidates {t[11]}")
+print(f"params [{params}] ({time.time() - t0:.1f} s on the emulator): {res.stats}\n  rounds {t[8]} cached slots {t[13]} cached commits {t[12]} "
+      f"evaluated by the replay {t[11]} | whole-workgroup iterations {t[9]} (path vertices {t[10]}) wide {t[14]} local {t[15]}\n"
+      f"  rounds ended by: entries used up {t[16]}, a slot without a cache entry {t[17]}, an entry too long for the replay {t[18]}, too heavy {t[19]}")
