@@ -69,6 +69,7 @@ struct SkArgs {
     unsigned* q0;
     unsigned* q1;
     unsigned* term_bits;  // sample_tree's termination set, one bit per vertex; component c owns the words from (comp_off[c] >> 5) + c
+    unsigned* spec_bits;  // ... and the evaluators' prediction of it (same layout)
     float4* pr;       // [m] (x, y, z, radius) of every vertex in one 16-byte record (k_sk_lift_init): one gather instead of two
     unsigned long long* best;  // claim race: (d2 bits << 32) | path position
     unsigned* touched;
@@ -517,17 +518,18 @@ __device__ __forceinline__ bool sk_claim_items(const SkArgs& A, int c, int base,
 //       path is the first `len` ancestors of its tip -- state enters only through `len` (where the walk meets the
 //       termination set), through "is the tip still unallocated" and through the parent id read at the walk's end;
 //   (2) branches far apart do not touch each other's walks.
-// So one workgroup per component runs the loop literally -- one wavefront REPLAYS it in order against the termination set,
-// kept as a bitmap in LDS -- and the expensive part, the claims, comes from a cache that the whole workgroup fills
-// speculatively: each round the first SK_ENT unallocated vertices of the distance order are looked at, up to one per
-// wavefront (those not predicted to be swallowed by an earlier one) is walked against the state at the start of the
-// round, and the candidates of all those paths are dealt over the workgroup (each finds its nearest path vertex in LDS).
-// The replay then takes the entries in order: dead (claimed meanwhile) -> skip; cached path still the true path (none of
-// its vertices terminated since) -> commit the cached claims; otherwise (walk cut short by an earlier branch of this
-// round, or no cache entry: a tip predicted to be swallowed that survived) the replay wavefront evaluates the branch
-// itself on the spot when it is small, or ends the round there (the entry then heads the next round, where a path too
-// long or too heavy for one wavefront is worked on by the whole workgroup).  Whatever the speculation guessed, the
-// result is the sequential loop's: the cache is only ever used for the path the loop would have walked.
+// So one workgroup per component runs the loop LITERALLY and speculates around it, asynchronously (no barrier in between):
+//   * wavefront 0, the REPLAY, walks the distance order; the termination set is a bitmap in LDS.  For the next unallocated
+//     vertex (the loop's next tip) it looks the tip up in a cache of evaluated branches: cached path still the true path
+//     (none of its vertices terminated since, the vertex behind it was terminated already) -> commit the cached claims;
+//     no entry, or a stale one -> it evaluates the branch itself on the spot;
+//   * the other wavefronts, the EVALUATORS, run ahead of it: each takes the next few positions of the order, skips what is
+//     allocated or predicted to be swallowed by a cached tip nearby, walks the first other one against the bitmap as it
+//     is at that moment, finds the claims of that path (the candidates around the path against its vertices) and
+//     publishes path + claims as a cache entry.  What they see of the bitmap while the replay changes it does not matter:
+//     an entry is only ever used for the path the sequential loop walks.
+// A path too long or too heavy for one wavefront stops everybody: the whole workgroup works on that one branch
+// (`one` mode, barriers), then the two roles resume.
 #define SK_SMALL_WORK (1 << 18)  // candidate points x path vertices one workgroup takes on point-centric, unpruned
 #define SK_ITERS_PER_LAUNCH 32
 #define SK_LPATH 1024
@@ -537,10 +539,12 @@ __device__ __forceinline__ bool sk_claim_items(const SkArgs& A, int c, int base,
 // masked at the start, which sit at the tail of the distance order and are never looked at): one bit per vertex.  In LDS
 // while the workgroup runs (loaded from / flushed to the component's words of A.term_bits at the launch boundaries), in
 // global memory for a component too large for the LDS words.
-#define SK_BM_WORDS 8192  // 262,144 vertices
+#define SK_BM_WORDS 4096  // 131,072 vertices
 struct SkBm {
     unsigned* lds;
     unsigned* glb;
+    unsigned* spec_lds;  // the PREDICTED termination set (what the published evaluations will terminate): same layout
+    unsigned* spec_glb;
     bool in_lds;
 };
 __device__ __forceinline__ bool bm_test(const SkBm& B, int v) {
@@ -550,6 +554,14 @@ __device__ __forceinline__ bool bm_test(const SkBm& B, int v) {
 __device__ __forceinline__ void bm_set(const SkBm& B, int v) {
     if (B.in_lds) atomicOr(&B.lds[v >> 5], 1u << (v & 31));
     else wg_or(&B.glb[v >> 5], 1u << (v & 31));
+}
+__device__ __forceinline__ bool sp_test(const SkBm& B, int v) {
+    const unsigned w = B.in_lds ? B.spec_lds[v >> 5] : ld_wg(&B.spec_glb[v >> 5]);
+    return (w >> (v & 31)) & 1u;
+}
+__device__ __forceinline__ void sp_set(const SkBm& B, int v) {
+    if (B.in_lds) atomicOr(&B.spec_lds[v >> 5], 1u << (v & 31));
+    else wg_or(&B.spec_glb[v >> 5], 1u << (v & 31));
 }
 // allocation / termination / branch-id stamp of a point (path.py:112-122,135-136).  branch_ids keeps the LAST writer; ids
 // grow with the order of the loop, so "last" is a max -- commutative, which lets the lanes of a commit race.
@@ -583,18 +595,19 @@ __device__ __forceinline__ unsigned wave_incl_scan_u(unsigned v, int lane) {
 }
 
 // LDS of k_sk_select.  Two modes share the space: `one` = a single branch worked on by the whole workgroup
-// (paths up to SK_LPATH vertices), `slot[]` = one cached branch per wavefront (short paths) + one for the replay's own.
-#define SK_NSLOT 16    // = SK_MAX_WAVES: cached evaluations per round
-#define SK_LATE SK_NSLOT  // index of the slot the replay wavefront evaluates into
-#define SK_ENT 256     // unallocated vertices of the distance order a round looks at
+// (paths up to SK_LPATH vertices), `slot[]` = the scratch of one evaluation per wavefront (short paths).
+#define SK_NSLOT 16    // = SK_MAX_WAVES: evaluation scratch per wavefront
+#define SK_NCACHE 32   // cache entries (one lane each in the replay's look-up)
+#define SK_OWN SK_NCACHE  // the replay's private entry
 #define SK_WPATH 64    // a cached walk is ONE row of the ancestor table
 #define SK_WCHUNK 8    // path vertices per bounding box of a cached path (sk_on_path)
 #define SK_WROWS 256   // (x, y) cell rows around a cached path: up to four per lane
-#define SK_WAVE_WORK (1 << 20)  // candidate points x path vertices per cached branch
+#define SK_WAVE_WORK (1 << 20)  // candidate points x path vertices an evaluator takes on
 #define SK_WAVE_CAND 16384
-#define SK_ROUND_ITEMS 32       // candidates per thread and round
-#define SK_CL_CAP 512           // claimed points a cache entry holds (more: the whole workgroup evaluates the entry)
-#define SK_LATE_CAND 1024       // candidates the replay wavefront takes on by itself
+#define SK_CL_CAP 384           // claimed points a cache entry holds (more: the whole workgroup works on the branch)
+#define SK_LATE_CAND 4096       // candidates the replay wavefront takes on by itself
+#define SK_RWIN 4               // the replay's window: SK_RWIN x 64 positions of the distance order in registers
+#define SK_LOOKAHEAD 2048       // the scout stays within this many positions of the replay
 struct SkSelOne {
     int lpath[SK_LPATH];
     float lpx[SK_LPATH], lpy[SK_LPATH], lpz[SK_LPATH], lpr[SK_LPATH];
@@ -610,8 +623,25 @@ struct SkSelSlot {
 };
 union SkSelLds {
     SkSelOne one;
-    SkSelSlot slot[SK_NSLOT + 1];
+    SkSelSlot slot[SK_NSLOT];
 };
+// a cache entry: what the replay needs to commit a branch
+struct SkCacheEnt {
+    int path[SK_WPATH];      // root side first
+    unsigned cl[SK_CL_CAP];  // the claimed points
+};
+enum { SK_C_EMPTY = 0, SK_C_ALLOC = 1, SK_C_BUSY = 2, SK_C_READY = 3 };  // entry states (ALLOC: taken, tag not yet written)
+enum { SK_M_RUN = 0, SK_M_ONE = 1, SK_M_DONE = 2, SK_M_PAUSE = 3 };      // what the workgroup does: replay + evaluators /
+// the whole workgroup on one branch / component finished / this launch's share of steps is used up
+// LDS words shared between wavefronts WITHOUT a barrier in between: relaxed atomics at workgroup scope (never cached in a
+// register over a spin), release / acquire fences around the data they publish
+__device__ __forceinline__ int lds_ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// ... read ONCE per wavefront: a word another wavefront may change at any moment must not be seen differently by the lanes of a
+// wavefront that branches on it (one LDS read in hardware; on the CPU emulator the lanes run one after the other)
+__device__ __forceinline__ int lds_ld_u(const int* p) { return __builtin_amdgcn_readfirstlane(lds_ld(p)); }
+__device__ __forceinline__ void lds_st(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+#define SK_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup")
+#define SK_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup")
 
 // row r with row_off[r] <= t < row_off[r+1]
 __device__ __forceinline__ int sk_find_row(const uint32_t* row_off, int nrows, uint32_t t) {
@@ -620,26 +650,24 @@ __device__ __forceinline__ int sk_find_row(const uint32_t* row_off, int nrows, u
     return lo;
 }
 
-// what a walk leaves behind for the claim pass / the replay (LDS, one set per slot)
+// the facts of a walk
 struct SkSlotInfo {
-    int len, term, parent, nrows, ncand, big;
+    int len, term, nrows, ncand, big;
     float rp;
 };
 
 // One wavefront walks `tip` against the termination set as it is NOW (trace_route, path.py:9-16: lane j inspects the j-th
 // ancestor; the first terminated one, or the step past the root, ends the walk), then gathers position / radius of its
 // path into slot S, the (x, y) rows of grid cells around it and how many candidate points they hold.  All 64 lanes call.
-// The parent id is the value at the time of the walk: for a cached walk that is the start of the round (the replay corrects
-// it from tv_hit), for the replay's own evaluation it is final (the caller fences this wavefront's stamps first).
 __device__ __forceinline__ SkSlotInfo sk_walk(const SkArgs& A, const SkBm& B, SkSelSlot& S, int base, int n, int tip, int xoff,
-                                              int W, int lane) {
+                                              int lane) {
     const StGrid* g = A.grid;
     SkSlotInfo I;
     const int node = lane == 0 ? tip : A.anc[(int64_t)(base + tip) * SK_ANC + lane - 1];
     const bool end = node < 0 || bm_test(B, node);
     const unsigned long long eb = __ballot(end);
     I.big = eb == 0ull;
-    I.len = 0; I.term = -1; I.nrows = 0; I.ncand = 0; I.parent = -1; I.rp = 0.0f;
+    I.len = 0; I.term = -1; I.nrows = 0; I.ncand = 0; I.rp = 0.0f;
     if (I.big) return I;
     const int len = __ffsll(eb) - 1;
     I.len = len;
@@ -648,12 +676,6 @@ __device__ __forceinline__ SkSlotInfo sk_walk(const SkArgs& A, const SkBm& B, Sk
     if (lane < 3) { S.lo[lane] = 0x7fffffff; S.hi[lane] = (int)0x80000000; }
     if (lane == 3) S.rk = 0u;
     __builtin_amdgcn_wave_barrier();
-    // the parent id is read BEFORE anything is stamped (path.py:128-136); termination -1 reads branch_ids[-1] = the last
-    // vertex (quirk kept)
-    if (len >= 2) {
-        // (uniform address: one request; agent scope = read where the stamps' atomics act, never a stale line of this CU's L1)
-        I.parent = ld(&A.branch_of[base + (I.term < 0 ? n - 1 : I.term)]);
-    }
     if (lane < len) {
         const float4 q4 = A.pr[base + node];
         S.path[qi] = node; S.p[qi] = q4;
@@ -708,7 +730,7 @@ __device__ __forceinline__ SkSlotInfo sk_walk(const SkArgs& A, const SkBm& B, Sk
     I.ncand = (int)run;
     if (lane == 0) S.row_off[nrows] = run;
     __builtin_amdgcn_wave_barrier();
-    I.big = I.ncand > SK_WAVE_CAND || I.ncand > SK_ROUND_ITEMS * W || (int64_t)I.ncand * len > A.wave_work;
+    I.big = I.ncand > SK_WAVE_CAND || (int64_t)I.ncand * len > A.wave_work;
     return I;
 }
 
@@ -762,26 +784,117 @@ __device__ __forceinline__ bool sk_on_path(const SkSelSlot& S, int len, float rp
     return bd2 < rp2 && sqrtf(bd2) < bw;  // path.py:35-40
 }
 
+// rows of four candidates at once: the four binary searches advance in lockstep (a fixed number of steps), so that their
+// dependent LDS reads overlap instead of queueing behind each other
+__device__ __forceinline__ void sk_find_rows4(const uint32_t* row_off, int nrows, const uint32_t (&t)[4], int (&row)[4]) {
+    int lo[4] = {0, 0, 0, 0}, hi[4] = {nrows, nrows, nrows, nrows};
+    for (int span = nrows; span > 1; span = (span + 1) >> 1) {  // uniform trip count >= ceil(log2(nrows))
+        uint32_t v[4];
+        int mid[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { mid[u] = (lo[u] + hi[u]) >> 1; v[u] = row_off[mid[u]]; }  // (converged: mid == lo, a no-op)
+#pragma unroll
+        for (int u = 0; u < 4; u++) { if (v[u] <= t[u]) lo[u] = mid[u]; else hi[u] = mid[u]; }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) row[u] = lo[u];
+}
+
+// One wavefront evaluates the branch of `tip` against the termination set as it is NOW: the walk, then the claims of that
+// path (select_path_points, path.py:19-46: every candidate point around the path finds its nearest path vertex) into E.
+// big = the branch needs the whole workgroup (walk longer than one ancestor row, too many cell rows / candidates / claims).
+// All 64 lanes call; S is this wavefront's scratch.
+__device__ __forceinline__ SkSlotInfo sk_evaluate(const SkArgs& A, const SkBm& B, SkSelSlot& S, SkCacheEnt& E, int& ncl_out, int base,
+                                                  int n, int tip, int xoff, int lane, int cand_cap) {
+    SkSlotInfo I = sk_walk(A, B, S, base, n, tip, xoff, lane);
+    ncl_out = 0;
+    if (I.big) return I;
+    if (I.ncand > cand_cap) { I.big = 1; return I; }
+    if (lane < I.len) E.path[lane] = S.path[lane];
+    int ncl = 0;
+    const float4* __restrict__ recs = A.recs;
+    for (int t0 = 0; t0 < I.ncand; t0 += 256) {
+        uint32_t t[4];
+        int row[4];
+        float4 r4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int tt = t0 + u * 64 + lane;
+            t[u] = (uint32_t)(tt < I.ncand ? tt : I.ncand - 1);
+        }
+        sk_find_rows4(S.row_off, I.nrows, t, row);
+#pragma unroll
+        for (int u = 0; u < 4; u++) r4[u] = recs[S.row_first[row[u]] + (t[u] - S.row_off[row[u]])];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int p = (int)__float_as_uint(r4[u].w) - base;  // (outside [0, n): another component's point)
+            const bool on = t0 + u * 64 + lane < I.ncand && p >= 0 && p < n && sk_on_path(S, I.len, I.rp, r4[u]);
+            const unsigned long long m = __ballot(on);
+            if (on) {
+                const int at = ncl + __popcll(m & ((1ull << lane) - 1ull));
+                if (at < SK_CL_CAP) E.cl[at] = (unsigned)p;
+            }
+            ncl += __popcll(m);
+        }
+    }
+    ncl_out = ncl;
+    if (ncl > SK_CL_CAP) I.big = 1;
+    return I;
+}
+
+// The replay commits a branch (path.py:112-136): the parent id is read first (where this launch's stamps are: agent scope,
+// after this wavefront's earlier stamps have completed), then path and claims are stamped.  The vertex the parent id is read
+// from may be among the stamped ones: its stamp waits for the read.
+__device__ __forceinline__ void sk_commit(const SkArgs& A, const SkBm& B, const SkCacheEnt& E, int len, int termv, int ncl, int base,
+                                          int n, int lane, int& nb, int& total) {
+    const bool keep = len >= 2;  // path.py:125-126: shorter paths still consume their points
+    const int id = keep ? nb : -1;
+    const int tvv = termv < 0 ? n - 1 : termv;  // termination -1 reads branch_ids[-1] = the LAST vertex (quirk kept)
+    int parent = -1;
+    if (keep) {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        parent = ld(&A.branch_of[base + tvv]);  // (uniform address: one request)
+    }
+    __builtin_amdgcn_wave_barrier();  // (every lane has issued its read before any lane stamps)
+    bool deferred = false;
+    if (lane < len) {
+        const int v = E.path[lane];
+        if (keep) A.path_verts[base + total + lane] = v;
+        if (keep && v == tvv) deferred = true; else sk_mark(A, B, base, v, id);
+    }
+    for (int i = lane; i < ncl; i += 64) {
+        const int p = (int)E.cl[i];
+        if (keep && p == tvv) deferred = true; else sk_mark(A, B, base, p, id);
+    }
+    if (keep) {
+        if (lane == 0) {
+            A.branch_parent[base + nb] = parent;
+            A.branch_off[base + nb] = total;
+            A.branch_len[base + nb] = len;
+        }
+        if (deferred && parent >= -1) sk_mark(A, B, base, tvv, id);  // (always true: makes the stamp wait for the read)
+        nb++; total += len;
+    }
+}
+
 __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
     long long t_last = A.ticks ? wall_clock64() : 0;
     __shared__ long long tk[8];  // phase timers (developer aid), touched by thread 0 only
     if (A.ticks && threadIdx.x == 0) for (int i_ = 0; i_ < 8; i_++) tk[i_] = 0;
     __shared__ unsigned long long s_red[SK_MAX_WAVES];
     __shared__ SkSelLds L;
-    __shared__ unsigned bm_words[SK_BM_WORDS];           // termination set (see SkBm)
-    __shared__ unsigned cl[SK_NSLOT][SK_CL_CAP], cl_n[SK_NSLOT];  // the claimed points of every cached branch
+    __shared__ unsigned bm_words[SK_BM_WORDS], sp_words[SK_BM_WORDS];  // termination set and its prediction (see SkBm)
+    __shared__ SkCacheEnt cache[SK_NCACHE + 1];
+    __shared__ int c_state[SK_NCACHE], c_tip[SK_NCACHE + 1], c_pos[SK_NCACHE], c_len[SK_NCACHE + 1], c_term[SK_NCACHE + 1],
+        c_ncl[SK_NCACHE + 1], c_big[SK_NCACHE + 1];
+    __shared__ float4 c_tipp[SK_NCACHE];  // position + radius of a cached tip (the evaluators' prediction)
+    __shared__ int s_mode, s_rpos, s_big_tip, s_nb2, s_tot2, s_steps;
+    __shared__ int mb_state[SK_MAX_WAVES], mb_tip[SK_MAX_WAVES], mb_pos[SK_MAX_WAVES];  // one mailbox per evaluator: the scout's next job
+    __shared__ float4 mb_tp[SK_MAX_WAVES];
     __shared__ uint32_t s_scan[SK_MAX_WAVES + 1];
     __shared__ float cb_lo[3][SK_LPATH / SK_CHUNK], cb_hi[3][SK_LPATH / SK_CHUNK];  // chunk boxes of a long path
     __shared__ int s_lo[3], s_hi[3];
     __shared__ int s_term;
-    __shared__ int w_cnt[SK_MAX_WAVES], w_tail[SK_MAX_WAVES];
-    __shared__ int ent_v[SK_ENT];            // the round's entries: the first unallocated vertices of the window, in order
-    __shared__ float4 ent_p[SK_ENT];         // ... their position and radius
-    __shared__ signed char ent_slot[SK_ENT];  // ... their cache slot (-1: none)
-    __shared__ int slot_ent[SK_NSLOT], s_nc, s_ne, s_nb2, s_tot2;
-    __shared__ SkSlotInfo sl[SK_NSLOT + 1];
-    __shared__ int tvs[SK_NSLOT];        // the vertex each cached branch reads its parent id from (-2: none)
-    __shared__ unsigned tv_hit[SK_NSLOT];  // bit s: cached branch s stamps that vertex
     const int c = blockIdx.x, tid = threadIdx.x, W = (int)blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nw = (W + 63) >> 6;
     if (A.s_done[c]) return;
@@ -795,9 +908,15 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
     SkBm B;
     B.lds = bm_words;
     B.glb = A.term_bits + (base >> 5) + c;
+    B.spec_lds = sp_words;
+    B.spec_glb = A.spec_bits + (base >> 5) + c;
     const int nwords = (n + 31) >> 5;
     B.in_lds = nwords <= SK_BM_WORDS;
-    if (B.in_lds) for (int i = tid; i < nwords; i += W) bm_words[i] = B.glb[i];
+    if (B.in_lds) for (int i = tid; i < nwords; i += W) { bm_words[i] = B.glb[i]; sp_words[i] = 0u; }
+    else for (int i = tid; i < nwords; i += W) B.spec_glb[i] = 0u;  // (the prediction starts afresh with every launch)
+    if (tid < SK_NCACHE) c_state[tid] = SK_C_EMPTY;
+    if (tid < SK_MAX_WAVES) mb_state[tid] = 0;
+    if (tid == 0) { s_mode = SK_M_RUN; s_rpos = A.s_cursor[c]; }
     __syncthreads();
 #define SK_FLUSH_BM()                                                             \
     do {                                                                          \
@@ -812,51 +931,274 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
                              A.s_ntouched[c]);
     }
     SK_TICK(0);
-    int win_base = A.s_cursor[c], total = A.s_total[c], nb = A.s_nb[c];  // per-component state lives in registers
-    int wv = -1;         // my window entry: component-local vertex, -1 = none
-    float4 wq = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // ... its position and radius
-    bool wtail = false;  // my entry marks the end of the selectable vertices (initial distance <= 0, or end of the list)
-    bool need_fill = true;
-    const int nslot_max = nw < SK_NSLOT ? nw : SK_NSLOT;
-    for (int iter = 0; iter < A.iters_per_launch; iter++) {
-        // 1. the round's entries = the first unallocated vertices of the distance-sorted order (path.py:92: the farthest
-        //    unallocated vertex is the first of them).  A window of W order positions is held in registers; liveness is a
-        //    bit test, so finding the entries costs no global access until the window is used up.
-        int ne = 0;
-        bool exhausted = false;
-        for (;;) {
-            if (need_fill) {
-                const int j = win_base + tid;
-                wv = -1; wtail = false;
-                if (j < n) {
-                    wv = (int)order[j] - base;
-                    wtail = !(A.order_init[base + j] > 0.0f);
-                    if (!wtail) wq = A.pr[base + wv];
-                } else if (j == n) {
-                    wtail = true;
+    int total = A.s_total[c], nb = A.s_nb[c];  // per-component state lives in registers (uniform over the workgroup)
+    int steps_left = A.iters_per_launch;       // branches the replay may select in this launch
+    for (;;) {
+        if (wave == 0) {
+            // ---------------------------------------------------------------- the replay ---
+            // Positions of the distance order in registers: SK_RWIN x 64, position rb + 64 g + lane; the next window is
+            // requested as soon as this one is in use.  path.py:92: the farthest unallocated vertex = the first position
+            // whose vertex is not terminated.
+            int ov[SK_RWIN], nv[SK_RWIN];
+            bool ot[SK_RWIN], nt[SK_RWIN];  // tail: end of the selectable vertices (initial distance <= 0, or end of the list)
+            int rb = lds_ld_u(&s_rpos);
+#define SK_LOAD_WIN(rb_, v_, t_)                                                                   \
+    _Pragma("unroll") for (int gq = 0; gq < SK_RWIN; gq++) {                                       \
+        const int j_ = (rb_) + gq * 64 + lane;                                                     \
+        v_[gq] = -1; t_[gq] = false;                                                               \
+        if (j_ < n) { v_[gq] = (int)order[j_] - base; t_[gq] = !(A.order_init[base + j_] > 0.0f); } \
+        else if (j_ == n) t_[gq] = true;                                                           \
+    }
+            SK_LOAD_WIN(rb, ov, ot)
+            SK_LOAD_WIN(rb + SK_RWIN * 64, nv, nt)
+            int cur = 0;
+            int why = SK_M_RUN;
+            long long rt = A.ticks ? wall_clock64() : 0;
+#define SK_RTICK(i) do { if (A.ticks && lane == 0) { const long long now_ = wall_clock64(); A.ticks[i] += now_ - rt; rt = now_; } } while (0)
+            for (;;) {
+                __builtin_amdgcn_wave_barrier();  // (the stamps of the previous step are in the bitmap)
+                int first = -1, tail = -1;
+#pragma unroll
+                for (int gq = 0; gq < SK_RWIN; gq++) {
+                    const int e = gq * 64 + lane;
+                    const bool lv = ov[gq] >= 0 && !ot[gq] && e >= cur && !bm_test(B, ov[gq]);
+                    const unsigned long long bal = __ballot(lv), tb = __ballot(ot[gq]);
+                    if (first < 0 && bal) first = gq * 64 + __ffsll(bal) - 1;
+                    if (tail < 0 && tb) tail = gq * 64 + __ffsll(tb) - 1;
                 }
-                need_fill = false;
+                if (first < 0 || (tail >= 0 && tail < first)) {
+                    if (tail >= 0) { why = SK_M_DONE; break; }  // path.py:94-95: nothing selectable is left
+                    rb += SK_RWIN * 64;  // the next window
+#pragma unroll
+                    for (int gq = 0; gq < SK_RWIN; gq++) { ov[gq] = nv[gq]; ot[gq] = nt[gq]; }
+                    SK_LOAD_WIN(rb + SK_RWIN * 64, nv, nt)
+                    cur = 0;
+                    if (lane == 0) lds_st(&s_rpos, rb);
+                    continue;
+                }
+                if (steps_left == 0) { why = SK_M_PAUSE; if (lane == 0) lds_st(&s_rpos, rb + first); break; }
+                int tip = -1;
+#pragma unroll
+                for (int gq = 0; gq < SK_RWIN; gq++)
+                    if ((first >> 6) == gq) tip = __builtin_amdgcn_readlane(ov[gq], first & 63);
+                const int rpos = rb + first;
+                if (lane == 0) lds_st(&s_rpos, rpos);
+                SK_RTICK(20);
+                // the cache: entries of positions the replay has passed are dropped, the entry of this tip is looked up
+                int e = -1;
+                {
+                    int st = SK_C_EMPTY;
+                    if (lane < SK_NCACHE) {
+                        st = lds_ld(&c_state[lane]);
+                        if (st == SK_C_READY && lds_ld(&c_pos[lane]) < rpos) { lds_st(&c_state[lane], SK_C_EMPTY); st = SK_C_EMPTY; }
+                    }
+                    const unsigned long long mb = __ballot(st >= SK_C_BUSY && lds_ld(&c_tip[lane & (SK_NCACHE - 1)]) == tip && lane < SK_NCACHE);
+                    if (mb) {
+                        e = __ffsll(mb) - 1;
+                        while (lds_ld_u(&c_state[e]) != SK_C_READY) {  // an evaluator is at it: it does not wait for anything
+                            __builtin_amdgcn_s_sleep(1);
+                            __builtin_amdgcn_wave_barrier();
+                            if (A.ticks && lane == 0) A.ticks[14] += 1;
+                        }
+                        SK_ACQUIRE();
+                    }
+                }
+                bool big = false, done = false;
+                if (A.ticks && lane == 0) A.ticks[e >= 0 ? 16 : 19] += 1;
+                if (e >= 0) {
+                    if (lds_ld(&c_big[e])) { big = true; if (A.ticks && lane == 0) A.ticks[18] += 1; }
+                    else {
+                        // the cached path is the true path iff none of its vertices has been terminated since its walk
+                        const int len = lds_ld(&c_len[e]);
+                        const bool hit = lane < len && bm_test(B, cache[e].path[lane]);
+                        if (__ballot(hit) == 0ull) {
+                            sk_commit(A, B, cache[e], len, lds_ld(&c_term[e]), lds_ld(&c_ncl[e]), base, n, lane, nb, total);
+                            done = true;
+                            if (A.ticks && lane == 0) A.ticks[12] += 1;
+                        } else if (A.ticks && lane == 0) A.ticks[17] += 1;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane == 0) lds_st(&c_state[e], SK_C_EMPTY);
+                    SK_RTICK(21);
+                }
+                if (!done && !big) {
+                    // no entry (a tip nobody evaluated: predicted to be swallowed, or the evaluators are behind), or the walk
+                    // has been cut short since: the replay evaluates the branch itself against the state as it is now
+                    int ncl = 0;
+                    const SkSlotInfo I = sk_evaluate(A, B, L.slot[0], cache[SK_OWN], ncl, base, n, tip, xoff, lane, A.late_cand);
+                    if (I.big) big = true;
+                    else {
+                        __builtin_amdgcn_wave_barrier();
+                        sk_commit(A, B, cache[SK_OWN], I.len, I.term, ncl, base, n, lane, nb, total);
+                    }
+                    if (A.ticks && lane == 0) A.ticks[11] += 1;
+                    SK_RTICK(22);
+                }
+                if (big) { why = SK_M_ONE; if (lane == 0) s_big_tip = tip; break; }
+                cur = first + 1;
+                steps_left--;
+                if (A.ticks && lane == 0) A.ticks[8] += 1;
             }
-            const bool live = wv >= 0 && !wtail && !bm_test(B, wv);
-            const unsigned long long lb = __ballot(live), tb = __ballot(wtail);
-            __syncthreads();  // (w_cnt of the previous pass has been read)
-            if (lane == 0) { w_cnt[wave] = __popcll(lb); w_tail[wave] = tb != 0ull; }
-            __syncthreads();
-            int before = 0, tot = 0, anytail = 0;
-            for (int w = 0; w < nw; w++) { const int k = w_cnt[w]; before += w < wave ? k : 0; tot += k; anytail |= w_tail[w]; }
-            if (tot == 0) {
-                if (anytail) { exhausted = true; break; }
-                win_base += W; need_fill = true;  // nothing left in this window
-                continue;
+#undef SK_RTICK
+#undef SK_LOAD_WIN
+            if (lane == 0) { s_nb2 = nb; s_tot2 = total; s_steps = steps_left; }
+            SK_RELEASE();
+            if (lane == 0) lds_st(&s_mode, why);
+        } else if (wave == 1 && nw >= 3) {
+            // ------------------------------------------------------------------ the scout ---
+            // walks the distance order AHEAD of the replay and hands the evaluators what will probably be a tip: a vertex
+            // that is neither terminated nor predicted to be (by the evaluations published so far, or by lying within the
+            // radius of a tip that is being evaluated).  A wrong guess only costs time (the replay evaluates what it misses).
+            int ov[SK_RWIN], nv[SK_RWIN];
+            bool ot[SK_RWIN], nt[SK_RWIN];
+            float4 op[SK_RWIN], np[SK_RWIN];
+            int rb = lds_ld_u(&s_rpos);
+#define SK_LOAD_SWIN(rb_, v_, t_, p_)                                                              \
+    _Pragma("unroll") for (int gq = 0; gq < SK_RWIN; gq++) {                                       \
+        const int j_ = (rb_) + gq * 64 + lane;                                                     \
+        v_[gq] = -1; t_[gq] = false; p_[gq] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);                 \
+        if (j_ < n) {                                                                              \
+            v_[gq] = (int)order[j_] - base; t_[gq] = !(A.order_init[base + j_] > 0.0f);            \
+            if (!t_[gq]) p_[gq] = A.pr[base + v_[gq]];                                             \
+        } else if (j_ == n) t_[gq] = true;                                                         \
+    }
+            SK_LOAD_SWIN(rb, ov, ot, op)
+            SK_LOAD_SWIN(rb + SK_RWIN * 64, nv, nt, np)
+            int cur = 0;
+            bool at_end = false;
+            for (;;) {
+                __builtin_amdgcn_wave_barrier();
+                if (lds_ld_u(&s_mode) != SK_M_RUN) break;
+                if (at_end) { __builtin_amdgcn_s_sleep(16); continue; }
+                const int rp = lds_ld_u(&s_rpos);
+                if (rb + cur > rp + SK_LOOKAHEAD) { __builtin_amdgcn_s_sleep(8); continue; }
+                if (rb + SK_RWIN * 64 <= rp) {  // the replay has overtaken this window: go where it is
+                    rb = rp;
+                    SK_LOAD_SWIN(rb, ov, ot, op)
+                    SK_LOAD_SWIN(rb + SK_RWIN * 64, nv, nt, np)
+                    cur = 0;
+                    continue;
+                }
+                int first = -1, tail = -1;
+#pragma unroll
+                for (int gq = 0; gq < SK_RWIN; gq++) {
+                    const int e = gq * 64 + lane;
+                    const bool lv = ov[gq] >= 0 && !ot[gq] && e >= cur && rb + e >= rp && !bm_test(B, ov[gq]) && !sp_test(B, ov[gq]);
+                    const unsigned long long bal = __ballot(lv), tb = __ballot(ot[gq]);
+                    if (first < 0 && bal) first = gq * 64 + __ffsll(bal) - 1;
+                    if (tail < 0 && tb) tail = gq * 64 + __ffsll(tb) - 1;
+                }
+                if (first < 0 || (tail >= 0 && tail < first)) {
+                    if (tail >= 0) { at_end = true; continue; }
+                    rb += SK_RWIN * 64;
+#pragma unroll
+                    for (int gq = 0; gq < SK_RWIN; gq++) { ov[gq] = nv[gq]; ot[gq] = nt[gq]; op[gq] = np[gq]; }
+                    SK_LOAD_SWIN(rb + SK_RWIN * 64, nv, nt, np)
+                    cur = 0;
+                    continue;
+                }
+                cur = first + 1;
+                int tip = -1;
+                float4 tp = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+                for (int gq = 0; gq < SK_RWIN; gq++)
+                    if ((first >> 6) == gq) {
+                        tip = __builtin_amdgcn_readlane(ov[gq], first & 63);
+                        tp.x = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(op[gq].x), first & 63));
+                        tp.y = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(op[gq].y), first & 63));
+                        tp.z = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(op[gq].z), first & 63));
+                        tp.w = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(op[gq].w), first & 63));
+                    }
+                const int mypos = rb + first;
+                // within the radius of an earlier tip whose evaluation is under way or done (its claims are not all in the
+                // prediction yet): it will almost surely be swallowed by that branch
+                bool sh = false;
+                if (lane < SK_NCACHE && lds_ld(&c_state[lane]) >= SK_C_BUSY) {
+                    const int cp = lds_ld(&c_pos[lane]);
+                    if (cp < mypos && cp >= rp) {
+                        const float4 u = c_tipp[lane];
+                        const float ur = u.w * A.prune_factor;
+                        const float dx = tp.x - u.x, dy = tp.y - u.y, dz = tp.z - u.z;
+                        sh = dx * dx + dy * dy + dz * dz < ur * ur;
+                    }
+                }
+                if (lane >= 32 && lane - 32 < SK_MAX_WAVES && lds_ld(&mb_state[lane - 32]) == 1) {  // ... or still in a mailbox
+                    const float4 u = mb_tp[lane - 32];
+                    const float ur = u.w * A.prune_factor;
+                    const float dx = tp.x - u.x, dy = tp.y - u.y, dz = tp.z - u.z;
+                    sh = sh || (lds_ld(&mb_pos[lane - 32]) < mypos && dx * dx + dy * dy + dz * dz < ur * ur);
+                }
+                if (__ballot(sh)) { if (A.ticks && lane == 0) A.ticks[24] += 1; continue; }
+                // a free mailbox (evaluators are the wavefronts 2 ..)
+                int w = -1;
+                for (;;) {
+                    const unsigned long long fb = __ballot(lane >= 2 && lane < nw && lds_ld(&mb_state[lane]) == 0);
+                    if (fb) { w = __ffsll(fb) - 1; break; }
+                    if (lds_ld_u(&s_mode) != SK_M_RUN) break;
+                    __builtin_amdgcn_s_sleep(2);
+                    __builtin_amdgcn_wave_barrier();
+                }
+                if (w < 0) break;
+                if (lane == 0) { mb_tip[w] = tip; mb_pos[w] = mypos; mb_tp[w] = tp; }
+                SK_RELEASE();
+                if (lane == 0) lds_st(&mb_state[w], 1);
             }
-            const int rank = before + __popcll(lb & ((1ull << lane) - 1ull));
-            if (live && rank < SK_ENT) { ent_v[rank] = wv; ent_p[rank] = wq; }
-            ne = tot < SK_ENT ? tot : SK_ENT;
-            if (tid < SK_NSLOT) { cl_n[tid] = 0u; tv_hit[tid] = 0u; tvs[tid] = -2; }
-            __syncthreads();
-            break;
+#undef SK_LOAD_SWIN
+        } else if (wave >= 2) {
+            // ------------------------------------------------------------- an evaluator ---
+            SkSelSlot& S = L.slot[wave];
+            for (;;) {
+                __builtin_amdgcn_wave_barrier();
+                if (lds_ld_u(&s_mode) != SK_M_RUN) break;
+                if (lds_ld_u(&mb_state[wave]) != 1) { __builtin_amdgcn_s_sleep(2); continue; }
+                SK_ACQUIRE();
+                const int tip = mb_tip[wave], mypos = mb_pos[wave];
+                const float4 tp = mb_tp[wave];
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) lds_st(&mb_state[wave], 0);  // (the scout may queue the next one while this one is evaluated)
+                if (mypos < lds_ld_u(&s_rpos)) { if (A.ticks && lane == 0) atomicAdd((unsigned long long*)&A.ticks[25], 1ull); continue; }
+                // a cache entry of my own
+                int e = -1;
+                for (;;) {
+                    const unsigned long long fb = __ballot(lane < SK_NCACHE && lds_ld(&c_state[lane]) == SK_C_EMPTY);
+                    if (fb) {
+                        const int cand = __ffsll(fb) - 1;
+                        int ok = 0;
+                        if (lane == 0) ok = atomicCAS(&c_state[cand], (int)SK_C_EMPTY, (int)SK_C_ALLOC) == SK_C_EMPTY;
+                        if (__builtin_amdgcn_readfirstlane(ok)) { e = cand; break; }
+                        continue;
+                    }
+                    if (lds_ld_u(&s_mode) != SK_M_RUN) break;  // (the replay frees entries as it passes them -- unless it has stopped)
+                    __builtin_amdgcn_s_sleep(4);
+                    __builtin_amdgcn_wave_barrier();
+                }
+                if (e < 0) break;
+                if (mypos < lds_ld_u(&s_rpos)) {  // the replay went past it while this wavefront waited
+                    if (lane == 0) lds_st(&c_state[e], SK_C_EMPTY);
+                    if (A.ticks && lane == 0) atomicAdd((unsigned long long*)&A.ticks[25], 1ull);
+                    continue;
+                }
+                if (lane == 0) { c_tip[e] = tip; c_pos[e] = mypos; c_tipp[e] = tp; }
+                SK_RELEASE();
+                if (lane == 0) lds_st(&c_state[e], SK_C_BUSY);
+                int ncl = 0;
+                const SkSlotInfo I = sk_evaluate(A, B, S, cache[e], ncl, base, n, tip, xoff, lane, SK_WAVE_CAND);
+                if (lane == 0) { c_len[e] = I.len; c_term[e] = I.term; c_ncl[e] = ncl; c_big[e] = I.big; }
+                if (!I.big) {  // what this branch will terminate, for the scout
+                    if (lane < I.len) sp_set(B, cache[e].path[lane]);
+                    for (int i = lane; i < ncl; i += 64) sp_set(B, (int)cache[e].cl[i]);
+                }
+                SK_RELEASE();
+                if (lane == 0) lds_st(&c_state[e], SK_C_READY);
+                if (A.ticks && lane == 0) atomicAdd((unsigned long long*)&A.ticks[13], 1ull);
+            }
         }
-        if (exhausted) {  // path.py:94-95 (uniform)
+        __syncthreads();  // both roles have stopped: no evaluation is in flight, the cache is dead
+        const int mode = s_mode;
+        nb = s_nb2; total = s_tot2; steps_left = s_steps;
+        const int win_base = s_rpos;
+        SK_TICK(4);
+        if (mode == SK_M_DONE) {  // path.py:94-95 (uniform)
             SK_FLUSH_BM();
             if (tid == 0) {
                 A.s_done[c] = 1; A.s_len[c] = 0; A.s_wide[c] = 0; A.n_branches[c] = nb; A.s_nb[c] = nb; A.s_total[c] = total;
@@ -867,287 +1209,20 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
             SK_TICK_FLUSH();
             return;
         }
-        SK_TICK(7);
-        // 2. which entries get a cache slot?  A tip within the radius of an earlier chosen tip will almost surely be
-        //    swallowed by that branch: it gets none (if the guess is wrong the replay evaluates it itself).  The round's
-        //    entries end where the slots run out.  One wavefront; entry e = 64 g + lane.
-        if (wave == 0) {
-            float4 ep[SK_ENT / 64];
-            bool avail[SK_ENT / 64];
-            int mine[SK_ENT / 64];
-#pragma unroll
-            for (int gq = 0; gq < SK_ENT / 64; gq++) {
-                const int e = gq * 64 + lane;
-                avail[gq] = e < ne;
-                mine[gq] = -1;
-                ep[gq] = avail[gq] ? ent_p[e] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            }
-            int chosen = 0, cut = ne;
-            for (;;) {
-                int first = -1;
-#pragma unroll
-                for (int gq = 0; gq < SK_ENT / 64; gq++) {
-                    const unsigned long long bal = __ballot(avail[gq]);
-                    if (first < 0 && bal) first = gq * 64 + __ffsll(bal) - 1;
-                }
-                if (first < 0) break;
-                if (chosen == nslot_max) { cut = first; break; }  // out of wavefronts: the round ends before this entry
-                const float4 u = ent_p[first];
-                const float ur = u.w * A.prune_factor;
-#pragma unroll
-                for (int gq = 0; gq < SK_ENT / 64; gq++) {
-                    const int e = gq * 64 + lane;
-                    if (e == first) { avail[gq] = false; mine[gq] = chosen; }
-                    else if (avail[gq] && e > first) {
-                        const float dx = ep[gq].x - u.x, dy = ep[gq].y - u.y, dz = ep[gq].z - u.z;
-                        if (dx * dx + dy * dy + dz * dz < ur * ur) avail[gq] = false;
-                    }
-                }
-                if (lane == 0) slot_ent[chosen] = first;
-                chosen++;
-            }
-#pragma unroll
-            for (int gq = 0; gq < SK_ENT / 64; gq++) {
-                const int e = gq * 64 + lane;
-                if (e < SK_ENT) ent_slot[e] = (signed char)mine[gq];
-            }
-            if (lane == 0) { s_nc = chosen; s_ne = cut; }
+        if (mode == SK_M_PAUSE) {
+            SK_FLUSH_BM();
+            if (tid == 0) { A.s_len[c] = 0; A.s_wide[c] = 0; A.s_cursor[c] = win_base; A.s_total[c] = total; A.s_nb[c] = nb; }
+            SK_TICK_FLUSH();
+            return;
         }
-        __syncthreads();
-        int nc = s_nc;
-        ne = s_ne;
-        SK_TICK(1);
-        // 3. cached walks: wavefront s traces its entry through ONE ancestor-table row against the state at the start of
-        //    the round.
-        if (wave < nc) {
-            const SkSlotInfo I = sk_walk(A, B, L.slot[wave], base, n, ent_v[slot_ent[wave]], xoff, W, lane);
-            if (lane == 0) {
-                sl[wave] = I;
-                tvs[wave] = (!I.big && I.len >= 2) ? (I.term < 0 ? n - 1 : I.term) : -2;
-            }
-        }
-        __syncthreads();
-        SK_TICK(2);
-        if (!sl[0].big) {
-            // slots after the first oversized one (or past the per-round item budget) are not evaluated this round.
-            // pre[k] = candidates of the slots before k: workgroup-uniform, so it lives in scalar registers.
-            int pre[SK_NSLOT + 1];
-            pre[0] = 0;
-            {
-                int cand_l = 0, big_l = 0;
-                if (lane < SK_NSLOT && lane < nc) { cand_l = sl[lane].ncand; big_l = sl[lane].big; }
-                bool open = true;
-                int k_cut = nc;
-#pragma unroll
-                for (int k = 0; k < SK_NSLOT; k++) {
-                    int add = 0;
-                    if (k < nc && open) {
-                        const int cand_k = __builtin_amdgcn_readlane(cand_l, k), big_k = __builtin_amdgcn_readlane(big_l, k);
-                        if (big_k || pre[k] + cand_k > SK_ROUND_ITEMS * W) { open = false; k_cut = k; }
-                        else add = cand_k;
-                    }
-                    pre[k + 1] = pre[k] + add;
-                }
-                nc = k_cut;  // slots [nc, s_nc) have no cache entry (the replay ends the round at a big one)
-            }
-            const int T = pre[SK_NSLOT];
-            // 4. claims of the cached paths (select_path_points, path.py:19-46), point-centric: the candidates of ALL slots
-            //    are dealt out over the workgroup; each finds ITS nearest path vertex from LDS.  A claimed point joins its
-            //    slot's list; if it is the vertex a (later) slot reads its parent id from, that slot learns who stamps it.
-            for (int idx = tid; idx < nc * SK_WPATH; idx += W) {  // ... the paths stamp their own vertices, too
-                const int s_ = idx / SK_WPATH, q_ = idx % SK_WPATH;
-                if (q_ < sl[s_].len && sl[s_].len >= 2) {
-                    const int v = L.slot[s_].path[q_];
-                    for (int k = 0; k < nc; k++) if (tvs[k] == v) atomicOr(&tv_hit[k], 1u << s_);
-                }
-            }
-            const int nround = (T + W - 1) / W;
-            if (A.ticks && tid == 0) { A.ticks[23] += wall_clock64() - t_last; A.ticks[24] += T; }
-            for (int k0 = 0; k0 < nround; k0 += 4) {
-                float4 r4[4];
-                int ss[4];
-                long long ct0 = (A.ticks && tid == 0) ? wall_clock64() : 0;
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int gi = (k0 + u) * W + tid;
-                    ss[u] = -1;
-                    r4[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                    if (k0 + u < nround && gi < T) {
-                        int sidx = 0, acc = 0;
-#pragma unroll
-                        for (int k = 1; k < SK_NSLOT; k++)
-                            if (gi >= pre[k]) { sidx = k; acc = pre[k]; }  // pre[] is non-decreasing and ends at T > gi
-                        const SkSelSlot& S = L.slot[sidx];
-                        const uint32_t t = (uint32_t)(gi - acc);
-                        const int row = sk_find_row(S.row_off, sl[sidx].nrows, t);
-                        r4[u] = recs[S.row_first[row] + (t - S.row_off[row])];
-                        ss[u] = sidx;
-                    }
-                }
-#ifndef ST_HIPEMU
-                if (A.ticks && tid == 0) {  // developer aid: where does a batch of four candidates spend its time?
-                    long long ct1 = wall_clock64();
-                    A.ticks[25] += ct1 - ct0;  // indexing: slot, row, address
-                    __builtin_amdgcn_s_waitcnt(0);
-                    ct0 = wall_clock64();
-                    A.ticks[26] += ct0 - ct1;  // waiting for the four records
-                }
-#endif
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int p = ss[u] >= 0 ? (int)__float_as_uint(r4[u].w) - base : -1;
-                    // (p outside [0, n): another component's point)
-                    const bool on = p >= 0 && p < n && sk_on_path(L.slot[ss[u]], sl[ss[u]].len, sl[ss[u]].rp, r4[u]);
-                    // append to the slot's list, one reservation per wavefront and slot (a returning atomic per point on ONE
-                    // LDS word serialises the whole workgroup: measured 32 us per round instead of 8)
-                    unsigned long long todo = __ballot(on);
-                    while (todo) {  // (wave-uniform; the lanes of a wavefront hold one or two slots)
-                        const int s0 = __builtin_amdgcn_readlane(ss[u], __ffsll(todo) - 1);
-                        const unsigned long long m = __ballot(on && ss[u] == s0);
-                        unsigned at0 = 0u;
-                        if (lane == __ffsll(m) - 1) at0 = atomicAdd(&cl_n[s0], (unsigned)__popcll(m));
-                        at0 = (unsigned)__builtin_amdgcn_readlane((int)at0, __ffsll(m) - 1);
-                        if (on && ss[u] == s0) {
-                            const unsigned at = at0 + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
-                            if (at < SK_CL_CAP) cl[s0][at] = (unsigned)p;
-                        }
-                        todo &= ~m;
-                    }
-                    if (on && sl[ss[u]].len >= 2)
-                        for (int k = 0; k < nc; k++) if (tvs[k] == p) atomicOr(&tv_hit[k], 1u << ss[u]);
-                }
-                if (A.ticks && tid == 0) { A.ticks[27] += wall_clock64() - ct0; A.ticks[28] += 1; }  // nearest vertex + append
-            }
-            __syncthreads();  // every list is complete
-            SK_TICK(3);
-        }
-        if (!sl[0].big && cl_n[0] <= SK_CL_CAP) {
-            // 5. the replay: ONE wavefront runs the sequential loop over the round's entries.
-            if (wave == 0) {
-                int ev[SK_ENT / 64];
-#pragma unroll
-                for (int gq = 0; gq < SK_ENT / 64; gq++) {
-                    const int e = gq * 64 + lane;
-                    ev[gq] = e < ne ? ent_v[e] : -1;
-                }
-                int cur = 0, commits = 0, lates = 0;
-                long long rt = A.ticks ? wall_clock64() : 0;
-#define SK_RTICK(i) do { if (A.ticks && lane == 0) { const long long now_ = wall_clock64(); A.ticks[i] += now_ - rt; rt = now_; } } while (0)
-                for (;;) {
-                    __builtin_amdgcn_wave_barrier();  // (the stamps of the previous step are in the bitmap)
-                    int first = -1;  // the first entry at or after `cur` that is still unallocated: the loop's next tip
-#pragma unroll
-                    for (int gq = 0; gq < SK_ENT / 64; gq++) {
-                        const int e = gq * 64 + lane;
-                        const bool lv = ev[gq] >= 0 && e >= cur && !bm_test(B, ev[gq]);
-                        const unsigned long long bal = __ballot(lv);
-                        if (first < 0 && bal) first = gq * 64 + __ffsll(bal) - 1;
-                    }
-                    if (first < 0) { if (A.ticks && lane == 0) A.ticks[16] += 1; break; }
-                    const int s = (int)ent_slot[first];
-                    const int tip = ent_v[first];
-                    bool done = false;
-                    SK_RTICK(20);
-                    if (s >= 0 && s < nc) {
-                        // the cached path is the true path iff none of its vertices has been terminated since its walk
-                        const SkSelSlot& S = L.slot[s];
-                        const int len = sl[s].len;
-                        const bool hit = lane < len && bm_test(B, S.path[lane]);
-                        if (__ballot(hit) == 0ull && cl_n[s] <= SK_CL_CAP) {
-                            const bool keep = len >= 2;  // path.py:125-126: shorter paths still consume their points
-                            const int id = keep ? nb : -1;
-                            if (lane < len) {
-                                const int v = S.path[lane];
-                                if (keep) A.path_verts[base + total + lane] = v;
-                                sk_mark(A, B, base, v, id);
-                            }
-                            const unsigned cn = cl_n[s];
-                            for (unsigned i = lane; i < cn; i += 64) sk_mark(A, B, base, (int)cl[s][i], id);
-                            if (keep) {
-                                if (lane == 0) {
-                                    A.branch_parent[base + nb] = sl[s].parent;
-                                    A.branch_off[base + nb] = total;
-                                    A.branch_len[base + nb] = len;
-                                }
-                                // whose parent id did this branch just become?  (branch_ids keeps the last writer)
-                                if (lane < SK_NSLOT && ((tv_hit[lane] >> s) & 1u)) sl[lane].parent = id;
-                                nb++; total += len;
-                            }
-                            done = true;
-                            commits++;
-                        }
-                        SK_RTICK(21);
-                    } else if (s >= nc) {
-                        if (A.ticks && lane == 0) A.ticks[17] += 1;
-                        break;  // a slot the round did not evaluate (oversized, or past the item budget): it heads the next round
-                    }
-                    if (!done) {
-                        // no cache entry (a tip predicted to be swallowed that survived), or the walk has been cut short by a
-                        // branch of this round: this wavefront evaluates the branch itself against the state as it is now --
-                        // unless it is too long / too heavy, then the round ends here.
-                        SkSelSlot& S = L.slot[SK_LATE];
-                        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // this wavefront's stamps have reached the L2
-                        const SkSlotInfo I = sk_walk(A, B, S, base, n, tip, xoff, W, lane);
-                        if (I.big || I.ncand > A.late_cand || (int64_t)I.ncand * I.len > 16 * (int64_t)A.late_cand) {
-                            if (A.ticks && lane == 0) A.ticks[18 + (I.big ? 0 : 1)] += 1;
-                            break;
-                        }
-                        const bool keep = I.len >= 2;
-                        const int id = keep ? nb : -1;
-                        for (int t0 = 0; t0 < I.ncand; t0 += 256) {
-                            float4 r4[4];
-#pragma unroll
-                            for (int u = 0; u < 4; u++) {
-                                const int t = t0 + u * 64 + lane;
-                                r4[u] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xffffffffu));
-                                if (t < I.ncand) {
-                                    const int row = sk_find_row(S.row_off, I.nrows, (uint32_t)t);
-                                    r4[u] = recs[S.row_first[row] + ((uint32_t)t - S.row_off[row])];
-                                }
-                            }
-#pragma unroll
-                            for (int u = 0; u < 4; u++) {
-                                if (t0 + u * 64 + lane >= I.ncand) continue;
-                                const int p = (int)__float_as_uint(r4[u].w) - base;
-                                if (p < 0 || p >= n) continue;  // other component
-                                if (!sk_on_path(S, I.len, I.rp, r4[u])) continue;
-                                sk_mark(A, B, base, p, id);
-                                if (keep) for (int k = 0; k < nc; k++) if (tvs[k] == p) sl[k].parent = id;
-                            }
-                        }
-                        if (lane < I.len) {
-                            const int v = S.path[lane];
-                            if (keep) A.path_verts[base + total + lane] = v;
-                            sk_mark(A, B, base, v, id);
-                            if (keep) for (int k = 0; k < nc; k++) if (tvs[k] == v) sl[k].parent = id;
-                        }
-                        if (keep) {
-                            if (lane == 0) {
-                                A.branch_parent[base + nb] = I.parent;
-                                A.branch_off[base + nb] = total;
-                                A.branch_len[base + nb] = I.len;
-                            }
-                            nb++; total += I.len;
-                        }
-                        lates++;
-                        SK_RTICK(22);
-                    }
-                    cur = first + 1;
-                }
-#undef SK_RTICK
-                if (lane == 0) {
-                    s_nb2 = nb; s_tot2 = total;
-                    if (A.ticks) { A.ticks[8] += 1; A.ticks[12] += commits; A.ticks[13] += nc; A.ticks[11] += lates; }
-                }
-            }
-            __syncthreads();
-            nb = s_nb2; total = s_tot2;
-            SK_TICK(4);
-            continue;
-        }
-        // ---- `one` mode: entry 0 needs the whole workgroup ----
-        const int far = ent_v[0];
-        __syncthreads();  // slot data is dead; its space is reused below
+        steps_left--;
+        // back to the two roles after this branch: every entry is free again, the evaluators go on where they were
+        if (tid < SK_NCACHE) c_state[tid] = SK_C_EMPTY;
+        if (tid < SK_MAX_WAVES) mb_state[tid] = 0;
+        if (tid == 0) s_mode = SK_M_RUN;
+        // ---- `one` mode: this branch needs the whole workgroup ----
+        const int far = s_big_tip;
+        __syncthreads();  // (the resets above are published; the evaluators' scratch is reused below)
         int len = -1;
         for (unsigned chunk = 0; len < 0; chunk += blockDim.x) {
             const unsigned j = chunk + tid;
@@ -1354,9 +1429,6 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
         __syncthreads();
         SK_TICK(5);
     }
-    SK_FLUSH_BM();
-    if (tid == 0) { A.s_len[c] = 0; A.s_wide[c] = 0; A.s_cursor[c] = win_base; A.s_total[c] = total; A.s_nb[c] = nb; }
-    SK_TICK_FLUSH();
 #undef SK_FLUSH_BM
 }
 
@@ -1438,7 +1510,7 @@ static void sk_layout(StArena& a, int64_t m, int64_t C, SkLayout* s, int nseg = 
     s->q0 = a.take<unsigned>(sk_queue_words(m, C));  // SSSP frontier: SK_FS shard segments + the overflow area (sk_q_reserve)
     s->q1 = a.take<unsigned>(sk_queue_words(m, C));
     s->touched = a.take<unsigned>(m);
-    s->term_bits = a.take<unsigned>(sk_term_words(m, C));
+    s->term_bits = a.take<unsigned>(2 * sk_term_words(m, C));  // the termination set, then the predicted one (SkBm)
     s->pr = a.take<float4>(m);
     s->best = a.take<unsigned long long>(m);
     s->anc = a.take<int>((int64_t)SK_ANC * m);
@@ -1578,7 +1650,7 @@ extern "C" int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, c
     A.dist = dist; A.pred = pred; A.root_local = root_local; A.tree_dist = tree_dist;
     A.branch_parent = branch_parent; A.branch_off = branch_off; A.branch_len = branch_len; A.n_branches = n_branches;
     A.path_verts = path_verts; A.branch_of = branch_of;
-    A.dist_ord = s.dist_ord; A.stamp = s.stamp; A.q0 = s.q0; A.q1 = s.q1; A.term_bits = s.term_bits; A.pr = s.pr;
+    A.dist_ord = s.dist_ord; A.stamp = s.stamp; A.q0 = s.q0; A.q1 = s.q1; A.term_bits = s.term_bits; A.spec_bits = s.term_bits + sk_term_words(m, n_comp); A.pr = s.pr;
     A.best = s.best; A.touched = s.touched; A.anc = s.anc; A.cnt = s.cnt; A.fcnt = s.cnt + 8;
     A.fseg = (unsigned)sk_fseg(m, n_comp);
     A.s_done = s.s_done; A.s_len = s.s_len; A.s_cur_id = s.s_cur_id; A.s_cur_off = s.s_cur_off; A.s_nb = s.s_nb;
@@ -1688,7 +1760,7 @@ extern "C" int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, c
         for (;;) {  // second pass only if the deferred check found plateau vertices: predecessors completed, selection redone
             (void)hipMemsetAsync(&s.cnt[5], 0, 3 * sizeof(unsigned), stream);  // finished components, branches, path vertices
             const float* distances = (stages & 2) ? tree_dist : dist;
-            (void)hipMemsetAsync(s.term_bits, 0, sk_term_words(m, n_comp) * sizeof(unsigned), stream);
+            (void)hipMemsetAsync(s.term_bits, 0, 2 * sk_term_words(m, n_comp) * sizeof(unsigned), stream);
             hipLaunchKernelGGL(k_sk_lift_init, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A);
             for (int span = 1; span < SK_ANC; span *= 2)  // direct ancestor table by doubling
                 hipLaunchKernelGGL(k_sk_anc_pass, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A, span);
