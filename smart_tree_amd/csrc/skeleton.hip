@@ -69,7 +69,6 @@ struct SkArgs {
     unsigned* q0;
     unsigned* q1;
     unsigned* term_bits;  // sample_tree's termination set, one bit per vertex; component c owns the words from (comp_off[c] >> 5) + c
-    unsigned* spec_bits;  // ... and the evaluators' prediction of it (same layout)
     float4* pr;       // [m] (x, y, z, radius) of every vertex in one 16-byte record (k_sk_lift_init): one gather instead of two
     unsigned long long* best;  // claim race: (d2 bits << 32) | path position
     unsigned* touched;
@@ -100,7 +99,6 @@ struct SkArgs {
     int iters_per_launch;
     int wave_work;       // select: candidate points x path vertices of one speculative branch (beyond: whole workgroup)
     int local_items;     // select: (path vertex, cell row) pairs one workgroup claims path-centric by itself
-    int late_cand;       // select: candidate points the replay wavefront evaluates by itself (more: the round ends at that entry)
     int long_mode;       // select: paths that fit the LDS path buffer but are too much work for the plain point-centric claim are
                          // claimed by the workgroup itself with chunk-pruned distance tests (below), not handed to k_sk_claim
     long long* ticks;  // optional developer aid: per-phase wall_clock64 sums of k_sk_select (tuning[15])
@@ -512,24 +510,9 @@ __device__ __forceinline__ bool sk_claim_items(const SkArgs& A, int c, int base,
 }
 
 // ------------------------------------------------------------------------------ select ---
-// sample_tree (path.py:49-140) is a sequential greedy loop: take the farthest unallocated vertex, walk towards the root
-// until an allocated ("terminated") vertex, claim the points within the path's radii, repeat.  Two facts make it parallel:
-//   (1) the claims of a branch are a pure function of its PATH (select_path_points, path.py:19-46: geometry only), and a
-//       path is the first `len` ancestors of its tip -- state enters only through `len` (where the walk meets the
-//       termination set), through "is the tip still unallocated" and through the parent id read at the walk's end;
-//   (2) branches far apart do not touch each other's walks.
-// So one workgroup per component runs the loop LITERALLY and speculates around it, asynchronously (no barrier in between):
-//   * wavefront 0, the REPLAY, walks the distance order; the termination set is a bitmap in LDS.  For the next unallocated
-//     vertex (the loop's next tip) it looks the tip up in a cache of evaluated branches: cached path still the true path
-//     (none of its vertices terminated since, the vertex behind it was terminated already) -> commit the cached claims;
-//     no entry, or a stale one -> it evaluates the branch itself on the spot;
-//   * the other wavefronts, the EVALUATORS, run ahead of it: each takes the next few positions of the order, skips what is
-//     allocated or predicted to be swallowed by a cached tip nearby, walks the first other one against the bitmap as it
-//     is at that moment, finds the claims of that path (the candidates around the path against its vertices) and
-//     publishes path + claims as a cache entry.  What they see of the bitmap while the replay changes it does not matter:
-//     an entry is only ever used for the path the sequential loop walks.
-// A path too long or too heavy for one wavefront stops everybody: the whole workgroup works on that one branch
-// (`one` mode, barriers), then the two roles resume.
+// One workgroup per component; speculative rounds of up to one branch per wavefront with an in-order replay (k_sk_select
+// below).  The selection state is the termination set, a bitmap in LDS (SkBm), and the branch ids, stamped straight into
+// the caller's array with a max (branch_ids keeps the last writer, ids grow with the order of the loop).
 #define SK_SMALL_WORK (1 << 18)  // candidate points x path vertices one workgroup takes on point-centric, unpruned
 #define SK_ITERS_PER_LAUNCH 32
 #define SK_LPATH 1024
@@ -539,12 +522,10 @@ __device__ __forceinline__ bool sk_claim_items(const SkArgs& A, int c, int base,
 // masked at the start, which sit at the tail of the distance order and are never looked at): one bit per vertex.  In LDS
 // while the workgroup runs (loaded from / flushed to the component's words of A.term_bits at the launch boundaries), in
 // global memory for a component too large for the LDS words.
-#define SK_BM_WORDS 4096  // 131,072 vertices
+#define SK_BM_WORDS 8192  // 262,144 vertices
 struct SkBm {
     unsigned* lds;
     unsigned* glb;
-    unsigned* spec_lds;  // the PREDICTED termination set (what the published evaluations will terminate): same layout
-    unsigned* spec_glb;
     bool in_lds;
 };
 __device__ __forceinline__ bool bm_test(const SkBm& B, int v) {
@@ -554,14 +535,6 @@ __device__ __forceinline__ bool bm_test(const SkBm& B, int v) {
 __device__ __forceinline__ void bm_set(const SkBm& B, int v) {
     if (B.in_lds) atomicOr(&B.lds[v >> 5], 1u << (v & 31));
     else wg_or(&B.glb[v >> 5], 1u << (v & 31));
-}
-__device__ __forceinline__ bool sp_test(const SkBm& B, int v) {
-    const unsigned w = B.in_lds ? B.spec_lds[v >> 5] : ld_wg(&B.spec_glb[v >> 5]);
-    return (w >> (v & 31)) & 1u;
-}
-__device__ __forceinline__ void sp_set(const SkBm& B, int v) {
-    if (B.in_lds) atomicOr(&B.spec_lds[v >> 5], 1u << (v & 31));
-    else wg_or(&B.spec_glb[v >> 5], 1u << (v & 31));
 }
 // allocation / termination / branch-id stamp of a point (path.py:112-122,135-136).  branch_ids keeps the LAST writer; ids
 // grow with the order of the loop, so "last" is a max -- commutative, which lets the lanes of a commit race.
@@ -589,25 +562,26 @@ __device__ __forceinline__ void sk_finish_branch(const SkArgs& A, const SkBm& B,
 #define SK_TICK_FLUSH() do { if (A.ticks && tid == 0) for (int i_ = 0; i_ < 8; i_++) A.ticks[i_] += tk[i_]; } while (0)
 
 // ---- wavefront helpers (all 64 lanes must call) ----
+__device__ __forceinline__ float wave_readlane_f(float v, int src) { return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), src)); }
+__device__ __forceinline__ int wave_min_i(int v) { for (int d = 32; d > 0; d >>= 1) { const int o = __shfl_xor(v, d); v = o < v ? o : v; } return v; }
+__device__ __forceinline__ int wave_max_i(int v) { for (int d = 32; d > 0; d >>= 1) { const int o = __shfl_xor(v, d); v = o > v ? o : v; } return v; }
+__device__ __forceinline__ unsigned wave_max_u(unsigned v) { for (int d = 32; d > 0; d >>= 1) { const unsigned o = __shfl_xor(v, d); v = o > v ? o : v; } return v; }
+__device__ __forceinline__ unsigned wave_or_u(unsigned v) { for (int d = 32; d > 0; d >>= 1) v |= __shfl_xor(v, d); return v; }
 __device__ __forceinline__ unsigned wave_incl_scan_u(unsigned v, int lane) {
     for (int d = 1; d < 64; d <<= 1) { const unsigned o = __shfl_up(v, (unsigned)d); if (lane >= d) v += o; }
     return v;
 }
 
 // LDS of k_sk_select.  Two modes share the space: `one` = a single branch worked on by the whole workgroup
-// (paths up to SK_LPATH vertices), `slot[]` = the scratch of one evaluation per wavefront (short paths).
-#define SK_NSLOT 16    // = SK_MAX_WAVES: evaluation scratch per wavefront
-#define SK_NCACHE 32   // cache entries (one lane each in the replay's look-up)
-#define SK_OWN SK_NCACHE  // the replay's private entry
-#define SK_WPATH 64    // a cached walk is ONE row of the ancestor table
-#define SK_WCHUNK 8    // path vertices per bounding box of a cached path (sk_on_path)
-#define SK_WROWS 256   // (x, y) cell rows around a cached path: up to four per lane
-#define SK_WAVE_WORK (1 << 20)  // candidate points x path vertices an evaluator takes on
+// (paths up to SK_LPATH vertices), `slot[]` = one speculative branch per wavefront (short paths).
+#define SK_WSLOTS 16   // = SK_MAX_WAVES
+#define SK_WENT 32     // window entries looked at per round (those predicted to be swallowed get no slot)
+#define SK_WPATH 64    // a speculative walk is ONE row of the ancestor table
+#define SK_WROWS 256   // (x, y) cell rows around a speculative path: up to four per lane
+#define SK_WAVE_WORK (1 << 20)  // candidate points x path vertices per speculative branch
 #define SK_WAVE_CAND 16384
-#define SK_CL_CAP 384           // claimed points a cache entry holds (more: the whole workgroup works on the branch)
-#define SK_LATE_CAND 4096       // candidates the replay wavefront takes on by itself
-#define SK_RWIN 4               // the replay's window: SK_RWIN x 64 positions of the distance order in registers
-#define SK_LOOKAHEAD 2048       // the scout stays within this many positions of the replay
+#define SK_ROUND_ITEMS 32       // candidates per thread and round
+#define SK_CL_KEEP 4            // claimed points a thread remembers in LDS; further ones are found again through a bit mask
 struct SkSelOne {
     int lpath[SK_LPATH];
     float lpx[SK_LPATH], lpy[SK_LPATH], lpz[SK_LPATH], lpr[SK_LPATH];
@@ -619,29 +593,11 @@ struct SkSelSlot {
     uint32_t row_off[SK_WROWS + 1], row_first[SK_WROWS];
     int lo[3], hi[3];  // cell bounding box of the path (LDS min / max)
     unsigned rk;       // ordered bits of the largest radius
-    float4 blo[SK_WPATH / SK_WCHUNK], bhi[SK_WPATH / SK_WCHUNK];  // bounding boxes of SK_WCHUNK consecutive path vertices
 };
 union SkSelLds {
     SkSelOne one;
-    SkSelSlot slot[SK_NSLOT];
+    SkSelSlot slot[SK_WSLOTS];
 };
-// a cache entry: what the replay needs to commit a branch
-struct SkCacheEnt {
-    int path[SK_WPATH];      // root side first
-    unsigned cl[SK_CL_CAP];  // the claimed points
-};
-enum { SK_C_EMPTY = 0, SK_C_ALLOC = 1, SK_C_BUSY = 2, SK_C_READY = 3 };  // entry states (ALLOC: taken, tag not yet written)
-enum { SK_M_RUN = 0, SK_M_ONE = 1, SK_M_DONE = 2, SK_M_PAUSE = 3 };      // what the workgroup does: replay + evaluators /
-// the whole workgroup on one branch / component finished / this launch's share of steps is used up
-// LDS words shared between wavefronts WITHOUT a barrier in between: relaxed atomics at workgroup scope (never cached in a
-// register over a spin), release / acquire fences around the data they publish
-__device__ __forceinline__ int lds_ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-// ... read ONCE per wavefront: a word another wavefront may change at any moment must not be seen differently by the lanes of a
-// wavefront that branches on it (one LDS read in hardware; on the CPU emulator the lanes run one after the other)
-__device__ __forceinline__ int lds_ld_u(const int* p) { return __builtin_amdgcn_readfirstlane(lds_ld(p)); }
-__device__ __forceinline__ void lds_st(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-#define SK_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup")
-#define SK_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup")
 
 // row r with row_off[r] <= t < row_off[r+1]
 __device__ __forceinline__ int sk_find_row(const uint32_t* row_off, int nrows, uint32_t t) {
@@ -650,251 +606,60 @@ __device__ __forceinline__ int sk_find_row(const uint32_t* row_off, int nrows, u
     return lo;
 }
 
-// the facts of a walk
-struct SkSlotInfo {
-    int len, term, nrows, ncand, big;
-    float rp;
-};
-
-// One wavefront walks `tip` against the termination set as it is NOW (trace_route, path.py:9-16: lane j inspects the j-th
-// ancestor; the first terminated one, or the step past the root, ends the walk), then gathers position / radius of its
-// path into slot S, the (x, y) rows of grid cells around it and how many candidate points they hold.  All 64 lanes call.
-__device__ __forceinline__ SkSlotInfo sk_walk(const SkArgs& A, const SkBm& B, SkSelSlot& S, int base, int n, int tip, int xoff,
-                                              int lane) {
-    const StGrid* g = A.grid;
-    SkSlotInfo I;
-    const int node = lane == 0 ? tip : A.anc[(int64_t)(base + tip) * SK_ANC + lane - 1];
-    const bool end = node < 0 || bm_test(B, node);
-    const unsigned long long eb = __ballot(end);
-    I.big = eb == 0ull;
-    I.len = 0; I.term = -1; I.nrows = 0; I.ncand = 0; I.rp = 0.0f;
-    if (I.big) return I;
-    const int len = __ffsll(eb) - 1;
-    I.len = len;
-    I.term = __shfl(node, len);
-    const int qi = len - 1 - lane;  // walk order -> root side first
-    if (lane < 3) { S.lo[lane] = 0x7fffffff; S.hi[lane] = (int)0x80000000; }
-    if (lane == 3) S.rk = 0u;
-    __builtin_amdgcn_wave_barrier();
-    if (lane < len) {
-        const float4 q4 = A.pr[base + node];
-        S.path[qi] = node; S.p[qi] = q4;
-        const int cx = (int)floorf((q4.x - g->lo[0]) / g->cell), cy = (int)floorf((q4.y - g->lo[1]) / g->cell),
-                  cz = (int)floorf((q4.z - g->lo[2]) / g->cell);
-        atomicMax(&S.rk, st_f2ord(q4.w));  // path.py:31
-        atomicMin(&S.lo[0], cx); atomicMin(&S.lo[1], cy); atomicMin(&S.lo[2], cz);
-        atomicMax(&S.hi[0], cx); atomicMax(&S.hi[1], cy); atomicMax(&S.hi[2], cz);
+// Watch table of a speculative round (LDS, open addressing): the points whose marks the replay will ask for -- the tips of
+// the round's entries, every slot's walk and the vertex its parent id is read from: at most SK_WENT + SK_WSLOTS x
+// (SK_WPATH + 1) keys, so the table (SK_WT slots) never fills.  A claim of point p by slot s ORs bit s into p's word IF p is
+// watched; nobody ever asks about the other claimed points.
+#define SK_WT 4096
+#define SK_WT_EMPTY 0xffffffffu
+__device__ __forceinline__ unsigned sk_wt_hash(unsigned key) { return (key * 0x9E3779B1u) >> 20; }  // 12 bits
+__device__ __forceinline__ void sk_wt_insert(unsigned* wkey, unsigned* wmask, unsigned key, unsigned bits) {
+    for (unsigned h = sk_wt_hash(key);; h = (h + 1u) & (SK_WT - 1u)) {
+        const unsigned old = atomicCAS(&wkey[h], SK_WT_EMPTY, key);
+        if (old == SK_WT_EMPTY || old == key) { if (bits) atomicOr(&wmask[h], bits); return; }
     }
-    __builtin_amdgcn_wave_barrier();
-    if (lane < (len + SK_WCHUNK - 1) / SK_WCHUNK) {  // chunk boxes for the claim (sk_on_path)
-        float4 lo = S.p[lane * SK_WCHUNK], hi = lo;
-        for (int qj = lane * SK_WCHUNK + 1; qj < len && qj < (lane + 1) * SK_WCHUNK; qj++) {
-            const float4 q = S.p[qj];
-            lo.x = q.x < lo.x ? q.x : lo.x; lo.y = q.y < lo.y ? q.y : lo.y; lo.z = q.z < lo.z ? q.z : lo.z;
-            hi.x = q.x > hi.x ? q.x : hi.x; hi.y = q.y > hi.y ? q.y : hi.y; hi.z = q.z > hi.z ? q.z : hi.z;
-        }
-        S.blo[lane] = lo; S.bhi[lane] = hi;
-    }
-    const float rp = st_ord2f(S.rk);
-    I.rp = rp;
-    int reach = rp > 0.0f ? (int)ceilf(rp / g->cell) : 0;
-    if (reach < 1) reach = 1;
-    const int x0 = st_max(S.lo[0] - reach, 0), x1 = st_min(S.hi[0] + reach, g->seg_dim0 - 1);
-    const int y0 = st_max(S.lo[1] - reach, 0), y1 = st_min(S.hi[1] + reach, g->dim[1] - 1);
-    const int z0 = st_max(S.lo[2] - reach, 0), z1 = st_min(S.hi[2] + reach, g->dim[2] - 1);
-    const int nx = x1 - x0 + 1, ny = y1 - y0 + 1;
-    const int nrows = (nx > 0 && ny > 0 && z0 <= z1) ? nx * ny : 0;
-    I.nrows = nrows;
-    I.big = nrows > SK_WROWS;
-    if (I.big) return I;
-    uint32_t cnt[SK_WROWS / 64], first[SK_WROWS / 64];
-#pragma unroll
-    for (int ch = 0; ch < SK_WROWS / 64; ch++) {  // all loads first, then the scans
-        const int rr = ch * 64 + lane;
-        cnt[ch] = 0u; first[ch] = 0u;
-        if (rr < nrows) {
-            const int64_t row = ((int64_t)(xoff + x0 + rr / ny) * g->dim[1] + (y0 + rr % ny)) * g->dim[2];
-            first[ch] = A.cell_start[row + z0];
-            cnt[ch] = A.cell_start[row + z1 + 1] - first[ch];
-        }
-    }
-    uint32_t run = 0u;
-#pragma unroll
-    for (int ch = 0; ch < SK_WROWS / 64; ch++) {
-        if (ch * 64 >= nrows) break;  // wave-uniform
-        const uint32_t inc = wave_incl_scan_u(cnt[ch], lane);
-        const int rr = ch * 64 + lane;
-        if (rr < nrows) { S.row_off[rr] = run + inc - cnt[ch]; S.row_first[rr] = first[ch]; }
-        run += __shfl(inc, 63);
-    }
-    I.ncand = (int)run;
-    if (lane == 0) S.row_off[nrows] = run;
-    __builtin_amdgcn_wave_barrier();
-    I.big = I.ncand > SK_WAVE_CAND || (int64_t)I.ncand * len > A.wave_work;
-    return I;
 }
-
-// nearest path vertex of one candidate point (select_path_points, path.py:19-46): ascending scan, ties keep the first path
-// vertex.  The path is cut into chunks of SK_WCHUNK consecutive vertices with their bounding boxes; a chunk whose box is no
-// closer than the best vertex so far (or than the path radius) is skipped.  The box distance is evaluated with the SAME
-// float32 operations, in the same order, as the vertex distance ((dx*dx + dy*dy) + dz*dz): rounding is monotone, so it never
-// exceeds the distance to any vertex inside -- the nearest vertex (ties: the first on the path) is the one the full scan
-// finds, and a vertex at or beyond the path radius can never make a point "claimed".  Most candidates (they come from the
-// cells around the path's bounding box) reject most chunks: 2-3x fewer distance evaluations and LDS reads.  Returns "claimed".
-__device__ __forceinline__ bool sk_on_path(const SkSelSlot& S, int len, float rp, const float4& r4) {
-    float bd2 = __uint_as_float(0x7f800000u), bw = 0.0f;
-    const float rp2 = rp * rp;
-#define SK_NEAREST(q)                                                              \
-    {                                                                              \
-        const float dx = r4.x - (q).x, dy = r4.y - (q).y, dz = r4.z - (q).z;       \
-        float d2 = dx * dx;                                                        \
-        float tt = dy * dy;                                                        \
-        d2 = d2 + tt;                                                              \
-        tt = dz * dz;                                                              \
-        d2 = d2 + tt;                                                              \
-        if (d2 < bd2) { bd2 = d2; bw = (q).w; }                                    \
-    }
-    for (int ch = 0; ch * SK_WCHUNK < len; ch++) {
-        const float4 lo = S.blo[ch], hi = S.bhi[ch];
-        float e0 = lo.x - r4.x, e1 = lo.y - r4.y, e2 = lo.z - r4.z;
-        const float a0 = r4.x - hi.x, a1 = r4.y - hi.y, a2 = r4.z - hi.z;
-        e0 = e0 > a0 ? e0 : a0; e1 = e1 > a1 ? e1 : a1; e2 = e2 > a2 ? e2 : a2;
-        e0 = e0 > 0.0f ? e0 : 0.0f; e1 = e1 > 0.0f ? e1 : 0.0f; e2 = e2 > 0.0f ? e2 : 0.0f;
-        float lb = e0 * e0;
-        float tb = e1 * e1;
-        lb = lb + tb;
-        tb = e2 * e2;
-        lb = lb + tb;
-        if (lb >= bd2 || lb >= rp2) continue;
-        const int q0 = ch * SK_WCHUNK;
-        if (q0 + SK_WCHUNK <= len) {
-#pragma unroll
-            for (int j = 0; j < SK_WCHUNK; j += 4) {  // four path vertices per step: their LDS reads are in flight together
-                const float4 p0 = S.p[q0 + j], p1 = S.p[q0 + j + 1], p2 = S.p[q0 + j + 2], p3 = S.p[q0 + j + 3];
-                SK_NEAREST(p0) SK_NEAREST(p1) SK_NEAREST(p2) SK_NEAREST(p3)
-            }
-        } else {
-            for (int qi = q0; qi < len; qi++) {
-                const float4 q = S.p[qi];
-                SK_NEAREST(q)
-            }
-        }
-    }
-#undef SK_NEAREST
-    return bd2 < rp2 && sqrtf(bd2) < bw;  // path.py:35-40
-}
-
-// rows of four candidates at once: the four binary searches advance in lockstep (a fixed number of steps), so that their
-// dependent LDS reads overlap instead of queueing behind each other
-__device__ __forceinline__ void sk_find_rows4(const uint32_t* row_off, int nrows, const uint32_t (&t)[4], int (&row)[4]) {
-    int lo[4] = {0, 0, 0, 0}, hi[4] = {nrows, nrows, nrows, nrows};
-    for (int span = nrows; span > 1; span = (span + 1) >> 1) {  // uniform trip count >= ceil(log2(nrows))
-        uint32_t v[4];
-        int mid[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) { mid[u] = (lo[u] + hi[u]) >> 1; v[u] = row_off[mid[u]]; }  // (converged: mid == lo, a no-op)
-#pragma unroll
-        for (int u = 0; u < 4; u++) { if (v[u] <= t[u]) lo[u] = mid[u]; else hi[u] = mid[u]; }
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++) row[u] = lo[u];
-}
-
-// One wavefront evaluates the branch of `tip` against the termination set as it is NOW: the walk, then the claims of that
-// path (select_path_points, path.py:19-46: every candidate point around the path finds its nearest path vertex) into E.
-// big = the branch needs the whole workgroup (walk longer than one ancestor row, too many cell rows / candidates / claims).
-// All 64 lanes call; S is this wavefront's scratch.
-__device__ __forceinline__ SkSlotInfo sk_evaluate(const SkArgs& A, const SkBm& B, SkSelSlot& S, SkCacheEnt& E, int& ncl_out, int base,
-                                                  int n, int tip, int xoff, int lane, int cand_cap) {
-    SkSlotInfo I = sk_walk(A, B, S, base, n, tip, xoff, lane);
-    ncl_out = 0;
-    if (I.big) return I;
-    if (I.ncand > cand_cap) { I.big = 1; return I; }
-    if (lane < I.len) E.path[lane] = S.path[lane];
-    int ncl = 0;
-    const float4* __restrict__ recs = A.recs;
-    for (int t0 = 0; t0 < I.ncand; t0 += 256) {
-        uint32_t t[4];
-        int row[4];
-        float4 r4[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int tt = t0 + u * 64 + lane;
-            t[u] = (uint32_t)(tt < I.ncand ? tt : I.ncand - 1);
-        }
-        sk_find_rows4(S.row_off, I.nrows, t, row);
-#pragma unroll
-        for (int u = 0; u < 4; u++) r4[u] = recs[S.row_first[row[u]] + (t[u] - S.row_off[row[u]])];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int p = (int)__float_as_uint(r4[u].w) - base;  // (outside [0, n): another component's point)
-            const bool on = t0 + u * 64 + lane < I.ncand && p >= 0 && p < n && sk_on_path(S, I.len, I.rp, r4[u]);
-            const unsigned long long m = __ballot(on);
-            if (on) {
-                const int at = ncl + __popcll(m & ((1ull << lane) - 1ull));
-                if (at < SK_CL_CAP) E.cl[at] = (unsigned)p;
-            }
-            ncl += __popcll(m);
-        }
-    }
-    ncl_out = ncl;
-    if (ncl > SK_CL_CAP) I.big = 1;
-    return I;
-}
-
-// The replay commits a branch (path.py:112-136): the parent id is read first (where this launch's stamps are: agent scope,
-// after this wavefront's earlier stamps have completed), then path and claims are stamped.  The vertex the parent id is read
-// from may be among the stamped ones: its stamp waits for the read.
-__device__ __forceinline__ void sk_commit(const SkArgs& A, const SkBm& B, const SkCacheEnt& E, int len, int termv, int ncl, int base,
-                                          int n, int lane, int& nb, int& total) {
-    const bool keep = len >= 2;  // path.py:125-126: shorter paths still consume their points
-    const int id = keep ? nb : -1;
-    const int tvv = termv < 0 ? n - 1 : termv;  // termination -1 reads branch_ids[-1] = the LAST vertex (quirk kept)
-    int parent = -1;
-    if (keep) {
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        parent = ld(&A.branch_of[base + tvv]);  // (uniform address: one request)
-    }
-    __builtin_amdgcn_wave_barrier();  // (every lane has issued its read before any lane stamps)
-    bool deferred = false;
-    if (lane < len) {
-        const int v = E.path[lane];
-        if (keep) A.path_verts[base + total + lane] = v;
-        if (keep && v == tvv) deferred = true; else sk_mark(A, B, base, v, id);
-    }
-    for (int i = lane; i < ncl; i += 64) {
-        const int p = (int)E.cl[i];
-        if (keep && p == tvv) deferred = true; else sk_mark(A, B, base, p, id);
-    }
-    if (keep) {
-        if (lane == 0) {
-            A.branch_parent[base + nb] = parent;
-            A.branch_off[base + nb] = total;
-            A.branch_len[base + nb] = len;
-        }
-        if (deferred && parent >= -1) sk_mark(A, B, base, tvv, id);  // (always true: makes the stamp wait for the read)
-        nb++; total += len;
+__device__ __forceinline__ int sk_wt_find(const unsigned* wkey, unsigned key) {
+    for (unsigned h = sk_wt_hash(key);; h = (h + 1u) & (SK_WT - 1u)) {
+        const unsigned k = wkey[h];
+        if (k == key) return (int)h;
+        if (k == SK_WT_EMPTY) return -1;
     }
 }
 
+// select: one workgroup per component.  sample_tree (path.py:49-140) is a sequential greedy loop -- take the
+// farthest unallocated vertex, walk to the skeleton, claim the points within the path's radius -- but
+// branches far apart do not interact, so each ROUND speculates: wavefront s takes the s-th farthest
+// unallocated vertex, walks it and marks (bit s of the point's watch-table word) every watched point its branch would allocate, all
+// against the state at the start of the round.  A scan in order then replays the sequential semantics from
+// the marks: a tip already marked by an accepted earlier slot would never have been selected (skipped); a
+// walk (or the vertex the parent id is read from) touched by an accepted earlier slot would have come out
+// differently -- the round stops there and the rest is retried next round; everything else is exactly what the
+// sequential loop produces and is committed (ids / offsets by prefix over the accepted slots;
+// branch_of = max id = last writer).  Slot 0 is always accepted, so every round makes progress.  A path
+// too long for one wavefront is worked on by the whole workgroup (`one` mode); one too long even for that
+// is handed to the chip-wide k_sk_claim and finished at the head of the next launch.
 __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
     long long t_last = A.ticks ? wall_clock64() : 0;
     __shared__ long long tk[8];  // phase timers (developer aid), touched by thread 0 only
     if (A.ticks && threadIdx.x == 0) for (int i_ = 0; i_ < 8; i_++) tk[i_] = 0;
     __shared__ unsigned long long s_red[SK_MAX_WAVES];
     __shared__ SkSelLds L;
-    __shared__ unsigned bm_words[SK_BM_WORDS], sp_words[SK_BM_WORDS];  // termination set and its prediction (see SkBm)
-    __shared__ SkCacheEnt cache[SK_NCACHE + 1];
-    __shared__ int c_state[SK_NCACHE], c_tip[SK_NCACHE + 1], c_pos[SK_NCACHE], c_len[SK_NCACHE + 1], c_term[SK_NCACHE + 1],
-        c_ncl[SK_NCACHE + 1], c_big[SK_NCACHE + 1];
-    __shared__ float4 c_tipp[SK_NCACHE];  // position + radius of a cached tip (the evaluators' prediction)
-    __shared__ int s_mode, s_rpos, s_big_tip, s_nb2, s_tot2, s_steps;
-    __shared__ int mb_state[SK_MAX_WAVES], mb_tip[SK_MAX_WAVES], mb_pos[SK_MAX_WAVES];  // one mailbox per evaluator: the scout's next job
-    __shared__ float4 mb_tp[SK_MAX_WAVES];
+    __shared__ unsigned cl_list[SK_CL_KEEP][1024];  // claimed points of this round, SK_CL_KEEP private entries per thread
     __shared__ uint32_t s_scan[SK_MAX_WAVES + 1];
+    __shared__ unsigned wt_key[SK_WT], wt_mask[SK_WT];  // watch table (see above)
     __shared__ float cb_lo[3][SK_LPATH / SK_CHUNK], cb_hi[3][SK_LPATH / SK_CHUNK];  // chunk boxes of a long path
+    __shared__ unsigned bm_words[SK_BM_WORDS];  // termination set (see SkBm)
     __shared__ int s_lo[3], s_hi[3];
     __shared__ int s_term;
+    __shared__ int w_cnt[SK_WSLOTS], w_tail[SK_WSLOTS], cand_v[SK_WENT];  // the round's entries: first live window vertices
+    __shared__ float4 cand_p[SK_WENT];
+    __shared__ int sl_ent[SK_WSLOTS], s_nb2, s_tot2;
+    __shared__ unsigned s_alive;
+    __shared__ int sl_len[SK_WSLOTS], sl_term[SK_WSLOTS], sl_parent[SK_WSLOTS], sl_nrows[SK_WSLOTS], sl_ncand[SK_WSLOTS],
+        sl_big[SK_WSLOTS], sl_id[SK_WSLOTS], sl_off[SK_WSLOTS];
+    __shared__ float sl_rp[SK_WSLOTS];
+    __shared__ unsigned sl_walkm[SK_WSLOTS];
     const int c = blockIdx.x, tid = threadIdx.x, W = (int)blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nw = (W + 63) >> 6;
     if (A.s_done[c]) return;
@@ -908,15 +673,9 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
     SkBm B;
     B.lds = bm_words;
     B.glb = A.term_bits + (base >> 5) + c;
-    B.spec_lds = sp_words;
-    B.spec_glb = A.spec_bits + (base >> 5) + c;
     const int nwords = (n + 31) >> 5;
     B.in_lds = nwords <= SK_BM_WORDS;
-    if (B.in_lds) for (int i = tid; i < nwords; i += W) { bm_words[i] = B.glb[i]; sp_words[i] = 0u; }
-    else for (int i = tid; i < nwords; i += W) B.spec_glb[i] = 0u;  // (the prediction starts afresh with every launch)
-    if (tid < SK_NCACHE) c_state[tid] = SK_C_EMPTY;
-    if (tid < SK_MAX_WAVES) mb_state[tid] = 0;
-    if (tid == 0) { s_mode = SK_M_RUN; s_rpos = A.s_cursor[c]; }
+    if (B.in_lds) for (int i = tid; i < nwords; i += W) bm_words[i] = B.glb[i];
     __syncthreads();
 #define SK_FLUSH_BM()                                                             \
     do {                                                                          \
@@ -931,274 +690,54 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
                              A.s_ntouched[c]);
     }
     SK_TICK(0);
-    int total = A.s_total[c], nb = A.s_nb[c];  // per-component state lives in registers (uniform over the workgroup)
-    int steps_left = A.iters_per_launch;       // branches the replay may select in this launch
-    for (;;) {
-        if (wave == 0) {
-            // ---------------------------------------------------------------- the replay ---
-            // Positions of the distance order in registers: SK_RWIN x 64, position rb + 64 g + lane; the next window is
-            // requested as soon as this one is in use.  path.py:92: the farthest unallocated vertex = the first position
-            // whose vertex is not terminated.
-            int ov[SK_RWIN], nv[SK_RWIN];
-            bool ot[SK_RWIN], nt[SK_RWIN];  // tail: end of the selectable vertices (initial distance <= 0, or end of the list)
-            int rb = lds_ld_u(&s_rpos);
-#define SK_LOAD_WIN(rb_, v_, t_)                                                                   \
-    _Pragma("unroll") for (int gq = 0; gq < SK_RWIN; gq++) {                                       \
-        const int j_ = (rb_) + gq * 64 + lane;                                                     \
-        v_[gq] = -1; t_[gq] = false;                                                               \
-        if (j_ < n) { v_[gq] = (int)order[j_] - base; t_[gq] = !(A.order_init[base + j_] > 0.0f); } \
-        else if (j_ == n) t_[gq] = true;                                                           \
-    }
-            SK_LOAD_WIN(rb, ov, ot)
-            SK_LOAD_WIN(rb + SK_RWIN * 64, nv, nt)
-            int cur = 0;
-            int why = SK_M_RUN;
-            long long rt = A.ticks ? wall_clock64() : 0;
-#define SK_RTICK(i) do { if (A.ticks && lane == 0) { const long long now_ = wall_clock64(); A.ticks[i] += now_ - rt; rt = now_; } } while (0)
-            for (;;) {
-                __builtin_amdgcn_wave_barrier();  // (the stamps of the previous step are in the bitmap)
-                int first = -1, tail = -1;
-#pragma unroll
-                for (int gq = 0; gq < SK_RWIN; gq++) {
-                    const int e = gq * 64 + lane;
-                    const bool lv = ov[gq] >= 0 && !ot[gq] && e >= cur && !bm_test(B, ov[gq]);
-                    const unsigned long long bal = __ballot(lv), tb = __ballot(ot[gq]);
-                    if (first < 0 && bal) first = gq * 64 + __ffsll(bal) - 1;
-                    if (tail < 0 && tb) tail = gq * 64 + __ffsll(tb) - 1;
-                }
-                if (first < 0 || (tail >= 0 && tail < first)) {
-                    if (tail >= 0) { why = SK_M_DONE; break; }  // path.py:94-95: nothing selectable is left
-                    rb += SK_RWIN * 64;  // the next window
-#pragma unroll
-                    for (int gq = 0; gq < SK_RWIN; gq++) { ov[gq] = nv[gq]; ot[gq] = nt[gq]; }
-                    SK_LOAD_WIN(rb + SK_RWIN * 64, nv, nt)
-                    cur = 0;
-                    if (lane == 0) lds_st(&s_rpos, rb);
-                    continue;
-                }
-                if (steps_left == 0) { why = SK_M_PAUSE; if (lane == 0) lds_st(&s_rpos, rb + first); break; }
-                int tip = -1;
-#pragma unroll
-                for (int gq = 0; gq < SK_RWIN; gq++)
-                    if ((first >> 6) == gq) tip = __builtin_amdgcn_readlane(ov[gq], first & 63);
-                const int rpos = rb + first;
-                if (lane == 0) lds_st(&s_rpos, rpos);
-                SK_RTICK(20);
-                // the cache: entries of positions the replay has passed are dropped, the entry of this tip is looked up
-                int e = -1;
-                {
-                    int st = SK_C_EMPTY;
-                    if (lane < SK_NCACHE) {
-                        st = lds_ld(&c_state[lane]);
-                        if (st == SK_C_READY && lds_ld(&c_pos[lane]) < rpos) { lds_st(&c_state[lane], SK_C_EMPTY); st = SK_C_EMPTY; }
+    int win_base = A.s_cursor[c], total = A.s_total[c], nb = A.s_nb[c];  // per-component state lives in registers
+    int wv = -1;         // my window entry: component-local vertex, -1 = none
+    float wx = 0.0f, wy = 0.0f, wz = 0.0f, wr = 0.0f;  // ... its position and radius (for step 1b)
+    bool wtail = false;  // my entry marks the end of the selectable vertices (initial distance <= 0, or end of the list)
+    bool need_fill = true;
+    for (int iter = 0; iter < A.iters_per_launch; iter++) {
+        // 1. the farthest unallocated vertices (path.py:92) = the first live entries of the distance-sorted order.
+        //    A window of W entries is held in registers / LDS; its flags are cleared as points get allocated, so
+        //    finding the next tips costs no global access until the window is used up.
+        int nc = 0, ne = 0;
+        bool exhausted = false;
+        for (;;) {
+            if (need_fill) {
+                const int j = win_base + tid;
+                wv = -1; wtail = false;
+                if (j < n) {
+                    wv = (int)order[j] - base;
+                    wtail = !(A.order_init[base + j] > 0.0f);
+                    if (!wtail) {
+                        const float4 q = A.pr[base + wv];
+                        wx = q.x; wy = q.y; wz = q.z; wr = q.w;
                     }
-                    const unsigned long long mb = __ballot(st >= SK_C_BUSY && lds_ld(&c_tip[lane & (SK_NCACHE - 1)]) == tip && lane < SK_NCACHE);
-                    if (mb) {
-                        e = __ffsll(mb) - 1;
-                        while (lds_ld_u(&c_state[e]) != SK_C_READY) {  // an evaluator is at it: it does not wait for anything
-                            __builtin_amdgcn_s_sleep(1);
-                            __builtin_amdgcn_wave_barrier();
-                            if (A.ticks && lane == 0) A.ticks[14] += 1;
-                        }
-                        SK_ACQUIRE();
-                    }
+                } else if (j == n) {
+                    wtail = true;
                 }
-                bool big = false, done = false;
-                if (A.ticks && lane == 0) A.ticks[e >= 0 ? 16 : 19] += 1;
-                if (e >= 0) {
-                    if (lds_ld(&c_big[e])) { big = true; if (A.ticks && lane == 0) A.ticks[18] += 1; }
-                    else {
-                        // the cached path is the true path iff none of its vertices has been terminated since its walk
-                        const int len = lds_ld(&c_len[e]);
-                        const bool hit = lane < len && bm_test(B, cache[e].path[lane]);
-                        if (__ballot(hit) == 0ull) {
-                            sk_commit(A, B, cache[e], len, lds_ld(&c_term[e]), lds_ld(&c_ncl[e]), base, n, lane, nb, total);
-                            done = true;
-                            if (A.ticks && lane == 0) A.ticks[12] += 1;
-                        } else if (A.ticks && lane == 0) A.ticks[17] += 1;
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    if (lane == 0) lds_st(&c_state[e], SK_C_EMPTY);
-                    SK_RTICK(21);
-                }
-                if (!done && !big) {
-                    // no entry (a tip nobody evaluated: predicted to be swallowed, or the evaluators are behind), or the walk
-                    // has been cut short since: the replay evaluates the branch itself against the state as it is now
-                    int ncl = 0;
-                    const SkSlotInfo I = sk_evaluate(A, B, L.slot[0], cache[SK_OWN], ncl, base, n, tip, xoff, lane, A.late_cand);
-                    if (I.big) big = true;
-                    else {
-                        __builtin_amdgcn_wave_barrier();
-                        sk_commit(A, B, cache[SK_OWN], I.len, I.term, ncl, base, n, lane, nb, total);
-                    }
-                    if (A.ticks && lane == 0) A.ticks[11] += 1;
-                    SK_RTICK(22);
-                }
-                if (big) { why = SK_M_ONE; if (lane == 0) s_big_tip = tip; break; }
-                cur = first + 1;
-                steps_left--;
-                if (A.ticks && lane == 0) A.ticks[8] += 1;
+                need_fill = false;
             }
-#undef SK_RTICK
-#undef SK_LOAD_WIN
-            if (lane == 0) { s_nb2 = nb; s_tot2 = total; s_steps = steps_left; }
-            SK_RELEASE();
-            if (lane == 0) lds_st(&s_mode, why);
-        } else if (wave == 1 && nw >= 3) {
-            // ------------------------------------------------------------------ the scout ---
-            // walks the distance order AHEAD of the replay and hands the evaluators what will probably be a tip: a vertex
-            // that is neither terminated nor predicted to be (by the evaluations published so far, or by lying within the
-            // radius of a tip that is being evaluated).  A wrong guess only costs time (the replay evaluates what it misses).
-            int ov[SK_RWIN], nv[SK_RWIN];
-            bool ot[SK_RWIN], nt[SK_RWIN];
-            float4 op[SK_RWIN], np[SK_RWIN];
-            int rb = lds_ld_u(&s_rpos);
-#define SK_LOAD_SWIN(rb_, v_, t_, p_)                                                              \
-    _Pragma("unroll") for (int gq = 0; gq < SK_RWIN; gq++) {                                       \
-        const int j_ = (rb_) + gq * 64 + lane;                                                     \
-        v_[gq] = -1; t_[gq] = false; p_[gq] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);                 \
-        if (j_ < n) {                                                                              \
-            v_[gq] = (int)order[j_] - base; t_[gq] = !(A.order_init[base + j_] > 0.0f);            \
-            if (!t_[gq]) p_[gq] = A.pr[base + v_[gq]];                                             \
-        } else if (j_ == n) t_[gq] = true;                                                         \
-    }
-            SK_LOAD_SWIN(rb, ov, ot, op)
-            SK_LOAD_SWIN(rb + SK_RWIN * 64, nv, nt, np)
-            int cur = 0;
-            bool at_end = false;
-            for (;;) {
-                __builtin_amdgcn_wave_barrier();
-                if (lds_ld_u(&s_mode) != SK_M_RUN) break;
-                if (at_end) { __builtin_amdgcn_s_sleep(16); continue; }
-                const int rp = lds_ld_u(&s_rpos);
-                if (rb + cur > rp + SK_LOOKAHEAD) { __builtin_amdgcn_s_sleep(8); continue; }
-                if (rb + SK_RWIN * 64 <= rp) {  // the replay has overtaken this window: go where it is
-                    rb = rp;
-                    SK_LOAD_SWIN(rb, ov, ot, op)
-                    SK_LOAD_SWIN(rb + SK_RWIN * 64, nv, nt, np)
-                    cur = 0;
-                    continue;
-                }
-                int first = -1, tail = -1;
-#pragma unroll
-                for (int gq = 0; gq < SK_RWIN; gq++) {
-                    const int e = gq * 64 + lane;
-                    const bool lv = ov[gq] >= 0 && !ot[gq] && e >= cur && rb + e >= rp && !bm_test(B, ov[gq]) && !sp_test(B, ov[gq]);
-                    const unsigned long long bal = __ballot(lv), tb = __ballot(ot[gq]);
-                    if (first < 0 && bal) first = gq * 64 + __ffsll(bal) - 1;
-                    if (tail < 0 && tb) tail = gq * 64 + __ffsll(tb) - 1;
-                }
-                if (first < 0 || (tail >= 0 && tail < first)) {
-                    if (tail >= 0) { at_end = true; continue; }
-                    rb += SK_RWIN * 64;
-#pragma unroll
-                    for (int gq = 0; gq < SK_RWIN; gq++) { ov[gq] = nv[gq]; ot[gq] = nt[gq]; op[gq] = np[gq]; }
-                    SK_LOAD_SWIN(rb + SK_RWIN * 64, nv, nt, np)
-                    cur = 0;
-                    continue;
-                }
-                cur = first + 1;
-                int tip = -1;
-                float4 tp = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-#pragma unroll
-                for (int gq = 0; gq < SK_RWIN; gq++)
-                    if ((first >> 6) == gq) {
-                        tip = __builtin_amdgcn_readlane(ov[gq], first & 63);
-                        tp.x = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(op[gq].x), first & 63));
-                        tp.y = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(op[gq].y), first & 63));
-                        tp.z = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(op[gq].z), first & 63));
-                        tp.w = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(op[gq].w), first & 63));
-                    }
-                const int mypos = rb + first;
-                // within the radius of an earlier tip whose evaluation is under way or done (its claims are not all in the
-                // prediction yet): it will almost surely be swallowed by that branch
-                bool sh = false;
-                if (lane < SK_NCACHE && lds_ld(&c_state[lane]) >= SK_C_BUSY) {
-                    const int cp = lds_ld(&c_pos[lane]);
-                    if (cp < mypos && cp >= rp) {
-                        const float4 u = c_tipp[lane];
-                        const float ur = u.w * A.prune_factor;
-                        const float dx = tp.x - u.x, dy = tp.y - u.y, dz = tp.z - u.z;
-                        sh = dx * dx + dy * dy + dz * dz < ur * ur;
-                    }
-                }
-                if (lane >= 32 && lane - 32 < SK_MAX_WAVES && lds_ld(&mb_state[lane - 32]) == 1) {  // ... or still in a mailbox
-                    const float4 u = mb_tp[lane - 32];
-                    const float ur = u.w * A.prune_factor;
-                    const float dx = tp.x - u.x, dy = tp.y - u.y, dz = tp.z - u.z;
-                    sh = sh || (lds_ld(&mb_pos[lane - 32]) < mypos && dx * dx + dy * dy + dz * dz < ur * ur);
-                }
-                if (__ballot(sh)) { if (A.ticks && lane == 0) A.ticks[24] += 1; continue; }
-                // a free mailbox (evaluators are the wavefronts 2 ..)
-                int w = -1;
-                for (;;) {
-                    const unsigned long long fb = __ballot(lane >= 2 && lane < nw && lds_ld(&mb_state[lane]) == 0);
-                    if (fb) { w = __ffsll(fb) - 1; break; }
-                    if (lds_ld_u(&s_mode) != SK_M_RUN) break;
-                    __builtin_amdgcn_s_sleep(2);
-                    __builtin_amdgcn_wave_barrier();
-                }
-                if (w < 0) break;
-                if (lane == 0) { mb_tip[w] = tip; mb_pos[w] = mypos; mb_tp[w] = tp; }
-                SK_RELEASE();
-                if (lane == 0) lds_st(&mb_state[w], 1);
+            // "still unallocated" = not in the termination set (the vertices masked at the start sit behind the tail)
+            const bool live = wv >= 0 && !wtail && !bm_test(B, wv);
+            const unsigned long long lb = __ballot(live), tb = __ballot(wtail);
+            __syncthreads();  // (w_cnt / cand_v of the previous pass have been read)
+            if (lane == 0) { w_cnt[wave] = __popcll(lb); w_tail[wave] = tb != 0ull; }
+            for (int i = tid; i < SK_WT; i += W) { wt_key[i] = SK_WT_EMPTY; wt_mask[i] = 0u; }  // this round's watch table
+            __syncthreads();
+            int before = 0, tot = 0, anytail = 0;
+            for (int w = 0; w < nw; w++) { const int k = w_cnt[w]; before += w < wave ? k : 0; tot += k; anytail |= w_tail[w]; }
+            if (tot == 0) {
+                if (anytail) { exhausted = true; break; }
+                win_base += W; need_fill = true;  // nothing left in this window
+                continue;
             }
-#undef SK_LOAD_SWIN
-        } else if (wave >= 2) {
-            // ------------------------------------------------------------- an evaluator ---
-            SkSelSlot& S = L.slot[wave];
-            for (;;) {
-                __builtin_amdgcn_wave_barrier();
-                if (lds_ld_u(&s_mode) != SK_M_RUN) break;
-                if (lds_ld_u(&mb_state[wave]) != 1) { __builtin_amdgcn_s_sleep(2); continue; }
-                SK_ACQUIRE();
-                const int tip = mb_tip[wave], mypos = mb_pos[wave];
-                const float4 tp = mb_tp[wave];
-                __builtin_amdgcn_wave_barrier();
-                if (lane == 0) lds_st(&mb_state[wave], 0);  // (the scout may queue the next one while this one is evaluated)
-                if (mypos < lds_ld_u(&s_rpos)) { if (A.ticks && lane == 0) atomicAdd((unsigned long long*)&A.ticks[25], 1ull); continue; }
-                // a cache entry of my own
-                int e = -1;
-                for (;;) {
-                    const unsigned long long fb = __ballot(lane < SK_NCACHE && lds_ld(&c_state[lane]) == SK_C_EMPTY);
-                    if (fb) {
-                        const int cand = __ffsll(fb) - 1;
-                        int ok = 0;
-                        if (lane == 0) ok = atomicCAS(&c_state[cand], (int)SK_C_EMPTY, (int)SK_C_ALLOC) == SK_C_EMPTY;
-                        if (__builtin_amdgcn_readfirstlane(ok)) { e = cand; break; }
-                        continue;
-                    }
-                    if (lds_ld_u(&s_mode) != SK_M_RUN) break;  // (the replay frees entries as it passes them -- unless it has stopped)
-                    __builtin_amdgcn_s_sleep(4);
-                    __builtin_amdgcn_wave_barrier();
-                }
-                if (e < 0) break;
-                if (mypos < lds_ld_u(&s_rpos)) {  // the replay went past it while this wavefront waited
-                    if (lane == 0) lds_st(&c_state[e], SK_C_EMPTY);
-                    if (A.ticks && lane == 0) atomicAdd((unsigned long long*)&A.ticks[25], 1ull);
-                    continue;
-                }
-                if (lane == 0) { c_tip[e] = tip; c_pos[e] = mypos; c_tipp[e] = tp; }
-                SK_RELEASE();
-                if (lane == 0) lds_st(&c_state[e], SK_C_BUSY);
-                int ncl = 0;
-                const SkSlotInfo I = sk_evaluate(A, B, S, cache[e], ncl, base, n, tip, xoff, lane, SK_WAVE_CAND);
-                if (lane == 0) { c_len[e] = I.len; c_term[e] = I.term; c_ncl[e] = ncl; c_big[e] = I.big; }
-                if (!I.big) {  // what this branch will terminate, for the scout
-                    if (lane < I.len) sp_set(B, cache[e].path[lane]);
-                    for (int i = lane; i < ncl; i += 64) sp_set(B, (int)cache[e].cl[i]);
-                }
-                SK_RELEASE();
-                if (lane == 0) lds_st(&c_state[e], SK_C_READY);
-                if (A.ticks && lane == 0) atomicAdd((unsigned long long*)&A.ticks[13], 1ull);
-            }
+            const int rank = before + __popcll(lb & ((1ull << lane) - 1ull));
+            if (live && rank < SK_WENT) { cand_v[rank] = wv; cand_p[rank] = make_float4(wx, wy, wz, wr); }
+            ne = tot < SK_WENT ? tot : SK_WENT;
+            __syncthreads();
+            break;
         }
-        __syncthreads();  // both roles have stopped: no evaluation is in flight, the cache is dead
-        const int mode = s_mode;
-        nb = s_nb2; total = s_tot2; steps_left = s_steps;
-        const int win_base = s_rpos;
-        SK_TICK(4);
-        if (mode == SK_M_DONE) {  // path.py:94-95 (uniform)
+        if (exhausted) {  // path.py:94-95 (uniform)
             SK_FLUSH_BM();
             if (tid == 0) {
                 A.s_done[c] = 1; A.s_len[c] = 0; A.s_wide[c] = 0; A.n_branches[c] = nb; A.s_nb[c] = nb; A.s_total[c] = total;
@@ -1209,20 +748,301 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
             SK_TICK_FLUSH();
             return;
         }
-        if (mode == SK_M_PAUSE) {
-            SK_FLUSH_BM();
-            if (tid == 0) { A.s_len[c] = 0; A.s_wide[c] = 0; A.s_cursor[c] = win_base; A.s_total[c] = total; A.s_nb[c] = nb; }
-            SK_TICK_FLUSH();
-            return;
+        SK_TICK(7);
+        // 1b. which entries get a wavefront?  A tip within the radius of an earlier chosen tip will almost surely
+        //     be swallowed by that branch: it gets no slot (if the guess is wrong the replay below simply stops
+        //     there).  Every wavefront runs this little greedy pass itself -- no barrier, no LDS.
+        int my_slot = -1;  // lane e < ne: slot of entry e (-1: none)
+        int my_ent = 0;    // the entry this wavefront speculates on (wave < nc)
+        int ent_v = -1;
+        {
+            float ex = 0.0f, ey = 0.0f, ez = 0.0f, er = 0.0f;
+            if (lane < ne) {
+                ent_v = cand_v[lane];
+                const float4 e4 = cand_p[lane];
+                ex = e4.x; ey = e4.y; ez = e4.z; er = e4.w * A.prune_factor;
+                if (wave == 0) sk_wt_insert(wt_key, wt_mask, (unsigned)ent_v, 0u);  // the replay asks who claimed this tip
+            }
+            int shadowed = 0, chosen = 0;
+            for (int u = 0; u < ne; u++) {
+                if (__builtin_amdgcn_readlane(shadowed, u)) continue;
+                if (chosen == nw) { ne = u; break; }  // out of wavefronts: the round ends before this entry
+                chosen++;
+                const float ux = wave_readlane_f(ex, u), uy = wave_readlane_f(ey, u), uz = wave_readlane_f(ez, u),
+                            ur = wave_readlane_f(er, u);
+                const float dx = ex - ux, dy = ey - uy, dz = ez - uz;
+                if (lane > u && dx * dx + dy * dy + dz * dz < ur * ur) shadowed = 1;
+            }
+            const unsigned long long cb = __ballot(lane < ne && !shadowed);
+            nc = __popcll(cb);
+            if (lane < ne && !shadowed) my_slot = __popcll(cb & ((1ull << lane) - 1ull));
+            unsigned long long rest = cb;
+            for (int k = 0; k < wave && rest; k++) rest &= rest - 1ull;
+            my_ent = rest ? __ffsll(rest) - 1 : 0;
         }
-        steps_left--;
-        // back to the two roles after this branch: every entry is free again, the evaluators go on where they were
-        if (tid < SK_NCACHE) c_state[tid] = SK_C_EMPTY;
-        if (tid < SK_MAX_WAVES) mb_state[tid] = 0;
-        if (tid == 0) s_mode = SK_M_RUN;
-        // ---- `one` mode: this branch needs the whole workgroup ----
-        const int far = s_big_tip;
-        __syncthreads();  // (the resets above are published; the evaluators' scratch is reused below)
+        SK_TICK(1);
+        // 2. speculative walks: wavefront s traces its entry through ONE ancestor-table row (trace_route,
+        //    path.py:9-16: lane j inspects the j-th ancestor; the first allocated one, or the step past the root,
+        //    ends the walk), then gathers radius / position of its path, the (x, y) rows of grid cells around it
+        //    and how many candidate points they hold.
+        if (wave < nc) {
+            SkSelSlot& S = L.slot[wave];
+            const int tip = cand_v[my_ent];
+            const int node = lane == 0 ? tip : A.anc[(int64_t)(base + tip) * SK_ANC + lane - 1];
+            const bool end = node < 0 || bm_test(B, node);
+            const unsigned long long eb = __ballot(end);
+            int big = eb == 0ull, len = 0, termv = -1, nrows = 0, ncand = 0, parent = -1;
+            float rp = 0.0f;
+            if (!big) {
+                len = __ffsll(eb) - 1;
+                termv = __shfl(node, len);
+                const int qi = len - 1 - lane;  // walk order -> root side first
+                if (lane < 3) { S.lo[lane] = 0x7fffffff; S.hi[lane] = (int)0x80000000; }
+                if (lane == 3) S.rk = 0u;
+                __builtin_amdgcn_wave_barrier();
+                // the parent id is read BEFORE anything is stamped (path.py:128-136); termination -1 reads
+                // branch_ids[-1] = the last vertex (quirk kept)
+                if (lane == 0 && len >= 2) parent = ld(&A.branch_of[base + (termv < 0 ? n - 1 : termv)]);
+                // watched: the walk (marked by its own slot) and the vertex the parent id is read from
+                if (lane < len) sk_wt_insert(wt_key, wt_mask, (unsigned)node, 1u << wave);
+                else if (lane == len) sk_wt_insert(wt_key, wt_mask, (unsigned)(termv < 0 ? n - 1 : termv), 0u);
+                if (lane < len) {
+                    const float4 q4 = A.pr[base + node];
+                    const float x = q4.x, y = q4.y, z = q4.z, r = q4.w;
+                    S.path[qi] = node; S.p[qi] = q4;
+                    const int cx = (int)floorf((x - g->lo[0]) / g->cell), cy = (int)floorf((y - g->lo[1]) / g->cell),
+                              cz = (int)floorf((z - g->lo[2]) / g->cell);
+                    atomicMax(&S.rk, st_f2ord(r));  // path.py:31
+                    atomicMin(&S.lo[0], cx); atomicMin(&S.lo[1], cy); atomicMin(&S.lo[2], cz);
+                    atomicMax(&S.hi[0], cx); atomicMax(&S.hi[1], cy); atomicMax(&S.hi[2], cz);
+                }
+                __builtin_amdgcn_wave_barrier();
+                rp = st_ord2f(S.rk);
+                int reach = rp > 0.0f ? (int)ceilf(rp / g->cell) : 0;
+                if (reach < 1) reach = 1;
+                const int x0 = st_max(S.lo[0] - reach, 0), x1 = st_min(S.hi[0] + reach, g->seg_dim0 - 1);
+                const int y0 = st_max(S.lo[1] - reach, 0), y1 = st_min(S.hi[1] + reach, g->dim[1] - 1);
+                const int z0 = st_max(S.lo[2] - reach, 0), z1 = st_min(S.hi[2] + reach, g->dim[2] - 1);
+                const int nx = x1 - x0 + 1, ny = y1 - y0 + 1;
+                nrows = (nx > 0 && ny > 0 && z0 <= z1) ? nx * ny : 0;
+                big = nrows > SK_WROWS;
+                if (!big) {
+                    uint32_t cnt[SK_WROWS / 64], first[SK_WROWS / 64];
+#pragma unroll
+                    for (int ch = 0; ch < SK_WROWS / 64; ch++) {  // all loads first, then the scans
+                        const int rr = ch * 64 + lane;
+                        cnt[ch] = 0u; first[ch] = 0u;
+                        if (rr < nrows) {
+                            const int64_t row = ((int64_t)(xoff + x0 + rr / ny) * g->dim[1] + (y0 + rr % ny)) * g->dim[2];
+                            first[ch] = A.cell_start[row + z0];
+                            cnt[ch] = A.cell_start[row + z1 + 1] - first[ch];
+                        }
+                    }
+                    uint32_t run = 0u;
+#pragma unroll
+                    for (int ch = 0; ch < SK_WROWS / 64; ch++) {
+                        if (ch * 64 >= nrows) break;  // wave-uniform
+                        const uint32_t inc = wave_incl_scan_u(cnt[ch], lane);
+                        const int rr = ch * 64 + lane;
+                        if (rr < nrows) { S.row_off[rr] = run + inc - cnt[ch]; S.row_first[rr] = first[ch]; }
+                        run += __shfl(inc, 63);
+                    }
+                    ncand = (int)run;
+                    if (lane == 0) S.row_off[nrows] = (uint32_t)ncand;
+                    big = ncand > SK_WAVE_CAND || ncand > SK_ROUND_ITEMS * W || (int64_t)ncand * len > A.wave_work;
+                }
+            }
+            if (lane == 0) {
+                sl_len[wave] = len; sl_term[wave] = termv; sl_parent[wave] = parent; sl_nrows[wave] = nrows; sl_ncand[wave] = ncand;
+                sl_big[wave] = big; sl_rp[wave] = rp; sl_ent[wave] = my_ent;
+            }
+        }
+        __syncthreads();
+        SK_TICK(2);
+        if (!sl_big[0]) {
+            // slots after the first oversized one (or past the per-round item budget) wait for a later round.
+            // pre[k] = candidates of the slots before k: workgroup-uniform, so it lives in scalar registers.
+            int pre[SK_WSLOTS + 1];
+            pre[0] = 0;
+            {
+                // lane k reads slot k's numbers once (one LDS round trip), the scan below takes them out with readlane
+                int cand_l = 0, big_l = 0, ent_l = 0;
+                if (lane < SK_WSLOTS && lane < nc) { cand_l = sl_ncand[lane]; big_l = sl_big[lane]; ent_l = sl_ent[lane]; }
+                bool open = true;
+                int k_cut = nc;
+#pragma unroll
+                for (int k = 0; k < SK_WSLOTS; k++) {
+                    int add = 0;
+                    if (k < nc && open) {
+                        const int cand_k = __builtin_amdgcn_readlane(cand_l, k), big_k = __builtin_amdgcn_readlane(big_l, k);
+                        if (big_k || pre[k] + cand_k > SK_ROUND_ITEMS * W) { open = false; k_cut = k; }
+                        else add = cand_k;
+                    }
+                    pre[k + 1] = pre[k] + add;
+                }
+                if (k_cut < nc) { ne = __builtin_amdgcn_readlane(ent_l, k_cut); nc = k_cut; }
+            }
+            const int T = pre[SK_WSLOTS];
+            // 3. claims (select_path_points, path.py:19-46), point-centric: the candidates of ALL slots are dealt
+            //    out over the workgroup; each finds ITS nearest path vertex from LDS -- no atomics but the mark.
+            unsigned cl_bits = 0u;  // bit k: my k-th item was claimed but did not fit cl_list
+            int cl_n = 0;
+            const int nround = (T + W - 1) / W;
+            for (int k0 = 0; k0 < nround; k0 += 4) {
+                float4 r4[4];
+                int ss[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int gi = (k0 + u) * W + tid;
+                    ss[u] = -1;
+                    r4[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    if (k0 + u < nround && gi < T) {
+                        int sidx = 0, acc = 0;
+#pragma unroll
+                        for (int k = 1; k < SK_WSLOTS; k++)
+                            if (gi >= pre[k]) { sidx = k; acc = pre[k]; }  // pre[] is non-decreasing and ends at T > gi
+                        const SkSelSlot& S = L.slot[sidx];
+                        const uint32_t t = (uint32_t)(gi - acc);
+                        const int row = sk_find_row(S.row_off, sl_nrows[sidx], t);
+                        r4[u] = recs[S.row_first[row] + (t - S.row_off[row])];
+                        ss[u] = sidx;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (ss[u] < 0) continue;
+                    const int p = (int)__float_as_uint(r4[u].w) - base;
+                    if (p < 0 || p >= n) continue;  // other component
+                    const SkSelSlot& S = L.slot[ss[u]];
+                    const int len = sl_len[ss[u]];
+                    const float rp = sl_rp[ss[u]];
+                    float bd2 = __uint_as_float(0x7f800000u);
+                    int bq = 0;
+                    float bw = 0.0f;
+                    // ascending: ties keep the first path vertex.  Four path vertices per step: their LDS reads are in flight together
+#define SK_NEAREST(q, qi_)                                                                    \
+    {                                                                                          \
+        const float dx = r4[u].x - (q).x, dy = r4[u].y - (q).y, dz = r4[u].z - (q).z;          \
+        float d2 = dx * dx;                                                                    \
+        float tt = dy * dy;                                                                    \
+        d2 = d2 + tt;                                                                          \
+        tt = dz * dz;                                                                          \
+        d2 = d2 + tt;                                                                          \
+        if (d2 < bd2) { bd2 = d2; bq = (qi_); bw = (q).w; }                                    \
+    }
+                    int qi = 0;
+                    for (; qi + 4 <= len; qi += 4) {
+                        const float4 q0 = S.p[qi], q1 = S.p[qi + 1], q2 = S.p[qi + 2], q3 = S.p[qi + 3];
+                        SK_NEAREST(q0, qi) SK_NEAREST(q1, qi + 1) SK_NEAREST(q2, qi + 2) SK_NEAREST(q3, qi + 3)
+                    }
+                    for (; qi < len; qi++) {
+                        const float4 q = S.p[qi];
+                        SK_NEAREST(q, qi)
+                    }
+#undef SK_NEAREST
+                    (void)bq;
+                    if (bd2 < rp * rp && sqrtf(bd2) < bw) {  // path.py:35-40
+                        const int h = sk_wt_find(wt_key, (unsigned)p);
+                        if (h >= 0) atomicOr(&wt_mask[h], 1u << ss[u]);
+                        if (cl_n < SK_CL_KEEP) cl_list[cl_n][tid] = (unsigned)p | ((unsigned)ss[u] << 28);
+                        else cl_bits |= 1u << (k0 + u);
+                        cl_n++;
+                    }
+                }
+            }
+            __syncthreads();  // all marks are in the table
+            SK_TICK(3);
+            // 4. what did the earlier slots touch?  (walk + the vertex the parent id was read from; tip of every entry)
+            if (wave < nc) {
+                const SkSelSlot& S = L.slot[wave];
+                const int len = sl_len[wave], termv = sl_term[wave];
+                unsigned mk = 0u;
+                if (lane <= len) mk = wt_mask[sk_wt_find(wt_key, (unsigned)(lane < len ? S.path[len - 1 - lane] : (termv < 0 ? n - 1 : termv)))];
+                const unsigned walkm = wave_or_u(mk);
+                if (lane == 0) sl_walkm[wave] = walkm;
+            }
+            unsigned etip = 0u;
+            if (wave == 0 && lane < ne) etip = wt_mask[sk_wt_find(wt_key, (unsigned)ent_v)];
+            __syncthreads();
+            if (wave == 0) {  // the sequential replay over the entries, lane e holding entry e
+                if (my_slot >= nc) my_slot = -1;
+                const unsigned walkm = my_slot >= 0 ? sl_walkm[my_slot] : 0u;
+                const int mylen = my_slot >= 0 ? sl_len[my_slot] : 0;
+                unsigned alive = 0u;
+                int nb2 = nb, tot2 = total, commits = 0, my_id = -2, my_off = 0;
+                for (int e = 0; e < ne; e++) {
+                    if ((unsigned)__builtin_amdgcn_readlane((int)etip, e) & alive) continue;  // never selected
+                    const int sl = __builtin_amdgcn_readlane(my_slot, e);
+                    if (sl < 0) break;                                                         // guessed wrong: it lives
+                    if ((unsigned)__builtin_amdgcn_readlane((int)walkm, e) & alive) break;     // depends on an accepted slot
+                    alive |= 1u << sl;
+                    const int l = __builtin_amdgcn_readlane(mylen, e);
+                    const bool keep = l >= 2;  // path.py:125-126: shorter paths still consume their points
+                    if (lane == e) { my_id = keep ? nb2 : -1; my_off = tot2; }
+                    if (keep) { nb2++; tot2 += l; }
+                    commits++;
+                }
+                if (my_slot >= 0) { sl_id[my_slot] = my_id; sl_off[my_slot] = my_off; }
+                if (lane == 0) {
+                    s_alive = alive; s_nb2 = nb2; s_tot2 = tot2;
+                    if (A.ticks) { A.ticks[8] += 1; A.ticks[12] += commits; A.ticks[13] += nc; A.ticks[11] += T; }
+                }
+            }
+            __syncthreads();
+            const unsigned alive = s_alive;
+            nb = s_nb2; total = s_tot2;
+            // 5. commit the accepted slots (path.py:112-136), wipe every mark
+            if (wave < nc) {
+                const SkSelSlot& S = L.slot[wave];
+                const int len = sl_len[wave], id = sl_id[wave];
+                if (lane < len) {
+                    const int v = S.path[lane];
+                    if (id != -2) {
+                        if (id >= 0) A.path_verts[base + sl_off[wave] + lane] = v;  // (a dropped path shares its offset with the next one)
+                        sk_mark(A, B, base, v, id);
+                    }
+                }
+                if (lane == 0 && id >= 0) {
+                    A.branch_parent[base + id] = sl_parent[wave];
+                    A.branch_off[base + id] = sl_off[wave];
+                    A.branch_len[base + id] = len;
+                    if (A.ticks) A.ticks[10] += len;
+                }
+            }
+            const int kept_n = cl_n < SK_CL_KEEP ? cl_n : SK_CL_KEEP;
+            for (int j = 0; j < kept_n; j++) {
+                const unsigned e = cl_list[j][tid];
+                const int p = (int)(e & 0x0fffffffu), sidx = (int)(e >> 28);
+                if ((alive >> sidx) & 1u) {
+                    const int id = sl_id[sidx];
+                    sk_mark(A, B, base, p, id);
+                }
+            }
+            while (cl_bits) {  // the overflow: find the point again
+                const int k = __ffs(cl_bits) - 1;
+                cl_bits &= cl_bits - 1u;
+                const int gi = k * W + tid;
+                int sidx = 0, acc = 0;
+#pragma unroll
+                for (int k2 = 1; k2 < SK_WSLOTS; k2++)
+                    if (gi >= pre[k2]) { sidx = k2; acc = pre[k2]; }
+                if (!((alive >> sidx) & 1u)) continue;
+                const SkSelSlot& S = L.slot[sidx];
+                const uint32_t t = (uint32_t)(gi - acc);
+                const int row = sk_find_row(S.row_off, sl_nrows[sidx], t);
+                const int p = (int)__float_as_uint(recs[S.row_first[row] + (t - S.row_off[row])].w) - base;
+                {
+                    const int id = sl_id[sidx];
+                    sk_mark(A, B, base, p, id);
+                }
+            }
+            __syncthreads();  // (also: LDS of this round is dead)
+            SK_TICK(4);
+            continue;
+        }
+        // ---- `one` mode: candidate 0 needs the whole workgroup ----
+        const int far = cand_v[0];
+        __syncthreads();  // slot data is dead; its space is reused below
         int len = -1;
         for (unsigned chunk = 0; len < 0; chunk += blockDim.x) {
             const unsigned j = chunk + tid;
@@ -1372,10 +1192,15 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
                             if (d2 < bd2) { bd2 = d2; bw = L.one.lpr[qi]; }
                         }
                     }
-                    if (bd2 < rp2 && sqrtf(bd2) < bw) sk_mark(A, B, base, p, id);  // path.py:35-40
+                    if (bd2 < rp2 && sqrtf(bd2) < bw) {  // path.py:35-40
+                        sk_mark(A, B, base, p, id);
+                    }
                 }
             }
-            for (int qi = tid; qi < len; qi += blockDim.x) sk_mark(A, B, base, L.one.lpath[len - 1 - qi], id);  // path.py:112-113,135
+            for (int qi = tid; qi < len; qi += blockDim.x) {  // path.py:112-113,135
+                const int v = L.one.lpath[len - 1 - qi];
+                sk_mark(A, B, base, v, id);
+            }
             __syncthreads();
             SK_TICK(6);
             continue;
@@ -1395,6 +1220,7 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
             __syncthreads();
             sk_finish_branch(A, B, base, len, id, path_out, false, in_lds ? lq : A.touched + base, in_lds,
                              in_lds ? lq_ctl[0] : ld(&A.s_ntouched[c]));
+            need_fill = true;  // the window flags are rebuilt from the allocation state
             SK_TICK(6);
             continue;
         }
@@ -1423,14 +1249,23 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
                 d2 = d2 + tt;
                 if (d2 < bd2) { bd2 = d2; bq = qi; }
             }
-            if (bd2 < rp2 && sqrtf(bd2) < L.one.lpr[bq]) sk_mark(A, B, base, p, id);  // path.py:35-40
+            if (bd2 < rp2 && sqrtf(bd2) < L.one.lpr[bq]) {  // path.py:35-40
+                sk_mark(A, B, base, p, id);
+            }
         }
-        for (int qi = tid; qi < len; qi += blockDim.x) sk_mark(A, B, base, L.one.lpath[len - 1 - qi], id);  // path.py:112-113,135
+        for (int qi = tid; qi < len; qi += blockDim.x) {  // path.py:112-113,135
+            const int v = L.one.lpath[len - 1 - qi];
+            sk_mark(A, B, base, v, id);
+        }
         __syncthreads();
         SK_TICK(5);
     }
+    SK_FLUSH_BM();
+    if (tid == 0) { A.s_len[c] = 0; A.s_wide[c] = 0; A.s_cursor[c] = win_base; A.s_total[c] = total; A.s_nb[c] = nb; }
+    SK_TICK_FLUSH();
 #undef SK_FLUSH_BM
 }
+
 
 __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_claim(SkArgs A) {
     __shared__ unsigned lq[SK_LQ_CLAIM];
@@ -1510,7 +1345,7 @@ static void sk_layout(StArena& a, int64_t m, int64_t C, SkLayout* s, int nseg = 
     s->q0 = a.take<unsigned>(sk_queue_words(m, C));  // SSSP frontier: SK_FS shard segments + the overflow area (sk_q_reserve)
     s->q1 = a.take<unsigned>(sk_queue_words(m, C));
     s->touched = a.take<unsigned>(m);
-    s->term_bits = a.take<unsigned>(2 * sk_term_words(m, C));  // the termination set, then the predicted one (SkBm)
+    s->term_bits = a.take<unsigned>(sk_term_words(m, C));
     s->pr = a.take<float4>(m);
     s->best = a.take<unsigned long long>(m);
     s->anc = a.take<int>((int64_t)SK_ANC * m);
@@ -1547,7 +1382,7 @@ static void sk_layout(StArena& a, int64_t m, int64_t C, SkLayout* s, int nseg = 
 //   0 prune factor (x1000)   1 small_work   2 rounds per select launch   3 select launches per host read-back
 //   4 local_items   5 wave_work   6 SSSP levels per frontier launch   7 frontier launches per read-back   8 lanes per vertex
 //   9 length of the first frontier batch (in batches)   10 frontier workgroups   11 claim-grid cell cap (hundredths of the
-//   mean radius)   12 candidates the selection's replay wavefront evaluates by itself (-1: none, every such entry ends its round)
+//   mean radius)
 //   13 frontier: 0 = no look before the atomic, else vertices a workgroup relaxes per local level
 //   14 long-path claim inside the workgroup (1, default) or by the local / chip-wide path-centric claims (0)
 //   15 device pointer of 32 int64 phase timers / counters of k_sk_select
@@ -1555,8 +1390,7 @@ static void sk_layout(StArena& a, int64_t m, int64_t C, SkLayout* s, int nseg = 
 #define SK_MAX_LAUNCH_BATCH 32
 struct SkTuning {
     float prune_factor = 1.0f, grid_mean_mult = 1.0f;
-    int small_work = SK_SMALL_WORK, iters_per_launch = SK_ITERS_PER_LAUNCH, launch_batch = 24, local_items = 0, wave_work = SK_WAVE_WORK, long_mode = 1,
-        late_cand = SK_LATE_CAND;
+    int small_work = SK_SMALL_WORK, iters_per_launch = SK_ITERS_PER_LAUNCH, launch_batch = 24, local_items = 0, wave_work = SK_WAVE_WORK, long_mode = 1;
     int sssp_hops = 4, sssp_batch = 32, sssp_lanes = 64, sssp_first = 2, sssp_blocks = SK_SSSP_BLOCKS, sssp_lcap = SK_LQ;
     bool small_work_set = false, iters_set = false, long_set = false, launch_set = false;
     long long* ticks = nullptr;
@@ -1575,7 +1409,6 @@ struct SkTuning {
         if (has(9)) sssp_first = t[9] < 1 ? 1 : (t[9] > 8 ? 8 : (int)t[9]);
         if (has(10)) sssp_blocks = t[10] < 1 ? 1 : (t[10] > 8192 ? 8192 : (int)t[10]);
         if (has(11)) grid_mean_mult = (float)t[11] / 100.0f;
-        if (has(12)) late_cand = t[12] < 0 ? -1 : (int)t[12];
         if (has(13)) sssp_lcap = t[13] == 0 ? -SK_LQ : (t[13] > SK_LQ ? SK_LQ : (int)t[13]);
         if (has(14)) { long_mode = t[14] != 0; long_set = true; }
         if (has(15)) ticks = (long long*)(intptr_t)t[15];
@@ -1650,7 +1483,7 @@ extern "C" int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, c
     A.dist = dist; A.pred = pred; A.root_local = root_local; A.tree_dist = tree_dist;
     A.branch_parent = branch_parent; A.branch_off = branch_off; A.branch_len = branch_len; A.n_branches = n_branches;
     A.path_verts = path_verts; A.branch_of = branch_of;
-    A.dist_ord = s.dist_ord; A.stamp = s.stamp; A.q0 = s.q0; A.q1 = s.q1; A.term_bits = s.term_bits; A.spec_bits = s.term_bits + sk_term_words(m, n_comp); A.pr = s.pr;
+    A.dist_ord = s.dist_ord; A.stamp = s.stamp; A.q0 = s.q0; A.q1 = s.q1; A.term_bits = s.term_bits; A.pr = s.pr;
     A.best = s.best; A.touched = s.touched; A.anc = s.anc; A.cnt = s.cnt; A.fcnt = s.cnt + 8;
     A.fseg = (unsigned)sk_fseg(m, n_comp);
     A.s_done = s.s_done; A.s_len = s.s_len; A.s_cur_id = s.s_cur_id; A.s_cur_off = s.s_cur_off; A.s_nb = s.s_nb;
@@ -1659,7 +1492,7 @@ extern "C" int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, c
     A.s_cursor = s.s_cursor; A.s_wide = s.s_wide; A.order = s.order; A.order_init = s.order_init;
     const SkTuning T(tuning);
     A.ticks = T.ticks;
-    A.prune_factor = T.prune_factor; A.small_work = T.small_work; A.iters_per_launch = T.iters_per_launch; A.local_items = T.local_items; A.wave_work = T.wave_work; A.long_mode = T.long_mode; A.late_cand = T.late_cand;
+    A.prune_factor = T.prune_factor; A.small_work = T.small_work; A.iters_per_launch = T.iters_per_launch; A.local_items = T.local_items; A.wave_work = T.wave_work; A.long_mode = T.long_mode;
     // A batch of clouds advances in lockstep: a launch lasts as long as its slowest component, and a component that hands a
     // long path to the chip-wide claim kernel waits for everybody else's rounds.  Fewer hand-overs (the workgroup claims
     // paths up to 16x larger by itself) and shorter launches measured 2.98 -> 2.48 ms of skeleton stage per cloud at 8 clouds
@@ -1760,7 +1593,7 @@ extern "C" int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, c
         for (;;) {  // second pass only if the deferred check found plateau vertices: predecessors completed, selection redone
             (void)hipMemsetAsync(&s.cnt[5], 0, 3 * sizeof(unsigned), stream);  // finished components, branches, path vertices
             const float* distances = (stages & 2) ? tree_dist : dist;
-            (void)hipMemsetAsync(s.term_bits, 0, 2 * sk_term_words(m, n_comp) * sizeof(unsigned), stream);
+            (void)hipMemsetAsync(s.term_bits, 0, sk_term_words(m, n_comp) * sizeof(unsigned), stream);
             hipLaunchKernelGGL(k_sk_lift_init, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A);
             for (int span = 1; span < SK_ANC; span *= 2)  // direct ancestor table by doubling
                 hipLaunchKernelGGL(k_sk_anc_pass, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A, span);

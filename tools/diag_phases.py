@@ -62,8 +62,6 @@ with tuning.override({**knobs, tuning.TICKS: ticks.data_ptr()}):
     run_components(comps, medial, radius, ys)
 torch.cuda.synchronize()
 t = ticks.cpu().numpy()
-print(f"  phases (us): head {t[0]/100:.0f} replay + evaluators {t[4]/100:.0f} one-mode small {t[5]/100:.0f} long / local {t[6]/100:.0f} ({t[15]}) | replay steps {t[8]}: "
-      f"entry found {t[16]} (committed {t[12]}, stale {t[17]}, needs the workgroup {t[18]}), no entry {t[19]}; evaluated by the replay itself {t[11]}; "
-      f"spins on a busy entry {t[14]} | evaluations published {t[13]}, tips skipped as swallowed {t[24]}, behind the replay {t[25]} | "
-      f"one-mode iterations {t[9]} (path vertices {t[10]})\n"
-      f"  replay (us): finding the next tip {t[20]/100:.0f}, look-up + validation + commit {t[21]/100:.0f}, own evaluations {t[22]/100:.0f}")
+print(f"  phases (us, summed over components): head {t[0]/100:.0f} rank {t[7]/100:.0f} prune {t[1]/100:.0f} walk+rows {t[2]/100:.0f} claim {t[3]/100:.0f} "
+      f"validate+commit {t[4]/100:.0f} one-mode {t[5]/100:.0f} local {t[6]/100:.0f} ({t[15]}) | rounds {t[8]} slots {t[13]} commits {t[12]} "
+      f"one-mode iters {t[9]} (path vertices {t[10]}) wide {t[14]} cand {t[11]}")
