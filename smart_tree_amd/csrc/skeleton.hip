@@ -577,6 +577,7 @@ __device__ __forceinline__ unsigned wave_incl_scan_u(unsigned v, int lane) {
 #define SK_WSLOTS 16   // = SK_MAX_WAVES
 #define SK_WENT 32     // window entries looked at per round (those predicted to be swallowed get no slot)
 #define SK_WPATH 64    // a speculative walk is ONE row of the ancestor table
+#define SK_WCHUNK 8    // path vertices per bounding box in the claim of a speculative path
 #define SK_WROWS 256   // (x, y) cell rows around a speculative path: up to four per lane
 #define SK_WAVE_WORK (1 << 20)  // candidate points x path vertices per speculative branch
 #define SK_WAVE_CAND 16384
@@ -593,6 +594,7 @@ struct SkSelSlot {
     uint32_t row_off[SK_WROWS + 1], row_first[SK_WROWS];
     int lo[3], hi[3];  // cell bounding box of the path (LDS min / max)
     unsigned rk;       // ordered bits of the largest radius
+    float4 blo[SK_WPATH / SK_WCHUNK], bhi[SK_WPATH / SK_WCHUNK];  // bounding boxes of SK_WCHUNK consecutive path vertices
 };
 union SkSelLds {
     SkSelOne one;
@@ -817,6 +819,15 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
                     atomicMax(&S.hi[0], cx); atomicMax(&S.hi[1], cy); atomicMax(&S.hi[2], cz);
                 }
                 __builtin_amdgcn_wave_barrier();
+                if (lane < (len + SK_WCHUNK - 1) / SK_WCHUNK) {  // chunk boxes for the claim
+                    float4 lo = S.p[lane * SK_WCHUNK], hi = lo;
+                    for (int qj = lane * SK_WCHUNK + 1; qj < len && qj < (lane + 1) * SK_WCHUNK; qj++) {
+                        const float4 q = S.p[qj];
+                        lo.x = q.x < lo.x ? q.x : lo.x; lo.y = q.y < lo.y ? q.y : lo.y; lo.z = q.z < lo.z ? q.z : lo.z;
+                        hi.x = q.x > hi.x ? q.x : hi.x; hi.y = q.y > hi.y ? q.y : hi.y; hi.z = q.z > hi.z ? q.z : hi.z;
+                    }
+                    S.blo[lane] = lo; S.bhi[lane] = hi;
+                }
                 rp = st_ord2f(S.rk);
                 int reach = rp > 0.0f ? (int)ceilf(rp / g->cell) : 0;
                 if (reach < 1) reach = 1;
@@ -891,21 +902,39 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
             for (int k0 = 0; k0 < nround; k0 += 4) {
                 float4 r4[4];
                 int ss[4];
+                {
+                    // the rows of four candidates at once: the four binary searches advance in lockstep (a fixed number of
+                    // steps), so that their dependent LDS reads overlap instead of queueing behind each other
+                    const uint32_t* ro[4];
+                    int lo[4], hi[4];
+                    uint32_t tt[4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int gi = (k0 + u) * W + tid;
-                    ss[u] = -1;
-                    r4[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                    if (k0 + u < nround && gi < T) {
-                        int sidx = 0, acc = 0;
+                    for (int u = 0; u < 4; u++) {
+                        const int gi = (k0 + u) * W + tid;
+                        ss[u] = -1;
+                        ro[u] = L.slot[0].row_off; lo[u] = 0; hi[u] = 1; tt[u] = 0u;
+                        if (k0 + u < nround && gi < T) {
+                            int sidx = 0, acc = 0;
 #pragma unroll
-                        for (int k = 1; k < SK_WSLOTS; k++)
-                            if (gi >= pre[k]) { sidx = k; acc = pre[k]; }  // pre[] is non-decreasing and ends at T > gi
-                        const SkSelSlot& S = L.slot[sidx];
-                        const uint32_t t = (uint32_t)(gi - acc);
-                        const int row = sk_find_row(S.row_off, sl_nrows[sidx], t);
-                        r4[u] = recs[S.row_first[row] + (t - S.row_off[row])];
-                        ss[u] = sidx;
+                            for (int k = 1; k < SK_WSLOTS; k++)
+                                if (gi >= pre[k]) { sidx = k; acc = pre[k]; }  // pre[] is non-decreasing and ends at T > gi
+                            ss[u] = sidx;
+                            ro[u] = L.slot[sidx].row_off; hi[u] = sl_nrows[sidx]; tt[u] = (uint32_t)(gi - acc);
+                        }
+                    }
+#pragma unroll
+                    for (int step = 0; step < 8; step++) {  // SK_WROWS = 2^8 rows at most; a converged search repeats its last step
+                        uint32_t v[4];
+                        int mid[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) { mid[u] = (lo[u] + hi[u]) >> 1; v[u] = ro[u][mid[u]]; }
+#pragma unroll
+                        for (int u = 0; u < 4; u++) { if (v[u] <= tt[u]) lo[u] = mid[u]; else hi[u] = mid[u]; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        r4[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                        if (ss[u] >= 0) r4[u] = recs[L.slot[ss[u]].row_first[lo[u]] + (tt[u] - ro[u][lo[u]])];
                     }
                 }
 #pragma unroll
@@ -915,33 +944,51 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
                     if (p < 0 || p >= n) continue;  // other component
                     const SkSelSlot& S = L.slot[ss[u]];
                     const int len = sl_len[ss[u]];
-                    const float rp = sl_rp[ss[u]];
+                    const float rp = sl_rp[ss[u]], rp2 = rp * rp;
                     float bd2 = __uint_as_float(0x7f800000u);
-                    int bq = 0;
                     float bw = 0.0f;
-                    // ascending: ties keep the first path vertex.  Four path vertices per step: their LDS reads are in flight together
-#define SK_NEAREST(q, qi_)                                                                    \
+                    // ascending: ties keep the first path vertex.  The path is cut into chunks of SK_WCHUNK vertices with their
+                    // bounding boxes; a chunk whose box is no closer than the best vertex so far (or than the path radius) is
+                    // skipped -- exact for the reason given at the long-path claim below (same float32 operations, monotone
+                    // rounding); most candidates reject most chunks.
+#define SK_NEAREST(q)                                                                         \
     {                                                                                          \
         const float dx = r4[u].x - (q).x, dy = r4[u].y - (q).y, dz = r4[u].z - (q).z;          \
         float d2 = dx * dx;                                                                    \
-        float tt = dy * dy;                                                                    \
-        d2 = d2 + tt;                                                                          \
-        tt = dz * dz;                                                                          \
-        d2 = d2 + tt;                                                                          \
-        if (d2 < bd2) { bd2 = d2; bq = (qi_); bw = (q).w; }                                    \
+        float tq = dy * dy;                                                                    \
+        d2 = d2 + tq;                                                                          \
+        tq = dz * dz;                                                                          \
+        d2 = d2 + tq;                                                                          \
+        if (d2 < bd2) { bd2 = d2; bw = (q).w; }                                                \
     }
-                    int qi = 0;
-                    for (; qi + 4 <= len; qi += 4) {
-                        const float4 q0 = S.p[qi], q1 = S.p[qi + 1], q2 = S.p[qi + 2], q3 = S.p[qi + 3];
-                        SK_NEAREST(q0, qi) SK_NEAREST(q1, qi + 1) SK_NEAREST(q2, qi + 2) SK_NEAREST(q3, qi + 3)
-                    }
-                    for (; qi < len; qi++) {
-                        const float4 q = S.p[qi];
-                        SK_NEAREST(q, qi)
+                    for (int ch = 0; ch * SK_WCHUNK < len; ch++) {
+                        const float4 lo = S.blo[ch], hi = S.bhi[ch];
+                        float e0 = lo.x - r4[u].x, e1 = lo.y - r4[u].y, e2 = lo.z - r4[u].z;
+                        const float a0 = r4[u].x - hi.x, a1 = r4[u].y - hi.y, a2 = r4[u].z - hi.z;
+                        e0 = e0 > a0 ? e0 : a0; e1 = e1 > a1 ? e1 : a1; e2 = e2 > a2 ? e2 : a2;
+                        e0 = e0 > 0.0f ? e0 : 0.0f; e1 = e1 > 0.0f ? e1 : 0.0f; e2 = e2 > 0.0f ? e2 : 0.0f;
+                        float lb = e0 * e0;
+                        float tb = e1 * e1;
+                        lb = lb + tb;
+                        tb = e2 * e2;
+                        lb = lb + tb;
+                        if (lb >= bd2 || lb >= rp2) continue;
+                        const int q0 = ch * SK_WCHUNK;
+                        if (q0 + SK_WCHUNK <= len) {
+#pragma unroll
+                            for (int j = 0; j < SK_WCHUNK; j += 4) {  // four path vertices per step: their LDS reads are in flight together
+                                const float4 p0 = S.p[q0 + j], p1 = S.p[q0 + j + 1], p2 = S.p[q0 + j + 2], p3 = S.p[q0 + j + 3];
+                                SK_NEAREST(p0) SK_NEAREST(p1) SK_NEAREST(p2) SK_NEAREST(p3)
+                            }
+                        } else {
+                            for (int qi = q0; qi < len; qi++) {
+                                const float4 q = S.p[qi];
+                                SK_NEAREST(q)
+                            }
+                        }
                     }
 #undef SK_NEAREST
-                    (void)bq;
-                    if (bd2 < rp * rp && sqrtf(bd2) < bw) {  // path.py:35-40
+                    if (bd2 < rp2 && sqrtf(bd2) < bw) {  // path.py:35-40
                         const int h = sk_wt_find(wt_key, (unsigned)p);
                         if (h >= 0) atomicOr(&wt_mask[h], 1u << ss[u]);
                         if (cl_n < SK_CL_KEEP) cl_list[cl_n][tid] = (unsigned)p | ((unsigned)ss[u] << 28);
@@ -1127,12 +1174,15 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
         // the nearest vertex (ties: the first on the path) is the one the full scan finds.  The rows of grid cells around the
         // path are taken W at a time.  No hand-over to k_sk_claim, no launch boundary: in a batch of clouds every tree keeps
         // going at its own pace instead of waiting for the slowest one at every long path.
-        if (fits && !small && A.long_mode) {
-            const int nch = (len + SK_CHUNK - 1) / SK_CHUNK;
+        // (a path of more than a few vertices that the plain scan below could take goes this way, too, in chunks of eight: 2-3x fewer
+        // distance evaluations)
+        if (fits && len > 16 && (small || A.long_mode)) {
+            const int csz = len <= 8 * (SK_LPATH / SK_CHUNK) ? 8 : SK_CHUNK;  // vertices per chunk: at most SK_LPATH / SK_CHUNK boxes
+            const int nch = (len + csz - 1) / csz;
             if (tid < nch) {
                 float lo[3] = {__uint_as_float(0x7f800000u), __uint_as_float(0x7f800000u), __uint_as_float(0x7f800000u)};
                 float hi[3] = {__uint_as_float(0xff800000u), __uint_as_float(0xff800000u), __uint_as_float(0xff800000u)};
-                for (int qi = tid * SK_CHUNK; qi < len && qi < (tid + 1) * SK_CHUNK; qi++) {
+                for (int qi = tid * csz; qi < len && qi < (tid + 1) * csz; qi++) {
                     const float v[3] = {L.one.lpx[qi], L.one.lpy[qi], L.one.lpz[qi]};
 #pragma unroll
                     for (int a = 0; a < 3; a++) { lo[a] = v[a] < lo[a] ? v[a] : lo[a]; hi[a] = v[a] > hi[a] ? v[a] : hi[a]; }
@@ -1181,8 +1231,8 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
                         tt = e[2] * e[2];
                         lb = lb + tt;
                         if (lb >= bd2 || lb >= rp2) continue;  // nothing in this chunk can be strictly nearer / inside the radius
-                        const int q1 = (ch + 1) * SK_CHUNK < len ? (ch + 1) * SK_CHUNK : len;
-                        for (int qi = ch * SK_CHUNK; qi < q1; qi++) {  // ascending: ties keep the first path vertex
+                        const int q1 = (ch + 1) * csz < len ? (ch + 1) * csz : len;
+                        for (int qi = ch * csz; qi < q1; qi++) {  // ascending: ties keep the first path vertex
                             const float dx = r4.x - L.one.lpx[qi], dy = r4.y - L.one.lpy[qi], dz = r4.z - L.one.lpz[qi];
                             float d2 = dx * dx;
                             float t2 = dy * dy;
