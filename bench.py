@@ -9,11 +9,22 @@ A step = one pass of the hot path (CentreCloud -> blocks/voxelise -> UNet -> cla
 runs them in BATCHES of up to `--batch` clouds through one launch set (`Pipeline.process_clouds`: the batch index is
 carried through every kernel; results per cloud are bit-identical to one cloud at a time, tests/test_batch.py) and keeps
 `--streams` batches in flight (one host thread + HIP stream each), so that the single-workgroup skeleton stages of one
-batch overlap the chip-wide kernels of the other.  Exactly K clouds are processed in the timed region.
-Prints ONE JSON line (rank 0): throughput, the roofline of the dominant kernel measured live with HIP events on the
-launch stream, the aggregate gather-GEMM roofline, and -- at N = 1 -- the CPU baseline (the oracle: a port of the
-reference algorithm; the reference itself is CUDA-only) timed on this host's cores on one full cloud, whose skeleton
-is also compared with the GPU's for the same cloud (`parity_in_run`).
+batch overlap the chip-wide kernels of the other.  Every step of a pass is a DIFFERENT cloud (seeds rank * D .. rank * D
++ D - 1, D = min(K, 64): BASELINE configs[2] names seeds 0..63).
+
+Timed region: PASSES (5) passes of exactly K steps, each bracketed by barrier + synchronize on both sides; `value` is the
+MEDIAN pass (min / max / all passes are in `passes`).  Prints ONE JSON line (rank 0) with, beside the contract's fields:
+  roofline                  the kernel class with the largest summed launch duration in the timed region (HIP events on the
+                            launch stream), priced against the HBM peak
+  roofline_gather_scatter   the sparse-convolution family (gather / rule-GEMM / scatter) of the same timed region
+  single_cloud              SURVEY 8d's literal metric: median wall time of >= 5 `Pipeline.process_cloud(cloud=...)` calls
+                            with the cloud in PINNED HOST memory (the upload is inside the call), per-stage ms, and the
+                            convolution family's roofline for one cloud at a time
+  value_incl_host_upload    the same K steps with every cloud uploaded from pinned host memory inside the pass (copy stream,
+                            the next batch's upload overlaps the current batch's kernels); median of 3 passes
+  cpu_baseline              (N = 1) the oracle -- a port of the reference algorithm; the reference itself is CUDA-only --
+                            timed on this host's cores on one full cloud, whose skeleton is also compared with the GPU's
+                            for the same cloud (`parity_in_run`).
 
 Environment (all optional): ST_BENCH_ORDERED 3 (default: batches in flight take turns with voxelise .. network) / 1 (with the
 whole chip-filling phase) / 0 (free-running); ST_BENCH_MIN_UPTIME_S (30: the warm-up lasts until the process is that old);
@@ -51,7 +62,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MAX_BATCH = 64  # clouds per launch set  } measured on one MI355X (tools/sweep_batch.sh, profiles/r02_sweep_batch.txt, 384 steps, final kernels):
 STREAMS = 2     # batches in flight      } phases in turns: voxelise .. network 2 x 64 = 1.29 ms per cloud (3 x 64 the same); voxelise .. adjacency 2 x 64 = 1.32;
 FREE_STREAMS = 3  #                       } free-running: 3 x 64 = 1.25-1.27, 3 x 48 = 1.30, 2 x 64 = 1.29, 4 x 32 = 1.29, 4 x 48 = 1.32
-N_SEEDS = 4  # distinct clouds per rank, cycled
+MAX_DISTINCT = 64  # distinct clouds per rank (BASELINE configs[2]: seeds 0..63); fewer steps -> one cloud per step
+PASSES = 5         # timed passes of K steps; the median is reported
+UPLOAD_PASSES = 3
+SINGLE_CALLS = 7   # process_cloud calls of the single-cloud block
 ORDERED = int(os.environ.get("ST_BENCH_ORDERED", "3"))  # 3 (default): voxelise .. network of the batches in flight take turns; 1: voxelise .. adjacency; 0: free-running; 2: only the conv sequences
 SHORT_RUN_STEPS = 128  # below this a run is one or two rounds of batches: nothing to take turns with, the batches run free (unless ST_BENCH_ORDERED is set)
 
@@ -174,33 +188,71 @@ def parity_in_run(pipe, cloud, cpu_lc):
             "class_mismatch_fraction": cls_diff}
 
 
+def _gen_cloud(args):
+    """Pool worker: one synthetic cloud into the shared host buffer (no GPU is touched in the children)."""
+    n_points, seed, j = args
+    from smart_tree_amd.synthetic import sample_tree_cloud
+
+    _SHARED[j].numpy()[:] = sample_tree_cloud(n_points, seed=seed)["xyz"]
+    return j
+
+
+_SHARED = None
+
+
+def generate_clouds(n_points: int, seeds, procs: int):
+    """The synthetic clouds of this rank: [D, n, 3] float32 host tensor, generated by `procs` forked processes BEFORE the
+    process has a GPU context (1.4 s of numpy per 1M-point cloud on one core; rgb is all zeros in the generator)."""
+    global _SHARED
+    import multiprocessing as mp
+
+    _SHARED = torch.empty((len(seeds), n_points, 3), dtype=torch.float32).share_memory_()
+    jobs = [(n_points, int(s), j) for j, s in enumerate(seeds)]
+    if procs <= 1 or len(jobs) == 1:
+        for job in jobs:
+            _gen_cloud(job)
+    else:
+        with mp.get_context("fork").Pool(min(procs, len(jobs))) as pool:
+            list(pool.imap_unordered(_gen_cloud, jobs))
+    out, _SHARED = _SHARED, None
+    return out
+
+
 class CloudWorker:
     """S pipelines on S HIP streams of one process; resident 1M-point clouds; batches dealt from a shared list."""
 
-    def __init__(self, device, n_streams, n_points, rank):
+    def __init__(self, device, n_streams, host_xyz, rank):
         from smart_tree_amd.data_types.cloud import Cloud
-        from smart_tree_amd.synthetic import sample_tree_cloud
 
         self.device, self.S, self.rank = device, n_streams, rank
         self.pipes = [build_pipeline(device) for _ in range(n_streams)]
         self.streams = [torch.cuda.Stream(device=device) for _ in range(n_streams)]
+        self.copy_streams = [torch.cuda.Stream(device=device) for _ in range(n_streams)]
+        n_points = host_xyz.shape[1]
+        zeros = torch.zeros((n_points, 3), dtype=torch.float32).pin_memory()  # the generator's rgb: one host buffer serves every cloud
         self.host, self.clouds = [], []
-        for j in range(N_SEEDS):  # different seeds on every rank (independent trees); rank 0's first cloud is seed 0
-            c = sample_tree_cloud(n_points, seed=rank * N_SEEDS + j)
-            xyz, rgb = torch.from_numpy(c["xyz"]).pin_memory(), torch.from_numpy(c["rgb"]).pin_memory()
-            self.host.append((xyz, rgb))
-            self.clouds.append(Cloud(xyz=xyz.to(device), rgb=rgb.to(device)))
+        for j in range(host_xyz.shape[0]):
+            xyz = host_xyz[j].pin_memory()
+            self.host.append((xyz, zeros))
+            self.clouds.append(Cloud(xyz=xyz.to(device), rgb=zeros.to(device)))
         self.last = None
 
-    def batch_clouds(self, first, size, upload):
+    def batch_clouds(self, first, size):
+        return [self.clouds[(first + k) % len(self.clouds)] for k in range(size)]
+
+    def upload_batch(self, w, first, size):
+        """Host -> device copies of one batch on worker w's COPY stream (pinned buffers); returns (clouds, event)."""
         from smart_tree_amd.data_types.cloud import Cloud
 
-        ids = [(first + k) % len(self.clouds) for k in range(size)]
-        if not upload:
-            return [self.clouds[i] for i in ids]
-        # host -> device inside the step (pinned buffers, the worker's own stream): the PCIe-inclusive rate
-        return [Cloud(xyz=self.host[i][0].to(self.device, non_blocking=True), rgb=self.host[i][1].to(self.device, non_blocking=True))
-                for i in ids]
+        cs = self.copy_streams[w]
+        with torch.cuda.stream(cs):
+            out = []
+            for k in range(size):
+                xyz, rgb = self.host[(first + k) % len(self.host)]
+                out.append(Cloud(xyz=xyz.to(self.device, non_blocking=True), rgb=rgb.to(self.device, non_blocking=True)))
+            ev = torch.cuda.Event()
+            ev.record(cs)
+        return out, ev
 
     def run(self, batches, collect, upload=False, streams=None, mode=None):
         """`batches`: list of batch sizes, dealt to the worker threads from a shared counter.  streams: worker threads / HIP
@@ -245,13 +297,31 @@ class CloudWorker:
             try:
                 torch.cuda.set_device(self.device)  # the current device is thread-local: a new thread starts on device 0
                 with torch.cuda.stream(self.streams[w]):
+                    # upload mode: worker w owns batches w, w + S, ..: the NEXT one's host -> device copies are enqueued on the
+                    # copy stream before this one's kernels, so they overlap (the first upload of a worker overlaps the other
+                    # workers' kernels only)
+                    mine = list(range(w, len(batches), S)) if upload else None
+                    pending = self.upload_batch(w, starts[mine[0]], batches[mine[0]]) if upload and mine else None
+                    turn = 0
                     while True:
-                        with lock:
-                            i = state["next"]
-                            state["next"] += 1
-                        if i >= len(batches):
-                            break
-                        clouds = self.batch_clouds(starts[i], batches[i], upload)
+                        if upload:
+                            if turn >= len(mine):
+                                break
+                            i = mine[turn]
+                            turn += 1
+                            clouds, ev = pending
+                            pending = self.upload_batch(w, starts[mine[turn]], batches[mine[turn]]) if turn < len(mine) else None
+                            self.streams[w].wait_event(ev)
+                            for cl in clouds:  # allocated on the copy stream, used on this one
+                                cl.xyz.record_stream(self.streams[w])
+                                cl.rgb.record_stream(self.streams[w])
+                        else:
+                            with lock:
+                                i = state["next"]
+                                state["next"] += 1
+                            if i >= len(batches):
+                                break
+                            clouds = self.batch_clouds(starts[i], batches[i])
                         if ordered:
                             wide.acquire()
                             held = [True]
@@ -297,14 +367,51 @@ class CloudWorker:
             raise state["error"]
         return finished
 
-    def serial_ms(self):
-        """Untimed, for the record: one cloud at a time on one stream = the latency of a single process_cloud call."""
-        with torch.cuda.stream(self.streams[0]):
-            t1 = time.perf_counter()
-            for cloud in self.clouds[:2]:
-                self.pipes[0].process_cloud(cloud=cloud)
-            self.streams[0].synchronize()
-            return 1e3 * (time.perf_counter() - t1) / 2
+    def single_cloud(self, calls=SINGLE_CALLS):
+        """SURVEY 8d's literal metric: `Pipeline.process_cloud(cloud=...)` on ONE cloud that sits in pinned host memory (the
+        upload is part of the call, the skeleton is back on the host when it returns), one call at a time on one stream.
+        Median wall time of `calls` calls on different clouds; then, with the kernel timers on, per-stage ms and the
+        convolution family's roofline for a cloud alone on the GPU."""
+        from smart_tree_amd import profiling
+        from smart_tree_amd.data_types.cloud import Cloud
+
+        pipe, st = self.pipes[0], self.streams[0]
+        ids = [k % len(self.host) for k in range(calls)]
+
+        def one(k):
+            xyz, rgb = self.host[k]
+            sk = pipe.process_cloud(cloud=Cloud(xyz=xyz.to(self.device, non_blocking=True), rgb=rgb.to(self.device, non_blocking=True)))
+            st.synchronize()
+            return sk
+
+        with torch.cuda.stream(st):
+            for k in ids[:2]:
+                one(k)
+            ms = []
+            for k in ids:
+                t0 = time.perf_counter()
+                sk = one(k)
+                ms.append(1e3 * (time.perf_counter() - t0))
+            profiling.family_mode(False)
+            profiling.enable(True)
+            reps = min(3, len(ids))
+            for k in ids[:reps]:
+                one(k)
+            torch.cuda.synchronize()
+            profiling.enable(False)
+            stage = profiling.stage_ms(reps)
+            roof = profiling.roofline(HBM_PEAK_GBS, clouds_per_launch=1) or {}
+        ms_sorted = sorted(ms)
+        med = ms_sorted[len(ms_sorted) // 2]
+        n_points = int(self.host[0][0].shape[0])
+        gg = roof.get("gather_gemm") or {}
+        return {"what": "Pipeline.process_cloud(cloud=...) with the cloud in pinned host memory: upload + full path + skeleton back on the "
+                        "host, one call at a time (reference call shape: smart_tree/pipeline.py:55-93); median of the calls",
+                "calls": len(ms), "ms": round(med, 3), "ms_min": round(ms_sorted[0], 3), "ms_max": round(ms_sorted[-1], 3),
+                "points_per_s": n_points / (med * 1e-3), "stage_ms": stage,
+                "roofline_gather_scatter": {k: gg.get(k) for k in ("hbm_frac", "achieved_GBps", "peak", "total_ms", "launches", "useful_TFLOPs")},
+                "largest_kernel": {k: roof.get(k) for k in ("kernel", "frac", "avg_us", "launches", "total_ms")},
+                "branches_last_call": int(sum(len(t.branches) for t in sk.skeletons))}
 
 
 def extra_configs(device):
@@ -373,6 +480,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    # the synthetic clouds of this rank, generated by forked processes BEFORE this process has a GPU context: every step of a
+    # pass is a different cloud (BASELINE configs[2]: seeds 0..63; rank r draws r * D .. r * D + D - 1, rank 0's first is seed 0)
+    n_distinct = max(1, min(MAX_DISTINCT, args.steps))
+    t_gen = time.perf_counter()
+    host_xyz = generate_clouds(args.points, [rank * n_distinct + j for j in range(n_distinct)], max(1, usable_cores() // max(world, 1)))
+    t_gen = time.perf_counter() - t_gen
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     # ST_BENCH_DRYRUN=1 (developer aid): exercise the multi-rank control flow on a box with ONE GPU -- every rank uses
     # cuda:0 and the result gather runs over gloo with host tensors.  Never set by the driver.
@@ -421,7 +534,7 @@ def main():
     # for the record (one GPU only): the same K steps free-running -- the chip-filling phases of the batches in flight overlap,
     # which fills the bubbles at their host round trips (a few % more throughput) and stretches every kernel's launch bracket
     S_free = max(1, min(FREE_STREAMS, usable_cores(), max(1, args.steps // 16))) if world == 1 and ORDERED in (1, 3) and args.free_running else 0
-    worker = CloudWorker(device, max(S, S_free), args.points, rank)
+    worker = CloudWorker(device, max(S, S_free), host_xyz, rank)
 
     def run_steps(total, upload=False):
         finished.extend(worker.run(plan_batches(total, S, B), collect=world > 1, upload=upload, streams=S))
@@ -473,39 +586,47 @@ def main():
         warm_last_ms = None
     gather()
     fence()
-    serial_ms = worker.serial_ms() if warm > 0 else None
+    single = worker.single_cloud() if warm > 0 and world == 1 else None
     fence()
     # kernel timers of the timed region: the convolutions of a forward pass are bracketed ONCE as a family (a pair of events
     # around each of the 26 launches cost ~10 us apiece between kernels that otherwise run back to back); the per-class table
-    # comes from the solo pass below
+    # comes from the solo pass below.  The timers stay on over all passes: launch durations are averages over them.
     profiling.family_mode(True)
     profiling.enable(True)
     import gc
     gc.collect()
-    gc.disable()  # a short run is ONE pass of ~33 ms: a collection of the launch threads' garbage inside it is a millisecond
+    gc.disable()  # a short run is a pass of ~30 ms: a collection of the launch threads' garbage inside it is a millisecond
+    pass_s, host_cores = [], []
     try:
-        cpu0 = os.times()
-        t0 = time.perf_counter()
-        run_steps(args.steps)  # returns when every worker has synchronised its streams
-        gather()  # inside the timed region: the skeletons of all ranks end up on rank 0
-        fence()
-        dt = time.perf_counter() - t0
+        for _ in range(PASSES):
+            fence()
+            cpu0 = os.times()
+            t0 = time.perf_counter()
+            run_steps(args.steps)  # returns when every worker has synchronised its streams
+            gather()  # inside the timed region: the skeletons of all ranks end up on rank 0
+            fence()
+            dt_pass = time.perf_counter() - t0
+            cpu1 = os.times()
+            pass_s.append(dt_pass)
+            host_cores.append(((cpu1.user - cpu0.user) + (cpu1.system - cpu0.system)) / max(dt_pass, 1e-9))  # this rank's process
     finally:
         gc.enable()
-    cpu1 = os.times()
-    host_cores_used = ((cpu1.user - cpu0.user) + (cpu1.system - cpu0.system)) / max(dt, 1e-9)  # this rank's process
     profiling.enable(False)
     roof = profiling.roofline(HBM_PEAK_GBS, clouds_per_launch=max(plan_batches(args.steps, S, B)))
-    stage_ms = profiling.stage_ms(args.steps)
+    stage_ms = profiling.stage_ms(args.steps * PASSES)
     sk = worker.last
     last = {"trees": len(sk.skeletons), "branches": int(sum(len(t.branches) for t in sk.skeletons))}
-    # for the record: the same K clouds with the host -> device upload of every cloud inside the step (pinned host buffers)
-    fence()
-    t1 = time.perf_counter()
-    run_steps(args.steps, upload=True)
+    # the same K clouds with the host -> device upload of every cloud inside the pass (pinned host buffers, copy streams)
+    up_s = []
+    run_steps(args.steps, upload=True)  # (untimed: the copy streams' allocator pools)
     gather()
-    fence()
-    dt_up = time.perf_counter() - t1
+    for _ in range(UPLOAD_PASSES):
+        fence()
+        t1 = time.perf_counter()
+        run_steps(args.steps, upload=True)
+        gather()
+        fence()
+        up_s.append(time.perf_counter() - t1)
     free = None
     if S_free > 1:
         plan_free = plan_batches(args.steps, S_free, B)
@@ -536,41 +657,53 @@ def main():
         roof_solo = {"note": "one batch of %d clouds alone on the GPU (untimed extra pass): solo launch durations" % min(B, max(args.steps, 1))}
         roof_solo.update({k: full.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "launches", "avg_us",
                                                   "algorithmic_bytes_per_launch", "branch_selection", "gather_gemm", "all_kernels")})
-    if world > 1:
-        t = torch.tensor([dt, dt_up], dtype=torch.float64, device=coll_device)
+    if world > 1:  # every pass: the slowest rank
+        t = torch.tensor(pass_s + up_s, dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt, dt_up = float(t[0].item()), float(t[1].item())
+        pass_s, up_s = t[:PASSES].tolist(), t[PASSES:].tolist()
+    med = lambda v: sorted(v)[len(v) // 2]
+    dt, dt_up = med(pass_s), med(up_s)
 
     if rank == 0:
         value = world * args.steps * args.points / dt
         batches = plan_batches(args.steps, S, B)
+        gg = (roof or {}).pop("gather_gemm", None)
         out = {
             "metric": "points/sec end-to-end (voxelize->sparse-UNet->skeleton), 1M-pt tree",
-            "value": value, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": warm,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "passes": {"n": PASSES, "statistic": "median", "ms_per_step": [round(1e3 * v / args.steps, 4) for v in pass_s],
+                       "value_min": world * args.steps * args.points / max(pass_s), "value_max": world * args.steps * args.points / min(pass_s)},
+            "value_incl_host_upload": world * args.steps * args.points / dt_up,
+            "incl_host_upload": {"passes": UPLOAD_PASSES, "statistic": "median", "ms_per_step": [round(1e3 * v / args.steps, 4) for v in up_s],
+                                 "note": "every cloud of the pass is copied from pinned host memory inside the pass (24 bytes per point: xyz + rgb); "
+                                         "a worker enqueues its NEXT batch's copies on a copy stream before the current batch's kernels"},
             "config": {"workload": f"configs[1]: one {args.points}-point synthetic tree per rank per step, 2 cm voxels, "
                                    "noble-elevator-58 weights, full Pipeline path with prune/repair/smooth; steps run in "
                                    "batches of clouds through ONE launch set (Pipeline.process_clouds)",
-                       "distinct_clouds_per_rank": N_SEEDS, "parallelism": f"cloud-sharded x{world}",
+                       "distinct_clouds_per_rank": n_distinct, "seeds": f"{rank * n_distinct}..{rank * n_distinct + n_distinct - 1} (rank r: r * {n_distinct} + j)",
+                       "parallelism": f"cloud-sharded x{world}",
                        "clouds_per_launch_set": max(batches), "batches_in_timed_region": len(batches),
-                       "batches_in_flight_per_gpu": S, "host_threads_per_gpu": S, "warmup_steps_run": warm,
+                       "batches_in_flight_per_gpu": S, "host_threads_per_gpu": S,
+                       "warmup_requested": args.warmup, "warmup_steps_run": warm,
                        "schedule": {1: "the chip-filling phases (voxelise .. adjacency) of the batches in flight take turns; a batch's "
                                        "skeleton stage (one compute unit per tree) overlaps with the other batch's chip-filling phase",
                                     3: "the batches in flight take turns with voxelise .. network (half a phase apart): a batch's searches / "
                                        "components / adjacency and its skeleton stage (one compute unit per tree) overlap with the other "
                                        "batch's voxelisation and network, two networks never share the chip",
                                     0: "free-running", 2: "conv sequences take turns"}.get(ORDERED if S > 1 else 0),
-                       "single_cloud_latency_ms": None if serial_ms is None else round(serial_ms, 3),
                        "warmup_until_process_age_s": MIN_UPTIME,
-                       "host_cpu_cores_busy_in_timed_region": round(host_cores_used, 2),
+                       "cloud_generation_s": round(t_gen, 1),
+                       "host_cpu_cores_busy_in_timed_region": round(med(host_cores), 2),
                        "host_waits": "blocking (hipDeviceScheduleBlockingSync)" if blocking else "spinning (HIP default)",
                        "last_warmup_pass_ms_per_step": None if warm_last_ms is None else round(warm_last_ms, 3)},
-            "value_incl_host_upload": world * args.steps * args.points / dt_up,
             "parity_note": "results are checked against oracle/ (a CPU restatement pinned by goldens that the reference's own "
                            "glue code produced); the semantics of the reference's un-vendored third-party packages (spconv "
                            "voxel drop rule / hash order, FRNN tie order, cugraph tie-breaks) are restated, not pinned",
             "roofline": roof,
+            "roofline_gather_scatter": gg,
+            "single_cloud": single,
             "roofline_solo": roof_solo,
             "free_running": free,
             "stage_ms": stage_ms,

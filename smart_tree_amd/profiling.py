@@ -104,6 +104,21 @@ def kernel_family(name: str):
         _families[name].append((a, b, items))
 
 
+_cus = {}
+
+
+def compute_units(dev) -> int:
+    """Compute units of the device (for the chip share of a launch that cannot fill it)."""
+    key = str(dev)
+    if key not in _cus:
+        try:
+            idx = dev.index if getattr(dev, "index", None) is not None else torch.cuda.current_device()
+            _cus[key] = int(torch.cuda.get_device_properties(idx).multi_processor_count)
+        except Exception:  # noqa: BLE001 -- a diagnostic must not take the run down
+            _cus[key] = 256  # MI355X
+    return _cus[key]
+
+
 def add_kernel_time(name: str, total_ms: float, launches: int, total_bytes, chip_share: float = 1.0) -> None:
     """Kernel time the C library measured with its own HIP events (launch loops that live in C).  chip_share: the fraction of
     the 256 compute units the launch's grid can occupy (a one-workgroup-per-tree kernel on a batch of 20 trees: 20 / 256)."""

@@ -90,7 +90,7 @@ def run_components(comps: ComponentSet, medial_pts: torch.Tensor, radius: torch.
         # (24 B: id + xyz lookups), each claimed point raced and stamped once (16 B), plus the sorted-order cursor (8 B/vertex)
         res_ref = res
         profiling.add_kernel_time("k_sk_select", stats[4] * 1e-6, stats[5],
-                                  lambda: _select_bytes(res_ref, comps, m), chip_share=comps.n_components / float(torch.cuda.get_device_properties(dev).multi_processor_count))
+                                  lambda: _select_bytes(res_ref, comps, m), chip_share=comps.n_components / float(profiling.compute_units(dev)))
     return res
 
 
