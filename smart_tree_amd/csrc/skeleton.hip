@@ -166,6 +166,14 @@ __device__ __forceinline__ unsigned sk_q_reserve(unsigned* q, unsigned* fc, unsi
     return SK_FS * seg + atomicAdd(&fc[SK_FS], n);
 }
 
+// the same for the persistent form: the holes are written where another workgroup's agent-scope read finds them
+__device__ __forceinline__ unsigned sk_q_reserve_coop(unsigned* q, unsigned* fc, unsigned seg, unsigned shard, unsigned n) {
+    const unsigned at = atomicAdd(&fc[shard], n);
+    if (at + n <= seg) return shard * seg + at;
+    for (unsigned i = at; i < seg; i++) __hip_atomic_store(&q[shard * seg + i], SK_Q_HOLE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return SK_FS * seg + atomicAdd(&fc[SK_FS], n);
+}
+
 __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_init(SkArgs A) {
     const unsigned inf = st_f2ord(__uint_as_float(0x7f800000u));
     SK_VERTEX_LOOP(v) { A.dist_ord[v] = inf; A.stamp[v] = 0u; }
@@ -306,6 +314,149 @@ __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_sssp_round(SkArgs A, int r
     for (unsigned i = threadIdx.x; i < nloc; i += blockDim.x) qn[lq_base + i] = keep[i];
 }
 
+
+// ---- the same rounds in ONE launch: a persistent grid with a barrier between the rounds -----------------------------------
+// A launch per round costs its launch latency ~100 times over (a 1M-point tree: 96 rounds of 22-39 us, most of it the
+// launch) and a host read-back per batch of rounds.  Here the workgroups stay: round r ends at a grid barrier (one arrival
+// per workgroup on its group's counter, the last of a group on the top counter, everybody polls the top counter), the
+// frontier counters tell every workgroup whether another round is due.  Everything that crosses workgroups inside the
+// launch -- distances, queue entries, counters -- is read and written at agent scope (the L2s of the eight XCDs are not
+// coherent with each other for plain accesses); the adjacency is read-only.  The grid must be resident as a whole: the host
+// launches at most SK_COOP_BLOCKS workgroups of 256 lanes (four per compute unit) and a workgroup that waits longer than
+// ~2 s at a barrier gives up and flags the launch (the host then falls back to a launch per round).
+#define SK_COOP_BLOCKS 1024
+#define SK_COOP_GROUP 32
+#define SK_COOP_STRIDE 16  // words between the barrier counters (one 64-byte line each)
+__device__ __forceinline__ unsigned ld_u(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_u(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// bar[0] top counter, bar[SK_COOP_STRIDE * (1 + g)] counter of group g, bar[1] "gave up" flag.  Returns false on a time-out.
+__device__ __forceinline__ bool sk_grid_barrier(unsigned* bar, unsigned round) {
+    __shared__ int ok_;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // No __threadfence() on either side (it writes back / invalidates the L2: measured 35 us per barrier at 1024 workgroups
+        // against 4.3 without, tools/microbench/grid_barrier.hip): everything that crosses workgroups is an agent-scope atomic
+        // access, coherent by itself; the __syncthreads() above has waited for this workgroup's accesses to complete.
+        const unsigned G = gridDim.x, ngroups = (G + SK_COOP_GROUP - 1) / SK_COOP_GROUP, gidx = blockIdx.x / SK_COOP_GROUP;
+        const unsigned gsize = gidx + 1 == ngroups ? G - gidx * SK_COOP_GROUP : SK_COOP_GROUP;
+        const unsigned old = atomicAdd(&bar[SK_COOP_STRIDE * (1 + gidx)], 1u);
+        if (old % gsize == gsize - 1) atomicAdd(&bar[0], 1u);  // the last of its group in this round
+        const unsigned want = ngroups * (round + 1u);
+        int ok = 1;
+        const long long t0 = wall_clock64();
+        while (ld_u(&bar[0]) < want) {
+            __builtin_amdgcn_s_sleep(2);
+            if (ld_u(&bar[1]) != 0u || wall_clock64() - t0 > 200000000ll) { st_u(&bar[1], 1u); ok = 0; break; }  // (100 MHz clock)
+        }
+        ok_ = ok;
+    }
+    __syncthreads();
+    return ok_ != 0;
+}
+
+__global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_sssp_coop(SkArgs A, int hops, int glanes, int lcap, unsigned* bar, int max_rounds) {
+    __shared__ unsigned lq[2][SK_LQ];
+    __shared__ unsigned ln[3], lq_base;
+    __shared__ unsigned fpre[SK_FS + 2];
+    const unsigned seg = A.fseg, shard = blockIdx.x % SK_FS;
+    const bool lookfirst = lcap >= 0;
+    if (lcap < 0) lcap = -lcap;
+    const int lane = threadIdx.x & (glanes - 1);
+    const unsigned wave = threadIdx.x / glanes, nwv = blockDim.x / glanes;
+    const unsigned gw = blockIdx.x * nwv + wave, tw = gridDim.x * nwv;
+    for (int r = 0; r < max_rounds; r++) {
+        const unsigned* fc_in = A.fcnt + (r % 3) * (SK_FS + 1);
+        unsigned* fc_out = A.fcnt + ((r + 1) % 3) * (SK_FS + 1);
+        if (blockIdx.x == 0 && threadIdx.x <= SK_FS) st_u(&A.fcnt[((r + 2) % 3) * (SK_FS + 1) + threadIdx.x], 0u);
+        if (threadIdx.x == 0) {
+            unsigned run = 0;
+            for (int s_ = 0; s_ <= SK_FS; s_++) {
+                fpre[s_] = run;
+                const unsigned c_ = ld_u(&fc_in[s_]);
+                run += s_ < SK_FS && c_ > seg ? seg : c_;
+            }
+            fpre[SK_FS + 1] = run;
+        }
+        if (threadIdx.x < 3) ln[threadIdx.x] = 0;
+        __syncthreads();
+        const unsigned count = fpre[SK_FS + 1];
+        if (count == 0) {  // (the same for every workgroup: the counters were final at the barrier)
+            if (blockIdx.x == 0 && threadIdx.x == 0) st_u(&bar[2], (unsigned)r);  // rounds used (statistics)
+            return;
+        }
+        const unsigned* q = (r & 1) ? A.q1 : A.q0;
+        unsigned* qn = (r & 1) ? A.q0 : A.q1;
+        const unsigned round = (unsigned)r + 1u;
+#define SK_QPUSH(v_) st_u(&qn[sk_q_reserve_coop(qn, fc_out, seg, shard, 1u)], (v_))
+#define SK_RELAX_C(u, du, out, out_n)                                                                      \
+    {                                                                                                      \
+        const uint32_t s_ = A.row_off[u], e_ = A.row_off[(u) + 1];                                         \
+        for (uint32_t t = s_ + lane; t < e_; t += glanes) {                                                \
+            const unsigned v = A.col[t];                                                                   \
+            const unsigned o = st_f2ord((du) + A.wgt[t]);                                                  \
+            if (lookfirst && o >= ld_u(&A.dist_ord[v])) continue;                                          \
+            const unsigned old = atomicMin(&A.dist_ord[v], o);                                             \
+            if (o < old) {                                                                                 \
+                const unsigned slot = atomicAdd(out_n, 1u);                                                \
+                if (slot < SK_LQ) (out)[slot] = v;                                                         \
+                else if (atomicExch(&A.stamp[v], round) != round) SK_QPUSH(v);                             \
+            }                                                                                              \
+        }                                                                                                  \
+    }
+        for (unsigned f = gw; f < count; f += tw) {
+            int sh = 0;
+#pragma unroll
+            for (int s_ = 1; s_ <= SK_FS; s_++) sh = f >= fpre[s_] ? s_ : sh;
+            const unsigned u = ld_u(&q[(int64_t)sh * seg + (f - fpre[sh])]);
+            if (u == SK_Q_HOLE) continue;
+            const float du = st_ord2f(ld_u(&A.dist_ord[u]));
+            SK_RELAX_C(u, du, lq[0], &ln[0]);
+        }
+        int h = 1;
+        for (; h < hops; h++) {
+            __syncthreads();
+            const unsigned have = ln[(h - 1) % 3];
+            unsigned ncur = have < SK_LQ ? have : SK_LQ;
+            if (ncur == 0) break;
+            if (threadIdx.x == 0) ln[(h + 1) % 3] = 0;
+            const unsigned* in = lq[(h - 1) & 1];
+            unsigned* out = lq[h & 1];
+            if (ncur > (unsigned)lcap) {
+                for (unsigned i = lcap + threadIdx.x; i < ncur; i += blockDim.x) {
+                    const unsigned v = in[i];
+                    if (atomicExch(&A.stamp[v], round) != round) SK_QPUSH(v);
+                }
+                ncur = (unsigned)lcap;
+            }
+            for (unsigned i = wave; i < ncur; i += nwv) {
+                const unsigned u = in[i];
+                const float du = st_ord2f(ld_u(&A.dist_ord[u]));
+                SK_RELAX_C(u, du, out, &ln[h % 3]);
+            }
+        }
+#undef SK_RELAX_C
+        __syncthreads();
+        const unsigned have = ln[(h - 1) % 3];
+        const unsigned nrem = have < SK_LQ ? have : SK_LQ;
+        const unsigned* rem = lq[(h - 1) & 1];
+        unsigned* keep = lq[h & 1];
+        unsigned* keep_n = &ln[h % 3];
+        if (threadIdx.x == 0) *keep_n = 0;
+        __syncthreads();
+        for (unsigned i = threadIdx.x; i < nrem; i += blockDim.x) {
+            const unsigned v = rem[i];
+            if (atomicExch(&A.stamp[v], round) != round) keep[atomicAdd(keep_n, 1u)] = v;
+        }
+        __syncthreads();
+        const unsigned nloc = *keep_n;
+        if (threadIdx.x == 0 && nloc) lq_base = sk_q_reserve_coop(qn, fc_out, seg, shard, nloc);
+        __syncthreads();
+        for (unsigned i = threadIdx.x; i < nloc; i += blockDim.x) st_u(&qn[lq_base + i], keep[i]);
+#undef SK_QPUSH
+        if (!sk_grid_barrier(bar, (unsigned)r)) return;
+    }
+}
 
 __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_dist_out(SkArgs A) {
     SK_VERTEX_LOOP(v) A.dist[v] = st_ord2f(A.dist_ord[v]);
@@ -1363,7 +1514,7 @@ __global__ void __launch_bounds__(1024) k_sk_blk_tables(SkArgs A, int* blk_comp,
 #define SK_GRID_CELLS (1ll << 24)
 
 struct SkLayout {
-    unsigned *dist_ord, *stamp, *q0, *q1, *touched, *cnt, *s_ntouched, *sort_keys, *order;
+    unsigned *dist_ord, *stamp, *q0, *q1, *touched, *cnt, *s_ntouched, *sort_keys, *order, *coop_bar;
     float *s_rp, *order_init;
     unsigned* term_bits;
     float4* pr;
@@ -1401,6 +1552,7 @@ static void sk_layout(StArena& a, int64_t m, int64_t C, SkLayout* s, int nseg = 
     s->anc = a.take<int>((int64_t)SK_ANC * m);
     s->comp_of = a.take<int>(m);
     s->cnt = a.take<unsigned>(8 + 3 * (SK_FS + 1));  // [8] counters, then the frontier counters of three generations
+    s->coop_bar = a.take<unsigned>(SK_COOP_STRIDE * (2 + SK_COOP_BLOCKS / SK_COOP_GROUP));  // grid barrier of the persistent SSSP
     s->s_done = a.take<int>(C);
     s->s_len = a.take<int>(C);
     s->s_cur_id = a.take<int>(C);
@@ -1432,7 +1584,8 @@ static void sk_layout(StArena& a, int64_t m, int64_t C, SkLayout* s, int nseg = 
 //   0 prune factor (x1000)   1 small_work   2 rounds per select launch   3 select launches per host read-back
 //   4 local_items   5 wave_work   6 SSSP levels per frontier launch   7 frontier launches per read-back   8 lanes per vertex
 //   9 length of the first frontier batch (in batches)   10 frontier workgroups   11 claim-grid cell cap (hundredths of the
-//   mean radius)
+//   mean radius)   12 SSSP rounds in one persistent launch with grid barriers (1) or one launch per round (0, default: measured equal for
+//   one cloud, 5 % slower per step with two batches in flight -- the rounds are bound by their ~6 us per level, not by the launches)
 //   13 frontier: 0 = no look before the atomic, else vertices a workgroup relaxes per local level
 //   14 long-path claim inside the workgroup (1, default) or by the local / chip-wide path-centric claims (0)
 //   15 device pointer of 32 int64 phase timers / counters of k_sk_select
@@ -1442,6 +1595,7 @@ struct SkTuning {
     float prune_factor = 1.0f, grid_mean_mult = 1.0f;
     int small_work = SK_SMALL_WORK, iters_per_launch = SK_ITERS_PER_LAUNCH, launch_batch = 24, local_items = 0, wave_work = SK_WAVE_WORK, long_mode = 1;
     int sssp_hops = 4, sssp_batch = 32, sssp_lanes = 64, sssp_first = 2, sssp_blocks = SK_SSSP_BLOCKS, sssp_lcap = SK_LQ;
+    int sssp_coop = 0;
     bool small_work_set = false, iters_set = false, long_set = false, launch_set = false;
     long long* ticks = nullptr;
     explicit SkTuning(const int64_t* t) {
@@ -1459,6 +1613,7 @@ struct SkTuning {
         if (has(9)) sssp_first = t[9] < 1 ? 1 : (t[9] > 8 ? 8 : (int)t[9]);
         if (has(10)) sssp_blocks = t[10] < 1 ? 1 : (t[10] > 8192 ? 8192 : (int)t[10]);
         if (has(11)) grid_mean_mult = (float)t[11] / 100.0f;
+        if (has(12)) sssp_coop = t[12] != 0;
         if (has(13)) sssp_lcap = t[13] == 0 ? -SK_LQ : (t[13] > SK_LQ ? SK_LQ : (int)t[13]);
         if (has(14)) { long_mode = t[14] != 0; long_set = true; }
         if (has(15)) ticks = (long long*)(intptr_t)t[15];
@@ -1584,7 +1739,25 @@ extern "C" int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, c
     if (stages & 1) {
         hipLaunchKernelGGL(k_sk_init, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A);
         hipLaunchKernelGGL(k_sk_roots, dim3((unsigned)n_comp), dim3((unsigned)block_threads), 0, stream, A);
-        for (int r = 0;;) {  // frontier rounds in batches, one counter read-back per batch.  The first batch is twice as long:
+        bool coop_done = false;
+        if (T.sssp_coop) {
+            // every round in ONE launch (k_sk_sssp_coop); one read-back tells whether a workgroup gave up at a barrier
+#ifdef ST_HIPEMU
+            const unsigned cg = 1u;  // (the CPU emulator runs the workgroups of a launch one after the other)
+#else
+            const unsigned cg = fg < SK_COOP_BLOCKS ? fg : SK_COOP_BLOCKS;
+#endif
+            (void)hipMemsetAsync(s.coop_bar, 0, SK_COOP_STRIDE * (2 + SK_COOP_BLOCKS / SK_COOP_GROUP) * sizeof(unsigned), stream);
+            hipLaunchKernelGGL(k_sk_sssp_coop, dim3(cg), dim3(SK_WIDE_BLOCK), 0, stream, A, T.sssp_hops, T.sssp_lanes, T.sssp_lcap, s.coop_bar, 1 << 24);
+            unsigned hb[4];
+            ST_TRY(sk_read(hb, s.coop_bar, sizeof(hb), stream));
+            if (hb[1] == 0u) { coop_done = true; sssp_rounds = hb[2]; }
+            else {  // start over, one launch per round
+                hipLaunchKernelGGL(k_sk_init, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A);
+                hipLaunchKernelGGL(k_sk_roots, dim3((unsigned)n_comp), dim3((unsigned)block_threads), 0, stream, A);
+            }
+        }
+        for (int r = 0; !coop_done;) {  // frontier rounds in batches, one counter read-back per batch.  The first batch is twice as long:
             // a tree of a million points needs 65-96 launches, an empty round costs ~4 us, a read-back beside other clouds ~1 ms
             const int batch = r == 0 ? T.sssp_first * T.sssp_batch : T.sssp_batch;
             for (int b = 0; b < batch; b++, r++)

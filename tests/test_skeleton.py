@@ -162,7 +162,10 @@ def test_components_match_oracle(backend):
     {6: 1, 8: 16},               # SSSP: one level per launch, 16 lanes per vertex
     {6: 7, 7: 2},                # SSSP: seven levels per launch, read-back every second launch
     {6: 6, 13: 2, 10: 3},        # SSSP: three workgroups, at most two vertices per workgroup and local level (the rest goes back)
-], ids=["noprune", "prune4", "relaunch", "one", "long", "local", "wide", "mixed", "mixed-wide", "sssp-rows", "sssp-hops", "sssp-cap"])
+    {12: 1},                     # SSSP: every round in ONE persistent launch with grid barriers (the default is a launch per round)
+    {12: 1, 6: 7, 10: 3},        # ... seven levels per round, three workgroups
+], ids=["noprune", "prune4", "relaunch", "one", "long", "local", "wide", "mixed", "mixed-wide", "sssp-rows", "sssp-hops", "sssp-cap", "sssp-coop",
+        "sssp-coop-hops"])
 def test_sample_tree_strategies_agree(backend, params):
     """Branch selection has four claim strategies picked by size; each one alone must reproduce the oracle."""
     from smart_tree_amd.skeleton import tuning
