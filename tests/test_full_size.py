@@ -325,6 +325,77 @@ def test_config1_unet_every_layer_live_weights_full_size(million_point_voxels):
     np.testing.assert_allclose(net.trace["tail0"].cpu().numpy(), r, rtol=1e-3, atol=1e-3 * _rms(r))
 
 
+def test_config1_shipped_checkpoint_error_trace(million_point_voxels):
+    """Where does the float32 distance of the SHIPPED checkpoint (noble-elevator-58) enter?  Walks every block output of the
+    HIP network and of the float32 oracle network against the float64 oracle network and records, per layer,
+    max|x - fp64| / rms(fp64) for both (gpurun_out/shipped_checkpoint_trace.txt -> profiles/).  The HIP network must never be
+    further from float64 than 4x the float32 oracle (another float32 evaluation order of the same graph), layer by layer, and
+    the first layer whose float32-order noise exceeds 1e-4 is named: that is where the bar of north_star stops being
+    reachable in float32 for this checkpoint (a BatchNorm with var 6.6e-22 and |mean| 4e3)."""
+    vx = million_point_voxels
+    dev = torch.device("cuda:0")
+    w = uo.load_weights(WEIGHTS)
+    o64 = uo.OracleNet(w, dtype=torch.float64)
+    r64 = o64.forward(vx["feats"][:, :3], vx["coords"])
+    o32 = uo.OracleNet(w, dtype=torch.float32)
+    r32 = o32.forward(vx["feats"][:, :3], vx["coords"])
+    net = Smart_Tree(w, device=dev)
+    net.trace = {}
+    out = net.forward(sparse_from_batch(torch.from_numpy(vx["feats"][:, :3]), torch.from_numpy(vx["coords"]), dev))
+    lines, first_noisy = [], None
+    for name in LAYERS:
+        r = o64.trace[name].numpy()
+        scale = _rms(r)
+        e_hip = float(np.abs(net.trace[name].cpu().numpy() - r).max() / scale)
+        e_f32 = float(np.abs(o32.trace[name].numpy().astype(np.float64) - r).max() / scale)
+        # per channel: which output channel carries the layer's float32 noise?
+        d = np.abs(o32.trace[name].numpy().astype(np.float64) - r).max(axis=0) / scale
+        lines.append(f"{name:7s} rms {scale:10.4e}  hip {e_hip:9.3e}  fp32 oracle {e_f32:9.3e}  noisiest channel {int(d.argmax())} ({d.max():.3e}; "
+                     f"median channel {np.median(d):.3e})")
+        if first_noisy is None and e_f32 > 1e-4:
+            first_noisy = name
+        assert e_hip <= max(1e-4, 4 * e_f32), (name, e_hip, e_f32)
+    # ... and the three heads (per-voxel 8 -> 8 -> 4 -> {1, 3, 2} with two BatchNorms; the direction is normalised): the heads of
+    # the float32 oracle evaluated on the FLOAT64 network's last block output isolate what the heads alone add
+    x64 = o64.trace["tail0"]
+    for key, prefix in (("radius", "radius_head"), ("direction", "direction_head"), ("class_l", "class_head")):
+        r = r64[key]
+        scale = _rms(r)
+        e_hip = float(np.abs(out[key].cpu().numpy() - r).max() / scale)
+        e_f32 = float(np.abs(r32[key].astype(np.float64) - r).max() / scale)
+        h = o32.head(x64.to(torch.float32), prefix)
+        if key == "direction":
+            h = torch.nn.functional.normalize(h)
+        e_head = float(np.abs(h.numpy().astype(np.float64) - r).max() / scale)
+        lines.append(f"{key:9s} rms {scale:10.4e}  hip {e_hip:9.3e}  fp32 oracle {e_f32:9.3e}  float32 head on the float64 block output {e_head:9.3e}")
+        assert e_hip <= max(1e-4, 4 * e_f32), (key, e_hip, e_f32)
+    # ... and the inference tail exp(radius) * direction (model_inference.py:87-88): absolute errors of the log-radius are
+    # relative errors of the medial vector, and the normalised direction of a voxel whose raw direction is short is noisy
+    mv64, _ = uo.inference_tail(r64["radius"], r64["direction"], r64["class_l"])
+    with np.errstate(over="ignore", invalid="ignore"):
+        mv_hip = np.exp(out["radius"].cpu().numpy().astype(np.float64)) * out["direction"].cpu().numpy()
+        mv_f32 = np.exp(r32["radius"].astype(np.float64)) * r32["direction"]
+    fin = np.isfinite(mv64).all(axis=1) & (np.abs(mv64).max(axis=1) < 1e30)
+    scale = _rms(mv64[fin])
+    raw64 = o64.head(x64, "direction_head").numpy()
+    short = np.linalg.norm(raw64, axis=1) < 0.01 * _rms(raw64)
+    for what, sel in (("all voxels with a finite float64 medial vector", fin), ("... whose raw direction is not short (>= 1 % of its rms)", fin & ~short)):
+        e_hip = float(np.abs(mv_hip[sel] - mv64[sel]).max() / scale)
+        e_f32 = float(np.abs(mv_f32[sel] - mv64[sel]).max() / scale)
+        lines.append(f"medial vector, {what}: {int(sel.sum())} voxels, hip {e_hip:9.3e}  fp32 oracle {e_f32:9.3e}")
+    lines.append(f"log-radius: rms {_rms(r64['radius']):.3e}, max |hip - fp64| {float(np.abs(out['radius'].cpu().numpy() - r64['radius']).max()):.3e} "
+                 "(an absolute error of the log-radius is a relative error of the medial vector)")
+    out_dir = Path(__file__).resolve().parents[1] / "gpurun_out"
+    try:
+        out_dir.mkdir(exist_ok=True)
+        (out_dir / "shipped_checkpoint_trace.txt").write_text(
+            "# tests/test_full_size.py::test_config1_shipped_checkpoint_error_trace: noble-elevator-58 on the 1M-point tree's voxels;\n"
+            "# per block output: max|x - fp64 oracle| / rms(fp64) for the HIP network and for the float32 oracle network\n"
+            + "\n".join(lines) + f"\nfirst layer whose float32-order noise exceeds 1e-4: {first_noisy}\n")
+    except OSError:
+        pass
+
+
 def test_config5_half_precision_network_full_size_live_weights(million_point_voxels):
     """BASELINE.json configs[4] (extension; the reference's inference is float32): half-precision storage + f16
     matrix-core kernels on the >= 16-channel levels.  Compared with the float64 oracle that rounds weights and
