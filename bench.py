@@ -28,7 +28,7 @@ MEDIAN pass (min / max / all passes are in `passes`).  Prints ONE JSON line (ran
 
 Environment (all optional): ST_BENCH_ORDERED 3 (default: batches in flight take turns with voxelise .. network) / 1 (with the
 whole chip-filling phase) / 0 (free-running); ST_BENCH_MIN_UPTIME_S (30: the warm-up lasts until the process is that old);
-ST_BENCH_BLOCKING_SYNC (1: host waits block instead of spinning); ST_BENCH_TORCH_THREADS (1); ST_BENCH_SELECT_THREADS,
+ST_BENCH_BLOCKING_SYNC (1: host waits block instead of spinning; default: by the number of host cores); ST_BENCH_TORCH_THREADS (1); ST_BENCH_SELECT_THREADS,
 ST_SKELETON_PARAMS (developer knobs); ST_BENCH_DRYRUN=1 (multi-rank control flow on one GPU over gloo).
 """
 from __future__ import annotations
@@ -113,12 +113,11 @@ def plan_batches(steps: int, streams: int, max_batch: int):
     per_round = streams * max_batch
     n_batches = streams * ((steps + per_round - 1) // per_round)
     n_batches = min(n_batches, steps)
-    if n_batches == 2 and steps >= 8 and steps <= max_batch:
-        # a short run is ONE round of two batches: the second one's skeleton stage (one compute unit per tree, ~13 ms whatever
-        # the batch size) is exposed at the end, so it gets the smaller share (20 steps: 12 + 8 measured 1.83 ms per step
-        # against 1.85-1.90 for 10 + 10 / 11 + 9, profiles/r03_sweep_plan.txt)
-        first = (3 * steps + 2) // 5
-        return [first, steps - first]
+    if steps <= 32 and steps <= max_batch:
+        # a short run is ONE batch: with the clouds of a pass in one launch set the chip-filling kernels run at their best and
+        # the skeleton stage (one compute unit per tree + its helper workgroups, ~12 ms whatever the batch size) is exposed once.
+        # Measured at the driver's --steps 20 (round 4): 20 = 1.60 ms per step, 12 + 8 on two streams 1.62-1.66, 10 + 10 1.57-1.73.
+        return [steps]
     base, extra = divmod(steps, n_batches)
     return [base + (1 if i < extra else 0) for i in range(n_batches)]
 
@@ -492,7 +491,10 @@ def main():
     dryrun = os.environ.get("ST_BENCH_DRYRUN") == "1"
     if dryrun:
         local_rank = 0
-    blocking = os.environ.get("ST_BENCH_BLOCKING_SYNC", "1") == "1"
+    # host waits: spinning (the HIP default) when the host has cores to spare -- a worker thread then keeps a core busy, and a
+    # read-back returns a few tens of microseconds earlier (20 steps: 1.57-1.62 against 1.63-1.66 ms per step) --, blocking
+    # otherwise (eight ranks with two worker threads each on a small host)
+    blocking = os.environ.get("ST_BENCH_BLOCKING_SYNC", "0" if usable_cores() >= 8 * max(world, 1) else "1") == "1"
     if blocking:
         # host waits block on the completion interrupt instead of spinning (hipDeviceScheduleBlockingSync = 4; must be set
         # before the device's context exists).  Measured: 0.2 host cores busy instead of 1.93 for two batches in flight, at

@@ -37,6 +37,15 @@
 #define SK_ANC 64  // direct ancestors kept per vertex; longer walks hop 64 levels at a time (16 measured slower: every lane
                    // of a 1024-wide chunk hops j/SK_ANC times, so the chunk costs as much as its farthest lane)
 
+// A long-path claim handed to a component's helper workgroups: written by the component's own workgroup with agent-scope
+// stores (the helpers run on other compute units, possibly other XCDs), then `seq` is bumped.
+struct SkJob {
+    unsigned seq, done, quit;
+    int len, id, csz, nrows, ny, x0, y0, z0, z1, path_off;
+    float rp;
+    unsigned pad[2];
+};
+
 struct SkArgs {
     int C;
     int64_t m;
@@ -101,6 +110,12 @@ struct SkArgs {
     int local_items;     // select: (path vertex, cell row) pairs one workgroup claims path-centric by itself
     int long_mode;       // select: paths that fit the LDS path buffer but are too much work for the plain point-centric claim are
                          // claimed by the workgroup itself with chunk-pruned distance tests (below), not handed to k_sk_claim
+    // helper workgroups of the long-path claims (k_sk_select): the first n_helpers workgroups of the launch serve the large components
+    int n_helpers;
+    const int* hl_comp;   // [n_helpers] component a helper serves (-1: none)
+    const int* hl_rank;   // [n_helpers] its rank among that component's helpers (1 ..)
+    const int* c_nhelp;   // [C] helpers of a component
+    struct SkJob* jobs;   // [C]
     long long* ticks;  // optional developer aid: per-phase wall_clock64 sums of k_sk_select (tuning[15])
 };
 
@@ -664,6 +679,10 @@ __device__ __forceinline__ bool sk_claim_items(const SkArgs& A, int c, int base,
 // One workgroup per component; speculative rounds of up to one branch per wavefront with an in-order replay (k_sk_select
 // below).  The selection state is the termination set, a bitmap in LDS (SkBm), and the branch ids, stamped straight into
 // the caller's array with a max (branch_ids keeps the last writer, ids grow with the order of the loop).
+#define SK_HELP_MIN 8192
+#define SK_HELP_PER 4096
+#define SK_HELP_MAX 12
+#define SK_HELP_POOL 160
 #define SK_SMALL_WORK (1 << 18)  // candidate points x path vertices one workgroup takes on point-centric, unpruned
 #define SK_ITERS_PER_LAUNCH 32
 #define SK_LPATH 1024
@@ -678,6 +697,7 @@ struct SkBm {
     unsigned* lds;
     unsigned* glb;
     bool in_lds;
+    bool agent;  // the component has helper workgroups on other compute units: branch ids are stamped at agent scope
 };
 __device__ __forceinline__ bool bm_test(const SkBm& B, int v) {
     const unsigned w = B.in_lds ? B.lds[v >> 5] : ld_wg(&B.glb[v >> 5]);
@@ -691,7 +711,7 @@ __device__ __forceinline__ void bm_set(const SkBm& B, int v) {
 // grow with the order of the loop, so "last" is a max -- commutative, which lets the lanes of a commit race.
 __device__ __forceinline__ void sk_mark(const SkArgs& A, const SkBm& B, int base, int p, int id) {
     bm_set(B, p);
-    if (id >= 0) wg_max(&A.branch_of[base + p], id);
+    if (id >= 0) { if (B.agent) (void)atomicMax(&A.branch_of[base + p], id); else wg_max(&A.branch_of[base + p], id); }
 }
 
 // on-path test of the points a chip-wide claim touched (path.py:35-40) + their stamps
@@ -792,6 +812,101 @@ __device__ __forceinline__ int sk_wt_find(const unsigned* wkey, unsigned key) {
 // branch_of = max id = last writer).  Slot 0 is always accepted, so every round makes progress.  A path
 // too long for one wavefront is worked on by the whole workgroup (`one` mode); one too long even for that
 // is handed to the chip-wide k_sk_claim and finished at the head of the next launch.
+// The long-path claim, point-centric and exact (see k_sk_select, "A long path"): rows [r_begin, r_end) of the (x, y) cell rows
+// around the path are taken W at a time; every candidate point of those rows walks the path's chunks.  The path (positions,
+// radii) and its chunk boxes sit in LDS.  HELPER = false: the component's own workgroup (termination bits in its LDS bitmap);
+// HELPER = true: a helper workgroup on another compute unit -- bits and branch ids go to global memory at agent scope, the
+// component's workgroup folds the bits into its bitmap when the job is done.
+template <bool HELPER>
+__device__ __forceinline__ void sk_long_rows(const SkArgs& A, const SkBm& B, SkSelOne& O, const float (*cb_lo)[SK_LPATH / SK_CHUNK],
+                                             const float (*cb_hi)[SK_LPATH / SK_CHUNK], uint32_t* s_scan, int base, int n, int xoff,
+                                             int x0, int y0, int z0, int z1, int ny, int r_begin, int r_end, int len, int csz, float rp2,
+                                             int id) {
+    const StGrid* g = A.grid;
+    const float4* __restrict__ recs = A.recs;
+    const int tid = threadIdx.x, W = (int)blockDim.x;
+    const int nch = (len + csz - 1) / csz;
+    for (int r0 = r_begin; r0 < r_end; r0 += W) {
+        const int rr = r0 + tid, nr = r_end - r0 < W ? r_end - r0 : W;
+        uint32_t cnt = 0, first = 0;
+        if (rr < r_end) {
+            const int64_t row = ((int64_t)(xoff + x0 + rr / ny) * g->dim[1] + (y0 + rr % ny)) * g->dim[2];
+            first = A.cell_start[row + z0];
+            cnt = A.cell_start[row + z1 + 1] - first;
+        }
+        uint32_t tot;
+        const uint32_t off = block_exclusive_scan(cnt, s_scan, &tot);  // (its first barrier: the previous rows' tables are dead)
+        if (tid < nr) { O.row_off[tid] = off; O.row_first[tid] = first; }
+        if (tid == 0) O.row_off[nr] = tot;
+        __syncthreads();
+        for (uint32_t t = (uint32_t)tid; t < tot; t += (uint32_t)W) {
+            const int row = sk_find_row(O.row_off, nr, t);
+            const float4 r4 = recs[O.row_first[row] + (t - O.row_off[row])];
+            const int p = (int)__float_as_uint(r4.w) - base;
+            if (p < 0 || p >= n) continue;  // other component
+            float bd2 = __uint_as_float(0x7f800000u), bw = 0.0f;
+            for (int ch = 0; ch < nch; ch++) {
+                float e[3];
+                const float pv[3] = {r4.x, r4.y, r4.z};
+#pragma unroll
+                for (int a = 0; a < 3; a++) {
+                    const float below = cb_lo[a][ch] - pv[a], above = pv[a] - cb_hi[a][ch];
+                    const float m = below > above ? below : above;
+                    e[a] = m > 0.0f ? m : 0.0f;
+                }
+                float lb = e[0] * e[0];
+                float tt = e[1] * e[1];
+                lb = lb + tt;
+                tt = e[2] * e[2];
+                lb = lb + tt;
+                if (lb >= bd2 || lb >= rp2) continue;  // nothing in this chunk can be strictly nearer / inside the radius
+                const int q1 = (ch + 1) * csz < len ? (ch + 1) * csz : len;
+                for (int qi = ch * csz; qi < q1; qi++) {  // ascending: ties keep the first path vertex
+                    const float dx = r4.x - O.lpx[qi], dy = r4.y - O.lpy[qi], dz = r4.z - O.lpz[qi];
+                    float d2 = dx * dx;
+                    float t2 = dy * dy;
+                    d2 = d2 + t2;
+                    t2 = dz * dz;
+                    d2 = d2 + t2;
+                    if (d2 < bd2) { bd2 = d2; bw = O.lpr[qi]; }
+                }
+            }
+            if (bd2 < rp2 && sqrtf(bd2) < bw) {  // path.py:35-40
+                if (HELPER) {
+                    (void)atomicOr(&B.glb[p >> 5], 1u << (p & 31));
+                    if (id >= 0) (void)atomicMax(&A.branch_of[base + p], id);
+                } else {
+                    sk_mark(A, B, base, p, id);
+                }
+            }
+        }
+    }
+}
+
+// chunk boxes of the path in O (every thread calls; a barrier must follow before they are read)
+__device__ __forceinline__ void sk_chunk_boxes(const SkSelOne& O, float (*cb_lo)[SK_LPATH / SK_CHUNK], float (*cb_hi)[SK_LPATH / SK_CHUNK], int len,
+                                               int csz) {
+    const int tid = threadIdx.x, nch = (len + csz - 1) / csz;
+    if (tid < nch) {
+        float lo[3] = {__uint_as_float(0x7f800000u), __uint_as_float(0x7f800000u), __uint_as_float(0x7f800000u)};
+        float hi[3] = {__uint_as_float(0xff800000u), __uint_as_float(0xff800000u), __uint_as_float(0xff800000u)};
+        for (int qi = tid * csz; qi < len && qi < (tid + 1) * csz; qi++) {
+            const float v[3] = {O.lpx[qi], O.lpy[qi], O.lpz[qi]};
+#pragma unroll
+            for (int a = 0; a < 3; a++) { lo[a] = v[a] < lo[a] ? v[a] : lo[a]; hi[a] = v[a] > hi[a] ? v[a] : hi[a]; }
+        }
+#pragma unroll
+        for (int a = 0; a < 3; a++) { cb_lo[a][tid] = lo[a]; cb_hi[a][tid] = hi[a]; }
+    }
+}
+
+// agent-scope stores / loads of the job words (see SkJob)
+__device__ __forceinline__ void st_ai(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int ld_ai(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned ld_au(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_au(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#define SK_HELP_TIMEOUT 30000000ll  // 0.3 s of the 100 MHz wall clock: a helper / a wait that lasts longer gives up (flagged in A.fcnt[0])
+
 __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
     long long t_last = A.ticks ? wall_clock64() : 0;
     __shared__ long long tk[8];  // phase timers (developer aid), touched by thread 0 only
@@ -813,8 +928,53 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
         sl_big[SK_WSLOTS], sl_id[SK_WSLOTS], sl_off[SK_WSLOTS];
     __shared__ float sl_rp[SK_WSLOTS];
     __shared__ unsigned sl_walkm[SK_WSLOTS];
-    const int c = blockIdx.x, tid = threadIdx.x, W = (int)blockDim.x;
+    const int tid = threadIdx.x, W = (int)blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nw = (W + 63) >> 6;
+    if ((int)blockIdx.x < A.n_helpers) {
+        // ------------------------------------------------------------------ a helper workgroup ---
+        // serves ONE large component: waits for its workgroup to post a long-path claim (SkJob), takes its share of the cell
+        // rows around that path, stamps what it claims at agent scope, reports, waits for the next one -- until `quit`.
+        __shared__ unsigned h_seq, h_quit;
+        const int hc = A.hl_comp[blockIdx.x];
+        if (hc < 0 || A.s_done[hc]) return;  // (a finished component's workgroup leaves at once, too: nobody would send `quit`)
+        const int rank = A.hl_rank[blockIdx.x], nranks = A.c_nhelp[hc] + 1;
+        const int hbase = A.comp_off[hc], hn = A.comp_off[hc + 1] - hbase;
+        const int hxoff = A.comp_seg ? A.comp_seg[hc] * A.grid->seg_dim0 : 0;
+        SkBm HB;
+        HB.lds = nullptr; HB.glb = A.term_bits + (hbase >> 5) + hc; HB.in_lds = false; HB.agent = true;
+        SkJob* J = &A.jobs[hc];
+        unsigned seen = 0u;
+        const long long t_start = wall_clock64();
+        for (;;) {
+            if (tid == 0) {
+                h_seq = ld_au(&J->seq);
+                h_quit = ld_au(&J->quit) | (wall_clock64() - t_start > SK_HELP_TIMEOUT ? 1u : 0u);  // (a launch never lasts that long)
+            }
+            __syncthreads();
+            const unsigned sq = h_seq, qt = h_quit;
+            __syncthreads();
+            if (qt != 0u) return;
+            if (sq == seen) { __builtin_amdgcn_s_sleep(8); continue; }
+            seen = sq;
+            const int len = ld_ai(&J->len), id = ld_ai(&J->id), csz = ld_ai(&J->csz), nrows = ld_ai(&J->nrows), ny = ld_ai(&J->ny);
+            const int x0 = ld_ai(&J->x0), y0 = ld_ai(&J->y0), z0 = ld_ai(&J->z0), z1 = ld_ai(&J->z1), poff = ld_ai(&J->path_off);
+            const float rp = __uint_as_float((unsigned)ld_ai((const int*)&J->rp));
+            for (int qi = tid; qi < len; qi += W) {  // the path (root side first) and its positions / radii
+                const int v = ld_ai(&A.path_verts[hbase + poff + qi]);
+                const float4 q4 = A.pr[hbase + v];
+                L.one.lpx[qi] = q4.x; L.one.lpy[qi] = q4.y; L.one.lpz[qi] = q4.z; L.one.lpr[qi] = q4.w;
+            }
+            __syncthreads();
+            sk_chunk_boxes(L.one, cb_lo, cb_hi, len, csz);
+            __syncthreads();
+            const int per = (nrows + nranks - 1) / nranks;
+            const int rb = rank * per, re = rb + per < nrows ? rb + per : nrows;
+            sk_long_rows<true>(A, HB, L.one, cb_lo, cb_hi, s_scan, hbase, hn, hxoff, x0, y0, z0, z1, ny, rb, re, len, csz, rp * rp, id);
+            __syncthreads();  // every stamp of this workgroup has completed
+            if (tid == 0) (void)atomicAdd(&J->done, 1u);
+        }
+    }
+    const int c = (int)blockIdx.x - A.n_helpers;
     if (A.s_done[c]) return;
     const int base = A.comp_off[c], n = A.comp_off[c + 1] - base;
     const unsigned* order = A.order + base;
@@ -828,8 +988,13 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
     B.glb = A.term_bits + (base >> 5) + c;
     const int nwords = (n + 31) >> 5;
     B.in_lds = nwords <= SK_BM_WORDS;
+    const int nhelp = (A.n_helpers > 0 && B.in_lds) ? A.c_nhelp[c] : 0;  // helper workgroups of this component (long-path claims)
+    B.agent = nhelp > 0;
+    SkJob* J = &A.jobs[c];
+    unsigned job_seq = 0u;
     if (B.in_lds) for (int i = tid; i < nwords; i += W) bm_words[i] = B.glb[i];
     __syncthreads();
+#define SK_QUIT_HELPERS() do { if (nhelp > 0 && tid == 0) st_au(&J->quit, 1u); } while (0)
 #define SK_FLUSH_BM()                                                             \
     do {                                                                          \
         __syncthreads();                                                          \
@@ -891,6 +1056,7 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
             break;
         }
         if (exhausted) {  // path.py:94-95 (uniform)
+            SK_QUIT_HELPERS();
             SK_FLUSH_BM();
             if (tid == 0) {
                 A.s_done[c] = 1; A.s_len[c] = 0; A.s_wide[c] = 0; A.n_branches[c] = nb; A.s_nb[c] = nb; A.s_total[c] = total;
@@ -1267,7 +1433,7 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
         for (int qi = tid; qi < len; qi += blockDim.x) {
             const int w = len - 1 - qi;  // walk order -> root side first
             const int v = w < SK_LPATH ? L.one.lpath[w] : (int)ld_wg(&tmp[w]);
-            path_out[qi] = v;
+            st_ai(&path_out[qi], v);  // (agent scope: the component's helper workgroups read the path)
             const float4 q4 = A.pr[base + v];
             const float r = q4.w;
             const unsigned long long k = (unsigned long long)st_f2ord(r) << 32;
@@ -1329,78 +1495,44 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
         // distance evaluations)
         if (fits && len > 16 && (small || A.long_mode)) {
             const int csz = len <= 8 * (SK_LPATH / SK_CHUNK) ? 8 : SK_CHUNK;  // vertices per chunk: at most SK_LPATH / SK_CHUNK boxes
-            const int nch = (len + csz - 1) / csz;
-            if (tid < nch) {
-                float lo[3] = {__uint_as_float(0x7f800000u), __uint_as_float(0x7f800000u), __uint_as_float(0x7f800000u)};
-                float hi[3] = {__uint_as_float(0xff800000u), __uint_as_float(0xff800000u), __uint_as_float(0xff800000u)};
-                for (int qi = tid * csz; qi < len && qi < (tid + 1) * csz; qi++) {
-                    const float v[3] = {L.one.lpx[qi], L.one.lpy[qi], L.one.lpz[qi]};
-#pragma unroll
-                    for (int a = 0; a < 3; a++) { lo[a] = v[a] < lo[a] ? v[a] : lo[a]; hi[a] = v[a] > hi[a] ? v[a] : hi[a]; }
-                }
-#pragma unroll
-                for (int a = 0; a < 3; a++) { cb_lo[a][tid] = lo[a]; cb_hi[a][tid] = hi[a]; }
-            }
+            sk_chunk_boxes(L.one, cb_lo, cb_hi, len, csz);
             const int x0 = st_max(s_lo[0] - reach, 0), x1 = st_min(s_hi[0] + reach, g->seg_dim0 - 1);
             const int y0 = st_max(s_lo[1] - reach, 0), y1 = st_min(s_hi[1] + reach, g->dim[1] - 1);
             const int z0 = st_max(s_lo[2] - reach, 0), z1 = st_min(s_hi[2] + reach, g->dim[2] - 1);
             const int nx = x1 - x0 + 1, ny = y1 - y0 + 1;
             const int nrows = (nx > 0 && ny > 0 && z0 <= z1) ? nx * ny : 0;
             if (A.ticks && tid == 0) { A.ticks[9] += 1; A.ticks[10] += len; A.ticks[15] += 1; }
-            __syncthreads();  // chunk boxes published
-            for (int r0 = 0; r0 < nrows; r0 += W) {
-                const int rr = r0 + tid, nr = nrows - r0 < W ? nrows - r0 : W;
-                uint32_t cnt = 0, first = 0;
-                if (rr < nrows) {
-                    const int64_t row = ((int64_t)(xoff + x0 + rr / ny) * g->dim[1] + (y0 + rr % ny)) * g->dim[2];
-                    first = A.cell_start[row + z0];
-                    cnt = A.cell_start[row + z1 + 1] - first;
+            // a heavy claim is shared with the component's helper workgroups (other compute units): each takes an equal share of
+            // the cell rows; this workgroup takes the first, waits for the others and folds their termination bits into its bitmap
+            const bool help = nhelp > 0 && (nrows > W / 2 || len > 128);
+            int my_end = nrows;
+            if (help) {
+                __syncthreads();  // (the agent-scope stores of the path above have completed)
+                if (tid == 0) {
+                    st_ai(&J->len, len); st_ai(&J->id, id); st_ai(&J->csz, csz); st_ai(&J->nrows, nrows); st_ai(&J->ny, ny);
+                    st_ai(&J->x0, x0); st_ai(&J->y0, y0); st_ai(&J->z0, z0); st_ai(&J->z1, z1); st_ai(&J->path_off, cur_off);
+                    st_ai((int*)&J->rp, (int)__float_as_uint(rp));
+                    st_au(&J->done, 0u);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (waits for the stores above; they are write-through)
+                    st_au(&J->seq, ++job_seq);
+                    if (A.ticks) A.ticks[14] += 1;
                 }
-                uint32_t tot;
-                const uint32_t off = block_exclusive_scan(cnt, s_scan, &tot);  // (its first barrier: the previous rows' tables are dead)
-                if (tid < nr) { L.one.row_off[tid] = off; L.one.row_first[tid] = first; }
-                if (tid == 0) L.one.row_off[nr] = tot;
-                __syncthreads();
-                for (uint32_t t = (uint32_t)tid; t < tot; t += (uint32_t)W) {
-                    const int row = sk_find_row(L.one.row_off, nr, t);
-                    const float4 r4 = recs[L.one.row_first[row] + (t - L.one.row_off[row])];
-                    const int p = (int)__float_as_uint(r4.w) - base;
-                    if (p < 0 || p >= n) continue;  // other component
-                    float bd2 = __uint_as_float(0x7f800000u), bw = 0.0f;
-                    for (int ch = 0; ch < nch; ch++) {
-                        float e[3];
-                        const float pv[3] = {r4.x, r4.y, r4.z};
-#pragma unroll
-                        for (int a = 0; a < 3; a++) {
-                            const float below = cb_lo[a][ch] - pv[a], above = pv[a] - cb_hi[a][ch];
-                            const float m = below > above ? below : above;
-                            e[a] = m > 0.0f ? m : 0.0f;
-                        }
-                        float lb = e[0] * e[0];
-                        float tt = e[1] * e[1];
-                        lb = lb + tt;
-                        tt = e[2] * e[2];
-                        lb = lb + tt;
-                        if (lb >= bd2 || lb >= rp2) continue;  // nothing in this chunk can be strictly nearer / inside the radius
-                        const int q1 = (ch + 1) * csz < len ? (ch + 1) * csz : len;
-                        for (int qi = ch * csz; qi < q1; qi++) {  // ascending: ties keep the first path vertex
-                            const float dx = r4.x - L.one.lpx[qi], dy = r4.y - L.one.lpy[qi], dz = r4.z - L.one.lpz[qi];
-                            float d2 = dx * dx;
-                            float t2 = dy * dy;
-                            d2 = d2 + t2;
-                            t2 = dz * dz;
-                            d2 = d2 + t2;
-                            if (d2 < bd2) { bd2 = d2; bw = L.one.lpr[qi]; }
-                        }
-                    }
-                    if (bd2 < rp2 && sqrtf(bd2) < bw) {  // path.py:35-40
-                        sk_mark(A, B, base, p, id);
-                    }
-                }
+                my_end = (nrows + nhelp) / (nhelp + 1);
+                if (my_end > nrows) my_end = nrows;
             }
-            for (int qi = tid; qi < len; qi += blockDim.x) {  // path.py:112-113,135
-                const int v = L.one.lpath[len - 1 - qi];
-                sk_mark(A, B, base, v, id);
+            __syncthreads();  // chunk boxes published
+            sk_long_rows<false>(A, B, L.one, cb_lo, cb_hi, s_scan, base, n, xoff, x0, y0, z0, z1, ny, 0, my_end, len, csz, rp2, id);
+            for (int qi = tid; qi < len; qi += blockDim.x) sk_mark(A, B, base, L.one.lpath[len - 1 - qi], id);  // path.py:112-113,135
+            if (help) {
+                if (tid == 0) {
+                    const long long t0 = wall_clock64();
+                    while (ld_au(&J->done) < (unsigned)nhelp) {
+                        __builtin_amdgcn_s_sleep(2);
+                        if (wall_clock64() - t0 > SK_HELP_TIMEOUT) { st_au(&A.fcnt[0], 1u); break; }  // a helper never came: the host fails the call
+                    }
+                }
+                __syncthreads();
+                for (int i = tid; i < nwords; i += W) bm_words[i] |= ld_au(&B.glb[i]);  // what the helpers terminated
             }
             __syncthreads();
             SK_TICK(6);
@@ -1426,6 +1558,7 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
             continue;
         }
         if (!small) {  // hand the path to k_sk_claim; its points are finished at the next launch (uniform)
+            SK_QUIT_HELPERS();
             SK_FLUSH_BM();
             if (tid == 0) {
                 A.s_len[c] = len; A.s_rp[c] = rp; A.s_ntouched[c] = 0u; A.s_cur_off[c] = cur_off; A.s_cur_id[c] = id;
@@ -1461,10 +1594,12 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
         __syncthreads();
         SK_TICK(5);
     }
+    SK_QUIT_HELPERS();
     SK_FLUSH_BM();
     if (tid == 0) { A.s_len[c] = 0; A.s_wide[c] = 0; A.s_cursor[c] = win_base; A.s_total[c] = total; A.s_nb[c] = nb; }
     SK_TICK_FLUSH();
 #undef SK_FLUSH_BM
+#undef SK_QUIT_HELPERS
 }
 
 
@@ -1510,6 +1645,22 @@ __global__ void __launch_bounds__(1024) k_sk_blk_tables(SkArgs A, int* blk_comp,
     for (int b = total + tid; b < nblk_bound; b += 1024) blk_comp[b] = -1;
 }
 
+// Helper workgroups of the long-path claims: a component of >= SK_HELP_MIN vertices gets one helper per SK_HELP_PER vertices
+// (at most SK_HELP_MAX), in component order until the launch's n_helpers are used up.  One thread: a few thousand components.
+__global__ void k_sk_helper_tables(SkArgs A, int* hl_comp, int* hl_rank, int* c_nhelp) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    int at = 0;
+    for (int c = 0; c < A.C; c++) {
+        const int n = A.comp_off[c + 1] - A.comp_off[c];
+        int k = n >= SK_HELP_MIN ? n / SK_HELP_PER : 0;
+        k = k > SK_HELP_MAX ? SK_HELP_MAX : k;
+        if (k > A.n_helpers - at) k = A.n_helpers - at;
+        c_nhelp[c] = k;
+        for (int j = 0; j < k; j++) { hl_comp[at] = c; hl_rank[at] = j + 1; at++; }
+    }
+    for (; at < A.n_helpers; at++) { hl_comp[at] = -1; hl_rank[at] = 0; }
+}
+
 // ------------------------------------------------------------------------------- host side ---
 #define SK_GRID_CELLS (1ll << 24)
 
@@ -1522,7 +1673,8 @@ struct SkLayout {
     char* sort_ws;
     int64_t sort_bytes;
     unsigned long long* best;
-    int *anc, *comp_of, *s_done, *s_len, *s_cur_id, *s_cur_off, *s_nb, *s_total, *blk_comp, *blk_first, *blk_count;
+    int *anc, *comp_of, *s_done, *s_len, *s_cur_id, *s_cur_off, *s_nb, *s_total, *blk_comp, *blk_first, *blk_count, *hl_comp, *hl_rank, *c_nhelp;
+    SkJob* jobs;
     StGrid* g;
     uint32_t* cell_start;
     float4* recs;
@@ -1571,6 +1723,10 @@ static void sk_layout(StArena& a, int64_t m, int64_t C, SkLayout* s, int nseg = 
     s->blk_first = a.take<int>(C);
     s->blk_count = a.take<int>(C);
     s->blk_comp = a.take<int>(C + st_div_up(m, 1024));
+    s->hl_comp = a.take<int>(SK_HELP_POOL);
+    s->hl_rank = a.take<int>(SK_HELP_POOL);
+    s->c_nhelp = a.take<int>(C);
+    s->jobs = a.take<SkJob>(C);
     s->g = a.take<StGrid>(1);
     s->cell_start = a.take<uint32_t>(sk_grid_cells(nseg, m) + 1);
     s->recs = a.take<float4>(m);
@@ -1585,7 +1741,8 @@ static void sk_layout(StArena& a, int64_t m, int64_t C, SkLayout* s, int nseg = 
 //   4 local_items   5 wave_work   6 SSSP levels per frontier launch   7 frontier launches per read-back   8 lanes per vertex
 //   9 length of the first frontier batch (in batches)   10 frontier workgroups   11 claim-grid cell cap (hundredths of the
 //   mean radius)   12 SSSP rounds in one persistent launch with grid barriers (1) or one launch per round (0, default: measured equal for
-//   one cloud, 5 % slower per step with two batches in flight -- the rounds are bound by their ~6 us per level, not by the launches)
+//   one cloud, 5 % slower per step with two batches in flight -- the rounds are bound by their ~6 us per level, not by the launches);
+//   bits 8 ..: 1 + the number of helper workgroups of the branch selection's long-path claims (0 = by size)
 //   13 frontier: 0 = no look before the atomic, else vertices a workgroup relaxes per local level
 //   14 long-path claim inside the workgroup (1, default) or by the local / chip-wide path-centric claims (0)
 //   15 device pointer of 32 int64 phase timers / counters of k_sk_select
@@ -1595,7 +1752,7 @@ struct SkTuning {
     float prune_factor = 1.0f, grid_mean_mult = 1.0f;
     int small_work = SK_SMALL_WORK, iters_per_launch = SK_ITERS_PER_LAUNCH, launch_batch = 24, local_items = 0, wave_work = SK_WAVE_WORK, long_mode = 1;
     int sssp_hops = 4, sssp_batch = 32, sssp_lanes = 64, sssp_first = 2, sssp_blocks = SK_SSSP_BLOCKS, sssp_lcap = SK_LQ;
-    int sssp_coop = 0;
+    int sssp_coop = 0, helpers = -1;  // helpers: -1 = by size, else the number of helper workgroups of a select launch
     bool small_work_set = false, iters_set = false, long_set = false, launch_set = false;
     long long* ticks = nullptr;
     explicit SkTuning(const int64_t* t) {
@@ -1613,7 +1770,7 @@ struct SkTuning {
         if (has(9)) sssp_first = t[9] < 1 ? 1 : (t[9] > 8 ? 8 : (int)t[9]);
         if (has(10)) sssp_blocks = t[10] < 1 ? 1 : (t[10] > 8192 ? 8192 : (int)t[10]);
         if (has(11)) grid_mean_mult = (float)t[11] / 100.0f;
-        if (has(12)) sssp_coop = t[12] != 0;
+        if (has(12)) { sssp_coop = (t[12] & 1) != 0; if (t[12] >= 256) helpers = (int)(t[12] >> 8) - 1; }
         if (has(13)) sssp_lcap = t[13] == 0 ? -SK_LQ : (t[13] > SK_LQ ? SK_LQ : (int)t[13]);
         if (has(14)) { long_mode = t[14] != 0; long_set = true; }
         if (has(15)) ticks = (long long*)(intptr_t)t[15];
@@ -1695,6 +1852,7 @@ extern "C" int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, c
     A.s_total = s.s_total; A.s_rp = s.s_rp; A.s_ntouched = s.s_ntouched;
     A.blk_comp = s.blk_comp; A.blk_first = s.blk_first; A.blk_count = s.blk_count;
     A.s_cursor = s.s_cursor; A.s_wide = s.s_wide; A.order = s.order; A.order_init = s.order_init;
+    A.hl_comp = s.hl_comp; A.hl_rank = s.hl_rank; A.c_nhelp = s.c_nhelp; A.jobs = s.jobs; A.n_helpers = 0;
     const SkTuning T(tuning);
     A.ticks = T.ticks;
     A.prune_factor = T.prune_factor; A.small_work = T.small_work; A.iters_per_launch = T.iters_per_launch; A.local_items = T.local_items; A.wave_work = T.wave_work; A.long_mode = T.long_mode;
@@ -1707,7 +1865,14 @@ extern "C" int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, c
     // per cloud at 64 clouds per launch set, 2.00 -> 1.95 at 10).  One cloud alone keeps the chip-wide claim for its long paths
     // (the chip is idle then: 11.2 against 12.0 ms).
     int first_launches = T.launch_batch;
-    if (nseg > 1) {
+#ifdef ST_HIPEMU
+    const bool helpers_avail = false;
+#else
+    const bool helpers_avail = T.helpers != 0 && block_threads >= 256 && m >= SK_HELP_MIN;
+#endif
+    // Round 4: with helper workgroups for the long-path claims, one cloud alone runs like a batch as well -- one launch to the
+    // end, long paths claimed inside the launch (6.3 ms against 6.6 with the chip-wide claim at the launch boundaries).
+    if (nseg > 1 || helpers_avail) {
         if (!T.small_work_set) A.small_work = 1 << 20;
         if (!T.iters_set) A.iters_per_launch = 1 << 20;
         // ... so ONE launch pair normally ends every tree (a path too long for the workgroup's LDS still goes to k_sk_claim and
@@ -1796,6 +1961,15 @@ extern "C" int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, c
         // claim / finalize grid: workgroups per component proportional to its size, laid out by k_sk_blk_tables
         const int nblk = (int)st_min64((int64_t)n_comp + st_div_up(m, 1024), (int64_t)n_comp * SK_MAX_CLAIM_BLOCKS);
         hipLaunchKernelGGL(k_sk_blk_tables, dim3(1), dim3(1024), 0, stream, A, s.blk_comp, s.blk_first, s.blk_count, nblk);
+        // helper workgroups of the long-path claims (they sit in front of the components' workgroups in the grid, so they are
+        // resident before any component can wait for them; the CPU emulator runs workgroups one after the other: none there)
+#ifdef ST_HIPEMU
+        A.n_helpers = 0;
+#else
+        A.n_helpers = !helpers_avail ? 0 : (T.helpers >= 0 ? (T.helpers < SK_HELP_POOL ? T.helpers : SK_HELP_POOL)
+                                                           : (int)st_min64(SK_HELP_POOL, m / SK_HELP_PER));
+#endif
+        hipLaunchKernelGGL(k_sk_helper_tables, dim3(1), dim3(64), 0, stream, A, s.hl_comp, s.hl_rank, s.c_nhelp);
         // grid_cell < 0: cell = max(rad) / -grid_cell with the maximum reduced on the device (no host round trip)
         ST_TRY(st_grid_build(pts, m, grid_cell, sk_grid_cells(nseg, m), s.g, s.cell_start, s.recs, s.gws, s.gws_bytes, stream,
                              grid_cell < 0.0f ? -1.0f : 0.0f, grid_cell < 0.0f ? rad : nullptr, grid_cell < 0.0f ? m : 0,
@@ -1814,7 +1988,7 @@ extern "C" int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, c
         double select_ms = 0.0;
         bool plateaus_pending = defer_plateaus;
         for (;;) {  // second pass only if the deferred check found plateau vertices: predecessors completed, selection redone
-            (void)hipMemsetAsync(&s.cnt[5], 0, 3 * sizeof(unsigned), stream);  // finished components, branches, path vertices
+            (void)hipMemsetAsync(&s.cnt[5], 0, 4 * sizeof(unsigned), stream);  // finished components, branches, path vertices; fcnt[0] = helper time-out flag
             const float* distances = (stages & 2) ? tree_dist : dist;
             (void)hipMemsetAsync(s.term_bits, 0, sk_term_words(m, n_comp) * sizeof(unsigned), stream);
             hipLaunchKernelGGL(k_sk_lift_init, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A);
@@ -1838,12 +2012,14 @@ extern "C" int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, c
             for (int batch = first_launches;; batch = batch > 4 ? 4 : batch) {  // launch pairs per counter read-back: a long first
                 // batch, short ones for the stragglers (a finished launch pair still costs its ~10 us of launch latency)
                 for (int b = 0; b < batch; b++, iters++) {
+                    if (A.n_helpers > 0) (void)hipMemsetAsync(s.jobs, 0, (size_t)n_comp * sizeof(SkJob), stream);
                     if (time_sel) (void)hipEventRecord(ev[2 * b], stream);
-                    hipLaunchKernelGGL(k_sk_select, dim3((unsigned)n_comp), dim3((unsigned)block_threads), 0, stream, A);
+                    hipLaunchKernelGGL(k_sk_select, dim3((unsigned)(A.n_helpers + n_comp)), dim3((unsigned)block_threads), 0, stream, A);
                     if (time_sel) (void)hipEventRecord(ev[2 * b + 1], stream);
                     hipLaunchKernelGGL(k_sk_claim, dim3((unsigned)nblk), dim3(SK_WIDE_BLOCK), 0, stream, A);
                 }
-                ST_TRY(sk_read(h, s.cnt, sizeof(unsigned) * 8, stream));
+                ST_TRY(sk_read(h, s.cnt, sizeof(unsigned) * 9, stream));  // (h[8] = fcnt[0]: a helper workgroup never answered)
+                ST_REQUIRE(h[8] == 0u, "skeleton: a helper workgroup of the branch selection timed out");
                 if (time_sel)
                     for (int b = 0; b < batch; b++) {
                         float ms = 0.0f;
