@@ -610,6 +610,7 @@ def main():
             dt_pass = time.perf_counter() - t0
             cpu1 = os.times()
             pass_s.append(dt_pass)
+            profiling.settle()  # (between the timed brackets: the byte counts of this pass, so that its tables can be freed)
             host_cores.append(((cpu1.user - cpu0.user) + (cpu1.system - cpu0.system)) / max(dt_pass, 1e-9))  # this rank's process
     finally:
         gc.enable()

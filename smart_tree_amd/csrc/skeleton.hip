@@ -683,6 +683,7 @@ __device__ __forceinline__ bool sk_claim_items(const SkArgs& A, int c, int base,
 #define SK_HELP_PER 4096
 #define SK_HELP_MAX 12
 #define SK_HELP_POOL 160
+#define SK_HELP_SEGS 32
 #define SK_SMALL_WORK (1 << 18)  // candidate points x path vertices one workgroup takes on point-centric, unpruned
 #define SK_ITERS_PER_LAUNCH 32
 #define SK_LPATH 1024
@@ -1868,7 +1869,10 @@ extern "C" int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, c
 #ifdef ST_HIPEMU
     const bool helpers_avail = false;
 #else
-    const bool helpers_avail = T.helpers != 0 && block_threads >= 256 && m >= SK_HELP_MIN;
+    // Helper workgroups spin while they wait: fine when the call has the chip to itself (one cloud, one modest batch: -4 % /
+    // -2.4 % per cloud), a loss when another batch's chip-filling kernels want the compute units (two 64-cloud batches in
+    // flight: +5 % per cloud).  By default a call of up to SK_HELP_SEGS clouds uses them; tuning code 12 overrides.
+    const bool helpers_avail = T.helpers != 0 && block_threads >= 256 && m >= SK_HELP_MIN && (T.helpers > 0 || nseg <= SK_HELP_SEGS);
 #endif
     // Round 4: with helper workgroups for the long-path claims, one cloud alone runs like a batch as well -- one launch to the
     // end, long paths claimed inside the launch (6.3 ms against 6.6 with the chip-wide claim at the launch boundaries).

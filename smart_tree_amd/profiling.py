@@ -126,6 +126,25 @@ def add_kernel_time(name: str, total_ms: float, launches: int, total_bytes, chip
         _external[name].append((float(total_ms), int(launches), total_bytes, min(1.0, max(float(chip_share), 0.0))))
 
 
+def settle() -> None:
+    """Evaluate every pending byte / flop thunk NOW and keep the numbers only.  A thunk pins what it counts (a conv's neighbour
+    table, a selection's result arrays); a timed region of several passes calls this between passes -- outside the timed
+    brackets -- so that the tables of all its batches do not pile up in HBM until the tables are read."""
+    global _generation
+    torch.cuda.synchronize()
+    val = lambda t: float(t() if callable(t) else t)
+    for recs in _kernels.values():
+        for i, r in enumerate(recs):
+            recs[i] = (r[0], r[1], val(r[2]), val(r[3]))
+    for recs in _families.values():
+        for i, r in enumerate(recs):
+            recs[i] = (r[0], r[1], [(val(b), val(f)) for b, f in r[2]])
+    for recs in _external.values():
+        for i, r in enumerate(recs):
+            recs[i] = (r[0], r[1], val(r[2]), r[3])
+    _generation += 1  # per-tensor caches keyed by (id, generation) must not outlive the tensors released here
+
+
 def stage_ms(steps: int):
     torch.cuda.synchronize()
     return {k: round(sum(a.elapsed_time(b) for a, b in v) / max(steps, 1), 3) for k, v in _stages.items()}

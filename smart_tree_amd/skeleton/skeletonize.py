@@ -87,20 +87,14 @@ def run_components(comps: ComponentSet, medial_pts: torch.Tensor, radius: torch.
         res.stats["branches"], res.stats["path_vertices"] = int(stats[6] & 0xFFFFFFFF), int(stats[6] >> 32)
     if stats[7] and stats[5]:
         # algorithmic bytes of the branch selection (SURVEY.md 8d "sample_tree"): each path vertex is written once
-        # (24 B: id + xyz lookups), each claimed point raced and stamped once (16 B), plus the sorted-order cursor (8 B/vertex)
-        res_ref = res
+        # (24 B: id + xyz lookups), each claimed point raced and stamped once (16 B), plus the sorted-order cursor (8 B/vertex).
+        # Only a device scalar is kept for later (the thunk must not pin the result arrays of every batch of a timed region).
+        claimed = (res.branch_of[:m] >= 0).sum()
+        path_vertices = float(res.stats.get("path_vertices", 0))
         profiling.add_kernel_time("k_sk_select", stats[4] * 1e-6, stats[5],
-                                  lambda: _select_bytes(res_ref, comps, m), chip_share=comps.n_components / float(profiling.compute_units(dev)))
+                                  lambda: path_vertices * 24.0 + float(claimed.item()) * 16.0 + m * 8.0,
+                                  chip_share=comps.n_components / float(profiling.compute_units(dev)))
     return res
-
-
-def _select_bytes(res: ComponentResult, comps: ComponentSet, m: int) -> float:
-    off = comps.comp_off.cpu().tolist()
-    nb = res.n_branches[: comps.n_components].cpu().tolist()
-    lens = res.branch_len.cpu()
-    path_vertices = sum(int(lens[off[c]: off[c] + nb[c]].sum()) for c in range(comps.n_components))
-    claimed = int((res.branch_of[:m] >= 0).sum().item())
-    return path_vertices * 24.0 + claimed * 16.0 + m * 8.0
 
 
 class Skeletonizer:

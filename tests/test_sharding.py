@@ -128,7 +128,8 @@ def test_bench_batch_plan():
                 assert sum(plan) == steps and all(0 < b <= cap for b in plan)
                 if plan:
                     eff = max(1, min(streams, steps // 16), min(streams, 3, steps // 6))  # fewer batches in flight for short runs
-                    assert max(plan) - min(plan) <= 1 and (len(plan) % eff == 0 or len(plan) == steps)
+                    assert max(plan) - min(plan) <= 1 and (len(plan) % eff == 0 or len(plan) == steps or plan == [steps])
+    # a short run that fits one launch set is ONE batch (round 4); above the cap it is split evenly over the streams
     assert bench.plan_batches(20, 3, 16) == [7, 7, 6] and bench.plan_batches(96, 3, 16) == [16] * 6
-    assert bench.plan_batches(20, 4, 24) == [7, 7, 6] and bench.plan_batches(192, 4, 24) == [24] * 8 and bench.plan_batches(5, 4, 24) == [5]
+    assert bench.plan_batches(20, 4, 24) == [20] and bench.plan_batches(192, 4, 24) == [24] * 8 and bench.plan_batches(5, 4, 24) == [5]
     assert bench.plan_batches(384, 3, 48) == [43] * 6 + [42] * 3 and bench.plan_batches(384, 3, 64) == [64] * 6
