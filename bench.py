@@ -539,7 +539,12 @@ def main():
     worker = CloudWorker(device, max(S, S_free), host_xyz, rank)
 
     def run_steps(total, upload=False):
-        finished.extend(worker.run(plan_batches(total, S, B), collect=world > 1, upload=upload, streams=S))
+        plan_ = plan_batches(total, S, B)
+        if upload and len(plan_) == 1 and total >= 8 and S > 1:
+            # with the uploads inside the pass, a lone batch would copy all of its clouds before its first kernel: two halves on
+            # two streams instead, the second half's copies overlap the first half's kernels
+            plan_ = [(total + 1) // 2, total // 2]
+        finished.extend(worker.run(plan_, collect=world > 1, upload=upload, streams=S))
 
     def gather():
         if world > 1:

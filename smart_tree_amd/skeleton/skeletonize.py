@@ -153,6 +153,55 @@ class _PackedBranch(BranchSkeleton):
         raise AttributeError(name)
 
 
+class _LazyTrees:
+    """List-like `skeletons` of a materialised DeviceSkeleton: tree i is built from the packed host arrays when somebody
+    asks for it (a cloud has ~170 trees, a batch thousands; building them all at the end of every launch set was ~1.5 ms
+    of interpreter time per 20 clouds, exposed at the tail of a pass).  A tree keeps its identity: the same object comes
+    back on every access, so edits made through it (host-side prune / repair / smooth) stay."""
+
+    def __init__(self, host, lo, hi, parent=None):
+        self._host, self._lo, self._n, self._parent, self._made = host, lo, hi - lo, parent, {}
+
+    def __len__(self):
+        return self._n
+
+    def _make(self, i):
+        t = self._made.get(i)
+        if t is None:
+            xyz_h, rad_h, rows, offs = self._host
+            g = self._lo + i
+            tree = _PackedTree.__new__(_PackedTree)
+            tree._id = i
+            tree._lazy = (xyz_h, rad_h, rows, offs[g], offs[g + 1])
+            if self._parent is not None:  # one cloud of a batch: the batch-level tree may have been read / edited already
+                src = self._parent._made.get(g - self._parent._lo)
+                if src is not None and "_branches" in src.__dict__:
+                    tree.__dict__["_branches"] = src.__dict__["_branches"]
+            self._made[i] = t = tree
+        return t
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self._make(j) for j in range(*i.indices(self._n))]
+        if i < 0:
+            i += self._n
+        if not 0 <= i < self._n:
+            raise IndexError(i)
+        return self._make(i)
+
+    def __iter__(self):
+        return (self._make(i) for i in range(self._n))
+
+    def touched(self) -> bool:
+        """Has anybody read the branch objects of a tree (and perhaps edited them)?"""
+        if any("_branches" in t.__dict__ for t in self._made.values()):
+            return True
+        if self._parent is not None:  # ... or of the batch-level tree this view was cut from
+            lo = self._lo - self._parent._lo
+            return any("_branches" in t.__dict__ for i, t in self._parent._made.items() if lo <= i < lo + self._n)
+        return False
+
+
 class DeviceSkeleton(DisjointTreeSkeleton):
     """A DisjointTreeSkeleton whose branches still live on the GPU as flat arrays.
 
@@ -295,13 +344,7 @@ class DeviceSkeleton(DisjointTreeSkeleton):
         if self._seg is not None:
             self._seg_host = blob[4 * P + 6 * B + T + 1:].view(torch.int32).tolist()
         self._host = (xyz_h, rad_h, rows, offs)
-        trees = []
-        for t in range(T):
-            tree = _PackedTree.__new__(_PackedTree)
-            tree._id = t
-            tree._lazy = (xyz_h, rad_h, rows, offs[t], offs[t + 1])
-            trees.append(tree)
-        return trees
+        return _LazyTrees(self._host, 0, T)
 
     def split(self) -> List[DisjointTreeSkeleton]:
         """Batched clouds: the skeleton of every cloud of the batch, trees renumbered from 0 inside each (what
@@ -314,18 +357,10 @@ class DeviceSkeleton(DisjointTreeSkeleton):
         for b in range(len(seg) - 1):
             part = _CloudSkeleton.__new__(_CloudSkeleton)
             part._dev, part._ops, part._seg, part._seg_host = None, {}, None, None
-            mine = []
-            for local, t in enumerate(trees[seg[b]: seg[b + 1]]):
-                if isinstance(t, _PackedTree):
-                    tree = _PackedTree.__new__(_PackedTree)
-                    tree._lazy = t._lazy
-                    if "_branches" in t.__dict__:  # somebody has read (perhaps edited: host-side prune / repair / smooth) the
-                        tree.__dict__["_branches"] = t.__dict__["_branches"]  # branch objects: the cloud's view keeps them
-                else:
-                    tree = TreeSkeleton(local, t.branches)
-                tree._id = local
-                mine.append(tree)
-            part._trees = mine
+            if isinstance(trees, _LazyTrees):
+                part._trees = _LazyTrees(trees._host, seg[b], seg[b + 1], parent=trees)
+            else:  # the trees were replaced by host objects (skeletons setter): plain copies with local ids
+                part._trees = [TreeSkeleton(local, t.branches) for local, t in enumerate(trees[seg[b]: seg[b + 1]])]
             part._host = self._host
             part._tree_range = (seg[b], seg[b + 1])
             out.append(part)
@@ -335,7 +370,8 @@ class DeviceSkeleton(DisjointTreeSkeleton):
         """What sharding.pack_skeleton builds branch by branch -- (table int64 [B,6], geom float32 [P,4]) -- cut out of
         the packed host arrays with a dozen tensor operations instead of five per branch."""
         trees = self.skeletons
-        if self._host is None or any("_branches" in t.__dict__ for t in trees):
+        edited = trees.touched() if isinstance(trees, _LazyTrees) else True
+        if self._host is None or edited:
             return None  # host-side edits may have happened: the caller walks the objects instead
         xyz_h, rad_h, rows, offs = self._host
         t0, t1 = getattr(self, "_tree_range", (0, len(offs) - 1))  # one cloud of a batch: its slice of the branch table
