@@ -93,6 +93,37 @@ def test_config1_million_point_tree_stagewise():
     assert n_branches > 100
 
 
+def test_config1_batch_of_million_point_trees_against_the_oracle():
+    """Three 1M-point trees (seeds 1-3: 320-545 branches) through ONE launch set -- the helper workgroups of the branch
+    selection's long-path claims are active for a call of this size, on the GPU only -- and every cloud's skeleton equals the
+    oracle's skeleton + post-processing of that cloud's labelled points, branch by branch (ids, parents, coordinates, radii)."""
+    dev = torch.device("cuda:0")
+    pipe = _pipeline(dev, 0.02)
+    clouds = []
+    for seed in (1, 2, 3):
+        c = sample_tree_cloud(1_000_000, seed=seed)
+        clouds.append(Cloud(xyz=torch.from_numpy(c["xyz"]).to(dev), rgb=torch.from_numpy(c["rgb"]).to(dev)))
+    parts = pipe.process_clouds(clouds)
+    lc = pipe.last_labelled_cloud
+    assert len(parts) == 3 and lc.n_seg == 3
+    off = lc.seg_off.cpu().tolist()
+    total = 0
+    for b, got in enumerate(parts):
+        sl = slice(off[b], off[b + 1])
+        trees = po.skeleton_from_labelled(lc.xyz[sl].cpu().numpy(), lc.medial_vector[sl].cpu().numpy(), lc.class_l[sl].cpu().numpy())
+        po.post_process(trees, True, 0.01, 0.02, True, True, 11)
+        assert len(got.skeletons) == len(trees) >= 1
+        for got_tree, rt in zip(got.skeletons, trees):
+            assert list(got_tree.branches) == list(rt.branches)
+            for k, rb in rt.branches.items():
+                gb = got_tree.branches[k]
+                assert gb.parent_id == rb.parent_id
+                np.testing.assert_array_equal(gb.xyz.numpy(), rb.xyz)
+                np.testing.assert_array_equal(gb.radii.numpy(), rb.radii)
+            total += len(rt.branches)
+    assert total > 600
+
+
 def test_config3_dense_canopy_properties():
     """5M points, 60 % foliage, 1 cm voxels: too big for the oracle in seconds -> invariants instead."""
     dev = torch.device("cuda:0")
