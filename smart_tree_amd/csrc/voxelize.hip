@@ -368,14 +368,19 @@ __global__ void __launch_bounds__(VX_BLOCK) k_vx_insert(const float* xyz, int64_
     const int64_t i0 = seg_off ? seg_off[seg] : 0, i1 = seg_off ? seg_off[seg + 1] : n;
     // a table that filled up (the host's capacity guess was too small: it retries with a larger one): stop inserting as soon as
     // the flag is seen (checked where a probe sequence gets long, vx_insert_min)
-    vx_stream_points(xyz, n, i0, i1, [&](int64_t i, float x, float y, float z) {
-        const float pt[3] = {x, y, z};
+    // ONE point per lane and step (the other streaming passes take four: three 16-byte loads): a point's memberships are a
+    // chain of dependent random accesses (slot look-up, compare-and-swap, minimum: ~4 us), and four points per lane in a row
+    // left half the chip's lanes empty while every busy lane walked four such chains (131 -> 100 us per 1M points; what is left
+    // is the pass's ~1M device-scope atomics, ~3 contended look-ups per voxel: cutting the cloud into four launches so that
+    // later points find settled voxels costs more in launches (4 x 27-40 us) than it saves)
+    for (int64_t i = i0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < i1; i += (int64_t)gridDim.x * blockDim.x) {
+        const float pt[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
         vx_for_each_block(pt, st, d, tab, p, [&](int b) {
             int c[3];
             if (!vx_coord(pt, b, blk_lof, blk_grid, p.vs, p.vs_inv, c)) return;
             if (vx_insert_min(slots, cap, st_pack_key(b, c[2], c[1], c[0]), (unsigned)i, &st->overflow) == 0) atomicOr(&st->overflow, 4u);
         });
-    });
+    }
 }
 
 // every occupied slot -> one record (representative point, block).  A workgroup stages the records of a tile of VX_EMIT_TILE
@@ -577,8 +582,12 @@ static int vx_voxelize(const float* xyz, const float* rgb, int64_t n, const int3
                        blk_hi);
     hipLaunchKernelGGL(k_vx_block_grid, dim3((unsigned)st_min64(st_div_up(3 * (int64_t)max_blocks, VX_BLOCK), 64)), dim3(VX_BLOCK), 0, stream,
                        st, max_blocks, (const unsigned*)blk_lo, (const unsigned*)blk_hi, p.vs, blk_lof, blk_grid);
-    hipLaunchKernelGGL(k_vx_insert, gs, dim3(VX_BLOCK), 0, stream, xyz, n, seg_off, st, (const int*)table, p, (const float*)blk_lof,
-                       (const int*)blk_grid, slots, (unsigned long long)cap);
+    {
+        const int64_t per = st_div_up(n > 0 ? n : 1, nseg);
+        const dim3 gi((unsigned)st_min64(st_div_up(per, VX_BLOCK) + 1, 8192), (unsigned)nseg);
+        hipLaunchKernelGGL(k_vx_insert, gi, dim3(VX_BLOCK), 0, stream, xyz, n, seg_off, st, (const int*)table, p, (const float*)blk_lof,
+                           (const int*)blk_grid, slots, (unsigned long long)cap);
+    }
     hipLaunchKernelGGL(k_vx_emit, dim3((unsigned)st_min64(st_div_up(cap, VX_EMIT_TILE), 4096)), dim3(VX_BLOCK), 0, stream,
                        (const VxSlot*)slots, (unsigned long long)cap, st, rec_b, rec_pt, max_voxels);
     if (nseg > 1) hipLaunchKernelGGL(k_vx_seg_vox_init, dim3(1), dim3(128), 0, stream, st, nseg, (const uint32_t*)&st->n_vox);
