@@ -584,6 +584,7 @@ static int vx_voxelize(const float* xyz, const float* rgb, int64_t n, const int3
                        st, max_blocks, (const unsigned*)blk_lo, (const unsigned*)blk_hi, p.vs, blk_lof, blk_grid);
     {
         const int64_t per = st_div_up(n > 0 ? n : 1, nseg);
+        // (every point in flight at once is the fastest: 95 us; 2048 / 1024 / 512 workgroups per cloud: 112 / 127 / 177 us)
         const dim3 gi((unsigned)st_min64(st_div_up(per, VX_BLOCK) + 1, 8192), (unsigned)nseg);
         hipLaunchKernelGGL(k_vx_insert, gi, dim3(VX_BLOCK), 0, stream, xyz, n, seg_off, st, (const int*)table, p, (const float*)blk_lof,
                            (const int*)blk_grid, slots, (unsigned long long)cap);
