@@ -700,12 +700,15 @@ struct SkBm {
     bool in_lds;
     bool agent;  // the component has helper workgroups on other compute units: branch ids are stamped at agent scope
 };
+// (a component too large for the LDS words keeps the set in global memory: at workgroup scope -- this XCD's L2 -- when only its
+// own workgroup touches it, at agent scope when helper workgroups on other compute units stamp it, too)
 __device__ __forceinline__ bool bm_test(const SkBm& B, int v) {
-    const unsigned w = B.in_lds ? B.lds[v >> 5] : ld_wg(&B.glb[v >> 5]);
+    const unsigned w = B.in_lds ? B.lds[v >> 5] : (B.agent ? ld(&B.glb[v >> 5]) : ld_wg(&B.glb[v >> 5]));
     return (w >> (v & 31)) & 1u;
 }
 __device__ __forceinline__ void bm_set(const SkBm& B, int v) {
     if (B.in_lds) atomicOr(&B.lds[v >> 5], 1u << (v & 31));
+    else if (B.agent) (void)atomicOr(&B.glb[v >> 5], 1u << (v & 31));
     else wg_or(&B.glb[v >> 5], 1u << (v & 31));
 }
 // allocation / termination / branch-id stamp of a point (path.py:112-122,135-136).  branch_ids keeps the LAST writer; ids
@@ -989,13 +992,13 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
     B.glb = A.term_bits + (base >> 5) + c;
     const int nwords = (n + 31) >> 5;
     B.in_lds = nwords <= SK_BM_WORDS;
-    const int nhelp = (A.n_helpers > 0 && B.in_lds) ? A.c_nhelp[c] : 0;  // helper workgroups of this component (long-path claims)
+    const int nhelp = A.n_helpers > 0 ? A.c_nhelp[c] : 0;  // helper workgroups of this component (long-path claims)
     B.agent = nhelp > 0;
     SkJob* J = &A.jobs[c];
     unsigned job_seq = 0u;
     if (B.in_lds) for (int i = tid; i < nwords; i += W) bm_words[i] = B.glb[i];
     __syncthreads();
-#define SK_QUIT_HELPERS() do { if (nhelp > 0 && tid == 0) st_au(&J->quit, 1u); } while (0)
+#define SK_QUIT_HELPERS() do { if (A.n_helpers > 0 && A.c_nhelp[c] > 0 && tid == 0) st_au(&J->quit, 1u); } while (0)  // (also when this workgroup does not use them: a component too large for the LDS bitmap)
 #define SK_FLUSH_BM()                                                             \
     do {                                                                          \
         __syncthreads();                                                          \
@@ -1505,7 +1508,7 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
             if (A.ticks && tid == 0) { A.ticks[9] += 1; A.ticks[10] += len; A.ticks[15] += 1; }
             // a heavy claim is shared with the component's helper workgroups (other compute units): each takes an equal share of
             // the cell rows; this workgroup takes the first, waits for the others and folds their termination bits into its bitmap
-            const bool help = nhelp > 0 && (nrows > W / 2 || len > 128);
+            const bool help = nhelp > 0 && (nrows > 128 || len > 64);  // (a job costs ~5-10 us of hand-shake; such a claim > 50 us alone)
             int my_end = nrows;
             if (help) {
                 __syncthreads();  // (the agent-scope stores of the path above have completed)
@@ -1533,7 +1536,7 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
                     }
                 }
                 __syncthreads();
-                for (int i = tid; i < nwords; i += W) bm_words[i] |= ld_au(&B.glb[i]);  // what the helpers terminated
+                if (B.in_lds) for (int i = tid; i < nwords; i += W) bm_words[i] |= ld_au(&B.glb[i]);  // what the helpers terminated
             }
             __syncthreads();
             SK_TICK(6);
