@@ -78,6 +78,7 @@ struct SkArgs {
     unsigned* q0;
     unsigned* q1;
     unsigned* term_bits;  // sample_tree's termination set, one bit per vertex; component c owns the words from (comp_off[c] >> 5) + c
+    unsigned* help_bits;  // the same layout: what helper workgroups terminated (agent scope), folded into term_bits / the LDS copy
     float4* pr;       // [m] (x, y, z, radius) of every vertex in one 16-byte record (k_sk_lift_init): one gather instead of two
     unsigned long long* best;  // claim race: (d2 bits << 32) | path position
     unsigned* touched;
@@ -700,15 +701,15 @@ struct SkBm {
     bool in_lds;
     bool agent;  // the component has helper workgroups on other compute units: branch ids are stamped at agent scope
 };
-// (a component too large for the LDS words keeps the set in global memory: at workgroup scope -- this XCD's L2 -- when only its
-// own workgroup touches it, at agent scope when helper workgroups on other compute units stamp it, too)
+// (a component too large for the LDS words keeps the set in global memory, at workgroup scope -- this XCD's L2: only its own
+// workgroup reads and writes it.  Helper workgroups stamp a SECOND set of words at agent scope, which the component's workgroup
+// folds into its own after every job.)
 __device__ __forceinline__ bool bm_test(const SkBm& B, int v) {
-    const unsigned w = B.in_lds ? B.lds[v >> 5] : (B.agent ? ld(&B.glb[v >> 5]) : ld_wg(&B.glb[v >> 5]));
+    const unsigned w = B.in_lds ? B.lds[v >> 5] : ld_wg(&B.glb[v >> 5]);
     return (w >> (v & 31)) & 1u;
 }
 __device__ __forceinline__ void bm_set(const SkBm& B, int v) {
     if (B.in_lds) atomicOr(&B.lds[v >> 5], 1u << (v & 31));
-    else if (B.agent) (void)atomicOr(&B.glb[v >> 5], 1u << (v & 31));
     else wg_or(&B.glb[v >> 5], 1u << (v & 31));
 }
 // allocation / termination / branch-id stamp of a point (path.py:112-122,135-136).  branch_ids keeps the LAST writer; ids
@@ -945,7 +946,7 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
         const int hbase = A.comp_off[hc], hn = A.comp_off[hc + 1] - hbase;
         const int hxoff = A.comp_seg ? A.comp_seg[hc] * A.grid->seg_dim0 : 0;
         SkBm HB;
-        HB.lds = nullptr; HB.glb = A.term_bits + (hbase >> 5) + hc; HB.in_lds = false; HB.agent = true;
+        HB.lds = nullptr; HB.glb = A.help_bits + (hbase >> 5) + hc; HB.in_lds = false; HB.agent = true;  // (the helpers' own words)
         SkJob* J = &A.jobs[hc];
         unsigned seen = 0u;
         const long long t_start = wall_clock64();
@@ -1536,7 +1537,11 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
                     }
                 }
                 __syncthreads();
-                if (B.in_lds) for (int i = tid; i < nwords; i += W) bm_words[i] |= ld_au(&B.glb[i]);  // what the helpers terminated
+                const unsigned* hw = A.help_bits + (base >> 5) + c;  // what the helpers terminated
+                for (int i = tid; i < nwords; i += W) {
+                    const unsigned w = ld_au(&hw[i]);
+                    if (B.in_lds) bm_words[i] |= w; else if (w) wg_or(&B.glb[i], w);
+                }
             }
             __syncthreads();
             SK_TICK(6);
@@ -1702,7 +1707,7 @@ static void sk_layout(StArena& a, int64_t m, int64_t C, SkLayout* s, int nseg = 
     s->q0 = a.take<unsigned>(sk_queue_words(m, C));  // SSSP frontier: SK_FS shard segments + the overflow area (sk_q_reserve)
     s->q1 = a.take<unsigned>(sk_queue_words(m, C));
     s->touched = a.take<unsigned>(m);
-    s->term_bits = a.take<unsigned>(sk_term_words(m, C));
+    s->term_bits = a.take<unsigned>(2 * sk_term_words(m, C));  // the termination set, then the helpers' words
     s->pr = a.take<float4>(m);
     s->best = a.take<unsigned long long>(m);
     s->anc = a.take<int>((int64_t)SK_ANC * m);
@@ -1849,7 +1854,7 @@ extern "C" int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, c
     A.dist = dist; A.pred = pred; A.root_local = root_local; A.tree_dist = tree_dist;
     A.branch_parent = branch_parent; A.branch_off = branch_off; A.branch_len = branch_len; A.n_branches = n_branches;
     A.path_verts = path_verts; A.branch_of = branch_of;
-    A.dist_ord = s.dist_ord; A.stamp = s.stamp; A.q0 = s.q0; A.q1 = s.q1; A.term_bits = s.term_bits; A.pr = s.pr;
+    A.dist_ord = s.dist_ord; A.stamp = s.stamp; A.q0 = s.q0; A.q1 = s.q1; A.term_bits = s.term_bits; A.help_bits = s.term_bits + sk_term_words(m, n_comp); A.pr = s.pr;
     A.best = s.best; A.touched = s.touched; A.anc = s.anc; A.cnt = s.cnt; A.fcnt = s.cnt + 8;
     A.fseg = (unsigned)sk_fseg(m, n_comp);
     A.s_done = s.s_done; A.s_len = s.s_len; A.s_cur_id = s.s_cur_id; A.s_cur_off = s.s_cur_off; A.s_nb = s.s_nb;
@@ -1997,7 +2002,7 @@ extern "C" int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, c
         for (;;) {  // second pass only if the deferred check found plateau vertices: predecessors completed, selection redone
             (void)hipMemsetAsync(&s.cnt[5], 0, 4 * sizeof(unsigned), stream);  // finished components, branches, path vertices; fcnt[0] = helper time-out flag
             const float* distances = (stages & 2) ? tree_dist : dist;
-            (void)hipMemsetAsync(s.term_bits, 0, sk_term_words(m, n_comp) * sizeof(unsigned), stream);
+            (void)hipMemsetAsync(s.term_bits, 0, 2 * sk_term_words(m, n_comp) * sizeof(unsigned), stream);
             hipLaunchKernelGGL(k_sk_lift_init, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A);
             for (int span = 1; span < SK_ANC; span *= 2)  // direct ancestor table by doubling
                 hipLaunchKernelGGL(k_sk_anc_pass, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A, span);
