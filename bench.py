@@ -62,7 +62,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MAX_BATCH = 64  # clouds per launch set  } measured on one MI355X (tools/sweep_batch.sh, profiles/r02_sweep_batch.txt, 384 steps, final kernels):
 STREAMS = 2     # batches in flight      } phases in turns: voxelise .. network 2 x 64 = 1.29 ms per cloud (3 x 64 the same); voxelise .. adjacency 2 x 64 = 1.32;
 FREE_STREAMS = 3  #                       } free-running: 3 x 64 = 1.25-1.27, 3 x 48 = 1.30, 2 x 64 = 1.29, 4 x 32 = 1.29, 4 x 48 = 1.32
-MAX_DISTINCT = 64  # distinct clouds per rank (BASELINE configs[2]: seeds 0..63); fewer steps -> one cloud per step
+MAX_DISTINCT = int(os.environ.get("ST_BENCH_DISTINCT", "64"))  # distinct clouds per rank (BASELINE configs[2]: seeds 0..63); fewer steps -> one
+#                                                              cloud per step.  ST_BENCH_DISTINCT=4: round 3's four cycled clouds (comparison aid)
 PASSES = 5         # timed passes of K steps; the median is reported
 UPLOAD_PASSES = 3
 SINGLE_CALLS = 7   # process_cloud calls of the single-cloud block

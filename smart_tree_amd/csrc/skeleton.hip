@@ -1498,7 +1498,10 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
         // going at its own pace instead of waiting for the slowest one at every long path.
         // (a path of more than a few vertices that the plain scan below could take goes this way, too, in chunks of eight: 2-3x fewer
         // distance evaluations)
-        if (fits && len > 16 && (small || A.long_mode)) {
+        // (a SHORT path that is not small -- a radius outlier: a few vertices, a metre of reach, more candidates than the plain scan's
+        // budget -- goes this way as well: handing it to k_sk_claim would end the launch for this tree, and in a batch the tree would
+        // wait for every other tree of the launch; configs[3], two canopies side by side: 68 -> one launch)
+        if (fits && (len > 16 ? (small || A.long_mode) : (!small && A.long_mode))) {
             const int csz = len <= 8 * (SK_LPATH / SK_CHUNK) ? 8 : SK_CHUNK;  // vertices per chunk: at most SK_LPATH / SK_CHUNK boxes
             sk_chunk_boxes(L.one, cb_lo, cb_hi, len, csz);
             const int x0 = st_max(s_lo[0] - reach, 0), x1 = st_min(s_hi[0] + reach, g->seg_dim0 - 1);
