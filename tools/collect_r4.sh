@@ -34,5 +34,7 @@ cp gpurun_out/trace_steps20.txt gpurun_out/${tag}_timeline_steps20.txt
 ST_BENCH_DRYRUN=1 ST_BENCH_MIN_UPTIME_S=5 timeout -s KILL 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 16 --warmup 2 > gpurun_out/${tag}_dryrun_2ranks.json 2> gpurun_out/${tag}_dryrun_2ranks.err
 timeout -s KILL 600 python tools/parity_stress.py 300 > gpurun_out/${tag}_parity_stress.txt 2>&1
 tail -2 gpurun_out/${tag}_parity_stress.txt
-( timeout 1200 python -m pytest tests -q -m gpu -x 2>&1 | tail -3 ) > gpurun_out/${tag}_gpu_tests.txt 2>&1
+( for b in 10 12; do echo "== --steps 20 --batch $b"; timeout 300 python bench.py --steps 20 --batch $b --no-cpu-baseline --no-extras 2>/dev/null | python tools/show_bench.py /dev/stdin | head -3; done ) > gpurun_out/${tag}_steps20_plans.txt 2>&1
+( timeout 400 python tools/probe_canopy.py "" "12=256" 2>&1 | grep "^params" ) > gpurun_out/${tag}_canopy_probe_final.txt 2>&1
+( timeout 1500 python -m pytest tests -q -m gpu -x 2>&1 | grep -E "passed|failed|error" | tail -3 ) > gpurun_out/${tag}_gpu_tests.txt 2>&1
 cat gpurun_out/${tag}_gpu_tests.txt
