@@ -662,7 +662,7 @@ def main():
         worker.run([min(B, max(args.steps, 1))], collect=False, streams=1)
         torch.cuda.synchronize()
         profiling.enable(False)
-        full = profiling.roofline(HBM_PEAK_GBS)
+        full = profiling.roofline(HBM_PEAK_GBS, clouds_per_launch=min(B, max(args.steps, 1)))  # (PMC traffic scaled to this batch)
         roof_solo = {"note": "one batch of %d clouds alone on the GPU (untimed extra pass): solo launch durations" % min(B, max(args.steps, 1))}
         roof_solo.update({k: full.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "launches", "avg_us",
                                                   "algorithmic_bytes_per_launch", "branch_selection", "gather_gemm", "all_kernels")})
