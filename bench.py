@@ -240,11 +240,15 @@ class CloudWorker:
     def batch_clouds(self, first, size):
         return [self.clouds[(first + k) % len(self.clouds)] for k in range(size)]
 
-    def upload_batch(self, w, first, size):
-        """Host -> device copies of one batch on worker w's COPY stream (pinned buffers); returns (clouds, event)."""
+    def upload_batch(self, w, first, size, after=None):
+        """Host -> device copies of one batch on worker w's COPY stream (pinned buffers); returns (clouds, event).  `after`: the
+        event of the previous batch's copies -- the batches of a pass go over PCIe one after the other, in batch order, each at the
+        full rate (two batches copying side by side both arrive late)."""
         from smart_tree_amd.data_types.cloud import Cloud
 
         cs = self.copy_streams[w]
+        if after is not None:
+            cs.wait_event(after)
         with torch.cuda.stream(cs):
             out = []
             for k in range(size):
@@ -264,6 +268,7 @@ class CloudWorker:
         starts = np.concatenate([[0], np.cumsum(batches)]).tolist()
         state = {"next": 0, "error": None, "wide_done": None}
         lock = threading.Lock()
+        up_cond, up_state = threading.Condition(), {"next": 0, "event": None}
         finished = []
         # Ordered chip-filling phases (ST_BENCH_ORDERED=1): the batches in flight take turns with the part of the pipeline whose
         # kernels fill the chip (voxelise .. adjacency): two such kernels gain nothing from sharing it, they only make each
@@ -301,7 +306,17 @@ class CloudWorker:
                     # copy stream before this one's kernels, so they overlap (the first upload of a worker overlaps the other
                     # workers' kernels only)
                     mine = list(range(w, len(batches), S)) if upload else None
-                    pending = self.upload_batch(w, starts[mine[0]], batches[mine[0]]) if upload and mine else None
+
+                    def upload_in_turn(i):  # batch i's copies are enqueued after batch i - 1's (host side) and run after them (event)
+                        with up_cond:
+                            while up_state["next"] != i and state["error"] is None:
+                                up_cond.wait(timeout=0.05)
+                            got = self.upload_batch(w, starts[i], batches[i], after=up_state["event"])
+                            up_state["next"], up_state["event"] = i + 1, got[1]
+                            up_cond.notify_all()
+                        return got
+
+                    pending = upload_in_turn(mine[0]) if upload and mine else None
                     turn = 0
                     while True:
                         if upload:
@@ -310,7 +325,7 @@ class CloudWorker:
                             i = mine[turn]
                             turn += 1
                             clouds, ev = pending
-                            pending = self.upload_batch(w, starts[mine[turn]], batches[mine[turn]]) if turn < len(mine) else None
+                            pending = upload_in_turn(mine[turn]) if turn < len(mine) else None
                             self.streams[w].wait_event(ev)
                             for cl in clouds:  # allocated on the copy stream, used on this one
                                 cl.xyz.record_stream(self.streams[w])
@@ -542,9 +557,12 @@ def main():
     def run_steps(total, upload=False):
         plan_ = plan_batches(total, S, B)
         if upload and len(plan_) == 1 and total >= 8 and S > 1:
-            # with the uploads inside the pass, a lone batch would copy all of its clouds before its first kernel: two halves on
-            # two streams instead, the second half's copies overlap the first half's kernels
-            plan_ = [(total + 1) // 2, total // 2]
+            # with the uploads inside the pass, a lone batch would copy all of its clouds before its first kernel: two launch sets on
+            # two streams instead, a small one whose copies are exposed (6 of 20 clouds) and a large one whose copies run under the
+            # small one's kernels.  Measured (profiles/r04_sweep_upload_plans.txt, 20 steps): 10 + 10 2.08-2.13 ms per step,
+            # 6 + 14 1.80-1.84, 4 + 16 1.84-1.86, 8 + 12 1.83-1.86, 2 + 18 1.84-1.88, 3 + 5 + 12 1.87-1.95.
+            k = max(2, int(round(0.3 * total)))
+            plan_ = [k, total - k]
         finished.extend(worker.run(plan_, collect=world > 1, upload=upload, streams=S))
 
     def gather():
