@@ -35,7 +35,11 @@ torch.cuda.synchronize()
 ms = 1e3 * (time.perf_counter() - t0) / (reps * len(clouds))
 print(f"{n} points, voxel {voxel}: {ms:.3f} ms per cloud (one at a time, {reps * len(clouds)} calls); "
       f"{len(sk.skeletons)} trees, {sum(len(t.branches) for t in sk.skeletons)} branches")
-profiling.compute_units(dev)  # (the first device-properties query of a process takes tens of ms: not inside a stage bracket)
+profiling.enable(True)  # one discarded pass with the timers on: their first use pays one-time costs (device query, event pools)
+for cl in clouds:
+    pipe.process_cloud(cloud=cl)
+profiling.stage_ms(len(clouds))
+profiling.enable(False)
 profiling.enable(True)
 for cl in clouds:
     pipe.process_cloud(cloud=cl)
