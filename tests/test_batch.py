@@ -117,6 +117,36 @@ def test_graph_stage_batch_equals_single(backend):
     assert not ((E[:, 0] < off[1]) & (E[:, 1] >= off[1])).any()  # no edge crosses clouds
 
 
+def test_batch_branch_selection_is_one_launch_with_radius_outliers(backend):
+    """In a batch every tree's selection runs to its end inside ONE k_sk_select launch: a tree that left the launch (a path handed
+    to the chip-wide claim) would wait for every other tree of the batch at the launch boundary.  Round 4 regression: SHORT paths
+    with a large reach (a radius outlier: a few vertices, more cell rows than the workgroup has lanes) were handed over --
+    configs[3], two canopies side by side, took three launches.  The result must not depend on any of this."""
+    from smart_tree_amd.skeleton.skeletonize import run_components
+
+    clouds = _clouds(backend, sizes=(2600, 1800))
+    for c in clouds:
+        c.medial_vector[::97] *= 15.0  # ~1 % of the points with a far-too-large radius
+    batch = Cloud.collate(clouds)
+    medial, radius = G.medial_points(batch.xyz, batch.medial_vector)
+    idx = outlier_removal(medial, radius.unsqueeze(1), 8, seg_off=batch.seg_off).nonzero().view(-1)
+    kept = batch.filter(idx)
+    medial, radius = medial[idx], radius[idx]
+    comps = G.nn_graph(medial, radius.clamp(min=0.02), K=16, seg_off=kept.seg_off).connected_cugraph_components(minimum_vertices=32)
+    res = run_components(comps, medial, radius, kept.xyz[:, 1].contiguous(), block_threads=256)
+    assert res.stats["branches"] > 4 and res.stats["select_launches"] == 1
+    off, vso = kept.seg_off.cpu().tolist(), comps.vert_seg_off.cpu().tolist()
+    for s, c in enumerate(clouds):  # ... and every cloud gets what it gets alone
+        m1, r1 = G.medial_points(c.xyz, c.medial_vector)
+        k1 = outlier_removal(m1, r1.unsqueeze(1), 8).nonzero().view(-1)
+        c1 = c.filter(k1)
+        m1, r1 = m1[k1], r1[k1]
+        comps1 = G.nn_graph(m1, r1.clamp(min=0.02), K=16).connected_cugraph_components(minimum_vertices=32)
+        res1 = run_components(comps1, m1, r1, c1.xyz[:, 1].contiguous(), block_threads=256)
+        n1 = int(comps1.vert_order.shape[0])
+        assert _eq(res.branch_of[vso[s]: vso[s] + n1], res1.branch_of[:n1])
+
+
 def _signature(sk):
     out = []
     for tree in sk.skeletons:
