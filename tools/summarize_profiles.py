@@ -19,6 +19,9 @@ for name in (f"{tag}_bench.json", f"{tag}_bench_steps20.json"):  # the default c
 stats = sorted(glob.glob(str(ROOT / "gpurun_out" / f"prof_{tag}" / "*" / "*kernel_stats.csv")), key=os.path.getmtime)
 if stats:
     shutil.copy(stats[-1], out / f"{tag}_kernel_stats.csv")
+stats20 = sorted(glob.glob(str(ROOT / "gpurun_out" / f"prof_{tag}_steps20" / "*" / "*kernel_stats.csv")), key=os.path.getmtime)
+if stats20:  # the DRIVER's command (--steps 20)
+    shutil.copy(stats20[-1], out / f"{tag}_kernel_stats_steps20.csv")
 
 
 def counter(pattern, name):
