@@ -1753,7 +1753,8 @@ static void sk_layout(StArena& a, int64_t m, int64_t C, SkLayout* s, int nseg = 
 //   4 local_items   5 wave_work   6 SSSP levels per frontier launch   7 frontier launches per read-back   8 lanes per vertex
 //   9 length of the first frontier batch (in batches)   10 frontier workgroups   11 claim-grid cell cap (hundredths of the
 //   mean radius)   12 SSSP rounds in one persistent launch with grid barriers (1) or one launch per round (0, default: measured equal for
-//   one cloud, 5 % slower per step with two batches in flight -- the rounds are bound by their ~6 us per level, not by the launches);
+//   one cloud, 1-3 % slower per step for a launch set of 20, 2.4 % with two batches in flight -- the rounds are bound by their ~6 us
+//   per level, not by the launches);
 //   bits 8 ..: 1 + the number of helper workgroups of the branch selection's long-path claims (0 = by size)
 //   13 frontier: 0 = no look before the atomic, else vertices a workgroup relaxes per local level
 //   14 long-path claim inside the workgroup (1, default) or by the local / chip-wide path-centric claims (0)
@@ -1880,9 +1881,10 @@ extern "C" int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, c
 #ifdef ST_HIPEMU
     const bool helpers_avail = false;
 #else
-    // Helper workgroups spin while they wait: fine when the call has the chip to itself (one cloud, one modest batch: -4 % /
-    // -2.4 % per cloud), a loss when another batch's chip-filling kernels want the compute units (two 64-cloud batches in
-    // flight: +5 % per cloud).  By default a call of up to SK_HELP_SEGS clouds uses them; tuning code 12 overrides.
+    // Helper workgroups spin while they wait: fine when the call has the chip to itself (one cloud -4 %, a launch set of 20 clouds
+    // -3 to -6 % per cloud), a loss when another batch's chip-filling kernels want the compute units (two 64-cloud batches in
+    // flight: +3.6 % per cloud; profiles/r04_sweep_code12.txt).  By default a call of up to SK_HELP_SEGS clouds uses them; tuning
+    // code 12 overrides.
     const bool helpers_avail = T.helpers != 0 && block_threads >= 256 && m >= SK_HELP_MIN && (T.helpers > 0 || nseg <= SK_HELP_SEGS);
 #endif
     // Round 4: with helper workgroups for the long-path claims, one cloud alone runs like a batch as well -- one launch to the

@@ -13,7 +13,7 @@ import os
 import threading
 
 DEFAULT = -(1 << 63)  # ST_TUNE_DEFAULT
-KNN_CELL_MEAN_MULT = 12  # pseudo code: hundredths of the mean bound that caps the search-grid cell (-> st_knn_radius_seg)
+KNN_CELL_MEAN_MULT = 16  # pseudo code (outside the library's 0..15): hundredths of the mean bound that caps the search-grid cell (-> st_knn_radius_seg)
 TICKS = 15
 
 _local = threading.local()
