@@ -16,6 +16,13 @@ from smart_tree_amd.skeleton.filter import outlier_removal  # noqa: E402
 from smart_tree_amd.skeleton.skeletonize import STAGE_SSSP, run_components  # noqa: E402
 from smart_tree_amd.synthetic import sample_tree_cloud  # noqa: E402
 
+import ctypes  # noqa: E402
+import os  # noqa: E402
+
+from smart_tree_amd import _lib  # noqa: E402
+
+if os.environ.get("ST_PROBE_LIB"):  # A/B aid: another build of the library (e.g. the previous revision's .so kept under _ab/)
+    _lib._LIB = _lib.declare(ctypes.CDLL(os.environ["ST_PROBE_LIB"]))
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 dev = torch.device("cuda:0")
 pipe = bench.build_pipeline(dev)
@@ -46,4 +53,13 @@ for params in (sys.argv[2:] or [""]):
             res = run_components(comps, medial, radius, ys, stages=STAGE_SSSP)
             torch.cuda.synchronize()
             best = min(best, time.perf_counter() - t0)
-    print(f"params [{params}]: SSSP + predecessors {best * 1e3:.3f} ms (best of 6), rounds {res.stats['sssp_rounds']}", flush=True)
+    full = 1e9
+    with tuning.override(knobs):
+        for _ in range(6):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            res2 = run_components(comps, medial, radius, ys)
+            torch.cuda.synchronize()
+            full = min(full, time.perf_counter() - t0)
+    print(f"params [{params}]: SSSP + predecessors {best * 1e3:.3f} ms (best of 6), rounds {res.stats['sssp_rounds']}; with the branch selection "
+          f"{full * 1e3:.3f} ms ({res2.stats['select_launches']} select launch(es), {res2.stats['branches']} branches)", flush=True)
