@@ -67,6 +67,7 @@ MAX_DISTINCT = int(os.environ.get("ST_BENCH_DISTINCT", "64"))  # distinct clouds
 PASSES = 5         # timed passes of K steps; the median is reported
 UPLOAD_PASSES = 3
 SINGLE_CALLS = 7   # process_cloud calls of the single-cloud block
+REP_SET = 20       # clouds of the ground-truth-medial launch set (representative_inputs)
 ORDERED = int(os.environ.get("ST_BENCH_ORDERED", "3"))  # 3 (default): voxelise .. network of the batches in flight take turns; 1: voxelise .. adjacency; 0: free-running; 2: only the conv sequences
 SHORT_RUN_STEPS = 128  # below this a run is one or two rounds of batches: nothing to take turns with, the batches run free (unless ST_BENCH_ORDERED is set)
 
@@ -123,8 +124,43 @@ def plan_batches(steps: int, streams: int, max_batch: int):
     return [base + (1 if i < extra else 0) for i in range(n_batches)]
 
 
+def literal_query_seconds(xyz, medial_vector, class_l, workers=-1):
+    """BASELINE.md section 2's LITERAL branch query, timed: for every branch the reference's `select_path_points`
+    (skeleton/path.py:19-46) asks for the nearest path vertex of ALL points of the component (`nn(points, path_points, r =
+    max path radius)`, K = 1) -- here scipy's cKDTree over the path, queried with every component point, all cores.  The port
+    (oracle/skeleton_oracle.c so_sample_tree) inverts the query (path vertices look up the points around them in a grid), like
+    the GPU path; both give the same claimed sets.  Returns (seconds of the literal queries, seconds of the port's sample_tree
+    on the same components, branches)."""
+    from scipy.spatial import cKDTree
+
+    from oracle import skeleton_oracle as so
+
+    sel = np.isin(class_l.reshape(-1), (0,))
+    sk = so.skeletonize(xyz[sel], medial_vector[sel])
+    pts_all = (xyz[sel] + medial_vector[sel])[np.nonzero(sk.keep_mask)[0]].astype(np.float32)
+    mv = medial_vector[sel][np.nonzero(sk.keep_mask)[0]]
+    rad_all = np.sqrt((mv * mv).sum(1)).astype(np.float32)
+    t_lit = t_port = 0.0
+    n_br = 0
+    for comp in sk.components:
+        pts, rad = pts_all[comp.vertex_ids], rad_all[comp.vertex_ids]
+        t0 = time.perf_counter()
+        so.sample_tree(pts, rad, comp.preds, comp.tree_dist)
+        t_port += time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for b in comp.branches:
+            path = pts[b.verts]
+            r = float(rad[b.verts].max())
+            d, i = cKDTree(path).query(pts, k=1, distance_upper_bound=r, workers=workers)
+            hit = np.isfinite(d)
+            _ = hit & (d < np.where(hit, rad[b.verts][np.minimum(i, len(path) - 1)], 0.0))  # path.py:35-40
+            n_br += 1
+        t_lit += time.perf_counter() - t0
+    return t_lit, t_port, n_br
+
+
 def cpu_baseline(n_points: int):
-    """The oracle pipeline on the host cores, one full cloud (bounded: ~10 s).  Returns (json entry, oracle trees, labelled)."""
+    """The oracle pipeline on the host cores, one full cloud (bounded: ~10 s).  Returns (json entry, labelled cloud)."""
     from oracle import pipeline_oracle as po
     from oracle import unet_oracle as uo
     from smart_tree_amd.synthetic import sample_tree_cloud
@@ -142,9 +178,16 @@ def cpu_baseline(n_points: int):
     po.post_process(trees)
     dt = time.perf_counter() - t0
     timings["skeleton"], timings["post_process"] = t2 - t1, time.perf_counter() - t2
+    t_lit, t_port, n_br = literal_query_seconds(lc["xyz"], lc["medial_vector"], lc["class_l"])
+    dt_literal = dt - t_port + t_lit
     entry = {"value": n_points / dt, "unit": "points/s", "cores": cores, "kind": "port",
-             "note": "port of the reference algorithm with the per-branch all-points NN query inverted (claim by path "
-                     "vertex) exactly like the GPU path: faster than the literal query, i.e. a conservative baseline",
+             "note": "port of the reference algorithm with an INVERTED branch query (path vertices look up the points around them) and a "
+                     "single-threaded C graph stage; it is NOT the reference's CPU path (the reference has none: spconv / FRNN / cugraph "
+                     "are CUDA-only).  `value_literal_query` is the same run with the branch selection's time replaced by "
+                     "BASELINE.md section 2's literal all-points nearest-path-vertex query per branch (scipy cKDTree, workers = all cores)",
+             "value_literal_query": n_points / dt_literal,
+             "literal_query": {"seconds_literal_queries": round(t_lit, 3), "seconds_port_sample_tree": round(t_port, 3),
+                               "branches": n_br, "seconds_whole_path": round(dt_literal, 2)},
              "sample": f"1 x {n_points}-point synthetic tree (seed 0), full pipeline, {dt:.1f} s; the graph stage of the "
                        "port is single-threaded C, the UNet uses torch-CPU on all cores",
              "stage_s": {k: round(v, 3) for k, v in timings.items()},
@@ -193,20 +236,26 @@ def _gen_cloud(args):
     n_points, seed, j = args
     from smart_tree_amd.synthetic import sample_tree_cloud
 
-    _SHARED[j].numpy()[:] = sample_tree_cloud(n_points, seed=seed)["xyz"]
+    c = sample_tree_cloud(n_points, seed=seed)
+    _SHARED[j].numpy()[:] = c["xyz"]
+    if _SHARED_MV is not None and j < _SHARED_MV.shape[0]:
+        _SHARED_MV[j].numpy()[:] = c["medial_vector"]
     return j
 
 
 _SHARED = None
+_SHARED_MV = None
 
 
-def generate_clouds(n_points: int, seeds, procs: int):
+def generate_clouds(n_points: int, seeds, procs: int, n_mv: int = 0):
     """The synthetic clouds of this rank: [D, n, 3] float32 host tensor, generated by `procs` forked processes BEFORE the
-    process has a GPU context (1.4 s of numpy per 1M-point cloud on one core; rgb is all zeros in the generator)."""
-    global _SHARED
+    process has a GPU context (1.4 s of numpy per 1M-point cloud on one core; rgb is all zeros in the generator).  n_mv: the
+    generator's exact medial vectors of the first n_mv clouds are kept as well ([n_mv, n, 3]; `representative_inputs`)."""
+    global _SHARED, _SHARED_MV
     import multiprocessing as mp
 
     _SHARED = torch.empty((len(seeds), n_points, 3), dtype=torch.float32).share_memory_()
+    _SHARED_MV = torch.empty((min(n_mv, len(seeds)), n_points, 3), dtype=torch.float32).share_memory_() if n_mv > 0 else None
     jobs = [(n_points, int(s), j) for j, s in enumerate(seeds)]
     if procs <= 1 or len(jobs) == 1:
         for job in jobs:
@@ -214,8 +263,8 @@ def generate_clouds(n_points: int, seeds, procs: int):
     else:
         with mp.get_context("fork").Pool(min(procs, len(jobs))) as pool:
             list(pool.imap_unordered(_gen_cloud, jobs))
-    out, _SHARED = _SHARED, None
-    return out
+    out, mv, _SHARED, _SHARED_MV = _SHARED, _SHARED_MV, None, None
+    return (out, mv) if n_mv > 0 else out
 
 
 class CloudWorker:
@@ -468,12 +517,189 @@ def extra_configs(device):
         branches = int(sum(len(t.branches) for sk in sks for t in sk.skeletons))
         out[key] = {"ms_per_cloud": round(ms, 2), "points_per_s": round(n / ms * 1e3), "clouds_per_launch_set": nb,
                     "voxels_per_cloud": int((len(lc._base) if hasattr(lc, "_base") else len(lc)) / nb), "branches_per_cloud": branches / nb,
-                    "skeleton_stage": "runs" if branches else "empty (this checkpoint labels no voxel of the synthetic trees as branch: "
-                                                               "the time is voxelise + network + class filter)",
+                    "skeleton_stage": "runs" if branches else "empty: this checkpoint's log-radius head is a constant (-6.24: 1.9 mm) on the "
+                                                               "synthetic trees, so the outlier filter (8 neighbours within the own radius) "
+                                                               "removes every point -- every voxel IS classed branch; the time is voxelise + "
+                                                               "network + class filter + outlier filter",
                     "gather_gemm": {k: gg.get(k) for k in ("hbm_frac", "achieved_GBps", "useful_TFLOPs", "f32_matrix_frac", "total_ms", "launches")},
                     "stage_ms_per_cloud": profiling.stage_ms(nb)}
         del pipe, clouds
         torch.cuda.empty_cache()
+    return out
+
+
+def _skeleton_signature(trees):
+    """(tree, branch id, parent id, xyz bytes, radii bytes) of every branch: equal signatures = identical skeletons."""
+    sig = []
+    for t, tree in enumerate(trees):
+        for k, b in tree.branches.items():
+            xyz = b.xyz.numpy() if hasattr(b.xyz, "numpy") else b.xyz
+            rad = b.radii.numpy() if hasattr(b.radii, "numpy") else b.radii
+            sig.append((t, int(k), int(b.parent_id), np.ascontiguousarray(xyz, np.float32).tobytes(),
+                        np.ascontiguousarray(rad, np.float32).reshape(-1).tobytes()))
+    return sig
+
+
+def _select_phase_table(ticks) -> dict:
+    """k_sk_select's in-kernel phase timers (tuning code 15; 100 MHz wall clock, summed over the components of the call)."""
+    t = ticks.cpu().numpy()
+    us = lambda i: round(float(t[i]) / 100.0, 1)
+    return {"rounds": int(t[8]), "speculated_slots": int(t[13]), "commits": int(t[12]), "whole_workgroup_claims": int(t[9]),
+            "claims_shared_with_helpers": int(t[14]), "candidates": int(t[11]),
+            "phase_us": {"head": us(0), "window": us(7), "prune": us(1), "walk_rows": us(2), "claim": us(3), "replay_commit": us(4),
+                         "one_mode": us(5), "long_mode": us(6)}}
+
+
+def gt_branch_clouds(device, xyz_list, mv_list, voxel):
+    """Branch clouds with the GENERATOR's exact medial vectors: every cloud centred (CentreCloud) and voxelised on the GPU exactly
+    as ModelInference does, its inner representative points paired with the ground-truth medial vector of that point -- the regime
+    the skeleton stage is built for (reference skeleton/skeletonize.py:33-47: medial points collapsed onto the branch axes)."""
+    from smart_tree_amd.data_types.cloud import Cloud
+    from smart_tree_amd.dataset.augmentations import AugmentationPipeline, CentreCloud
+    from smart_tree_amd.dataset.dataset import voxelize_blocks
+
+    pre = AugmentationPipeline([CentreCloud()])
+    out = []
+    for xyz, mv in zip(xyz_list, mv_list):
+        c = pre(Cloud(xyz=xyz.to(device), rgb=None))
+        vb = voxelize_blocks(c.xyz, None, voxel)
+        keep = vb.mask.bool().nonzero().view(-1)
+        out.append(Cloud(xyz=vb.feats[keep, :3].contiguous(), medial_vector=mv.to(device)[vb.point_index[keep]].contiguous()))
+    return out
+
+
+def representative_inputs(device, host_xyz, host_mv, n_set=20, n_points=N_POINTS, calls=5, check_parity=True, training_scale=True):
+    """The skeleton stage on inputs of the regime the reference runs it in (verdict of round 4: the shipped checkpoints' outputs
+    on the 10 m benchmark tree at 2 cm are far outside their training distribution, so the skeleton stage of the headline consumes
+    an arbitrary graph of a few hundred short branches):
+      (a) configs[1]'s trees with their GROUND-TRUTH medial vectors -> Skeletonizer.forward + post_process: one cloud per call and
+          `n_set` clouds in one launch set; ms, graph size, SSSP rounds, the selection's rounds / phases; the single-call result is
+          compared with the oracle (identical = ids, parents, coordinates, radii of every branch);
+      (b) a tree of the checkpoint's training scale (generator scale 0.3: ~3 m tall; 1 cm voxels, reference conf/training.yaml:18,
+          46-47) through the WHOLE pipeline, compared with the oracle's skeleton of the GPU's labelled cloud, with the network's
+          accuracy against the synthetic ground truth (direction cosine, log-radius) beside it."""
+    from oracle import pipeline_oracle as po
+    from smart_tree_amd import profiling
+    from smart_tree_amd.data_types.cloud import Cloud
+    from smart_tree_amd.dataset.dataset import voxelize_blocks
+    from smart_tree_amd.skeleton import skeletonize, tuning
+    from smart_tree_amd.synthetic import sample_tree_cloud
+
+    out = {}
+    pipe = build_pipeline(device)
+    sk = pipe.skeletonizer
+    n_set = min(n_set, host_xyz.shape[0], host_mv.shape[0])
+    clouds = gt_branch_clouds(device, [host_xyz[j] for j in range(n_set)], [host_mv[j] for j in range(n_set)], VOXEL)
+
+    def run(cloud):
+        s = sk.forward(cloud)
+        pipe.post_process(s)
+        _ = s.skeletons  # materialise: device post-processing, one device-to-host copy
+        parts = s.split()
+        torch.cuda.synchronize()
+        return s, parts
+
+    def timed(cloud, reps):
+        run(cloud)
+        ms = []
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run(cloud)
+            ms.append(1e3 * (time.perf_counter() - t0))
+        return sorted(ms)[len(ms) // 2]
+
+    def profile(cloud, n_clouds):
+        ticks = torch.zeros(32, dtype=torch.int64, device=device)
+        skeletonize.reset_helper_stats()
+        profiling.family_mode(False)
+        profiling.enable(True)
+        with tuning.override({tuning.TICKS: ticks.data_ptr()}):
+            s, parts = run(cloud)
+        profiling.enable(False)
+        table = _select_phase_table(ticks)
+        rows = profiling.kernel_table()
+        sel = rows.get("k_sk_select")
+        hs = skeletonize.helper_stats()
+        return s, parts, {"stage_ms_per_cloud": profiling.stage_ms(n_clouds), "select": table,
+                          "select_launch_ms": None if sel is None else round(sel["total_ms"], 3),
+                          "select_algorithmic_bytes": None if sel is None else sel["bytes_per_launch"] * sel["launches"],
+                          "helpers": hs}
+
+    # (a) one cloud per call
+    ms1 = timed(clouds[0], calls)
+    s, parts, prof = profile(clouds[0], 1)
+    entry = {"what": "Skeletonizer.forward + post_process on the seed-0 tree's inner voxel representatives with the generator's exact "
+                     "medial vectors; median of %d calls, results on the host" % calls,
+             "ms": round(ms1, 3), "graph_vertices": int(len(clouds[0])), "trees": len(s.skeletons),
+             "branches": int(sum(len(t.branches) for t in s.skeletons)), **prof}
+    if check_parity:
+        c0 = clouds[0]
+        trees = po.skeleton_from_labelled(c0.xyz.cpu().numpy(), c0.medial_vector.cpu().numpy(), np.zeros((len(c0), 1), np.float32))
+        po.post_process(trees)
+        entry["parity"] = "identical" if _skeleton_signature(s.skeletons) == _skeleton_signature(trees) else "DIFFERENT"
+        entry["oracle_branches"] = int(sum(len(t.branches) for t in trees))
+    out["configs[1] tree, ground-truth medial vectors, one cloud per call"] = entry
+    # (a) n_set clouds in one launch set
+    if n_set > 1:
+        batch = Cloud.collate(clouds)
+        msb = timed(batch, 3)
+        s, parts, prof = profile(batch, n_set)
+        same_first = _skeleton_signature(parts[0].skeletons) == _skeleton_signature(
+            run(clouds[0])[0].skeletons)
+        out["configs[1] trees (seeds 0..%d), ground-truth medial vectors, one launch set" % (n_set - 1)] = {
+            "clouds": n_set, "ms_per_set": round(msb, 3), "ms_per_cloud": round(msb / n_set, 3), "graph_vertices": int(len(batch)),
+            "branches": int(sum(len(t.branches) for p_ in parts for t in p_.skeletons)),
+            "first_cloud_equals_its_single_call": bool(same_first), **prof}
+    del clouds
+    if not training_scale:
+        return out
+    # (b) a tree of the training scale through the whole pipeline
+    c = sample_tree_cloud(n_points, seed=0, scale=0.3)
+    pipe1 = build_pipeline(device, voxel=0.01)
+    cloud = Cloud(xyz=torch.from_numpy(c["xyz"]).to(device), rgb=torch.from_numpy(c["rgb"]).to(device))
+    pipe1.process_cloud(cloud=cloud)
+    ms = []
+    for _ in range(calls):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        skel = pipe1.process_cloud(cloud=cloud)
+        torch.cuda.synchronize()
+        ms.append(1e3 * (time.perf_counter() - t0))
+    profiling.family_mode(False)
+    profiling.enable(True)
+    skel = pipe1.process_cloud(cloud=cloud)
+    torch.cuda.synchronize()
+    profiling.enable(False)
+    stage = profiling.stage_ms(1)
+    lc = pipe1.last_labelled_cloud
+    xyz, mv, cls = lc.xyz.cpu().numpy(), lc.medial_vector.cpu().numpy(), lc.class_l.cpu().numpy()
+    entry = {"what": "sample_tree_cloud(%d, seed 0, scale 0.3) -- a ~3 m tree, the size of the checkpoint's 4 m training crops -- at 1 cm "
+                     "voxels through Pipeline.process_cloud (cloud resident in HBM); median of %d calls" % (n_points, calls),
+             "ms": round(sorted(ms)[len(ms) // 2], 3), "voxels_inner": int(len(lc)),
+             "branch_voxels": int((cls.reshape(-1) == 0).sum()), "trees": len(skel.skeletons),
+             "branches": int(sum(len(t.branches) for t in skel.skeletons)), "stage_ms": stage}
+    # the network against the synthetic ground truth of the same representative points
+    pre = pipe1.preprocessing(cloud)
+    vb = voxelize_blocks(pre.xyz, None, 0.01)
+    keep = vb.mask.bool().nonzero().view(-1)
+    if int(keep.shape[0]) == len(lc):
+        gt = torch.from_numpy(c["medial_vector"]).to(device)[vb.point_index[keep]].cpu().numpy().astype(np.float64)
+        r_gt, r_net = np.linalg.norm(gt, axis=1), np.linalg.norm(mv.astype(np.float64), axis=1)
+        ok = (r_gt > 0) & (r_net > 0) & np.isfinite(r_net)
+        cos = np.sum(gt[ok] * mv[ok], axis=1) / (r_gt[ok] * r_net[ok])
+        lr_gt, lr_net = np.log(r_gt[ok]), np.log(r_net[ok])
+        entry["network_vs_ground_truth"] = {
+            "direction_cosine_mean": float(np.mean(cos)), "direction_cosine_median": float(np.median(cos)),
+            "log_radius_median_net": float(np.median(lr_net)), "log_radius_median_truth": float(np.median(lr_gt)),
+            "log_radius_correlation": float(np.corrcoef(lr_gt, lr_net)[0, 1]) if ok.sum() > 2 else None,
+            "log_radius_abs_err_median": float(np.median(np.abs(lr_net - lr_gt))),
+            "classed_branch_fraction": float((cls.reshape(-1) == 0).mean())}
+    if check_parity:
+        trees = po.skeleton_from_labelled(xyz, mv, cls)
+        po.post_process(trees)
+        entry["parity"] = "identical" if _skeleton_signature(skel.skeletons) == _skeleton_signature(trees) else "DIFFERENT"
+    out["training-scale tree (scale 0.3, 1 cm), whole pipeline"] = entry
     return out
 
 
@@ -499,7 +725,10 @@ def main():
     # pass is a different cloud (BASELINE configs[2]: seeds 0..63; rank r draws r * D .. r * D + D - 1, rank 0's first is seed 0)
     n_distinct = max(1, min(MAX_DISTINCT, args.steps))
     t_gen = time.perf_counter()
-    host_xyz = generate_clouds(args.points, [rank * n_distinct + j for j in range(n_distinct)], max(1, usable_cores() // max(world, 1)))
+    want_rep = world == 1 and not args.no_extras
+    n_rep = min(REP_SET, n_distinct) if want_rep else 0
+    gen = generate_clouds(args.points, [rank * n_distinct + j for j in range(n_distinct)], max(1, usable_cores() // max(world, 1)), n_mv=n_rep)
+    host_xyz, host_mv = gen if n_rep > 0 else (gen, None)
     t_gen = time.perf_counter() - t_gen
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     # ST_BENCH_DRYRUN=1 (developer aid): exercise the multi-rank control flow on a box with ONE GPU -- every rank uses
@@ -581,38 +810,42 @@ def main():
     # batch still grows during the next few (hipMalloc synchronises the device: measured 2.1 instead of 1.55 ms per cloud
     # when the timed region started after one warm-up batch per stream)
     plan = plan_batches(args.steps, S, B)
-    warm = max(args.warmup, sum(plan)) if args.warmup > 0 and plan else 0
-    if warm:
-        finished.extend(worker.run(plan + plan_batches(warm - sum(plan), S, B), collect=world > 1, streams=S))
-        # ... repeated until two consecutive passes agree to 5 %: a process that starts right
-        # after another GPU process has exited runs with inflated host round trips for its first seconds (measured on the
-        # gpurun boxes: 3.0 instead of 1.55 ms per cloud, gone a few seconds later).  Warm-up is untimed; the K steps
-        # are timed once.
-        # ... and for at least MIN_UPTIME seconds of process life.  Measured on the gpurun boxes (profiles/
-        # r02_after_another_process.txt): in the round-end sequence pytest -> smoke -> bench the passes of the first ~15-20 s
-        # agree with each other at 2.5-2.9 ms per cloud (the two-passes-agree rule alone stopped there) and then drop to 1.3.
+    # SETTLE (untimed, reported as `settle_s` / `settle_steps`; not the warm-up the flag asks for): whole passes over the very batches
+    # the timed region will run, until two consecutive passes agree to 5 % AND the process is MIN_UPTIME seconds old.  Why: every
+    # stream has its own allocator pool, and batches differ a little in their voxel / vertex counts -- a pool that has seen only
+    # one batch still grows during the next few (hipMalloc synchronises the device: measured 2.1 instead of 1.55 ms per cloud when
+    # the timed region started after one warm-up batch per stream); and a process that starts right after another GPU process has
+    # exited -- the round-end sequence pytest -> smoke -> bench -- runs with inflated host round trips for its first ~15-20 s on the
+    # gpurun boxes (profiles/r02_after_another_process.txt: passes agree with each other at 2.5-2.9 ms per cloud, then drop to 1.3).
+    settle_steps, t_settle = 0, time.perf_counter()
+    warm_last_ms = None
+    if plan and MIN_UPTIME >= 0:
         prev = None
         while True:
-            finished.clear()  # (multi-rank: only the last warm-up pass is gathered)
+            finished.clear()  # (multi-rank: only the last pass is gathered)
             profiling.family_mode(True)
-            profiling.enable(True)  # the warm-up passes run exactly what the timed pass runs, kernel timers included
+            profiling.enable(True)  # the settle passes run exactly what the timed pass runs, kernel timers included
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             finished.extend(worker.run(plan, collect=world > 1, streams=S))
             torch.cuda.synchronize()
             cur = time.perf_counter() - t0
-            warm += sum(plan)
+            settle_steps += sum(plan)
             uptime = time.perf_counter() - T_PROCESS
             if (prev is not None and abs(cur - prev) <= 0.05 * prev and uptime >= MIN_UPTIME) or uptime > MIN_UPTIME + 45.0:
                 break
             prev = cur
         profiling.enable(False)
         warm_last_ms = 1e3 * cur / max(sum(plan), 1)
-    else:
-        warm_last_ms = None
+    settle_s = time.perf_counter() - t_settle
+    # WARM-UP: exactly --warmup steps, untimed, right before the timed region
+    warm = max(0, int(args.warmup))
+    if warm:
+        finished.clear()
+        finished.extend(worker.run(plan_batches(warm, S, B), collect=world > 1, streams=S))
     gather()
     fence()
-    single = worker.single_cloud() if warm > 0 and world == 1 else None
+    single = worker.single_cloud() if world == 1 else None
     fence()
     # kernel timers of the timed region: the convolutions of a forward pass are bracketed ONCE as a family (a pair of events
     # around each of the 26 launches cost ~10 us apiece between kernels that otherwise run back to back); the per-class table
@@ -713,7 +946,13 @@ def main():
                        "parallelism": f"cloud-sharded x{world}",
                        "clouds_per_launch_set": max(batches), "batches_in_timed_region": len(batches),
                        "batches_in_flight_per_gpu": S, "host_threads_per_gpu": S,
-                       "warmup_requested": args.warmup, "warmup_steps_run": warm,
+                       "settle_s": round(settle_s, 1), "settle_steps": settle_steps,
+                       "settle_note": "untimed passes over the timed region's own batches before the --warmup steps, until two passes agree "
+                                      "to 5 % and the process is `warmup_until_process_age_s` old (allocator pools, clock ramp after "
+                                      "another GPU process)",
+                       "value_incl_host_upload": world * args.steps * args.points / dt_up,
+                       "ms_per_step_incl_host_upload": 1e3 * dt_up / args.steps,
+                       "single_cloud_ms": None if single is None else single["ms"],
                        "schedule": {1: "the chip-filling phases (voxelise .. adjacency) of the batches in flight take turns; a batch's "
                                        "skeleton stage (one compute unit per tree) overlaps with the other batch's chip-filling phase",
                                     3: "the batches in flight take turns with voxelise .. network (half a phase apart): a batch's searches / "
@@ -741,8 +980,11 @@ def main():
             out["cpu_baseline"] = entry
             out.update(parity_in_run(worker.pipes[0], worker.clouds[0], cpu_lc))
         if world == 1 and not args.no_extras:
+            from smart_tree_amd.skeleton import skeletonize
+            out["helper_workgroups"] = skeletonize.helper_stats()  # lost > 0: a fall-back of the helper protocol ran (slower, not wrong)
             del worker
             torch.cuda.empty_cache()
+            out["representative_inputs"] = representative_inputs(device, host_xyz, host_mv, n_set=n_rep, n_points=args.points)
             out["other_configs"] = extra_configs(device)
         print(json.dumps(out))
     if world > 1:

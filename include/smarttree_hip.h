@@ -169,7 +169,8 @@ int64_t st_component_csr_workspace_bytes(int64_t m);
 int st_component_csr(const int64_t* edges, const float* w, int64_t E, const int32_t* new_id, int64_t m, uint32_t* row_off,
                      uint32_t* col, float* wgt, void* ws, int64_t ws_bytes, void* stream);
 int64_t st_skeleton_workspace_bytes(int64_t m, int64_t n_comp);
-/* stats_host[6] = branches of the cloud | path vertices << 32 (sample_tree stage).
+/* stats_host: optional, 16 x int64 (see csrc/skeleton.hip): [0] SSSP rounds .. [6] = branches of the cloud | path vertices << 32
+ * (sample_tree stage), [7] in: time the select launches, [8] helper workgroups were lost (fall-back ran), [9] helper workgroups launched.
  * comp_size_host is unused and may be NULL (the claim grid is laid out on the device from comp_off); grid_cell < 0:
  * cell = max(max(rad) / -grid_cell, 1e-4) with the maximum reduced on the device -- neither costs the caller a read-back */
 int st_skeleton_components(int n_comp, const int32_t* comp_off, const int32_t* comp_size_host, int64_t m, const float* pts,
@@ -279,7 +280,7 @@ int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, const int32_
                                int block_threads, float* dist, int32_t* pred, int32_t* root_local, float* tree_dist,
                                int32_t* branch_parent, int32_t* branch_off, int32_t* branch_len, int32_t* n_branches,
                                int32_t* path_verts, int32_t* branch_of, int64_t* stats_host, void* ws, int64_t ws_bytes,
-                               void* stream, const int64_t* tuning /*NULL = defaults; 16 entries, see csrc/skeleton.hip "Tuning of
+                               void* stream, const int64_t* tuning /*NULL = defaults; 24 entries, see csrc/skeleton.hip "Tuning of
                                one call": per-call strategy / sweep knobs (no process-global state)*/);
 int st_post_process_seg(int n_trees, const int32_t* tree_off, const int32_t* parent, const int32_t* start, const int32_t* len,
                         float* xyz, const float* rad_in, float* rad_out, uint8_t* keep, uint8_t* repaired, uint8_t* smoothed,

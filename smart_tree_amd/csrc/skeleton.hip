@@ -28,6 +28,8 @@
 #include "st_common.h"
 #include "st_grid.h"
 
+#include <atomic>
+
 #define SK_MAX_WAVES 16
 #define SK_EMPTY64 0xffffffffffffffffull
 #define SK_WIDE_BLOCK 256  // block size of the vertex / frontier kernels
@@ -44,7 +46,7 @@ struct SkJob {
     int len, id, csz, nrows, ny, x0, y0, z0, z1, path_off;
     float rp;
     unsigned gone;  // a helper left because its life time ran out: the component's workgroup posts no more jobs
-    unsigned pad;
+    unsigned alive;  // the component's workgroup is resident (a helper that never sees it gives up after `help_announce`)
 };
 
 struct SkArgs {
@@ -118,6 +120,7 @@ struct SkArgs {
     const int* hl_rank;   // [n_helpers] its rank among that component's helpers (1 ..)
     const int* c_nhelp;   // [C] helpers of a component
     struct SkJob* jobs;   // [C]
+    long long help_lifetime, help_timeout, help_announce;  // time-outs of the helper protocol, ticks of the 100 MHz wall clock
     long long* ticks;  // optional developer aid: per-phase wall_clock64 sums of k_sk_select (tuning[15])
 };
 
@@ -911,14 +914,25 @@ __device__ __forceinline__ void st_ai(int* p, int v) { __hip_atomic_store(p, v, 
 __device__ __forceinline__ int ld_ai(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned ld_au(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_au(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// Time-outs of the helper protocol (100 MHz wall clock).  They exist so that a workgroup that never becomes resident cannot hang the
-// GPU; neither is an error: a helper whose life time ran out says so (`gone`) and leaves, a component's workgroup that waits too long
-// for an answer claims the helpers' shares itself (the stamps are idempotent: bits are ORed, branch ids are a maximum) and goes on
-// without helpers.  A select launch of a very large cloud may legitimately last seconds: the life time is generous.
-#ifndef SK_HELP_LIFETIME  // (a test build shortens both to exercise the fall-backs: tools/run_helper_loss_test.sh)
-#define SK_HELP_LIFETIME 3000000000ll  // 30 s
-#define SK_HELP_TIMEOUT 500000000ll    // 5 s waiting for one job's answers
-#endif
+// Time-outs of the helper protocol (100 MHz wall clock; SkArgs.help_*; tuning codes 16-18 in microseconds).  They exist so that a
+// workgroup that never becomes resident cannot hang the GPU; none is an error: a helper whose life time ran out -- or whose component's
+// workgroup has not announced itself (`alive`) within `help_announce`: the chip is full of other work, the helper only takes a
+// compute unit away from it -- says so (`gone`) and leaves; a component's workgroup that waits too long for an answer claims the
+// helpers' shares itself (the stamps are idempotent: bits are ORed, branch ids are a maximum) and goes on without helpers.  A select
+// launch of a very large cloud may legitimately last seconds: the life time is generous.  tests/test_helpers.py shortens all three
+// to exercise every fall-back against the shipped library.
+#define SK_HELP_LIFETIME_US 30000000ll  // 30 s
+#define SK_HELP_TIMEOUT_US 5000000ll    // 5 s waiting for one job's answers
+#define SK_HELP_ANNOUNCE_US 50000ll     // 50 ms for the component's workgroup to become resident
+
+// Ordering across compute units (helper protocol).  Everything a helper and its component's workgroup exchange is written and read
+// with agent-scope atomics (served at the memory side, never from a stale L2 line of another XCD), but a RELAXED atomic only says
+// where an access is performed, not when: stores and no-return atomics of a wavefront may still be in flight when a later store of
+// ANOTHER wavefront (the `done` count, the `seq` word) becomes visible -- s_barrier does not wait for vector memory.  So: every
+// wavefront that wrote payload issues an agent-scope release fence (s_waitcnt vmcnt(0) + write-back) BEFORE the workgroup barrier in
+// front of the flag, the flag is written with release semantics, and the reader fences with acquire after it has seen the flag.
+__device__ __forceinline__ void sk_release_agent() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }
+__device__ __forceinline__ void sk_acquire_agent() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
 
 __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
     long long t_last = A.ticks ? wall_clock64() : 0;
@@ -962,15 +976,19 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
             if (tid == 0) {
                 h_seq = ld_au(&J->seq);
                 unsigned q_ = ld_au(&J->quit);
-                if (!q_ && wall_clock64() - t_start > SK_HELP_LIFETIME) { st_au(&J->gone, 1u); q_ = 1u; }
+                if (!q_) {
+                    const long long waited = wall_clock64() - t_start;
+                    if (waited > A.help_lifetime || (waited > A.help_announce && !ld_au(&J->alive))) { st_au(&J->gone, 1u); q_ = 1u; }
+                }
                 h_quit = q_;
             }
             __syncthreads();
             const unsigned sq = h_seq, qt = h_quit;
             __syncthreads();
             if (qt != 0u) return;
-            if (sq == seen) { __builtin_amdgcn_s_sleep(8); continue; }
+            if (sq == seen) { __builtin_amdgcn_s_sleep(16); continue; }
             seen = sq;
+            sk_acquire_agent();  // pairs with the release store of `seq`: the job words and the path are visible
             const int len = ld_ai(&J->len), id = ld_ai(&J->id), csz = ld_ai(&J->csz), nrows = ld_ai(&J->nrows), ny = ld_ai(&J->ny);
             const int x0 = ld_ai(&J->x0), y0 = ld_ai(&J->y0), z0 = ld_ai(&J->z0), z1 = ld_ai(&J->z1), poff = ld_ai(&J->path_off);
             const float rp = __uint_as_float((unsigned)ld_ai((const int*)&J->rp));
@@ -985,8 +1003,9 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
             const int per = (nrows + nranks - 1) / nranks;
             const int rb = rank * per, re = rb + per < nrows ? rb + per : nrows;
             sk_long_rows<true>(A, HB, L.one, cb_lo, cb_hi, s_scan, hbase, hn, hxoff, x0, y0, z0, z1, ny, rb, re, len, csz, rp * rp, id);
-            __syncthreads();  // every stamp of this workgroup has completed
-            if (tid == 0) (void)atomicAdd(&J->done, 1u);
+            sk_release_agent();  // EVERY wavefront: its stamps (no-return atomics) have been performed ...
+            __syncthreads();     // ... before any wavefront is past this barrier
+            if (tid == 0) (void)__hip_atomic_fetch_add(&J->done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     const int c = (int)blockIdx.x - A.n_helpers;
@@ -1009,6 +1028,7 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
     SkJob* J = &A.jobs[c];
     unsigned job_seq = 0u;
     if (B.in_lds) for (int i = tid; i < nwords; i += W) bm_words[i] = B.glb[i];
+    if (nhelp > 0 && tid == 0) st_au(&J->alive, 1u);  // (a helper that does not see this within `help_announce` gives up)
     __syncthreads();
 #define SK_QUIT_HELPERS() do { if (A.n_helpers > 0 && A.c_nhelp[c] > 0 && tid == 0) st_au(&J->quit, 1u); } while (0)  // (also when this workgroup does not use them: a component too large for the LDS bitmap)
 #define SK_FLUSH_BM()                                                             \
@@ -1527,8 +1547,12 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
             int my_end = nrows;
             if (help) {
                 if (tid == 0) s_lost = ld_au(&J->gone);
-                __syncthreads();  // (the agent-scope stores of the path above have completed)
-                if (s_lost) { help = false; nhelp = 0; }  // (uniform) a helper's life time ran out: alone from here on
+                sk_release_agent();  // EVERY wavefront: its agent-scope stores of the path above have been performed ...
+                __syncthreads();     // ... before thread 0 publishes the job below
+                if (s_lost) {  // (uniform) a helper's life time ran out: alone from here on
+                    if (tid == 0) { st_au(&J->quit, 1u); st_au(&A.fcnt[0], 1u); }
+                    help = false; nhelp = 0;
+                }
             }
             if (help) {
                 if (tid == 0) {
@@ -1536,8 +1560,8 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
                     st_ai(&J->x0, x0); st_ai(&J->y0, y0); st_ai(&J->z0, z0); st_ai(&J->z1, z1); st_ai(&J->path_off, cur_off);
                     st_ai((int*)&J->rp, (int)__float_as_uint(rp));
                     st_au(&J->done, 0u);
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (waits for the stores above; they are write-through)
-                    st_au(&J->seq, ++job_seq);
+                    // release: the job words (and, through the barrier above, the path) are performed before `seq` can be seen
+                    __hip_atomic_store(&J->seq, ++job_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                     if (A.ticks) A.ticks[14] += 1;
                 }
                 my_end = (nrows + nhelp) / (nhelp + 1);
@@ -1551,13 +1575,14 @@ __global__ void __launch_bounds__(1024) k_sk_select(SkArgs A) {
                     const long long t0 = wall_clock64();
                     unsigned lost = 0u;
                     while (ld_au(&J->done) < (unsigned)nhelp) {
-                        __builtin_amdgcn_s_sleep(2);
-                        if (ld_au(&J->gone) != 0u || wall_clock64() - t0 > SK_HELP_TIMEOUT) { lost = 1u; break; }
+                        __builtin_amdgcn_s_sleep(12);  // (the helpers write to this line: do not hammer it)
+                        if (ld_au(&J->gone) != 0u || wall_clock64() - t0 > A.help_timeout) { lost = 1u; break; }
                     }
                     s_lost = lost;
                     if (lost) { st_au(&J->quit, 1u); st_au(&A.fcnt[0], 1u); }  // (fcnt[0]: a statistic -- helpers were lost in this call)
                 }
                 __syncthreads();
+                sk_acquire_agent();  // pairs with the helpers' release of `done`: their termination bits and branch ids are visible
                 if (s_lost) {  // (uniform) the answers did not come: claim the helpers' shares here -- whatever a late helper still
                     // stamps is what this workgroup stamps, too -- and go on without helpers
                     sk_long_rows<false>(A, B, L.one, cb_lo, cb_hi, s_scan, base, n, xoff, x0, y0, z0, z1, ny, my_end, nrows, len, csz, rp2, id);
@@ -1783,13 +1808,17 @@ static void sk_layout(StArena& a, int64_t m, int64_t C, SkLayout* s, int nseg = 
 //   13 frontier: 0 = no look before the atomic, else vertices a workgroup relaxes per local level
 //   14 long-path claim inside the workgroup (1, default) or by the local / chip-wide path-centric claims (0)
 //   15 device pointer of 32 int64 phase timers / counters of k_sk_select
+//   16 / 17 / 18 time-outs of the helper protocol in microseconds: a helper's life time, a component's wait for one job's answers,
+//   a helper's wait for its component's workgroup to announce itself (tests/test_helpers.py drives every fall-back with them)
 #define ST_TUNE_DEFAULT INT64_MIN
+#define ST_TUNE_ENTRIES 24
 #define SK_MAX_LAUNCH_BATCH 32
 struct SkTuning {
     float prune_factor = 1.0f, grid_mean_mult = 1.0f;
     int small_work = SK_SMALL_WORK, iters_per_launch = SK_ITERS_PER_LAUNCH, launch_batch = 24, local_items = 0, wave_work = SK_WAVE_WORK, long_mode = 1;
     int sssp_hops = 4, sssp_batch = 32, sssp_lanes = 32, sssp_first = 2, sssp_blocks = SK_SSSP_BLOCKS, sssp_lcap = SK_LQ;
     int sssp_coop = 0, helpers = -1;  // helpers: -1 = by size, else the number of helper workgroups of a select launch
+    long long help_lifetime_us = SK_HELP_LIFETIME_US, help_timeout_us = SK_HELP_TIMEOUT_US, help_announce_us = SK_HELP_ANNOUNCE_US;
     bool small_work_set = false, iters_set = false, long_set = false, launch_set = false;
     long long* ticks = nullptr;
     explicit SkTuning(const int64_t* t) {
@@ -1811,7 +1840,35 @@ struct SkTuning {
         if (has(13)) sssp_lcap = t[13] == 0 ? -SK_LQ : (t[13] > SK_LQ ? SK_LQ : (int)t[13]);
         if (has(14)) { long_mode = t[14] != 0; long_set = true; }
         if (has(15)) ticks = (long long*)(intptr_t)t[15];
+        if (has(16)) help_lifetime_us = t[16] < 0 ? 0 : t[16];
+        if (has(17)) help_timeout_us = t[17] < 0 ? 0 : t[17];
+        if (has(18)) help_announce_us = t[18] < 0 ? 0 : t[18];
     }
+};
+
+// Helper workgroups spin on a compute unit each (k_sk_select holds 142 KB of LDS: one workgroup per compute unit), so their number
+// is bounded by the DEVICE -- at most 5/8 of its compute units (160 of an MI355X's 256; a partition or a smaller part gets fewer, a
+// device of one compute unit none) -- and by what other calls of this process have out at the moment: two helper-enabled calls on
+// different streams share the budget instead of filling the chip with waiting workgroups between them.
+static std::atomic<int> g_helpers_out{0};
+static int sk_helper_cap() {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    const int cap = cus * 5 / 8;
+    return cap < SK_HELP_POOL ? cap : SK_HELP_POOL;
+}
+struct SkHelperLease {  // returned on every way out of the call
+    int n = 0;
+    int take(int want) {
+        const int cap = sk_helper_cap();
+        int cur = g_helpers_out.load();
+        do { n = want < cap - cur ? want : cap - cur; if (n <= 0) { n = 0; return 0; } } while (!g_helpers_out.compare_exchange_weak(cur, cur + n));
+        return n;
+    }
+    ~SkHelperLease() { if (n > 0) g_helpers_out.fetch_sub(n); }
 };
 
 extern "C" int64_t st_skeleton_workspace_bytes_seg(int64_t m, int64_t n_comp, int nseg) {
@@ -1840,10 +1897,11 @@ static int sk_read(void* dst, const void* src, size_t bytes, hipStream_t stream)
 // stages: 1 = roots + SSSP + predecessors, 2 = literal second SSSP into tree_dist, 4 = sample_tree
 // (on tree_dist if stage 2 ran, else on dist -- the two are bit-identical).
 // block_threads: lanes of the per-component select workgroup (0 = 1024).
-// stats_host (optional, 8 x int64): [0] SSSP rounds, [1] plateau rounds, [2] select/claim launch pairs, [3] lifting
+// stats_host (optional, 16 x int64): [0] SSSP rounds, [1] plateau rounds, [2] select/claim launch pairs, [3] lifting
 // levels; if stats_host[7] != 0 on entry, every k_sk_select launch is bracketed by HIP events on `stream` and
 // [4] = their summed duration in ns, [5] = number of launches (profiling aid for bench.py's roofline block);
-// [6] = branches of the cloud | path vertices << 32 (sizes st_assemble_branches' outputs without a read-back of its own).
+// [6] = branches of the cloud | path vertices << 32 (sizes st_assemble_branches' outputs without a read-back of its own);
+// [8] = 1 if helper workgroups were lost in this call (time-outs: their component's workgroup did the work), [9] = helper workgroups launched.
 //
 // Batched form (st_skeleton_components_seg): the components of `nseg` independent clouds in one call.  comp_seg [C] = cloud
 // of each component, vert_seg_off [nseg + 1] = the clouds' ranges in the renumbered vertex space (both device arrays,
@@ -1859,7 +1917,7 @@ extern "C" int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, c
                                       int64_t ws_bytes, void* stream_, const int64_t* tuning) {
     hipStream_t stream = (hipStream_t)stream_;
     const bool time_select = stats_host && stats_host[7] != 0;
-    if (stats_host) for (int i = 0; i < 7; i++) stats_host[i] = 0;
+    if (stats_host) for (int i = 0; i < 16; i++) if (i != 7) stats_host[i] = 0;
     if (n_comp <= 0 || m <= 0) return ST_OK;
     ST_REQUIRE(!(stages & 2) || tree_dist != nullptr, "skeleton: stage 2 needs a tree_dist buffer");
     if (block_threads <= 0) block_threads = 1024;
@@ -1892,6 +1950,7 @@ extern "C" int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, c
     A.hl_comp = s.hl_comp; A.hl_rank = s.hl_rank; A.c_nhelp = s.c_nhelp; A.jobs = s.jobs; A.n_helpers = 0;
     const SkTuning T(tuning);
     A.ticks = T.ticks;
+    A.help_lifetime = T.help_lifetime_us * 100; A.help_timeout = T.help_timeout_us * 100; A.help_announce = T.help_announce_us * 100;
     A.prune_factor = T.prune_factor; A.small_work = T.small_work; A.iters_per_launch = T.iters_per_launch; A.local_items = T.local_items; A.wave_work = T.wave_work; A.long_mode = T.long_mode;
     // A batch of clouds advances in lockstep: a launch lasts as long as its slowest component, and a component that hands a
     // long path to the chip-wide claim kernel waits for everybody else's rounds.  Fewer hand-overs (the workgroup claims
@@ -1902,15 +1961,16 @@ extern "C" int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, c
     // per cloud at 64 clouds per launch set, 2.00 -> 1.95 at 10).  One cloud alone keeps the chip-wide claim for its long paths
     // (the chip is idle then: 11.2 against 12.0 ms).
     int first_launches = T.launch_batch;
-#ifdef ST_HIPEMU
-    const bool helpers_avail = false;
-#else
     // Helper workgroups spin while they wait: fine when the call has the chip to itself (one cloud -4 %, a launch set of 20 clouds
     // -3 to -6 % per cloud), a loss when another batch's chip-filling kernels want the compute units (two 64-cloud batches in
     // flight: +3.6 % per cloud; profiles/r04_sweep_code12.txt).  By default a call of up to SK_HELP_SEGS clouds uses them; tuning
     // code 12 overrides.
-    const bool helpers_avail = T.helpers != 0 && block_threads >= 256 && m >= SK_HELP_MIN && (T.helpers > 0 || nseg <= SK_HELP_SEGS);
-#endif
+    // (the CPU emulator reports one compute unit and runs workgroups one after the other: sk_helper_cap() == 0, no helpers there)
+    SkHelperLease lease;
+    int helpers_want = 0;
+    if ((stages & 4) && T.helpers != 0 && block_threads >= 256 && m >= SK_HELP_MIN && (T.helpers > 0 || nseg <= SK_HELP_SEGS))
+        helpers_want = T.helpers > 0 ? T.helpers : (int)st_min64(SK_HELP_POOL, m / SK_HELP_PER);
+    const bool helpers_avail = lease.take(helpers_want) > 0;
     // Round 4: with helper workgroups for the long-path claims, one cloud alone runs like a batch as well -- one launch to the
     // end, long paths claimed inside the launch (6.3 ms against 6.6 with the chip-wide claim at the launch boundaries).
     if (nseg > 1 || helpers_avail) {
@@ -2003,13 +2063,8 @@ extern "C" int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, c
         const int nblk = (int)st_min64((int64_t)n_comp + st_div_up(m, 1024), (int64_t)n_comp * SK_MAX_CLAIM_BLOCKS);
         hipLaunchKernelGGL(k_sk_blk_tables, dim3(1), dim3(1024), 0, stream, A, s.blk_comp, s.blk_first, s.blk_count, nblk);
         // helper workgroups of the long-path claims (they sit in front of the components' workgroups in the grid, so they are
-        // resident before any component can wait for them; the CPU emulator runs workgroups one after the other: none there)
-#ifdef ST_HIPEMU
-        A.n_helpers = 0;
-#else
-        A.n_helpers = !helpers_avail ? 0 : (T.helpers >= 0 ? (T.helpers < SK_HELP_POOL ? T.helpers : SK_HELP_POOL)
-                                                           : (int)st_min64(SK_HELP_POOL, m / SK_HELP_PER));
-#endif
+        // normally resident before any component can wait for them; if not, the time-outs above apply)
+        A.n_helpers = lease.n;
         hipLaunchKernelGGL(k_sk_helper_tables, dim3(1), dim3(64), 0, stream, A, s.hl_comp, s.hl_rank, s.c_nhelp);
         // grid_cell < 0: cell = max(rad) / -grid_cell with the maximum reduced on the device (no host round trip)
         ST_TRY(st_grid_build(pts, m, grid_cell, sk_grid_cells(nseg, m), s.g, s.cell_start, s.recs, s.gws, s.gws_bytes, stream,
@@ -2085,7 +2140,11 @@ extern "C" int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, c
             stats_host[4] = timing_ok ? (int64_t)(select_ms * 1e6) : 0;
             stats_host[5] = timing_ok ? iters : 0;
         }
-        if (stats_host) { stats_host[2] = iters; stats_host[3] = SK_ANC; stats_host[6] = ((int64_t)h[7] << 32) | (int64_t)h[6]; }
+        if (stats_host) {
+            stats_host[2] = iters; stats_host[3] = SK_ANC; stats_host[6] = ((int64_t)h[7] << 32) | (int64_t)h[6];
+            stats_host[8] = h[8] != 0u;  // helper workgroups were lost in this call (a fall-back ran: slower, not wrong)
+            stats_host[9] = A.n_helpers;
+        }
     }
     ST_CHECK_LAUNCH();
     return ST_OK;

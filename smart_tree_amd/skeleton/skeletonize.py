@@ -45,6 +45,29 @@ class ComponentResult:
     stats: dict = None
 
 
+# What the helper workgroups of this process's skeleton calls did since reset_helper_stats(): {"calls", "with_helpers", "lost"}.
+# A lost helper is a fall-back (slower, not wrong); the GPU suite and bench.py assert that the product settings never lose one.
+_helper_lock = __import__("threading").Lock()
+_helper_stats = {"calls": 0, "with_helpers": 0, "lost": 0}
+
+
+def reset_helper_stats() -> None:
+    with _helper_lock:
+        _helper_stats.update(calls=0, with_helpers=0, lost=0)
+
+
+def helper_stats() -> dict:
+    with _helper_lock:
+        return dict(_helper_stats)
+
+
+def _note_helpers(stats: dict) -> None:
+    with _helper_lock:
+        _helper_stats["calls"] += 1
+        _helper_stats["with_helpers"] += 1 if stats["helpers"] > 0 else 0
+        _helper_stats["lost"] += stats["helpers_lost"]
+
+
 def run_components(comps: ComponentSet, medial_pts: torch.Tensor, radius: torch.Tensor, surface_y: torch.Tensor,
                    stages: int = STAGE_SSSP | STAGE_SAMPLE, block_threads: int = 0) -> ComponentResult:
     """SSSP from the lowest surface point, canonical predecessor tree, greedy branch extraction for
@@ -69,7 +92,7 @@ def run_components(comps: ComponentSet, medial_pts: torch.Tensor, radius: torch.
         res.n_branches.zero_()
     # no host-side facts needed: the library lays out the claim grid from comp_off and takes the grid cell as
     # max(rad) / GRID_DIV reduced on the device (grid_cell < 0), so this stage starts without a read-back
-    stats = (ctypes.c_int64 * 8)()
+    stats = (ctypes.c_int64 * 16)()
     stats[7] = 1 if profiling.enabled() else 0  # bracket every k_sk_select launch with HIP events
     nseg = comps.n_seg  # batched clouds: every cloud's components use their own slab of the claim grid
     ws = _lib.workspace(L.st_skeleton_workspace_bytes_seg(m, C, nseg), dev)
@@ -82,7 +105,9 @@ def run_components(comps: ComponentSet, medial_pts: torch.Tensor, radius: torch.
             _lib.ptr(res.branch_parent), _lib.ptr(res.branch_off), _lib.ptr(res.branch_len), _lib.ptr(res.n_branches),
             _lib.ptr(res.path_verts), _lib.ptr(res.branch_of), stats, _lib.ptr(ws), ws.numel(), _lib.stream(dev),
             tuning.skeleton_array()))
-    res.stats = {"sssp_rounds": stats[0], "plateau_rounds": stats[1], "select_launches": stats[2], "lift_levels": stats[3]}
+    res.stats = {"sssp_rounds": stats[0], "plateau_rounds": stats[1], "select_launches": stats[2], "lift_levels": stats[3],
+                 "helpers_lost": int(stats[8]), "helpers": int(stats[9])}
+    _note_helpers(res.stats)
     if stages & STAGE_SAMPLE:  # cloud totals from the select loop's last progress read-back
         res.stats["branches"], res.stats["path_vertices"] = int(stats[6] & 0xFFFFFFFF), int(stats[6] >> 32)
     if stats[7] and stats[5]:

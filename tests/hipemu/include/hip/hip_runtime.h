@@ -46,6 +46,10 @@ enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDevi
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 typedef int hipEvent_t;
+// one compute unit, workgroups one after the other: the library sizes its resident-workgroup schemes (helper workgroups) to zero
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 0 };
+inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 1; return hipSuccess; }
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = 0; return hipSuccess; }
 inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
@@ -441,6 +445,7 @@ template <class T> inline T max(T a, T b) { return a > b ? a : b; }
 #define __HIP_MEMORY_SCOPE_WORKGROUP 3
 #define __hip_atomic_load(p, order, scope) __atomic_load_n((p), (order))
 #define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), (order))
+#define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add((p), (v), (order))
 #define __hip_atomic_fetch_or(p, v, order, scope) __atomic_fetch_or((p), (v), (order))
 #define __hip_atomic_fetch_and(p, v, order, scope) __atomic_fetch_and((p), (v), (order))
 #define __hip_atomic_fetch_max(p, v, order, scope) hipemu_fetch_max((p), (v))

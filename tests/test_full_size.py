@@ -146,8 +146,12 @@ def test_config3_dense_canopy_properties():
     # (3) rulebook symmetry: subm pairs are mutual with mirrored offsets; strided pairs match their transpose
     pyr = ops.build_pyramid(vb.coords, 3)
     nbr = pyr.subm[0]
-    total_pairs = sum(int((pyr.subm[l] >= 0).sum()) for l in range(4))
-    assert total_pairs * (4 if True else 1) > 100_000_000 // 4  # the 14 subm convs see > 100M pairs in total
+    # BASELINE.json configs[3]: "rulebook > 100M active pairs" = the active (in, out) pairs the 14 submanifold 3x3x3 convolutions of
+    # one forward pass work through (model_blocks.py:107-156, 159-243: a head ResBlock on every level and a tail ResBlock on levels
+    # 0-2, two convolutions each -> 4 convs on levels 0-2, 2 on level 3)
+    convs_per_level = (4, 4, 4, 2)
+    pairs = [int((pyr.subm[l] >= 0).sum()) for l in range(4)]
+    assert sum(p * k for p, k in zip(pairs, convs_per_level)) > 100_000_000, pairs
     rng = torch.randint(0, m, (200_000,), device=dev)
     for k in (0, 5, 13, 20, 26):
         j = nbr[k, rng].long()
@@ -162,6 +166,22 @@ def test_config3_dense_canopy_properties():
     for tree in sk.skeletons:
         for b in tree.branches.values():
             assert b.parent_id < b._id and b.xyz.shape[0] == b.radii.shape[0] and torch.isfinite(b.xyz).all()
+    # (5) the skeleton half at FULL size against the oracle (skeleton/skeletonize.py:31-95, skeleton/path.py:49-140): the oracle's
+    #     skeleton + post-processing of the GPU's own labelled cloud equals the GPU's skeleton, branch by branch
+    lc = pipe.last_labelled_cloud
+    trees = po.skeleton_from_labelled(lc.xyz.cpu().numpy(), lc.medial_vector.cpu().numpy(), lc.class_l.cpu().numpy())
+    po.post_process(trees, True, 0.01, 0.02, True, True, 11)
+    assert len(sk.skeletons) == len(trees) >= 1
+    n_branches = 0
+    for got_tree, rt in zip(sk.skeletons, trees):
+        assert list(got_tree.branches) == list(rt.branches)
+        for k, rb in rt.branches.items():
+            gb = got_tree.branches[k]
+            assert gb.parent_id == rb.parent_id
+            np.testing.assert_array_equal(gb.xyz.numpy(), rb.xyz)
+            np.testing.assert_array_equal(gb.radii.numpy(), rb.radii)
+        n_branches += len(rt.branches)
+    assert n_branches >= 1
 
 
 def test_config1_brick_rulebooks_equal_hash_rulebooks_full_size():
