@@ -624,7 +624,7 @@ def representative_inputs(device, host_xyz, host_mv, n_set=20, n_points=N_POINTS
         return s, parts, {"stage_ms_per_cloud": profiling.stage_ms(n_clouds), "select": table,
                           "select_launch_ms": None if sel is None else round(sel["total_ms"], 3),
                           "select_algorithmic_bytes": None if sel is None else sel["bytes_per_launch"] * sel["launches"],
-                          "helpers": hs}
+                          "helpers": hs, "sssp_rounds": int(skeletonize.last_run_stats.get("sssp_rounds", -1))}
 
     # (a) one cloud per call
     ms1 = timed(clouds[0], calls)

@@ -272,7 +272,8 @@ int st_make_edges_seg(const int64_t* idx, const float* dist, int64_t n, int K, i
 int st_component_layout_seg(const int32_t* labels, int64_t n, int min_vertices, const int32_t* seg_off, int nseg,
                             int32_t* comp_size, int32_t* comp_off, int32_t* vert_order, int32_t* new_id,
                             int32_t* comp_seg /*[C]*/, int32_t* comp_seg_off /*[nseg+1]*/, int32_t* vert_seg_off /*[nseg+1]*/,
-                            int64_t* n_comp_host, int64_t* n_kept_host, void* ws, int64_t ws_bytes, void* stream);
+                            int64_t* n_comp_host, int64_t* n_kept_host, void* ws, int64_t ws_bytes, void* stream,
+                            int64_t* max_comp_host /*optional: vertices of the largest kept component (same read-back)*/);
 int64_t st_skeleton_workspace_bytes_seg(int64_t m, int64_t n_comp, int nseg);
 int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, const int32_t* comp_seg, const int32_t* vert_seg_off,
                                int nseg, int64_t m, const float* pts, const float* rad, const float* ysurf,
@@ -280,7 +281,7 @@ int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, const int32_
                                int block_threads, float* dist, int32_t* pred, int32_t* root_local, float* tree_dist,
                                int32_t* branch_parent, int32_t* branch_off, int32_t* branch_len, int32_t* n_branches,
                                int32_t* path_verts, int32_t* branch_of, int64_t* stats_host, void* ws, int64_t ws_bytes,
-                               void* stream, const int64_t* tuning /*NULL = defaults; 24 entries, see csrc/skeleton.hip "Tuning of
+                               void* stream, const int64_t* tuning /*NULL = defaults; 32 entries, see csrc/skeleton.hip "Tuning of
                                one call": per-call strategy / sweep knobs (no process-global state)*/);
 int st_post_process_seg(int n_trees, const int32_t* tree_off, const int32_t* parent, const int32_t* start, const int32_t* len,
                         float* xyz, const float* rad_in, float* rad_out, uint8_t* keep, uint8_t* repaired, uint8_t* smoothed,

@@ -88,7 +88,8 @@ SIGNATURES = {
     "st_component_csr_knn": (c_int, [P, P, I64, c_int, P, P, I64, P, P, P, P, I64, P]),
     "st_component_csr_knn_workspace_bytes": (I64, [I64, I64, c_int]),
     "st_make_edges_seg": (c_int, [P, P, I64, c_int, P, P, ctypes.POINTER(I64), P, c_int, P, I64, P]),
-    "st_component_layout_seg": (c_int, [P, I64, c_int, P, c_int, P, P, P, P, P, P, P, ctypes.POINTER(I64), ctypes.POINTER(I64), P, I64, P]),
+    "st_component_layout_seg": (c_int, [P, I64, c_int, P, c_int, P, P, P, P, P, P, P, ctypes.POINTER(I64), ctypes.POINTER(I64), P, I64, P,
+                                        ctypes.POINTER(I64)]),
     "st_skeleton_workspace_bytes_seg": (I64, [I64, I64, c_int]),
     "st_skeleton_components_seg": (c_int, [c_int, P, P, P, c_int, I64, P, P, P, P, P, P, c_float, c_int, c_int, P, P, P, P, P, P, P, P,
                                            P, P, ctypes.POINTER(I64), P, I64, P, ctypes.POINTER(I64)]),

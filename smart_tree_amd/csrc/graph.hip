@@ -418,7 +418,7 @@ __global__ void __launch_bounds__(GR_BLOCK) k_cl_rootflag(const int* label, cons
     GR_LOOP(i, n) {
         const bool root = label[i] == (int)i && size[i] >= minv;
         flag[i] = root ? 1u : 0u;
-        if (root) atomicAdd(kept, size[i]);  // vertices in kept components: known together with their number
+        if (root) { atomicAdd(kept, size[i]); atomicMax(kept + 1, size[i]); }  // vertices in kept components and the largest one: known together with their number
     }
 }
 __global__ void __launch_bounds__(GR_BLOCK) k_cl_rootlist(const uint32_t* flag_off, const int* label, const uint32_t* size,
@@ -467,7 +467,7 @@ __global__ void __launch_bounds__(GR_BLOCK) k_fill_i32(int* p, int64_t n, int v)
 
 extern "C" int64_t st_component_layout_workspace_bytes(int64_t n) {
     StArena a(nullptr, 0);
-    a.take<uint32_t>(n + 1);  // size (+ kept-vertex counter)
+    a.take<uint32_t>(n + 2);  // size (+ kept-vertex counter, largest kept component)
     a.take<uint32_t>(n + 1);  // flag / offsets
     a.take<uint32_t>(n);      // key
     a.take<uint32_t>(n);      // val
@@ -486,10 +486,12 @@ extern "C" int64_t st_component_layout_workspace_bytes(int64_t n) {
 extern "C" int st_component_layout_seg(const int32_t* labels, int64_t n, int min_vertices, const int32_t* seg_off, int nseg,
                                        int32_t* comp_size, int32_t* comp_off, int32_t* vert_order, int32_t* new_id,
                                        int32_t* comp_seg, int32_t* comp_seg_off, int32_t* vert_seg_off,
-                                       int64_t* n_comp_host, int64_t* n_kept_host, void* ws, int64_t ws_bytes, void* stream_) {
+                                       int64_t* n_comp_host, int64_t* n_kept_host, void* ws, int64_t ws_bytes, void* stream_,
+                                       int64_t* max_comp_host /*optional: vertices of the largest kept component*/) {
     hipStream_t stream = (hipStream_t)stream_;
     *n_comp_host = 0;
     *n_kept_host = 0;
+    if (max_comp_host) *max_comp_host = 0;
     ST_REQUIRE(nseg >= 1 && nseg <= ST_MAX_SEG, "component_layout: 1 <= clouds per batch <= %d", ST_MAX_SEG);
     ST_REQUIRE(nseg == 1 || (seg_off && comp_seg && comp_seg_off && vert_seg_off), "component_layout: a batch needs seg_off and the per-cloud outputs");
     if (n <= 0) {
@@ -497,7 +499,7 @@ extern "C" int st_component_layout_seg(const int32_t* labels, int64_t n, int min
         return ST_OK;
     }
     StArena a(ws, ws_bytes);
-    uint32_t* size = a.take<uint32_t>(n + 1);  // size[n] = number of vertices in kept components
+    uint32_t* size = a.take<uint32_t>(n + 2);  // size[n] = number of vertices in kept components, size[n + 1] = the largest one's
     uint32_t* flag = a.take<uint32_t>(n + 1);
     uint32_t* key = a.take<uint32_t>(n);
     uint32_t* val = a.take<uint32_t>(n);
@@ -507,14 +509,16 @@ extern "C" int st_component_layout_seg(const int32_t* labels, int64_t n, int min
     if (!a.ok() || !sw) { st_set_error("component_layout: workspace too small"); return ST_ERR_WORKSPACE; }
     const unsigned g = gr_grid(n);
     uint32_t minv = min_vertices > 0 ? (uint32_t)min_vertices : 0u;
-    (void)hipMemsetAsync(size, 0, (n + 1) * sizeof(uint32_t), stream);
+    (void)hipMemsetAsync(size, 0, (n + 2) * sizeof(uint32_t), stream);
     hipLaunchKernelGGL(k_cl_sizes, dim3(g), dim3(GR_BLOCK), 0, stream, labels, n, size);
     hipLaunchKernelGGL(k_cl_rootflag, dim3(g), dim3(GR_BLOCK), 0, stream, labels, (const uint32_t*)size, n, minv, flag, size + n);
     ST_TRY(st_exclusive_scan_u32(flag, flag, n, flag + n, sw, sb, stream));
-    uint32_t C = 0, m = 0;  // ONE round trip for both counts (a blocking read-back costs ~1 ms beside other clouds' kernels)
+    uint32_t C = 0, mk[2] = {0, 0};  // ONE round trip for the counts (a blocking read-back costs ~1 ms beside other clouds' kernels)
     (void)hipMemcpyAsync(&C, flag + n, sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
-    (void)hipMemcpyAsync(&m, size + n, sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+    (void)hipMemcpyAsync(mk, size + n, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
     st_stream_wait(stream);
+    const uint32_t m = mk[0];
+    if (max_comp_host) *max_comp_host = mk[1];
     ST_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_fill_i32, dim3(g), dim3(GR_BLOCK), 0, stream, new_id, n, -1);
     if (C == 0) {
@@ -559,7 +563,7 @@ extern "C" int st_component_layout(const int32_t* labels, int64_t n, int min_ver
                                    int32_t* vert_order, int32_t* new_id, int64_t* n_comp_host, int64_t* n_kept_host,
                                    void* ws, int64_t ws_bytes, void* stream_) {
     return st_component_layout_seg(labels, n, min_vertices, nullptr, 1, comp_size, comp_off, vert_order, new_id, nullptr, nullptr,
-                                   nullptr, n_comp_host, n_kept_host, ws, ws_bytes, stream_);
+                                   nullptr, n_comp_host, n_kept_host, ws, ws_bytes, stream_, nullptr);
 }
 
 // ---------------------------------------------------------------------------- component CSR ---

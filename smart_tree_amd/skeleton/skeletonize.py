@@ -61,7 +61,12 @@ def helper_stats() -> dict:
         return dict(_helper_stats)
 
 
+last_run_stats: dict = {}  # stats of the most recent run_components call of this process (diagnostics: bench.py, tools/)
+
+
 def _note_helpers(stats: dict) -> None:
+    global last_run_stats
+    last_run_stats = stats
     with _helper_lock:
         _helper_stats["calls"] += 1
         _helper_stats["with_helpers"] += 1 if stats["helpers"] > 0 else 0

@@ -445,6 +445,7 @@ template <class T> inline T max(T a, T b) { return a > b ? a : b; }
 #define __HIP_MEMORY_SCOPE_WORKGROUP 3
 #define __hip_atomic_load(p, order, scope) __atomic_load_n((p), (order))
 #define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), (order))
+#define __hip_atomic_exchange(p, v, order, scope) __atomic_exchange_n((p), (v), (order))
 #define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add((p), (v), (order))
 #define __hip_atomic_fetch_or(p, v, order, scope) __atomic_fetch_or((p), (v), (order))
 #define __hip_atomic_fetch_and(p, v, order, scope) __atomic_fetch_and((p), (v), (order))
@@ -455,6 +456,7 @@ template <class T> inline T hipemu_fetch_min(T* p, T v) { T o = *p; if (v < o) *
 inline long long wall_clock64() { return 0; }
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __builtin_amdgcn_s_sleep(x) ((void)0)
+#define ST_VMEM_DRAIN() ((void)0)
 
 // ---- atomics (fibers never run concurrently, plain RMW is exact) -------------------------
 template <class T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
