@@ -281,7 +281,7 @@ int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, const int32_
                                int block_threads, float* dist, int32_t* pred, int32_t* root_local, float* tree_dist,
                                int32_t* branch_parent, int32_t* branch_off, int32_t* branch_len, int32_t* n_branches,
                                int32_t* path_verts, int32_t* branch_of, int64_t* stats_host, void* ws, int64_t ws_bytes,
-                               void* stream, const int64_t* tuning /*NULL = defaults; 32 entries, see csrc/skeleton.hip "Tuning of
+                               void* stream, const int64_t* tuning /*NULL = defaults; 24 entries, see csrc/skeleton.hip "Tuning of
                                one call": per-call strategy / sweep knobs (no process-global state)*/);
 int st_post_process_seg(int n_trees, const int32_t* tree_off, const int32_t* parent, const int32_t* start, const int32_t* len,
                         float* xyz, const float* rad_in, float* rad_out, uint8_t* keep, uint8_t* repaired, uint8_t* smoothed,

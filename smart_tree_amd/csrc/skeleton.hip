@@ -198,14 +198,12 @@ __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_init(SkArgs A) {
     const unsigned inf = st_f2ord(__uint_as_float(0x7f800000u));
     SK_VERTEX_LOOP(v) { A.dist_ord[v] = inf; A.stamp[v] = 0u; }
     if (blockIdx.x == 0 && threadIdx.x < 8) A.cnt[threadIdx.x] = 0u;
-    if (blockIdx.x == 0)  // round 0's frontier = the roots k_sk_roots appends to the overflow area of q0
-        for (int i = threadIdx.x; i < 3 * (SK_FS + 1); i += blockDim.x) A.fcnt[i] = 0u;
+    if (blockIdx.x == 0)  // round 0's frontier = every component's root, in the overflow area of q0 (k_sk_roots)
+        for (int i = threadIdx.x; i < 3 * (SK_FS + 1); i += blockDim.x) A.fcnt[i] = i == SK_FS ? (unsigned)A.C : 0u;
 }
 
 // one workgroup per component: comp_of[], root = first minimum of the surface y (cloud.py:204-206)
-// frontier_min: only components of MORE than this many vertices enter the chip-wide frontier queue; -1 = all of them, INT_MAX =
-// none (the blocked SSSP seeds its own rounds)
-__global__ void __launch_bounds__(1024) k_sk_roots(SkArgs A, int frontier_min) {
+__global__ void __launch_bounds__(1024) k_sk_roots(SkArgs A) {
     __shared__ unsigned long long s_red[SK_MAX_WAVES];
     const int c = blockIdx.x, base = A.comp_off[c], n = A.comp_off[c + 1] - base;
     unsigned long long key = 0;
@@ -218,8 +216,8 @@ __global__ void __launch_bounds__(1024) k_sk_roots(SkArgs A, int frontier_min) {
     if (threadIdx.x == 0) {
         const int root = n > 0 ? (int)(0xffffffffu - (unsigned)(key & 0xffffffffu)) : 0;
         A.root_local[c] = root;
-        if (n > frontier_min) A.q0[(int64_t)SK_FS * A.fseg + atomicAdd(&A.fcnt[SK_FS], 1u)] = (unsigned)(base + root);  // round 0 frontier
-        if (n > 0 && frontier_min != 0x7fffffff) A.dist_ord[base + root] = st_f2ord(0.0f);  // (the blocked SSSP keeps distances by Morton position: k_bs_seed)
+        A.q0[(int64_t)SK_FS * A.fseg + c] = (unsigned)(base + root);  // round 0 frontier = every component's root
+        if (n > 0) A.dist_ord[base + root] = st_f2ord(0.0f);
     }
 }
 
@@ -478,219 +476,6 @@ __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_sssp_coop(SkArgs A, int ho
 #undef SK_QPUSH
         if (!sk_grid_barrier(bar, (unsigned)r)) return;
     }
-}
-
-// ---- blocked SSSP: spatial blocks relaxed to convergence in LDS, boundaries exchanged between launches ------------------------
-// The graph of a tree is deep, not wide: with exact medial vectors the points collapse onto the branch axes, the 16 nearest
-// neighbours of a vertex lie within ~5 mm of it, and the 12 m from the root to the farthest twig are ~2400 relaxation levels of
-// ~75 vertices each (profiles/r05_sssp_levels.txt; the shipped checkpoint's scattered output: ~360 fatter levels).  A chip-wide
-// level costs ~5.5 us of dependent memory-side round trips whatever carries it: 13 ms for such a tree.  (Built
-// and measured first: ONE workgroup per component with its frontier in LDS -- queue + workgroup-scope atomicMin, then an LDS
-// candidate table without global atomics: 35-50 ms for the 49k-vertex graph, 330-900 ms for the deep one; a compute unit's
-// memory pipeline takes a cache line per scattered access, and a level still waits for 2-3 of them.)
-// Here the DEPTH is cut instead: the vertices are ordered along a Morton curve of their positions and cut into blocks of SK_BS;
-// a round runs every block that has news -- one workgroup loads the block's distances and the edges that stay inside the block
-// into LDS, relaxes them to convergence there (a level = LDS atomics and one s_barrier, ~0.3 us; a block of a branch axis is
-// ~40 cm = ~80 levels), writes the distances back and offers fl32(d + w) over the edges that LEAVE the block with global
-// atomicMin; a target that improves is stamped "news in round r + 1" and its block is marked.  Rounds = the deepest chain of
-// blocks (tens), not of vertices (thousands).  Label-correcting relaxation reaches the least fixed point of
-// d[v] = min fl32(d[u] + w) in any order (every improvement is propagated: inside a block by the inner frontier, across blocks
-// by the stamps), so the distances equal the frontier launches' bit for bit.
-#define SK_BS 256          // vertices per block (= lanes of its workgroup)
-#define SK_BE 8192         // edges of a block's rows kept in LDS (64 KB); a block with more runs in "global mode" (below)
-#define SK_BG 16           // lanes per vertex row
-struct SkBEdge { unsigned tgt; float w; };
-// The blocked SSSP works in MORTON SPACE: position p = rank of a vertex along the curve; block = p / SK_BS.  `row`, `col`, `wgt`
-// are the adjacency re-written in that space (rows in position order, targets as positions: a block's rows are one contiguous
-// range), A.dist_ord and A.stamp are indexed by position while the rounds run (k_sk_dist_out translates back).
-struct SkBlocks {
-    const unsigned* perm;  // [m] position -> vertex
-    unsigned* pos;         // [m] vertex -> position
-    unsigned* row;         // [m + 1]
-    unsigned* col;         // [ecap_total] target positions
-    float* wgt;            // [ecap_total]
-    unsigned* active;      // [2][nblocks] active[r & 1][b] == r: block b runs in round r
-    unsigned* cnt;         // [4]: blocks marked for round r at cnt[r % 3]; cnt[3] != 0: the adjacency did not fit (the host falls back)
-    unsigned nblocks;
-    int64_t ecap_total;    // entries col / wgt can hold
-    int ecap;              // edges a block keeps in LDS (<= SK_BE; test hook: a small value forces the global mode)
-};
-
-__device__ __forceinline__ unsigned sk_morton10(unsigned x) {  // 10 bits -> every third bit
-    x &= 0x3ffu;
-    x = (x | (x << 16)) & 0x030000ffu;
-    x = (x | (x << 8)) & 0x0300f00fu;
-    x = (x | (x << 4)) & 0x030c30c3u;
-    x = (x | (x << 2)) & 0x09249249u;
-    return x;
-}
-// Morton keys of a position on a fixed lattice of 2^-14 m cells over [-32 m, 32 m)^3 (clouds are centred; what falls outside is
-// clamped: the order only has to be spatially coherent), 20 bits per axis in two words: pass 0 = the low 10 bits of every axis,
-// pass 1 = the high 10 bits, pass 2 = the component (three stable sorts, least significant first).  The fine word matters: with
-// 6 cm cells alone the vertices INSIDE a cell stay in index order, two blocks that share a cell split its vertices at random, and
-// a path along the axis changes block at every hop (measured: 696 rounds for the deep tree instead of ~100).
-__global__ void __launch_bounds__(SK_WIDE_BLOCK) k_bs_keys(SkArgs A, uint32_t* keys, uint32_t* vals, int pass) {
-    SK_VERTEX_LOOP(v) {
-        if (pass == 2) { keys[v] = (uint32_t)A.comp_of[vals[v]]; continue; }
-        const int64_t src = pass == 0 ? v : (int64_t)vals[v];
-        unsigned q[3];
-        for (int a = 0; a < 3; a++) {
-            float f = (A.pts[3 * src + a] + 32.0f) * 16384.0f;
-            f = f < 0.0f ? 0.0f : (f > 1048575.0f ? 1048575.0f : f);
-            q[a] = (unsigned)f;
-        }
-        const int sh = pass == 0 ? 0 : 10;
-        keys[v] = sk_morton10(q[0] >> sh) | (sk_morton10(q[1] >> sh) << 1) | (sk_morton10(q[2] >> sh) << 2);
-        if (pass == 0) vals[v] = (uint32_t)v;
-    }
-}
-// positions, the degree of every row in position order (scanned into B.row by the host), clean stamps / marks / counters
-__global__ void __launch_bounds__(SK_WIDE_BLOCK) k_bs_pos(SkArgs A, SkBlocks B) {
-    SK_VERTEX_LOOP(i) {
-        const unsigned v = B.perm[i];
-        B.pos[v] = (unsigned)i;
-        B.row[i] = A.row_off[v + 1] - A.row_off[v];
-        A.stamp[i] = 0xffffffffu;
-    }
-    for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < 2 * (int64_t)B.nblocks; b += (int64_t)gridDim.x * blockDim.x) B.active[b] = 0xffffffffu;
-    if (blockIdx.x == 0 && threadIdx.x < 4) B.cnt[threadIdx.x] = 0u;
-}
-// the adjacency in Morton space: SK_BG lanes copy the row of position i, targets translated
-__global__ void __launch_bounds__(SK_WIDE_BLOCK) k_bs_fill(SkArgs A, SkBlocks B) {
-    if ((int64_t)B.row[A.m] > B.ecap_total) {  // (uniform) does not fit: flag it, the host falls back to the frontier launches
-        if (blockIdx.x == 0 && threadIdx.x == 0) B.cnt[3] = 1u;
-        return;
-    }
-    const int lane = threadIdx.x & (SK_BG - 1);
-    const int64_t groups = ((int64_t)gridDim.x * blockDim.x) / SK_BG;
-    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / SK_BG; i < A.m; i += groups) {
-        const unsigned v = B.perm[i];
-        const uint32_t s0 = A.row_off[v], n = A.row_off[v + 1] - s0, d0 = B.row[i];
-        for (uint32_t k = (uint32_t)lane; k < n; k += SK_BG) { B.col[d0 + k] = B.pos[A.col[s0 + k]]; B.wgt[d0 + k] = A.wgt[s0 + k]; }
-    }
-}
-// round 0: every component's root has news
-__global__ void k_bs_seed(SkArgs A, SkBlocks B) {
-    if (B.cnt[3] != 0u) return;
-    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < A.C; c += gridDim.x * blockDim.x) {
-        if (A.comp_off[c + 1] <= A.comp_off[c]) continue;
-        const unsigned p = B.pos[A.comp_off[c] + A.root_local[c]];
-        A.dist_ord[p] = st_f2ord(0.0f);
-        A.stamp[p] = 0u;
-        if (atomicExch(&B.active[p / SK_BS], 0u) != 0u) atomicAdd(&B.cnt[0], 1u);
-    }
-}
-
-__global__ void __launch_bounds__(SK_BS) k_bs_round(SkArgs A, SkBlocks B, unsigned r) {
-    __shared__ unsigned d[SK_BS], irow[SK_BS + 1];
-    __shared__ unsigned news[SK_BS / 32], inq[2][SK_BS / 32];
-    __shared__ unsigned short q[2][SK_BS];
-    __shared__ unsigned qn[3];
-    __shared__ SkBEdge ed[SK_BE];
-    const int tid = threadIdx.x;
-    if (blockIdx.x == 0 && tid == 0) B.cnt[(r + 2) % 3] = 0u;  // (the counter of the round after next: read by the host two rounds ago at the latest)
-    const unsigned b = blockIdx.x;
-    if (B.active[(r & 1u) * B.nblocks + b] != r) return;  // (uniform; marked by an earlier launch -- marks for round r + 1 go to the other half)
-    const unsigned p0 = b * SK_BS;
-    const unsigned nb = (unsigned)((A.m - (int64_t)p0) < SK_BS ? (A.m - (int64_t)p0) : SK_BS);
-    const int lane = tid & (SK_BG - 1), grp = tid / SK_BG, wlane = tid & 63;
-    if (tid < SK_BS / 32) { news[tid] = 0u; inq[0][tid] = 0u; inq[1][tid] = 0u; }
-    if (tid < 3) qn[tid] = 0u;
-    const unsigned e0 = B.row[p0], ne = B.row[p0 + nb] - e0;
-    const bool local = ne <= (unsigned)B.ecap;  // (uniform) else: "global mode" -- no inner loop, a vertex with news offers every edge through memory
-    __syncthreads();
-    bool my_news = false;
-    unsigned my_d0 = 0u;  // what vertex `tid` had when the block was loaded
-    if ((unsigned)tid < nb) {
-        my_d0 = A.dist_ord[p0 + tid];
-        d[tid] = my_d0;
-        my_news = A.stamp[p0 + tid] == r;
-        if (my_news) atomicOr(&news[tid >> 5], 1u << (tid & 31));
-    }
-    if ((unsigned)tid < nb) irow[tid] = B.row[p0 + tid] - e0;
-    if (tid == 0) irow[nb] = ne;
-    if (local)
-        for (unsigned e = (unsigned)tid; e < ne; e += SK_BS) { SkBEdge x; x.tgt = B.col[e0 + e]; x.w = B.wgt[e0 + e]; ed[e] = x; }
-    long long t_a = A.ticks ? wall_clock64() : 0;
-    unsigned levels = 0;
-    if (local) {
-        {   // the vertices with news are the first frontier
-            const unsigned long long fm = __ballot(my_news);
-            unsigned base = 0u;
-            if (fm != 0ull && wlane == __ffsll((long long)fm) - 1) base = atomicAdd(&qn[0], (unsigned)__popcll(fm));
-            base = (unsigned)__shfl((int)base, fm != 0ull ? __ffsll((long long)fm) - 1 : 0);
-            if (my_news) { q[0][base + (unsigned)__popcll(fm & ((1ull << wlane) - 1ull))] = (unsigned short)tid; atomicOr(&inq[0][tid >> 5], 1u << (tid & 31)); }
-        }
-        // label-correcting levels over the edges that stay inside the block, all in LDS
-        for (unsigned L = 0;; L++) {
-            __syncthreads();  // generation L is complete; nobody still reads generation L - 1
-            const unsigned n = qn[L % 3];
-            if (n == 0u) break;  // uniform
-            levels = L + 1u;
-            if (tid == 0) qn[(L + 2) % 3] = 0u;
-            const unsigned short* in = q[L & 1];
-            unsigned short* out = q[(L + 1) & 1];
-            unsigned* in_bits = inq[L & 1];
-            unsigned* out_bits = inq[(L + 1) & 1];
-            for (unsigned i0 = 0; i0 < n; i0 += SK_BS / SK_BG) {
-                const unsigned i = i0 + (unsigned)grp;
-                unsigned t = 0u, e = 0u;
-                float dl = 0.0f;
-                if (i < n) {
-                    const unsigned l = in[i];
-                    if (lane == 0) atomicAnd(&in_bits[l >> 5], ~(1u << (l & 31)));
-                    t = irow[l] + (unsigned)lane; e = irow[l + 1];
-                    dl = st_ord2f(d[l]);  // (may have improved again since it was queued: the freshest value serves)
-                }
-                for (; t < e; t += SK_BG) {
-                    const SkBEdge x = ed[t];
-                    const unsigned tg = x.tgt - p0;
-                    if (tg >= nb) continue;  // (an edge that leaves the block waits for the export below)
-                    const unsigned o = st_f2ord(dl + x.w);
-                    if (o < d[tg] && o < atomicMin(&d[tg], o) && !((atomicOr(&out_bits[tg >> 5], 1u << (tg & 31)) >> (tg & 31)) & 1u))
-                        out[atomicAdd(&qn[(L + 1) % 3], 1u)] = (unsigned short)tg;  // (a handful of pushes per level)
-                }
-            }
-        }
-    }
-    __syncthreads();
-    if (A.ticks && tid == 0) {  // developer aid (tuning code 15): block runs, global-mode runs, inner levels, ticks of the inner loop
-        atomicAdd((unsigned long long*)&A.ticks[16], 1ull); atomicAdd((unsigned long long*)&A.ticks[17], local ? 0ull : 1ull);
-        atomicAdd((unsigned long long*)&A.ticks[18], (unsigned long long)levels); atomicAdd((unsigned long long*)&A.ticks[19], (unsigned long long)(wall_clock64() - t_a));
-        atomicMax((unsigned long long*)&A.ticks[20], (unsigned long long)levels);
-    }
-    // write back, and offer what LEAVES the block (every edge in global mode) for the vertices that improved here or came with news
-    if ((unsigned)tid < nb && d[tid] < my_d0) { (void)atomicMin(&A.dist_ord[p0 + tid], d[tid]); atomicOr(&news[tid >> 5], 1u << (tid & 31)); }  // (another block may have offered less meanwhile)
-    __syncthreads();
-    for (unsigned l0 = 0; l0 < SK_BS; l0 += SK_BS / SK_BG) {
-        const unsigned l = l0 + (unsigned)grp;
-        unsigned t = 0u, e = 0u;
-        float dl = 0.0f;
-        if (l < nb) {
-            if ((news[l >> 5] >> (l & 31)) & 1u) {
-                t = irow[l] + (unsigned)lane; e = irow[l + 1];
-                dl = st_ord2f(d[l]);
-            }
-        }
-        for (; t < e; t += SK_BG) {
-            unsigned p;
-            float w;
-            if (local) { const SkBEdge x = ed[t]; p = x.tgt; w = x.w; }
-            else { p = B.col[e0 + t]; w = B.wgt[e0 + t]; }
-            if (local && p - p0 < nb) continue;  // relaxed in LDS
-            const unsigned o = st_f2ord(dl + w);
-            if (o >= ld(&A.dist_ord[p])) continue;
-            if (o < atomicMin(&A.dist_ord[p], o)) {
-                __hip_atomic_store(&A.stamp[p], r + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (atomicExch(&B.active[((r + 1u) & 1u) * B.nblocks + p / SK_BS], r + 1u) != r + 1u) atomicAdd(&B.cnt[(r + 1u) % 3], 1u);
-            }
-        }
-    }
-}
-
-// distances back in vertex order (the blocked SSSP kept them by Morton position)
-__global__ void __launch_bounds__(SK_WIDE_BLOCK) k_bs_dist_out(SkArgs A, SkBlocks B) {
-    SK_VERTEX_LOOP(v) A.dist[v] = st_ord2f(A.dist_ord[B.pos[v]]);
 }
 
 __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_dist_out(SkArgs A) {
@@ -2025,20 +1810,14 @@ static void sk_layout(StArena& a, int64_t m, int64_t C, SkLayout* s, int nseg = 
 //   15 device pointer of 32 int64 phase timers / counters of k_sk_select
 //   16 / 17 / 18 time-outs of the helper protocol in microseconds: a helper's life time, a component's wait for one job's answers,
 //   a helper's wait for its component's workgroup to announce itself (tests/test_helpers.py drives every fall-back with them)
-//   19 an upper bound of the largest component's vertex count, if the caller knows one (the component layout reports it); unused
-//   20 SSSP form: 1 (default) = blocked (Morton blocks relaxed in LDS, k_bs_round), 0 = chip-wide frontier launches
-//   21 blocked SSSP: rounds per counter read-back (the first batch is twice as long)
-//   22 blocked SSSP: in-block edges a block keeps in LDS (test hook: a small value forces the global mode); default SK_BE
 #define ST_TUNE_DEFAULT INT64_MIN
-#define ST_TUNE_ENTRIES 32
+#define ST_TUNE_ENTRIES 24
 #define SK_MAX_LAUNCH_BATCH 32
 struct SkTuning {
     float prune_factor = 1.0f, grid_mean_mult = 1.0f;
     int small_work = SK_SMALL_WORK, iters_per_launch = SK_ITERS_PER_LAUNCH, launch_batch = 24, local_items = 0, wave_work = SK_WAVE_WORK, long_mode = 1;
     int sssp_hops = 4, sssp_batch = 32, sssp_lanes = 32, sssp_first = 2, sssp_blocks = SK_SSSP_BLOCKS, sssp_lcap = SK_LQ;
     int sssp_coop = 0, helpers = -1;  // helpers: -1 = by size, else the number of helper workgroups of a select launch
-    int64_t comp_bound = -1;
-    int sssp_blocked = 0, bs_batch = 24, bs_ecap = SK_BE;
     long long help_lifetime_us = SK_HELP_LIFETIME_US, help_timeout_us = SK_HELP_TIMEOUT_US, help_announce_us = SK_HELP_ANNOUNCE_US;
     bool small_work_set = false, iters_set = false, long_set = false, launch_set = false;
     long long* ticks = nullptr;
@@ -2064,10 +1843,6 @@ struct SkTuning {
         if (has(16)) help_lifetime_us = t[16] < 0 ? 0 : t[16];
         if (has(17)) help_timeout_us = t[17] < 0 ? 0 : t[17];
         if (has(18)) help_announce_us = t[18] < 0 ? 0 : t[18];
-        if (has(19)) comp_bound = t[19];
-        if (has(20)) sssp_blocked = t[20] != 0;
-        if (has(21)) bs_batch = t[21] < 1 ? 1 : (t[21] > 256 ? 256 : (int)t[21]);
-        if (has(22)) bs_ecap = t[22] < 0 ? 0 : (t[22] > SK_BE ? SK_BE : (int)t[22]);
     }
 };
 
@@ -2127,7 +1902,7 @@ static int sk_read(void* dst, const void* src, size_t bytes, hipStream_t stream)
 // [4] = their summed duration in ns, [5] = number of launches (profiling aid for bench.py's roofline block);
 // [6] = branches of the cloud | path vertices << 32 (sizes st_assemble_branches' outputs without a read-back of its own);
 // [8] = 1 if helper workgroups were lost in this call (time-outs: their component's workgroup did the work), [9] = helper workgroups launched,
-// [0] counts the rounds of the blocked SSSP when that form ran.
+
 //
 // Batched form (st_skeleton_components_seg): the components of `nseg` independent clouds in one call.  comp_seg [C] = cloud
 // of each component, vert_seg_off [nseg + 1] = the clouds' ranges in the renumbered vertex space (both device arrays,
@@ -2228,48 +2003,13 @@ extern "C" int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, c
         if (stats_host) stats_host[1] = round - 2;
         return ST_OK;
     };
-    // Roots, SSSP, canonical predecessors (not the plateau rounds).  The blocked form (default) or the chip-wide frontier launches.
-    auto run_sssp = [&](bool allow_blocked) -> int {
+    // Roots, SSSP, canonical predecessors (not the plateau rounds).
+    auto run_sssp = [&]() -> int {
         hipLaunchKernelGGL(k_sk_init, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A);
-        const bool blocked = allow_blocked && T.sssp_blocked && !T.sssp_coop;
-        hipLaunchKernelGGL(k_sk_roots, dim3((unsigned)n_comp), dim3((unsigned)block_threads), 0, stream, A, blocked ? 0x7fffffff : -1);
-        if (blocked) {
-            // Morton order (the sort keys' / order's arrays are idle until the selection), blocks, rounds in batches with one counter
-            // read-back per batch
-            SkBlocks B;
-            B.perm = s.order; B.pos = s.touched; B.row = s.q1; B.active = s.q0 /* >= m words >= 2 nblocks */; B.cnt = s.cnt + 8; B.nblocks = (unsigned)st_div_up(m, SK_BS); B.ecap = T.bs_ecap;
-            B.ecap_total = 32 * m;  // the ancestor table (64 words per vertex, filled only after the SSSP) holds 32 (target, weight) pairs per vertex
-            B.col = (unsigned*)s.anc; B.wgt = (float*)(s.anc + B.ecap_total);
-            for (int pass = 0; pass < (n_comp > 1 ? 3 : 2); pass++) {
-                int bits = 30;
-                if (pass == 2) { bits = 1; while ((1ll << bits) < n_comp) bits++; }
-                hipLaunchKernelGGL(k_bs_keys, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A, s.sort_keys, s.order, pass);
-                ST_TRY(st_radix_sort_pairs_u32(s.sort_keys, s.order, m, bits, s.sort_ws, s.sort_bytes, stream));
-            }
-            hipLaunchKernelGGL(k_bs_pos, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A, B);
-            ST_TRY(st_exclusive_scan_u32(B.row, B.row, m, B.row + m, s.sort_ws, s.sort_bytes, stream));
-            hipLaunchKernelGGL(k_bs_fill, dim3((unsigned)st_min64(st_div_up(m * SK_BG, SK_WIDE_BLOCK), 8192)), dim3(SK_WIDE_BLOCK), 0, stream, A, B);
-            hipLaunchKernelGGL(k_bs_seed, dim3((unsigned)st_div_up(n_comp, 256)), dim3(256), 0, stream, A, B);
-            bool fits = true;
-            for (unsigned r = 0;;) {
-                const int batch = r == 0 ? 2 * T.bs_batch : T.bs_batch;
-                for (int b = 0; b < batch; b++, r++) hipLaunchKernelGGL(k_bs_round, dim3(B.nblocks), dim3(SK_BS), 0, stream, A, B, r);
-                ST_TRY(sk_read(h, s.cnt, sizeof(unsigned) * 12, stream));
-                sssp_rounds = r;
-                if (h[8 + 3] != 0u) { fits = false; break; }  // more than 32 edges per vertex on average: the frontier launches take over
-                if (h[8 + r % 3] == 0u) break;
-                ST_REQUIRE(r < (1u << 24), "skeleton: blocked SSSP did not converge");
-            }
-            if (!fits) return -1000;
-            hipLaunchKernelGGL(k_bs_dist_out, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A, B);
-            hipLaunchKernelGGL(k_sk_preds, dim3((unsigned)st_min64(st_div_up(m * SK_PRED_LANES, SK_WIDE_BLOCK), 8192)), dim3(SK_WIDE_BLOCK), 0, stream, A);
-            if (stats_host) stats_host[0] = sssp_rounds;
-            return ST_OK;
-        }
-        bool coop_done = blocked;
-        const bool need_frontier = !blocked;
+        hipLaunchKernelGGL(k_sk_roots, dim3((unsigned)n_comp), dim3((unsigned)block_threads), 0, stream, A);
+        bool coop_done = false;
 
-        if (T.sssp_coop && need_frontier) {
+        if (T.sssp_coop) {
             // every round in ONE launch (k_sk_sssp_coop); one read-back tells whether a workgroup gave up at a barrier
 #ifdef ST_HIPEMU
             const unsigned cg = 1u;  // (the CPU emulator runs the workgroups of a launch one after the other)
@@ -2283,7 +2023,7 @@ extern "C" int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, c
             if (hb[1] == 0u) { coop_done = true; sssp_rounds = hb[2]; }
             else {  // start over, one launch per round
                 hipLaunchKernelGGL(k_sk_init, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A);
-                hipLaunchKernelGGL(k_sk_roots, dim3((unsigned)n_comp), dim3((unsigned)block_threads), 0, stream, A, -1);
+                hipLaunchKernelGGL(k_sk_roots, dim3((unsigned)n_comp), dim3((unsigned)block_threads), 0, stream, A);
             }
         }
         for (int r = 0; !coop_done;) {  // frontier rounds in batches, one counter read-back per batch.  The first batch is twice as long:
@@ -2304,11 +2044,7 @@ extern "C" int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, c
         return ST_OK;
     };
     if (stages & 1) {
-        {
-            int rc = run_sssp(true);
-            if (rc == -1000) rc = run_sssp(false);  // (the blocked form's adjacency did not fit its scratch)
-            ST_TRY(rc);
-        }
+        ST_TRY(run_sssp());
         // Vertices whose tight in-neighbours all sit on their own distance plateau (cnt[3]) are rare; with sample_tree
         // next, their count is not read back here (a blocking round trip costs ~1 ms beside other clouds' kernels,
         // DESIGN.md section 5) but arrives with the first progress read-back of the select loop, which is then redone.

@@ -9,13 +9,6 @@
 
 #define ST_WAVE 64
 
-// Wait until this wavefront's vector-memory operations have been performed (loads returned, stores and no-return atomics
-// acknowledged by the L2): s_barrier alone does not.  Inline asm, so that the compiler can neither move memory operations
-// across it nor drop it.  (tests/hipemu defines it away: there is no memory queue on the CPU.)
-#ifndef ST_VMEM_DRAIN
-#define ST_VMEM_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-#endif
-
 // ---- status / error text (C ABI: every entry point returns int, 0 = ok) -------------------
 enum StStatus : int {
     ST_OK = 0,

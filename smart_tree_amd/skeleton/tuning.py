@@ -1,6 +1,6 @@
 """Per-call tuning of the skeleton stage's kernels (test hook + sweep aid; the defaults are the product settings).
 
-The library keeps NO process-global knobs: `st_skeleton_components_seg` takes an optional array of 32 int64 (entry =
+The library keeps NO process-global knobs: `st_skeleton_components_seg` takes an optional array of 24 int64 (entry =
 "default" or a value, codes in csrc/skeleton.hip "Tuning of one call"), the neighbour searches an optional cap multiplier of
 their grid cell.  This module holds what the CALLING THREAD wants passed: `with tuning.override({5: -1, 14: 1}): ...` in
 tests/test_skeleton.py forces every claim strategy / SSSP form; `ST_SKELETON_PARAMS="3=24,9=3"` seeds the defaults of a
@@ -13,10 +13,10 @@ import os
 import threading
 
 DEFAULT = -(1 << 63)  # ST_TUNE_DEFAULT
-KNN_CELL_MEAN_MULT = 100  # pseudo code (outside the library's 0..31): hundredths of the mean bound that caps the search-grid cell (-> st_knn_radius_seg)
+KNN_CELL_MEAN_MULT = 100  # pseudo code (outside the library's 0..23): hundredths of the mean bound that caps the search-grid cell (-> st_knn_radius_seg)
 TICKS = 15
 HELP_LIFETIME_US, HELP_TIMEOUT_US, HELP_ANNOUNCE_US = 16, 17, 18  # time-outs of the helper protocol (tests/test_helpers.py)
-ENTRIES = 32
+ENTRIES = 24
 
 _local = threading.local()
 

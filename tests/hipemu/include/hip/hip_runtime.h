@@ -456,7 +456,6 @@ template <class T> inline T hipemu_fetch_min(T* p, T v) { T o = *p; if (v < o) *
 inline long long wall_clock64() { return 0; }
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __builtin_amdgcn_s_sleep(x) ((void)0)
-#define ST_VMEM_DRAIN() ((void)0)
 
 // ---- atomics (fibers never run concurrently, plain RMW is exact) -------------------------
 template <class T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }

@@ -159,16 +159,12 @@ def test_components_match_oracle(backend):
     {5: -1, 1: -1, 14: 0, 4: -1},       # ... handed to the chip-wide claim kernel
     {5: 300, 1: 2000, 4: 200},   # a mix: speculative slots, plain and long-path claims
     {5: 300, 1: 2000, 14: 0, 4: 200},   # a mix: slots, plain, local and chip-wide claims
-    {21: 1},                     # SSSP (default form: Morton blocks relaxed in LDS): a counter read-back after every round
-    {22: 0},                     # ... no in-block edges in LDS: every block in global mode (one hop per round through memory)
-    {22: 40},                    # ... a mix: blocks with more than 40 in-block edges in global mode
-    {20: 0, 6: 1, 8: 16},        # SSSP, frontier launches for every component: one level per launch, 16 lanes per vertex
-    {20: 0, 6: 7, 7: 2},         # ... seven levels per launch, read-back every second launch
-    {20: 0, 6: 6, 13: 2, 10: 3}, # ... three workgroups, at most two vertices per workgroup and local level (the rest goes back)
+    {6: 1, 8: 16},               # SSSP: one level per launch, 16 lanes per vertex
+    {6: 7, 7: 2},                # ... seven levels per launch, read-back every second launch
+    {6: 6, 13: 2, 10: 3},        # ... three workgroups, at most two vertices per workgroup and local level (the rest goes back)
     {12: 1},                     # SSSP: every round in ONE persistent launch with grid barriers
     {12: 1, 6: 7, 10: 3},        # ... seven levels per round, three workgroups
-], ids=["noprune", "prune4", "relaunch", "one", "long", "local", "wide", "mixed", "mixed-wide", "sssp-blocked-sync", "sssp-blocked-global",
-        "sssp-blocked-mixed", "sssp-rows",
+], ids=["noprune", "prune4", "relaunch", "one", "long", "local", "wide", "mixed", "mixed-wide", "sssp-rows",
         "sssp-hops", "sssp-cap", "sssp-coop", "sssp-coop-hops"])
 def test_sample_tree_strategies_agree(backend, params):
     """Branch selection has four claim strategies picked by size; each one alone must reproduce the oracle."""

@@ -65,4 +65,3 @@ t = ticks.cpu().numpy()
 print(f"  phases (us, summed over components): head {t[0]/100:.0f} rank {t[7]/100:.0f} prune {t[1]/100:.0f} walk+rows {t[2]/100:.0f} claim {t[3]/100:.0f} "
       f"validate+commit {t[4]/100:.0f} one-mode {t[5]/100:.0f} local {t[6]/100:.0f} ({t[15]}) | rounds {t[8]} slots {t[13]} commits {t[12]} "
       f"one-mode iters {t[9]} (path vertices {t[10]}) wide {t[14]} cand {t[11]}")
-print(f"  blocked SSSP: block runs {t[16]}, in global mode {t[17]}, inner levels {t[18]} (deepest {t[20]}), inner-loop ticks summed {t[19]/100:.0f} us")
