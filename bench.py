@@ -917,7 +917,12 @@ def main():
         roof_solo = {"note": "one batch of %d clouds alone on the GPU (untimed extra pass): solo launch durations" % min(B, max(args.steps, 1))}
         roof_solo.update({k: full.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "launches", "avg_us",
                                                   "algorithmic_bytes_per_launch", "branch_selection", "gather_gemm", "all_kernels")})
+    per_rank = None
     if world > 1:  # every pass: the slowest rank
+        mine = torch.tensor([sorted(pass_s)[len(pass_s) // 2], sorted(host_cores)[len(host_cores) // 2]], dtype=torch.float64, device=coll_device)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)  # (outside the timed region: each rank's own median pass and busy host cores, for the record)
+        per_rank = {"median_pass_ms": [round(1e3 * float(e[0]), 2) for e in every], "host_cpu_cores_busy": [round(float(e[1]), 2) for e in every]}
         t = torch.tensor(pass_s + up_s, dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         pass_s, up_s = t[:PASSES].tolist(), t[PASSES:].tolist()
@@ -963,6 +968,9 @@ def main():
                        "cloud_generation_s": round(t_gen, 1),
                        "host_cpu_cores_busy_in_timed_region": round(med(host_cores), 2),
                        "host_waits": "blocking (hipDeviceScheduleBlockingSync)" if blocking else "spinning (HIP default)",
+                       "host_cores_usable": usable_cores(), "per_rank": per_rank,
+                       "dry_run": "ST_BENCH_DRYRUN=1: every rank on cuda:0, collectives over gloo -- multi-rank control flow and host "
+                                  "contention only, NOT a scaling measurement" if dryrun else None,
                        "last_warmup_pass_ms_per_step": None if warm_last_ms is None else round(warm_last_ms, 3)},
             "parity_note": "results are checked against oracle/ (a CPU restatement pinned by goldens that the reference's own "
                            "glue code produced); the semantics of the reference's un-vendored third-party packages (spconv "

@@ -203,9 +203,14 @@ class _LazyTrees:
             tree = _PackedTree.__new__(_PackedTree)
             tree._id = i
             tree._lazy = (xyz_h, rad_h, rows, offs[g], offs[g + 1])
-            if self._parent is not None:  # one cloud of a batch: the batch-level tree may have been read / edited already
-                src = self._parent._made.get(g - self._parent._lo)
-                if src is not None and "_branches" in src.__dict__:
+            if self._parent is not None:
+                # one cloud of a batch: this view and the batch-level tree are the SAME tree under two ids.  They share one
+                # branch dictionary whichever of the two is read first (`_twin`: a tree that builds its branches hands them to
+                # its twin), so a host-side prune / repair / smooth made through one is seen through the other, and the
+                # parent's touched() / pack() notice edits made through a view.
+                src = self._parent._make(g - self._parent._lo)
+                tree.__dict__["_twin"], src.__dict__["_twin"] = src, tree
+                if "_branches" in src.__dict__:
                     tree.__dict__["_branches"] = src.__dict__["_branches"]
             self._made[i] = t = tree
         return t
@@ -443,8 +448,14 @@ class _PackedTree(TreeSkeleton):
                     fill(obj.__dict__, _id=j, parent_id=par, child_id=None, _pack=(xyz_h, rad_h, st + 1 - rp, st + 1 + ln, sm))
                     d[j] = obj
             self.__dict__["_branches"] = d
+            twin = self.__dict__.get("_twin")  # the same tree seen through the batch / through one cloud's view
+            if twin is not None and "_branches" not in twin.__dict__:
+                twin.__dict__["_branches"] = d
         return d
 
     @branches.setter
     def branches(self, value):
         self.__dict__["_branches"] = value
+        twin = self.__dict__.get("_twin")
+        if twin is not None:
+            twin.__dict__["_branches"] = value

@@ -271,3 +271,32 @@ def test_host_side_post_processing_of_a_batch_survives_split(backend):
     for one, got in zip(serial, parts):
         assert _signature(got) == one
     assert sum(len(one) for one in serial) > 2
+
+
+def test_a_cloud_view_and_the_batch_level_tree_share_their_branches(backend):
+    """a cloud's view (split()) and the batch-level skeleton are the same trees under two ids.  Whichever is read
+    first, they hold the SAME branch objects -- a host-side edit made through one is seen through the other -- and the batch-level
+    pack() notices that somebody has read (and may have edited) the branches through a view."""
+    clouds = _clouds(backend, sizes=(3000, 2000), scale=0.35) if backend.type == "cpu" else _clouds(backend, sizes=(40000, 30000), scale=0.8)
+    pipe = _pipeline(backend, 0.04 if backend.type == "cpu" else 0.03)
+    batch = pipe.preprocessing(Cloud.collate([Cloud(c.xyz, c.rgb) for c in clouds]))
+    lc = pipe.model_inference.forward(batch)
+    sk = pipe.skeletonizer.forward(lc.filter_by_class(pipe.branch_classes))
+    pipe.post_process(sk)
+    parts = sk.split()
+    assert sk.pack() is not None  # nobody has touched the branch objects yet: the packed arrays are authoritative
+    seg = sk._seg_host
+    b = next(i for i in range(len(parts)) if len(parts[i].skeletons) > 0 and parts[i].skeletons[0].branches)
+    child = parts[b].skeletons[0]
+    first = child.branches  # the VIEW is read first ...
+    parent = sk.skeletons[seg[b]]
+    assert parent.branches is first  # ... the batch-level tree built later holds the same objects
+    key = next(iter(first))
+    first[key].radii = first[key].radii * 2.0  # a host-side edit through the view
+    assert parent.branches[key].radii is first[key].radii
+    assert sk.pack() is None and parts[b].pack() is None  # both notice: the caller walks the objects instead
+    # and the other way round: the batch-level tree first
+    other = next((i for i in range(len(parts)) if i != b and len(parts[i].skeletons) > 0), None)
+    if other is not None:
+        top = sk.skeletons[seg[other]].branches
+        assert parts[other].skeletons[0].branches is top
