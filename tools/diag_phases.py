@@ -9,6 +9,11 @@ sys.path.insert(0, str(ROOT))
 import torch  # noqa: E402
 
 import bench  # noqa: E402
+
+import ctypes as _ct, os as _os
+from smart_tree_amd import _lib as _l
+if _os.environ.get("ST_PROBE_LIB"):  # A/B aid: another build of the library (e.g. the previous revision's .so kept under _ab/)
+    _l._LIB = _l.declare(_ct.CDLL(_os.environ["ST_PROBE_LIB"]))
 from smart_tree_amd import _lib  # noqa: E402
 from smart_tree_amd.data_types.cloud import Cloud  # noqa: E402
 from smart_tree_amd.skeleton import graph as G  # noqa: E402

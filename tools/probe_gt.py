@@ -15,6 +15,11 @@ training = (sys.argv[4] if len(sys.argv) > 4 else "0") == "1"
 
 import bench  # noqa: E402
 
+import ctypes as _ct, os as _os
+from smart_tree_amd import _lib as _l
+if _os.environ.get("ST_PROBE_LIB"):  # A/B aid: another build of the library (e.g. the previous revision's .so kept under _ab/)
+    _l._LIB = _l.declare(_ct.CDLL(_os.environ["ST_PROBE_LIB"]))
+
 host_xyz, host_mv = bench.generate_clouds(bench.N_POINTS, list(range(n_set)), min(n_set, bench.usable_cores()), n_mv=n_set)
 import torch  # noqa: E402
 
