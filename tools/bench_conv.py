@@ -11,6 +11,10 @@ from smart_tree_amd.data_types.cloud import Cloud
 from smart_tree_amd.synthetic import sample_tree_cloud
 from smart_tree_amd.dataset.dataset import voxelize_blocks
 from smart_tree_amd.model import sparse_ops as ops
+import ctypes as _ct, os as _os
+from smart_tree_amd import _lib as _l
+if _os.environ.get("ST_PROBE_LIB"):  # A/B aid: another build of the library (e.g. the previous revision's .so kept under _ab/)
+    _l._LIB = _l.declare(_ct.CDLL(_os.environ["ST_PROBE_LIB"]))
 dev = torch.device("cuda:0")
 pipe = bench.build_pipeline(dev)
 NPTS = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
