@@ -845,7 +845,7 @@ def main():
         finished.extend(worker.run(plan_batches(warm, S, B), collect=world > 1, streams=S))
     gather()
     fence()
-    single = worker.single_cloud() if world == 1 else None
+    single = worker.single_cloud() if world == 1 and args.warmup > 0 else None  # (--warmup 0: the PMC passes of tools/collect_r5.sh want the batch's launches alone)
     fence()
     # kernel timers of the timed region: the convolutions of a forward pass are bracketed ONCE as a family (a pair of events
     # around each of the 26 launches cost ~10 us apiece between kernels that otherwise run back to back); the per-class table
