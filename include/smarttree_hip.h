@@ -252,7 +252,10 @@ int st_knn_radius_seg(const float* src, int64_t n1, const float* dst, int64_t n2
  *           st_knn_radius_seg(...).idx[:, K-1] != -1 without the neighbour lists (K = 8; workspace as st_knn_radius_seg). */
 int st_radius_count_seg(const float* src, int64_t n1, const float* dst, int64_t n2, int K, float r, const float* bound,
                         int bound_mode, float cell_hint, uint8_t* mask, const int32_t* src_seg_off,
-                        const int32_t* dst_seg_off, int nseg, void* ws, int64_t ws_bytes, void* stream, float cell_mean_mult);
+                        const int32_t* dst_seg_off, int nseg, void* ws, int64_t ws_bytes, void* stream, float cell_mean_mult,
+                        const uint8_t* valid /* optional [n1], needs src == dst: the search runs over the points with valid[i] != 0 only
+                        (neighbours and queries alike; mask = 0 for the others) -- the class filter folded into outlier_removal
+                        without compacting the cloud in between */);
 /* components / adjacency straight from the neighbour search (idx / dist [n,K] of st_knn_radius_seg after the caller's radius
  * filter): the edge set is make_edges' (graph.py:52-60: (i, idx) for idx > vertex 0 of i's cloud) without materialising
  * the int64 edge list.  Same labels as st_connected_components on st_make_edges_seg's output; the CSR holds the same

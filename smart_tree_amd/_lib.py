@@ -83,7 +83,7 @@ SIGNATURES = {
     "st_build_strided_rulebook_seg": (c_int, [P, I64, P, P, I64, P, I64, P, P, I64, ctypes.POINTER(ctypes.c_int32), P, P, P, P, P, P]),
     "st_knn_workspace_bytes_seg": (I64, [I64, c_int]),
     "st_knn_radius_seg": (c_int, [P, I64, P, I64, c_int, c_float, P, c_int, c_float, P, P, P, P, c_int, P, I64, P, c_float]),
-    "st_radius_count_seg": (c_int, [P, I64, P, I64, c_int, c_float, P, c_int, c_float, P, P, P, c_int, P, I64, P, c_float]),
+    "st_radius_count_seg": (c_int, [P, I64, P, I64, c_int, c_float, P, c_int, c_float, P, P, P, c_int, P, I64, P, c_float, P]),
     "st_connected_components_knn": (c_int, [P, I64, c_int, P, P, P, I64, P]),
     "st_component_csr_knn": (c_int, [P, P, I64, c_int, P, P, I64, P, P, P, P, I64, P]),
     "st_component_csr_knn_workspace_bytes": (I64, [I64, I64, c_int]),

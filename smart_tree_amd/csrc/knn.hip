@@ -40,7 +40,7 @@ __device__ __forceinline__ unsigned grid_wave_max(unsigned v) { for (int d = 32;
 // one shuffle reduction per wavefront and one global atomic per workgroup and word (thousands of workgroups, each with its
 // own atomics on the same six addresses, spent 90 us on a 17 MB array -- the atomics, not the loads).
 // blockIdx.y = cloud (gridDim.y = 1, seg_off == nullptr: the whole array is one cloud)
-__global__ void __launch_bounds__(KNN_BLOCK) k_bound_max(const float* bound, int64_t n, StGrid* g, const int* seg_off) {
+__global__ void __launch_bounds__(KNN_BLOCK) k_bound_max(const float* bound, int64_t n, StGrid* g, const int* seg_off, const uint8_t* valid) {
     __shared__ unsigned m;
     __shared__ unsigned long long sum;
     if (threadIdx.x == 0) { m = 0u; sum = 0ull; }
@@ -50,6 +50,7 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_bound_max(const float* bound, int
     unsigned mine = 0u;
     unsigned long long fix = 0ull;  // sum of the bounds in 2^-16 units (a bound is a radius: metres; clamped so 2^40 of them fit)
     for (int64_t i = i0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < i1; i += (int64_t)gridDim.x * blockDim.x) {
+        if (valid && !valid[i]) continue;  // (a point that is not part of the search: see st_grid_build)
         const float b = bound[i];
         const unsigned o = st_f2ord(b);
         if (o > mine) mine = o;
@@ -132,8 +133,10 @@ __global__ void k_grid_dims(StGrid* g, float cell, int64_t max_cells, float r, i
 __global__ void k_grid_ncell1(const StGrid* g, int64_t* out) { *out = g->ncell + 1; }
 
 __global__ void __launch_bounds__(KNN_BLOCK) k_grid_count(const float* pts, int64_t n, const StGrid* g, uint32_t* counts,
-                                                          const int* seg_off, int nseg, uint32_t* pt_cell, uint32_t* pt_rank) {
+                                                          const int* seg_off, int nseg, uint32_t* pt_cell, uint32_t* pt_rank,
+                                                          const uint8_t* valid) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (valid && !valid[i]) { pt_cell[i] = 0xffffffffu; continue; }  // stays out of the table
         const int64_t c = st_grid_cell(g, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], st_seg_find(seg_off, nseg, i));
         pt_cell[i] = (uint32_t)c;
         pt_rank[i] = atomicAdd(&counts[c], 1u);
@@ -143,6 +146,7 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_grid_count(const float* pts, int6
 __global__ void __launch_bounds__(KNN_BLOCK) k_grid_fill(const float* pts, int64_t n, const uint32_t* cell_start,
                                                          const uint32_t* pt_cell, const uint32_t* pt_rank, float4* recs) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (pt_cell[i] == 0xffffffffu) continue;
         const uint32_t pos = cell_start[pt_cell[i]] + pt_rank[i];
         recs[pos] = make_float4(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], __uint_as_float((unsigned)i));
     }
@@ -160,7 +164,7 @@ int64_t st_grid_ws_bytes(int64_t n, int64_t max_cells) {
 // Builds grid over pts[n]; g (device struct), cell_start[max_cells+1], recs[n] are caller arrays.
 int st_grid_build(const float* pts, int64_t n, float cell, int64_t max_cells, StGrid* g, uint32_t* cell_start, float4* recs,
                   void* ws, int64_t ws_bytes, hipStream_t stream, float r, const float* bound, int64_t n_bound,
-                  const int* seg_off, int nseg, const int* bound_seg_off, float mean_mult) {
+                  const int* seg_off, int nseg, const int* bound_seg_off, float mean_mult, const uint8_t* valid) {
     if (nseg < 1 || nseg > ST_MAX_SEG) { st_set_error("grid: 1 <= clouds per batch <= %d (got %d)", ST_MAX_SEG, nseg); return ST_ERR_INVALID; }
     if (!seg_off) nseg = 1;
     StArena a(ws, ws_bytes);
@@ -184,7 +188,8 @@ int st_grid_build(const float* pts, int64_t n, float cell, int64_t max_cells, St
     const int64_t ncell = st_min64(max_cells, 128 * n + 65536);
     if (r < 0.0f && bound && n_bound > 0)
         hipLaunchKernelGGL(k_bound_max, dim3((unsigned)st_min64(st_div_up(n_bound, (int64_t)KNN_BLOCK * nseg * 8), 512 / nseg + 1), (unsigned)nseg),
-                           dim3(KNN_BLOCK), 0, stream, bound, n_bound, g, nseg > 1 ? (bound_seg_off ? bound_seg_off : seg_off) : (const int*)nullptr);
+                           dim3(KNN_BLOCK), 0, stream, bound, n_bound, g, nseg > 1 ? (bound_seg_off ? bound_seg_off : seg_off) : (const int*)nullptr,
+                           valid);
     hipLaunchKernelGGL(k_grid_dims, dim3(1), dim3(64), 0, stream, g, cell, ncell, r, nseg, mean_mult,
                        (r < 0.0f && bound) ? n_bound : (int64_t)0);
     if (getenv("ST_GRID_DEBUG")) {
@@ -199,7 +204,7 @@ int st_grid_build(const float* pts, int64_t n, float cell, int64_t max_cells, St
     hipLaunchKernelGGL(k_grid_ncell1, dim3(1), dim3(1), 0, stream, (const StGrid*)g, ncell1_dev);
     st_fill_u32_dev(cell_start, ncell + 1, ncell1_dev, 0u, stream);
     hipLaunchKernelGGL(k_grid_count, dim3(gb), dim3(KNN_BLOCK), 0, stream, pts, n, (const StGrid*)g, cell_start, seg_off, nseg,
-                       pt_cell, pt_rank);
+                       pt_cell, pt_rank, valid);
     ST_TRY(st_exclusive_scan_u32(cell_start, cell_start, ncell + 1, nullptr, scan_ws, scan_bytes, stream, ncell1_dev));
     hipLaunchKernelGGL(k_grid_fill, dim3(gb), dim3(KNN_BLOCK), 0, stream, pts, n, (const uint32_t*)cell_start,
                        (const uint32_t*)pt_cell, (const uint32_t*)pt_rank, recs);
@@ -292,13 +297,17 @@ __global__ void __launch_bounds__(KNN_BLOCK, 8) k_knn(const float* __restrict__ 
                                                    const uint32_t* __restrict__ cell_start, const float4* __restrict__ recs,
                                                    float r, const float* __restrict__ bound, int mode,
                                                    int64_t* __restrict__ idx_out, float* __restrict__ dist_out,
-                                                   const int* __restrict__ seg_off, int nseg, int cell_order) {
+                                                   const int* __restrict__ seg_off, int nseg, int cell_order,
+                                                   const uint8_t* __restrict__ valid = nullptr) {
     __shared__ uint32_t s_roff[KNN_WAVES][65], s_rfirst[KNN_WAVES][64];
     __shared__ unsigned long long s_rmask[KNN_WAVES][KNN_MASK_WORDS];  // bit p of word w: a (non-empty) row's candidates start at 64 w + p
     __shared__ __attribute__((aligned(16))) unsigned long long s_keys[KNN_WAVES][KNN_CAP];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int64_t i = (int64_t)blockIdx.x * KNN_WAVES + wave;
     if (i >= n1) return;  // wave-uniform; the kernel has no workgroup barrier
+    // valid (optional, with src == dst): only the points with valid[j] != 0 are part of the search -- the table holds only them, and
+    // only they are queried (cell order: the table's total is the number of queries; the caller has cleared the output)
+    if (valid && (cell_order ? i >= (int64_t)cell_start[g->ncell] : !valid[i])) return;
     // cell_order (src IS dst): wavefront p takes the p-th record of the cell-sorted point list instead of point p, so
     // neighbouring wavefronts search the same cells (their rows stay in L1 / L2); rows are written by original index, the
     // result does not depend on which wavefront computed it
@@ -497,7 +506,7 @@ extern "C" int st_knn_radius_seg(const float* src, int64_t n1, const float* dst,
     }
     const float cell_arg = cell_hint != 0.0f ? cell_hint : (r >= 0.0f ? r : -1.0f);
     ST_TRY(st_grid_build(dst, n2, cell_arg, knn_cells(n2, nseg), g, cell_start, recs, sub, sub_bytes, stream, r, bound, n1,
-                         dst_seg_off, nseg, src_seg_off, cell_hint < 0.0f ? (cell_mean_mult >= 0.0f ? cell_mean_mult : KNN_MEAN_MULT) : 0.0f));
+                         dst_seg_off, nseg, src_seg_off, cell_hint < 0.0f ? (cell_mean_mult >= 0.0f ? cell_mean_mult : KNN_MEAN_MULT) : 0.0f, nullptr));
     dim3 grid((unsigned)st_div_up(n1, KNN_WAVES)), block(KNN_BLOCK);
     const int cell_order = src == dst && n1 == n2 ? 1 : 0;
     if (K == 1)
@@ -519,8 +528,9 @@ extern "C" int st_knn_radius_seg(const float* src, int64_t n1, const float* dst,
 extern "C" int st_radius_count_seg(const float* src, int64_t n1, const float* dst, int64_t n2, int K, float r, const float* bound,
                                    int bound_mode, float cell_hint, uint8_t* mask, const int32_t* src_seg_off,
                                    const int32_t* dst_seg_off, int nseg, void* ws, int64_t ws_bytes, void* stream_,
-                                   float cell_mean_mult) {
+                                   float cell_mean_mult, const uint8_t* valid) {
     hipStream_t stream = (hipStream_t)stream_;
+    ST_REQUIRE(valid == nullptr || (src == dst && n1 == n2), "radius_count: a validity mask needs src == dst");
     ST_REQUIRE(K == 8, "radius_count: K must be 8 (outlier_removal's nb_points; got %d)", K);
     ST_REQUIRE(bound_mode == 0 || bound != nullptr, "radius_count: bound_mode needs a bound array");
     ST_REQUIRE(r >= 0.0f || bound != nullptr, "radius_count: r < 0 (radius = max(bound)) needs a bound array");
@@ -539,10 +549,11 @@ extern "C" int st_radius_count_seg(const float* src, int64_t n1, const float* ds
     }
     const float cell_arg = cell_hint != 0.0f ? cell_hint : (r >= 0.0f ? r : -1.0f);
     ST_TRY(st_grid_build(dst, n2, cell_arg, knn_cells(n2, nseg), g, cell_start, recs, sub, sub_bytes, stream, r, bound, n1,
-                         dst_seg_off, nseg, src_seg_off, cell_hint < 0.0f ? (cell_mean_mult >= 0.0f ? cell_mean_mult : KNN_MEAN_MULT) : 0.0f));
+                         dst_seg_off, nseg, src_seg_off, cell_hint < 0.0f ? (cell_mean_mult >= 0.0f ? cell_mean_mult : KNN_MEAN_MULT) : 0.0f, valid));
+    if (valid) (void)hipMemsetAsync(mask, 0, (size_t)n1, stream);  // (the points outside the search get no query: their answer is "no")
     hipLaunchKernelGGL((k_knn<8, true>), dim3((unsigned)st_div_up(n1, KNN_WAVES)), dim3(KNN_BLOCK), 0, stream, src, n1,
                        (const StGrid*)g, (const uint32_t*)cell_start, (const float4*)recs, r, bound, bound_mode,
-                       reinterpret_cast<int64_t*>(mask), (float*)nullptr, src_seg_off, nseg, src == dst && n1 == n2 ? 1 : 0);
+                       reinterpret_cast<int64_t*>(mask), (float*)nullptr, src_seg_off, nseg, src == dst && n1 == n2 ? 1 : 0, valid);
     ST_CHECK_LAUNCH();
     return ST_OK;
 }

@@ -54,4 +54,5 @@ int64_t st_grid_ws_bytes(int64_t n, int64_t max_cells);
 int st_grid_build(const float* pts, int64_t n, float cell, int64_t max_cells, StGrid* g, uint32_t* cell_start, float4* recs,
                   void* ws, int64_t ws_bytes, hipStream_t stream, float r = 0.0f, const float* bound = nullptr,
                   int64_t n_bound = 0, const int* seg_off = nullptr, int nseg = 1, const int* bound_seg_off = nullptr,
-                  float mean_mult = 0.0f);
+                  float mean_mult = 0.0f, const uint8_t* valid = nullptr /* [n] optional: only points with valid[i] != 0 enter the table
+                  (and the bound reductions): a search over a SUBSET of an array without compacting it first */);

@@ -212,11 +212,17 @@ class MaskedCloud(Cloud):
         return self.__dict__["_real"]
 
     def filter_by_class(self, classes) -> Cloud:
+        """Still pending (round 5): the class test joins the mask, and `Skeletonizer.forward`, the next thing the pipeline does,
+        folds its outlier filter into the same selection (`pending()`): ONE compaction and one host round trip for all three."""
         base, mask = self.__dict__["_base"], self.__dict__["_mask"]
         if self.__dict__["_real"] is not None or base.class_l is None:
             return self._cloud().filter_by_class(classes)
         wanted = torch.as_tensor(classes, device=base.class_l.device)
-        return base.filter(mask & torch.isin(base.class_l, wanted).view(-1))
+        return MaskedCloud(base, mask & torch.isin(base.class_l, wanted).view(-1))
+
+    def pending(self):
+        """(base cloud, boolean mask) while the selection has not been carried out, else None."""
+        return None if self.__dict__["_real"] is not None else (self.__dict__["_base"], self.__dict__["_mask"])
 
     def _map(self, fn) -> Cloud:
         return self._cloud()._map(fn)

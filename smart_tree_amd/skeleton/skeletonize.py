@@ -144,8 +144,16 @@ class Skeletonizer:
         """`cloud` may be a batch of independent clouds (Cloud.collate): every stage below then runs ONCE for all of
         them, and `.split()` of the result gives each cloud's skeleton -- identical to what it gets on its own."""
         with profiling.stage("outlier_removal"):
-            medial, radius = medial_points(cloud.xyz, cloud.medial_vector)
-            mask = outlier_removal(medial, radius.unsqueeze(1), nb_points=8, seg_off=cloud.seg_off)
+            pending = cloud.pending() if hasattr(cloud, "pending") else None
+            if pending is not None:
+                # the inner-block mask and the class filter are still pending (MaskedCloud): the outlier filter runs over that
+                # subset of the UNcompacted cloud, and one compaction (one host sync) serves all three selections
+                cloud, valid = pending
+                medial, radius = medial_points(cloud.xyz, cloud.medial_vector)
+                mask = outlier_removal(medial, radius.unsqueeze(1), nb_points=8, seg_off=cloud.seg_off, valid=valid)
+            else:
+                medial, radius = medial_points(cloud.xyz, cloud.medial_vector)
+                mask = outlier_removal(medial, radius.unsqueeze(1), nb_points=8, seg_off=cloud.seg_off)
             keep = mask.nonzero().view(-1)  # one compaction (one host sync) shared by every field
             cloud = cloud.filter(keep, assume_sorted=True)  # nonzero(): ascending
             medial, radius = medial.index_select(0, keep), radius.index_select(0, keep)

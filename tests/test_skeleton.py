@@ -398,3 +398,37 @@ def test_csr_from_tables_falls_back_to_the_edge_list_rows_without_the_larger_wor
         assert sorted(set(full)) == dedup, v
         longer += len(full) - len(dedup)
     assert longer > 0  # the fallback keeps both copies of the mutual pairs
+
+
+@pytest.mark.parametrize("batched", [False, True], ids=["one-cloud", "two-clouds"])
+def test_outlier_removal_over_a_subset_equals_filtering_first(backend, batched):
+    """Round 5: `outlier_removal(..., valid=mask)` (the class filter folded into the outlier filter: st_radius_count_seg's `valid`)
+    must give exactly what the reference's order of operations gives -- filter the cloud, then remove outliers (pipeline.py:67-71,
+    skeletonize.py:33-37) -- scattered back to the unfiltered array: the points outside the subset are neither queries nor neighbours."""
+    from smart_tree_amd.skeleton.filter import outlier_removal
+
+    rng = np.random.RandomState(11 + int(batched))
+    n = 6000
+    pts = rng.rand(n, 3).astype(np.float32) * np.array([1.0, 2.0, 1.0], np.float32)
+    rad = rng.uniform(0.01, 0.12, n).astype(np.float32)
+    valid = rng.rand(n) < 0.6
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(backend)
+    seg = torch.tensor([0, 2500, n], dtype=torch.int32, device=backend) if batched else None
+    got = outlier_removal(t(pts), t(rad).unsqueeze(1), nb_points=8, seg_off=seg, valid=t(valid)).cpu().numpy()
+    idx = np.nonzero(valid)[0]
+    sub_seg = None
+    if batched:
+        sub_seg = torch.tensor([0, int((idx < 2500).sum()), len(idx)], dtype=torch.int32, device=backend)
+    want_sub = outlier_removal(t(pts[idx]), t(rad[idx]).unsqueeze(1), nb_points=8, seg_off=sub_seg).cpu().numpy()
+    want = np.zeros(n, bool)
+    want[idx] = want_sub
+    np.testing.assert_array_equal(got, want)
+    assert 0 < want.sum() < len(idx)
+    ref = so.outlier_removal(pts[idx][: int((idx < 2500).sum())] if batched else pts[idx],
+                             rad[idx][: int((idx < 2500).sum())] if batched else rad[idx], 8)
+    np.testing.assert_array_equal(want_sub[: len(ref)], ref)  # ... and the filtered form is the oracle's
+    # the general search (nb_points != 8; the library searches K = 1, 8, 16) has no subset form: it filters, searches and scatters back
+    got16 = outlier_removal(t(pts), t(rad).unsqueeze(1), nb_points=16, seg_off=seg, valid=t(valid)).cpu().numpy()
+    want16 = np.zeros(n, bool)
+    want16[idx] = outlier_removal(t(pts[idx]), t(rad[idx]).unsqueeze(1), nb_points=16, seg_off=sub_seg).cpu().numpy()
+    np.testing.assert_array_equal(got16, want16)
