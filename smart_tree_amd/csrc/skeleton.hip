@@ -1851,13 +1851,16 @@ struct SkTuning {
 // device of one compute unit none) -- and by what other calls of this process have out at the moment: two helper-enabled calls on
 // different streams share the budget instead of filling the chip with waiting workgroups between them.
 static std::atomic<int> g_helpers_out{0};
-static int sk_helper_cap() {
+static int sk_cu_count() {  // compute units of the calling thread's current device (0 if it cannot be asked)
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
         (void)hipGetLastError();
         return 0;
     }
-    const int cap = cus * 5 / 8;
+    return cus;
+}
+static int sk_helper_cap() {
+    const int cap = sk_cu_count() * 5 / 8;
     return cap < SK_HELP_POOL ? cap : SK_HELP_POOL;
 }
 struct SkHelperLease {  // returned on every way out of the call
@@ -2011,11 +2014,11 @@ extern "C" int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, c
 
         if (T.sssp_coop) {
             // every round in ONE launch (k_sk_sssp_coop); one read-back tells whether a workgroup gave up at a barrier
-#ifdef ST_HIPEMU
-            const unsigned cg = 1u;  // (the CPU emulator runs the workgroups of a launch one after the other)
-#else
-            const unsigned cg = fg < SK_COOP_BLOCKS ? fg : SK_COOP_BLOCKS;
-#endif
+            // the grid must be resident as a whole: at most four workgroups of 256 lanes per compute unit (1024 on an MI355X; a device
+            // of ONE compute unit -- the CPU emulator, which runs the workgroups of a launch one after the other -- gets one workgroup)
+            const int cus = sk_cu_count();
+            const unsigned resident = cus > 1 ? (unsigned)st_min64(4ll * cus, SK_COOP_BLOCKS) : 1u;
+            const unsigned cg = fg < resident ? fg : resident;
             (void)hipMemsetAsync(s.coop_bar, 0, SK_COOP_STRIDE * (2 + SK_COOP_BLOCKS / SK_COOP_GROUP) * sizeof(unsigned), stream);
             hipLaunchKernelGGL(k_sk_sssp_coop, dim3(cg), dim3(SK_WIDE_BLOCK), 0, stream, A, T.sssp_hops, T.sssp_lanes, T.sssp_lcap, s.coop_bar, 1 << 24);
             unsigned hb[4];
