@@ -29,7 +29,7 @@ struct VxState {
     int lo[3], hi[3];    // block-id bounding box over ALL clouds of the call
     uint32_t n_blocks;
     uint32_t n_vox;
-    uint32_t overflow;   // bit0: block table, bit1: max_blocks, bit2: hash full, bit3: a block's voxel grid exceeds the 16-bit key fields
+    uint32_t overflow;   // bit0: block table, bit1: max_blocks, bit2: hash full, bit3: a block's voxel grid exceeds the 16-bit key fields, bit4: non-finite coordinates
     int table_cells;     // capacity of the block table per cloud (vx_table_cells)
     uint32_t seg_blk_off[ST_MAX_SEG + 1];  // first block of every cloud
     uint32_t seg_vox_off[ST_MAX_SEG + 1];  // first voxel of every cloud (written by the gather pass)
@@ -98,11 +98,14 @@ __global__ void __launch_bounds__(VX_BLOCK) k_vx_bbox(const float* xyz, int64_t 
     const int seg = blockIdx.y;
     const int64_t i0 = seg_off ? seg_off[seg] : 0, i1 = seg_off ? seg_off[seg + 1] : n;
     int l[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, h[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
+    bool finite = true;  // NaN / infinite coordinates have no block: the call fails with a message that says so
     vx_stream_points(xyz, n, i0, i1, [&](int64_t, float x, float y, float z) {
+        finite = finite && fabsf(x) <= 3.0e38f && fabsf(y) <= 3.0e38f && fabsf(z) <= 3.0e38f;
         const int q[3] = {vx_block_id(x, p), vx_block_id(y, p), vx_block_id(z, p)};
 #pragma unroll
         for (int a = 0; a < 3; a++) { l[a] = q[a] < l[a] ? q[a] : l[a]; h[a] = q[a] > h[a] ? q[a] : h[a]; }
     });
+    if (!finite) atomicOr(&st->overflow, 16u);
 #pragma unroll
     for (int a = 0; a < 3; a++) { l[a] = vx_wave_min(l[a]); h[a] = vx_wave_max(h[a]); }
     if ((threadIdx.x & 63) == 0)
@@ -598,6 +601,7 @@ static int vx_voxelize(const float* xyz, const float* rgb, int64_t n, const int3
     (void)hipMemcpyAsync(&h, st, sizeof(VxState), hipMemcpyDeviceToHost, stream);
     st_stream_wait(stream);
     ST_CHECK_LAUNCH();
+    ST_REQUIRE(!(h.overflow & 16u), "voxelize: the cloud holds non-finite coordinates (NaN or infinity)");
     ST_REQUIRE(!(h.overflow & 1u), "voxelize: the block-id bounding box of a cloud has more than %lld cells (raise max_blocks)",
                (long long)vx_table_cells(max_blocks, nseg));
     ST_REQUIRE(!(h.overflow & 2u), "voxelize: %u blocks exceed max_blocks=%d", h.n_blocks, max_blocks);

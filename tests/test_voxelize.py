@@ -94,3 +94,18 @@ def test_whole_cloud_grid_beyond_the_key_range_is_refused(backend):
         voxelize_cloud(xyz, None, 0.001)
     ok = voxelize_cloud(xyz, None, 0.01)  # 7000 cells: fine
     assert ok.coords.shape[0] == 2  # (the point ON the maximum face has no cell: PointToVoxel drops c == grid)
+
+
+@pytest.mark.parametrize("bad", [float("nan"), float("inf"), -float("inf")])
+def test_non_finite_coordinates_are_refused(backend, bad):
+    """A NaN / infinite coordinate has no block (the reference's torch.unique over block ids would group it somewhere arbitrary):
+    the call fails and says why, for one cloud and inside a batch."""
+    c = sample_tree_cloud(4000, seed=2, scale=0.5, max_depth=3)
+    xyz = c["xyz"].copy()
+    xyz[900, 1] = bad
+    with pytest.raises(RuntimeError, match="non-finite"):
+        voxelize_blocks(torch.from_numpy(xyz).to(backend), None, 0.02)
+    both = torch.from_numpy(np.concatenate([c["xyz"], xyz])).to(backend)
+    seg = torch.tensor([0, 4000, 8000], dtype=torch.int32, device=both.device)
+    with pytest.raises(RuntimeError, match="non-finite"):
+        voxelize_blocks(both, None, 0.02, seg_off=seg)
