@@ -52,6 +52,7 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_bound_max(const float* bound, int
     for (int64_t i = i0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < i1; i += (int64_t)gridDim.x * blockDim.x) {
         if (valid && !valid[i]) continue;  // (a point that is not part of the search: see st_grid_build)
         const float b = bound[i];
+        if (b != b) continue;  // a NaN bound admits nobody (knn_d2_max) and must not become the search radius of its cloud
         const unsigned o = st_f2ord(b);
         if (o > mine) mine = o;
         fix += (unsigned long long)(fminf(fmaxf(b, 0.0f), 128.0f) * 65536.0f);  // (NaN -> 0)
@@ -77,7 +78,9 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_grid_bbox(const float* pts, int64
     const int step3 = (int)(step % 3);
     int a = (int)(e0 % 3);
     for (int64_t e = e0; e < total; e += step, a = (a + step3) % 3) {
-        const unsigned o = st_f2ord(pts[e]);
+        const float pv = pts[e];
+        if (!(fabsf(pv) <= 3.0e38f)) continue;  // NaN / infinity: such a point is not part of the search (k_grid_count), it must not size the grid
+        const unsigned o = st_f2ord(pv);
 #pragma unroll
         for (int k = 0; k < 3; k++)
             if (a == k) { l[k] = o < l[k] ? o : l[k]; h[k] = o > h[k] ? o : h[k]; }
@@ -108,14 +111,16 @@ __global__ void k_grid_dims(StGrid* g, float cell, int64_t max_cells, float r, i
         }
         cell = fmaxf(cell, 1e-4f);
     }
-    if (!(cell > 0.0f)) cell = 1.0f;
+    if (!(cell > 0.0f) || !(cell <= 3.0e38f)) cell = 1.0f;
     g->nseg = nseg;
-    for (;;) {
+    for (int a = 0; a < 3; a++)
+        if (!(hi[a] >= lo[a])) { lo[a] = hi[a] = 0.0f; g->lo[a] = 0.0f; }  // no finite coordinate at all: an empty one-cell grid
+    for (int it = 0;; it++) {
         double total = (double)nseg;
         for (int a = 0; a < 3; a++) {
             float ext = (hi[a] - lo[a]) / cell;
             int d = ext < 2.0e9f ? (int)floorf(ext) + 1 : 0x7fffffff;
-            if (d < 1) d = 1;
+            if (d < 1 || it >= 300) d = 1;  // (300 doublings exceed every finite extent; the bound only guards against a loop that cannot end)
             g->dim[a] = d;
             total *= (double)d;
         }
@@ -137,7 +142,12 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_grid_count(const float* pts, int6
                                                           const uint8_t* valid) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         if (valid && !valid[i]) { pt_cell[i] = 0xffffffffu; continue; }  // stays out of the table
-        const int64_t c = st_grid_cell(g, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], st_seg_find(seg_off, nseg, i));
+        const float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+        // a NaN / infinite coordinate: filed under the first cell of its cloud (a cell index cannot be computed from it).  As a
+        // candidate it is nobody's neighbour -- every distance to it is NaN or infinite, the compare fails as the oracle's does --
+        // and as a query it finds nobody (k_knn)
+        const bool finite = fabsf(x) <= 3.0e38f && fabsf(y) <= 3.0e38f && fabsf(z) <= 3.0e38f;
+        const int64_t c = st_grid_cell(g, finite ? x : g->lo[0], finite ? y : g->lo[1], finite ? z : g->lo[2], st_seg_find(seg_off, nseg, i));
         pt_cell[i] = (uint32_t)c;
         pt_rank[i] = atomicAdd(&counts[c], 1u);
     }
@@ -338,8 +348,12 @@ __global__ void __launch_bounds__(KNN_BLOCK, 8) k_knn(const float* __restrict__ 
         d2_max = knn_d2_max(bnd, mode == 2);
     }
     const float cell = g->cell;
-    int reach = reach_r > 0.0f ? (int)ceilf(reach_r / cell) : 0;
+    const float reach_f = reach_r > 0.0f ? ceilf(reach_r / cell) : 0.0f;
+    int reach = reach_f < 1.0e6f ? (int)reach_f : 1000000;  // (an infinite bound reaches every cell; the clamp keeps the integer arithmetic defined)
     if (reach < 1) reach = 1;
+    // a query with a NaN / infinite coordinate has no neighbours (every distance is NaN or infinite)
+    const bool q_finite = fabsf(px) <= 3.0e38f && fabsf(py) <= 3.0e38f && fabsf(pz) <= 3.0e38f;
+    if (!q_finite) { px = g->lo[0]; py = g->lo[1]; pz = g->lo[2]; reach = 0; d2_max = -1.0f; }
     const int cx = (int)floorf((px - g->lo[0]) / cell), cy = (int)floorf((py - g->lo[1]) / cell), cz = (int)floorf((pz - g->lo[2]) / cell);
     const int xoff = seg * g->seg_dim0;  // the cloud's slab of cells
     const int x0 = st_max(cx - reach, 0), x1 = st_min(cx + reach, g->seg_dim0 - 1);
@@ -363,8 +377,9 @@ __global__ void __launch_bounds__(KNN_BLOCK, 8) k_knn(const float* __restrict__ 
             const float dxy2 = ex * ex + ey * ey;
             if (!(dxy2 > rs2)) {
                 const float rz = sqrtf(rs2 - dxy2);
-                const int za = st_max((int)floorf((pz - rz - g->lo[2]) / cell) - 1, z0),
-                          zb = st_min((int)floorf((pz + rz - g->lo[2]) / cell) + 1, z1);
+                // (clamped as floats: with an infinite bound rz is infinite and the integer conversion would be undefined)
+                const int za = (int)fmaxf(floorf((pz - rz - g->lo[2]) / cell) - 1.0f, (float)z0),
+                          zb = (int)fminf(floorf((pz + rz - g->lo[2]) / cell) + 1.0f, (float)z1);
                 if (za <= zb) {
                     const int64_t row = ((int64_t)(xoff + x) * g->dim[1] + y) * g->dim[2];
                     first = cell_start[row + za];

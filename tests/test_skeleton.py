@@ -220,6 +220,41 @@ def test_skeletonizer_empty_cloud(backend):
     assert sk.forward(few).skeletons == []
 
 
+@pytest.mark.parametrize("bad", [float("nan"), float("inf")])
+def test_non_finite_medial_vectors_are_nobodys_neighbours(backend, bad):
+    """A network output that overflowed (exp of a large log-radius) gives NaN / infinite medial points.  Every distance to such a
+    point is NaN or infinite, so it is nobody's neighbour and finds no neighbour (the oracle's compares fail the same way): the
+    skeleton equals the one of the cloud WITHOUT those points -- and the search grid must not try to span them (round 5: the
+    cell-size loop of the grid never ended on an infinite bounding box)."""
+    c = sample_tree_cloud(6000, seed=2, scale=0.5, max_depth=3)
+    mv = c["medial_vector"].copy()
+    hit = np.zeros(len(mv), bool)
+    hit[[17, 900]] = True
+    hit[3000:3010] = True
+    mv[17, 1] = bad
+    mv[900] = bad
+    mv[3000:3010, 2] = -bad
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(backend)
+    sk = Skeletonizer(K=16, min_connection_length=0.02, minimum_graph_vertices=32, device=backend)
+    zeros = lambda n: np.zeros((n, 1), np.float32)
+    got = sk.forward(Cloud(xyz=t(c["xyz"]), medial_vector=t(mv), class_l=t(zeros(len(mv)))))
+    ref = sk.forward(Cloud(xyz=t(c["xyz"][~hit]), medial_vector=t(c["medial_vector"][~hit]), class_l=t(zeros(int((~hit).sum())))))
+    assert len(got.skeletons) == len(ref.skeletons) >= 1
+    n_branches = 0
+    for a, b in zip(got.skeletons, ref.skeletons):
+        assert list(a.branches) == list(b.branches)
+        for k in a.branches:
+            assert a.branches[k].parent_id == b.branches[k].parent_id
+            assert torch.equal(a.branches[k].xyz, b.branches[k].xyz) and torch.equal(a.branches[k].radii, b.branches[k].radii)
+        n_branches += len(a.branches)
+    assert n_branches >= 5
+    # the searches themselves: -1 / NaN rows for the non-finite queries, no non-finite index anywhere
+    pts = t(c["xyz"] + mv)
+    idx, dist, _ = G.knn(pts, pts, K=8, r=0.1)
+    idx = idx.cpu().numpy()
+    assert (idx[hit] == -1).all() and not np.isin(idx, np.nonzero(hit)[0]).any()
+
+
 def test_sample_tree_reference_signature(backend):
     """skeleton/path.py sample_tree(medial_pts, medial_radii, preds, distances, all_points) on one component."""
     from smart_tree_amd.skeleton.path import sample_tree
