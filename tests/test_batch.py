@@ -240,6 +240,16 @@ def test_process_clouds_edge_cases(backend):
     tiny = _clouds(backend, sizes=(25, 30))
     parts = pipe.process_clouds([Cloud(c.xyz, c.rgb) for c in tiny])
     assert len(parts) == 2 and all(len(p.skeletons) == 0 for p in parts)
+    # a MIXED batch: clouds that give a skeleton next to clouds that give none (too few points; a flat sheet, whose blocks have no
+    # voxel range along z -- the reference's PointToVoxel drops every point of such a block; all points identical)
+    rng = np.random.RandomState(0)
+    sheet = torch.from_numpy(np.concatenate([rng.rand(3000, 2) * 3, np.zeros((3000, 1))], 1).astype(np.float32)).to(backend)
+    same = torch.tensor([[1.0, 2.0, 3.0]], device=backend).repeat(500, 1)
+    mix = [Cloud(clouds[0].xyz, clouds[0].rgb), Cloud(tiny[0].xyz, tiny[0].rgb), Cloud(sheet, torch.zeros_like(sheet)),
+           Cloud(clouds[0].xyz * 0.9, clouds[0].rgb), Cloud(same, torch.zeros_like(same))]
+    alone = [_signature(pipe.process_cloud(cloud=Cloud(c.xyz, c.rgb))) for c in mix]
+    parts = pipe.process_clouds([Cloud(c.xyz, c.rgb) for c in mix])
+    assert [_signature(p) for p in parts] == alone and [len(a) > 0 for a in alone] == [True, False, False, True, False]
     # the phase hooks a caller with several batches in flight schedules by (bench.py): once per call, in order, results unchanged
     calls = []
     pipe.model_inference.on_network_done = lambda: calls.append("network")
