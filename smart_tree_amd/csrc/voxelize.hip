@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(VX_BLOCK) k_vx_bbox(const float* xyz, int64_t 
     int l[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, h[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
     bool finite = true;  // NaN / infinite coordinates have no block: the call fails with a message that says so
     vx_stream_points(xyz, n, i0, i1, [&](int64_t, float x, float y, float z) {
-        finite = finite && fabsf(x) <= 3.0e38f && fabsf(y) <= 3.0e38f && fabsf(z) <= 3.0e38f;
+        if (!(fabsf(x) <= 3.0e38f && fabsf(y) <= 3.0e38f && fabsf(z) <= 3.0e38f)) { finite = false; return; }  // (no integer is computed from it)
         const int q[3] = {vx_block_id(x, p), vx_block_id(y, p), vx_block_id(z, p)};
 #pragma unroll
         for (int a = 0; a < 3; a++) { l[a] = q[a] < l[a] ? q[a] : l[a]; h[a] = q[a] > h[a] ? q[a] : h[a]; }
@@ -125,6 +125,7 @@ __global__ void __launch_bounds__(VX_BLOCK) k_vx_hist(const float* xyz, int64_t 
                                                       int* table) {
     __shared__ int h[VX_LDS_CELLS];
     int d[3];
+    if (st->overflow & 16u) return;  // non-finite coordinates: the call fails (vx_voxelize), nothing is computed from them
     if (!vx_dims(st, d)) { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) atomicOr(&st->overflow, 1u); return; }
     // a tree spans a few dozen blocks: count in LDS, flush once per workgroup (global atomics on a
     // handful of words would serialise a million points)
@@ -246,7 +247,7 @@ __global__ void __launch_bounds__(VX_BLOCK) k_vx_minmax(const float* xyz, int64_
                                                         const int* table, VxParams p, unsigned* blk_lo, unsigned* blk_hi) {
     __shared__ unsigned slo[VX_LDS_BLOCKS * 3], shi[VX_LDS_BLOCKS * 3];
     int d[3];
-    if (!vx_dims(st, d)) return;
+    if ((st->overflow & 16u) || !vx_dims(st, d)) return;
     const int seg = blockIdx.y;
     const int* tab = table + (int64_t)seg * (d[0] * d[1] * d[2]);
     const int64_t i0 = seg_off ? seg_off[seg] : 0, i1 = seg_off ? seg_off[seg + 1] : n;
@@ -365,7 +366,7 @@ __global__ void __launch_bounds__(VX_BLOCK) k_vx_insert(const float* xyz, int64_
                                                         const int* table, VxParams p, const float* blk_lof,
                                                         const int* blk_grid, VxSlot* slots, unsigned long long cap) {
     int d[3];
-    if (!vx_dims(st, d)) return;
+    if ((st->overflow & 16u) || !vx_dims(st, d)) return;
     const int seg = blockIdx.y;
     const int* tab = table + (int64_t)seg * (d[0] * d[1] * d[2]);
     const int64_t i0 = seg_off ? seg_off[seg] : 0, i1 = seg_off ? seg_off[seg + 1] : n;
