@@ -574,8 +574,7 @@ static int vx_voxelize(const float* xyz, const float* rgb, int64_t n, const int3
     p.max_blocks = max_blocks;
     p.nseg = nseg;
 
-    const dim3 gs = vx_grid_seg(n, nseg, 4096), gr = vx_grid_seg(n, nseg, 512 / (nseg < 8 ? nseg : 8) + 8);
-    const dim3 g1((unsigned)st_min64(st_div_up(st_div_up(n, nseg), VX_BLOCK) + 1, 4096), (unsigned)nseg);  // one lane per point
+    const dim3 gr = vx_grid_seg(n, nseg, 512 / (nseg < 8 ? nseg : 8) + 8);
     hipLaunchKernelGGL(k_vx_init, dim3(1), dim3(64), 0, stream, st, (int)vx_table_cells(max_blocks, nseg));
     (void)hipMemsetAsync(table, 0, vx_table_cells(max_blocks, nseg) * nseg * sizeof(int), stream);
     (void)hipMemsetAsync(slots, 0xff, cap * sizeof(VxSlot), stream);  // empty key, value = "no point yet"
