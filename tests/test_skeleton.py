@@ -255,6 +255,32 @@ def test_non_finite_medial_vectors_are_nobodys_neighbours(backend, bad):
     assert (idx[hit] == -1).all() and not np.isin(idx, np.nonzero(hit)[0]).any()
 
 
+def test_search_bounds_of_every_kind(backend):
+    """Per-query bounds that are infinite, NaN, negative, zero or huge, against brute force: an infinite bound reaches every point
+    (up to the search radius), a NaN / negative one admits nobody, zero admits exact duplicates only; and with the search radius
+    reduced on the device from the bounds (r < 0: outlier_removal) one infinite bound must not spoil the other queries."""
+    rng = np.random.RandomState(1)
+    pts = rng.rand(3000, 3).astype(np.float32)
+    bound = (0.02 + 0.05 * rng.rand(3000)).astype(np.float32)
+    odd = {5: np.inf, 77: np.nan, 100: -1.0, 200: 0.0, 300: 1e30}
+    for i, v in odd.items():
+        bound[i] = v
+    t = lambda a: torch.from_numpy(a).to(backend)
+    K = 8
+    idx, _, _ = G.knn(t(pts), t(pts), K=K, r=0.1, bound=t(bound), bound_mode=G.BOUND_LE)
+    idx = idx.cpu().numpy()
+    d = pts[:, None, :] - pts[None, :, :]
+    d2 = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
+    with np.errstate(invalid="ignore"):
+        for i in list(odd) + list(range(40)):
+            cand = np.nonzero((d2[i] < np.float32(0.1) ** 2) & (np.sqrt(d2[i]) <= bound[i]))[0]
+            want = cand[np.lexsort((cand, d2[i][cand]))][:K]
+            np.testing.assert_array_equal(idx[i][idx[i] >= 0], want, err_msg=f"query {i} (bound {bound[i]})")
+        keep = outlier_removal(t(pts), t(bound).unsqueeze(1), nb_points=8).cpu().numpy()
+        np.testing.assert_array_equal(keep, (np.sqrt(d2) < bound[:, None]).sum(1) >= 8)
+    assert keep[5] and keep[300] and not keep[77] and not keep[100] and not keep[200]
+
+
 def test_sample_tree_reference_signature(backend):
     """skeleton/path.py sample_tree(medial_pts, medial_radii, preds, distances, all_points) on one component."""
     from smart_tree_amd.skeleton.path import sample_tree
