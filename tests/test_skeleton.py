@@ -192,14 +192,16 @@ def test_components_with_duplicates_and_plateaus(backend):
     _compare_components(backend, pts, mv, block_threads=64)
 
 
-def test_skeletonizer_forward_objects(backend):
+@pytest.mark.parametrize("K,min_conn,min_vertices", [(16, 0.02, 32), (8, 0.02, 32), (16, 0.05, 10)])
+def test_skeletonizer_forward_objects(backend, K, min_conn, min_vertices):
+    """conf/pipeline.yaml's skeletonizer keywords (K, min_connection_length, minimum_graph_vertices) other than the defaults, too."""
     pts, mv = _tree(n=2000, seed=6)
-    ref = so.skeletonize(pts, mv)
+    ref = so.skeletonize(pts, mv, K=K, min_connection_length=min_conn, minimum_graph_vertices=min_vertices)
     t = lambda a: torch.from_numpy(a).to(backend)
-    sk = Skeletonizer(K=16, min_connection_length=0.02, minimum_graph_vertices=32, device=backend)
+    sk = Skeletonizer(K=K, min_connection_length=min_conn, minimum_graph_vertices=min_vertices, device=backend)
     sk.block_threads = 128
     out = sk.forward(Cloud(xyz=t(pts), medial_vector=t(mv)))
-    assert len(out.skeletons) == len(ref.components)
+    assert len(out.skeletons) == len(ref.components) >= 1 and sum(len(rc.branches) for rc in ref.components) >= 2
     kept = np.nonzero(ref.keep_mask)[0]
     medial = (pts + mv)[kept]
     radius = np.sqrt(((mv * mv)[:, 0] + (mv * mv)[:, 1]) + (mv * mv)[:, 2]).astype(np.float32)[kept]
