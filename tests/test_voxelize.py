@@ -29,6 +29,16 @@ def test_voxelize_tree(backend, n, voxel):
     assert out.coords.shape[0] > 0
 
 
+@pytest.mark.parametrize("block,buffer,voxel,min_points", [(3.0, 0.25, 0.03, 20), (0.7, 0.1, 0.013, 5), (8.0, 0.4, 0.1, 50), (2.5, 1.2, 0.04, 1)])
+def test_voxelize_other_block_geometries(backend, block, buffer, voxel, min_points):
+    """Block sizes that are not powers of two (the kernel divides instead of multiplying by the reciprocal), voxel sizes that do not
+    divide the block, other min_points: conf/tree-dataset.yaml's keywords away from the shipped values."""
+    c = sample_tree_cloud(9000, seed=5, scale=0.8)
+    xyz = vo.centre_cloud(c["xyz"])
+    out = _compare(xyz, np.zeros_like(xyz), voxel, backend, block_size=block, buffer_size=buffer, min_points=min_points)
+    assert out.coords.shape[0] > 100 and out.block_centres.shape[0] >= 2
+
+
 def test_voxelize_block_boundaries(backend):
     """Points exactly on block / halo faces, duplicates, a block below the min_points threshold."""
     rng = np.random.RandomState(1)
