@@ -159,6 +159,23 @@ def test_unet_random_weights_every_layer(backend):
         np.testing.assert_allclose(out[k].cpu().numpy(), ref[k], rtol=1e-4, atol=1e-4 * np.abs(ref[k]).max())
 
 
+def test_unet_of_the_training_config_depth(backend):
+    """conf/training.yaml:123-127 trains `unet_planes: [8, 16, 32]` -- one level fewer than the shipped checkpoints.  The depth is read
+    off the state dict; the three-level network (the deepest UBlock and the encoder / decoder / tail around it removed) must match
+    the oracle as the four-level one does."""
+    vx = _small_batch(n=5000, seed=9)
+    w = random_state_dict(uo.load_weights(WEIGHTS / "noble-elevator-58.npz"), seed=1)
+    gone = ("UNet.U.U.U.", "UNet.U.U.Encode", "UNet.U.U.Decode", "UNet.U.U.Tail")
+    w3 = {k: v for k, v in w.items() if not k.startswith(gone)}
+    assert len(w3) < len(w)
+    ref = uo.OracleNet(w3, dtype=torch.float64).forward(vx["feats"][:, :3], vx["coords"])
+    net = Smart_Tree(w3, device=backend)
+    assert net.depth == 2
+    out = net.forward(sparse_from_batch(torch.from_numpy(vx["feats"][:, :3]), torch.from_numpy(vx["coords"]), backend))
+    for k in out:
+        np.testing.assert_allclose(out[k].cpu().numpy(), ref[k], rtol=1e-4, atol=1e-4 * np.abs(ref[k]).max())
+
+
 def test_unet_half_precision_storage_mode(backend):
     """BASELINE.json configs[4] (an extension: the reference's inference is float32): levels with >= 16 channels keep
     features and weights in IEEE half, f16 matrix-core kernel with float32 accumulation.  Checked against the float64
