@@ -149,6 +149,40 @@ __global__ void __launch_bounds__(CONV_BLOCK) k_sparse_conv(const TIN* __restric
     }
 }
 
+// Any (Cin, Cout): one lane per output row and four output channels, plain loops.  Same order of operations per output element
+// as the instantiated kernels (offsets ascending, input channels ascending, one fmaf each): the same bits where both exist.
+__global__ void __launch_bounds__(CONV_BLOCK) k_sparse_conv_any(const float* __restrict__ x0, int c0, const float* __restrict__ x1, int cin,
+                                                                const int32_t* __restrict__ nbr, int K, int64_t n_out, int64_t nstride,
+                                                                const float* __restrict__ w, int cout, const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, const float* __restrict__ residual, int relu,
+                                                                float* __restrict__ y, const int32_t* __restrict__ row_order) {
+    const int64_t pos = (int64_t)blockIdx.x * CONV_BLOCK + threadIdx.x;
+    if (pos >= n_out) return;
+    const int co0 = (int)blockIdx.y * 4, nco = cout - co0 < 4 ? cout - co0 : 4;
+    const int32_t entry = row_order ? row_order[pos] : 0;
+    const int64_t o = row_order ? (int64_t)(entry & CONV_ROW_MASK) : pos;
+    const uint32_t live = conv_live_offsets(entry, K);
+    const int c1 = cin - c0;
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int k = 0; k < K; k++) {
+        if (K <= 32 && !((live >> k) & 1u)) continue;
+        const int idx = nbr ? nbr[(int64_t)k * nstride + o] : (int)o;
+        if (idx < 0) continue;
+        const float* __restrict__ wk = w + (int64_t)k * cin * cout + co0;
+        for (int ci = 0; ci < cin; ci++) {
+            const float xv = ci < c0 ? x0[(int64_t)idx * c0 + ci] : x1[(int64_t)idx * c1 + (ci - c0)];
+            for (int c = 0; c < nco; c++) acc[c] = fmaf(xv, wk[(int64_t)ci * cout + c], acc[c]);
+        }
+    }
+    for (int c = 0; c < nco; c++) {
+        float v = acc[c];
+        if (scale) v = fmaf(v, scale[co0 + c], shift[co0 + c]);
+        if (residual) v += residual[o * cout + co0 + c];
+        if (relu) v = v > 0.0f ? v : 0.0f;
+        y[o * cout + co0 + c] = v;
+    }
+}
+
 template <int CIN, int COT, class TIN = float, class TOUT = float>
 static int conv_launch(const TIN* x0, int c0, const TIN* x1, const int32_t* nbr, int K, int64_t n_out, int64_t nstride, const float* w,
                        int cout, const float* scale, const float* shift, const float* residual, int relu, TOUT* y,
@@ -920,8 +954,11 @@ extern "C" int st_sparse_conv_fwd(const float* x0, int c0, const float* x1, int 
     CONV_CASE(64, 32, 16)
     CONV_CASE(64, 64, 16)
 #undef CONV_CASE
-    st_set_error("conv: no kernel instance for cin=%d cout=%d", cin, cout);
-    return ST_ERR_INVALID;
+    // any other channel counts (a model config away from the shipped planes, e.g. colour as input channels 4-6): the generic kernel
+    hipLaunchKernelGGL(k_sparse_conv_any, dim3((unsigned)st_div_up(n_out, CONV_BLOCK), (unsigned)st_div_up(cout, 4)), dim3(CONV_BLOCK), 0, stream, x0, c0,
+                       x1, cin, nbr, K, n_out, nstride, w, cout, scale, shift, residual, relu, y, row_order);
+    ST_CHECK_LAUNCH();
+    return ST_OK;
 }
 
 // ----------------------------------------------------------------------------------- heads ---

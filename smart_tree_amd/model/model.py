@@ -66,7 +66,10 @@ class Smart_Tree:
             if key.endswith(".weight") and t.ndim == 5 and "_head." not in key:
                 name = key[: -len(".weight")]
                 self.w[name] = _conv_weight(t).to(self.device)
-                if self.w[name].shape[1] % 16 == 0 and self.w[name].shape[2] % 16 == 0:
+                cin_, cout_ = self.w[name].shape[1], self.w[name].shape[2]
+                if self.fp16 and not (ops.mfma_eligible(cin_, cout_, 16) or (cin_, cout_) in ((3, 8), (8, 8), (8, 16), (16, 8))):
+                    raise ValueError(f"fp16 storage mode has kernels for the shipped widths only (layer {name}: {cin_} -> {cout_})")
+                if ops.mfma_eligible(cin_, cout_, 16):  # (other widths: the generic kernel behind st_sparse_conv_fwd)
                     self.wp[name] = ops.mfma_weight(self.w[name])
                     if self.w[name].shape[1] % 32 == 0 or (self.w[name].shape[0] == 27 and ops.b3_eligible(*self.w[name].shape[1:], self.w[name].shape[1])):
                         self.wq[name] = ops.b3_weight(self.w[name])
@@ -75,7 +78,17 @@ class Smart_Tree:
             elif key.endswith(".running_mean") and "_head." not in key:
                 p = key[: -len(".running_mean")]
                 self.bn[p] = _Affine(sd, p, self.device)
-        self.head_params = self._pack_heads(sd).to(self.device)
+        # the fused head kernel holds the shipped head shapes (planes[0] = 8 -> 8 -> 4 -> 1 / 3 / 2); a model config with other
+        # `*_fc_planes` or `unet_planes[0]` (conf/training.yaml:123-127) runs its heads as pointwise convolutions instead
+        self.generic_heads = not self._heads_are_standard(sd)
+        self.head_params = None if self.generic_heads else self._pack_heads(sd).to(self.device)
+        if self.generic_heads:
+            self.head_layers = {}
+            for name in ("radius_head", "direction_head", "class_head"):
+                mat = lambda i: sd[f"{name}.sequence.{i}.weight"].reshape(sd[f"{name}.sequence.{i}.weight"].shape[0], -1).T.contiguous().float()
+                self.head_layers[name] = [(mat(0).unsqueeze(0).to(self.device), _Affine(sd, f"{name}.sequence.1", self.device)),
+                                          (mat(3).unsqueeze(0).to(self.device), _Affine(sd, f"{name}.sequence.4", self.device)),
+                                          (mat(6).unsqueeze(0).to(self.device), None)]
         self.use_bricks = True  # rulebooks from occupancy bricks when the input carries `brick_hint` (sparse.py); else hash tables
         self.spatial_order = True  # run the network on Morton-ordered rows (same values; see features()); traces keep input order
         self.trace = None  # set to a dict to record every block's output (input, head{l}, enc{l}, dec{l}, tail{l}): parity tests
@@ -86,6 +99,29 @@ class Smart_Tree:
 
     def to(self, device):
         return self if torch.device(device) == self.device else Smart_Tree(self._state, device, self.fp16)
+
+    @staticmethod
+    def _heads_are_standard(sd) -> bool:
+        for name, nout in (("radius_head", 1), ("direction_head", 3), ("class_head", 2)):
+            shapes = [tuple(sd[f"{name}.sequence.{i}.weight"].reshape(sd[f"{name}.sequence.{i}.weight"].shape[0], -1).shape) for i in (0, 3, 6)]
+            if shapes != [(8, 8), (4, 8), (nout, 4)]:
+                return False
+        return True
+
+    def _generic_heads(self, x: torch.Tensor, with_tail: bool):
+        """SparseFC heads (model_blocks.py:246-285) of any shape: pointwise convolutions with the BatchNorm affine and ReLU in their
+        epilogue; direction normalised as the reference's forward does (F.normalize), tail = model_inference.py:87-88."""
+        n = x.shape[0]
+        outs = []
+        for name in ("radius_head", "direction_head", "class_head"):
+            h = x
+            for w, aff in self.head_layers[name]:
+                h = ops.sparse_conv(h, w, None, n, scale=aff.scale if aff else None, shift=aff.shift if aff else None, relu=aff is not None)
+            outs.append(h)
+        radius, direction, class_l = outs[0], torch.nn.functional.normalize(outs[1]), outs[2]
+        if not with_tail:
+            return radius, direction, class_l, None, None
+        return radius, direction, class_l, torch.exp(radius) * direction, torch.argmax(class_l, dim=1, keepdim=True)
 
     @staticmethod
     def _pack_heads(sd) -> torch.Tensor:
@@ -179,11 +215,13 @@ class Smart_Tree:
         return x
 
     def forward(self, sparse_input) -> Dict[str, torch.Tensor]:
-        radius, direction, class_l, _, _ = ops.mlp_heads(self.features(sparse_input), self.head_params)
+        x = self.features(sparse_input)
+        radius, direction, class_l, _, _ = self._generic_heads(x, False) if self.generic_heads else ops.mlp_heads(x, self.head_params)
         return {"radius": radius, "direction": direction, "class_l": class_l}
 
     __call__ = forward
 
     def forward_fused_tail(self, sparse_input):
         """forward() plus ModelInference's exp(radius)*direction and argmax in the same kernel."""
-        return ops.mlp_heads(self.features(sparse_input), self.head_params, with_tail=True)
+        x = self.features(sparse_input)
+        return self._generic_heads(x, True) if self.generic_heads else ops.mlp_heads(x, self.head_params, with_tail=True)

@@ -240,8 +240,13 @@ def mfma_weight16_half(w: torch.Tensor) -> torch.Tensor:
     return mfma_weight(w).half()
 
 
+_MFMA_SHAPES = ((16, 16), (16, 32), (32, 16), (32, 32), (32, 64), (64, 32), (64, 64))  # the instantiated (Cin, Cout) of the matrix-core kernels
+
+
 def mfma_eligible(cin: int, cout: int, c0: int) -> bool:
-    return cin % 16 == 0 and cout % 16 == 0 and c0 % 16 == 0
+    """The matrix-core kernels exist for the shipped architecture's widths; any other (Cin, Cout) takes st_sparse_conv_fwd, whose
+    generic kernel handles every width."""
+    return (cin, cout) in _MFMA_SHAPES and c0 % 16 == 0
 
 
 def b3_eligible(cin: int, cout: int, c0: int) -> bool:

@@ -176,6 +176,80 @@ def test_unet_of_the_training_config_depth(backend):
         np.testing.assert_allclose(out[k].cpu().numpy(), ref[k], rtol=1e-4, atol=1e-4 * np.abs(ref[k]).max())
 
 
+@pytest.mark.parametrize("cin,cout,c0", [(6, 8, 6), (5, 7, 5), (24, 40, 12), (16, 48, 16), (128, 64, 64)])
+def test_conv_of_any_channel_counts(backend, cin, cout, c0):
+    """Channel counts no kernel is instantiated for (a model config away from the shipped planes; colour as input channels 4-6):
+    the generic kernel behind st_sparse_conv_fwd, with concat, BatchNorm affine, residual, ReLU and a row order, against float64."""
+    rng = np.random.RandomState(cin * 100 + cout)
+    n, n_in, K = 517, 490, 27
+    nbr = rng.randint(0, n_in, size=(K, n)).astype(np.int32)
+    nbr[rng.rand(K, n) < 0.5] = -1
+    x = rng.randn(n_in, cin).astype(np.float32)
+    w = (rng.randn(K, cin, cout) * 0.1).astype(np.float32)
+    scale, shift = rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.randn(cout).astype(np.float32)
+    res = rng.randn(n, cout).astype(np.float32)
+    order = rng.permutation(n).astype(np.int32)
+    ref = np.zeros((n, cout))
+    for k in range(K):
+        hit = nbr[k] >= 0
+        ref[hit] += x[nbr[k][hit]].astype(np.float64) @ w[k].astype(np.float64)
+    ref = np.maximum(ref * scale.astype(np.float64) + shift.astype(np.float64) + res.astype(np.float64), 0.0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(backend)
+    x0, x1 = (t(x[:, :c0]), t(x[:, c0:])) if c0 < cin else (t(x), None)
+    got = ops.sparse_conv(x0, t(w), t(nbr), n, x1=x1, scale=t(scale), shift=t(shift), residual=t(res), relu=True, row_order=t(order))
+    np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=2e-5, atol=2e-5 * np.abs(ref).max())
+    # pointwise (K = 1, no table), no epilogue
+    y = ops.sparse_conv(t(x[:n]), t(w[:1]), None, min(n, n_in)).cpu().numpy()
+    np.testing.assert_allclose(y, x[:min(n, n_in)].astype(np.float64) @ w[0].astype(np.float64), rtol=2e-5, atol=2e-5)
+
+
+def _other_architecture(template, planes, hidden, n_classes):
+    """The checkpoint's keys with other widths: unet_planes -> `planes`, head layers planes[0] -> hidden[0] -> hidden[1] -> outputs."""
+    cmap = dict(zip((8, 16, 32, 64), planes))
+    shapes = {}
+    for k, v in template.items():
+        name = k.split(".")[0]
+        if name.endswith("_head"):
+            i = int(k.split(".")[2])
+            nout = {"radius_head": 1, "direction_head": 3, "class_head": n_classes}[name]
+            widths = {0: (hidden[0], planes[0]), 1: (hidden[0],), 3: (hidden[1], hidden[0]), 4: (hidden[1],), 6: (nout, hidden[1])}[i]
+            shapes[k] = (widths[0], 1, 1, 1, widths[1]) if v.ndim == 5 else (() if v.ndim == 0 else (widths[0],))
+        elif v.ndim == 5 and (".Tail.sequence.0." in k or ".Tail.identity.0." in k):  # the concat of skip and decoded features: 2 x the level's width
+            shapes[k] = (cmap[v.shape[0]], *v.shape[1:4], 2 * cmap[v.shape[0]])
+        elif v.ndim == 5:
+            shapes[k] = (cmap[v.shape[0]], *v.shape[1:4], cmap.get(v.shape[4], v.shape[4]))  # (the input conv keeps its 3 channels)
+        else:
+            shapes[k] = () if v.ndim == 0 else (cmap[v.shape[0]],)
+    return random_state_dict({k: np.zeros(sh, np.float32) for k, sh in shapes.items()}, seed=4)
+
+
+@pytest.mark.parametrize("planes,hidden,n_classes", [((12, 24, 40, 72), (10, 6), 3), ((16, 32, 64, 128), (16, 8), 2)])
+def test_unet_of_another_architecture(backend, planes, hidden, n_classes):
+    """`unet_planes`, `*_fc_planes` and the number of classes are model-config keywords (conf/training.yaml:123-127): widths no
+    kernel is instantiated for run through the generic convolution, heads of other shapes as pointwise convolutions -- every block
+    output and the head outputs against the oracle, and the inference tail (exp(radius) * direction, first-max class)."""
+    vx = _small_batch(n=4000, seed=11)
+    w = _other_architecture(uo.load_weights(WEIGHTS / "noble-elevator-58.npz"), planes, hidden, n_classes)
+    oracle = uo.OracleNet(w, dtype=torch.float64)
+    ref = oracle.forward(vx["feats"][:, :3], vx["coords"])
+    net = Smart_Tree(w, device=backend)
+    assert net.planes == list(planes) and net.generic_heads
+    sp = sparse_from_batch(torch.from_numpy(vx["feats"][:, :3]), torch.from_numpy(vx["coords"]), backend)
+    net.trace = {}
+    out = net.forward(sp)
+    for name, got in net.trace.items():
+        want = oracle.trace[name].numpy()
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-4, atol=1e-4 * np.abs(want).max(), err_msg=name)
+    assert out["class_l"].shape[1] == n_classes
+    for k in out:
+        np.testing.assert_allclose(out[k].cpu().numpy(), ref[k], rtol=1e-4, atol=1e-4 * np.abs(ref[k]).max())
+    net.trace = None
+    r, d, c, mv, cls = net.forward_fused_tail(sp)
+    mv_ref, cls_ref = uo.inference_tail(r.cpu().numpy(), d.cpu().numpy(), c.cpu().numpy())
+    np.testing.assert_allclose(mv.cpu().numpy(), mv_ref, rtol=2e-6, atol=1e-30)
+    np.testing.assert_array_equal(cls.cpu().numpy(), cls_ref)
+
+
 def test_unet_half_precision_storage_mode(backend):
     """BASELINE.json configs[4] (an extension: the reference's inference is float32): levels with >= 16 channels keep
     features and weights in IEEE half, f16 matrix-core kernel with float32 accumulation.  Checked against the float64
