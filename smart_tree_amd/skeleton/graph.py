@@ -22,7 +22,7 @@ BOUND_NONE, BOUND_LE, BOUND_LT = 0, 1, 2
 
 def knn(src: torch.Tensor, dest: torch.Tensor, K: int = 50, r: float = 1.0, grid=None, bound: Optional[torch.Tensor] = None,
         bound_mode: int = BOUND_NONE, cell: float = 0.0, src_seg_off: Optional[torch.Tensor] = None,
-        dest_seg_off: Optional[torch.Tensor] = None):
+        dest_seg_off: Optional[torch.Tensor] = None, keep_kernel_width: bool = False):
     """The <= K nearest `dest` points of every `src` point with d^2 < r^2, ascending (ties: lower index).
 
     `bound` (per query) additionally keeps only d <= bound[i] (BOUND_LE) or d < bound[i] (BOUND_LT);
@@ -30,6 +30,18 @@ def knn(src: torch.Tensor, dest: torch.Tensor, K: int = 50, r: float = 1.0, grid
     src_seg_off / dest_seg_off ([B+1] int32, device): src and dest hold B independent clouds each; a query only sees
     its own cloud (additive keywords, Cloud.collate).
     """
+    if K not in (1, 8, 16):
+        # the kernels hold 1, 8 or 16 neighbours per query; any other K <= 16 is the first K columns of the next width (the rows
+        # are sorted by (distance, index), so the K nearest of 16 are the K nearest).  keep_kernel_width: the table keeps that
+        # width with the columns past K emptied (-1 / NaN) -- what the graph builders, which want a power of two, read
+        if not 1 <= K <= 16:
+            raise ValueError(f"knn: 1 <= K <= 16 (got {K}; the reference's skeletoniser uses 16)")
+        idx, dist, grid = knn(src, dest, 8 if K < 8 else 16, r, grid, bound, bound_mode, cell, src_seg_off, dest_seg_off)
+        if keep_kernel_width:
+            idx[:, K:] = -1
+            dist[:, K:] = float("nan")
+            return idx, dist, grid
+        return idx[:, :K].contiguous(), dist[:, :K].contiguous(), grid
     L = _lib.lib()
     dev = src.device
     src = src.contiguous().float()
@@ -111,7 +123,7 @@ def nn_graph(points: torch.Tensor, radii: torch.Tensor, K: int = 40, seg_off: Op
         g.seg_off = seg_off
         return g
     idxs, dists, _ = knn(points, points, K=K, r=-1.0, bound=radii, bound_mode=BOUND_LE, cell=-GRAPH_CELL_DIV,
-                         src_seg_off=seg_off, dest_seg_off=seg_off)
+                         src_seg_off=seg_off, dest_seg_off=seg_off, keep_kernel_width=True)
     return KnnGraph(points, idxs, dists, seg_off)  # the edge list (make_edges) is cut only if somebody reads .edges
 
 

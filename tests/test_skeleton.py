@@ -27,7 +27,7 @@ def _tree(n=2500, seed=4, voxel=0.04, exact_medial=False):
     return pts.astype(np.float32), mv.astype(np.float32)
 
 
-@pytest.mark.parametrize("K", [1, 8, 16])
+@pytest.mark.parametrize("K", [1, 8, 16, 4, 11])
 def test_knn_matches_oracle(backend, K):
     rng = np.random.RandomState(K)
     dst = rng.uniform(0, 1, (1500, 3)).astype(np.float32)
@@ -64,17 +64,19 @@ def test_knn_dense_neighbourhoods(backend, K, cell):
     np.testing.assert_array_equal(d.cpu().numpy(), ref_d)
 
 
-def test_outlier_and_graph_match_oracle(backend):
+@pytest.mark.parametrize("nb,K", [(8, 16), (4, 10), (5, 8)])
+def test_outlier_and_graph_match_oracle(backend, nb, K):
+    """nb_points / K other than the pipeline's (filter.py's own default is nb_points = 4): any K <= 16 is served by the next kernel width."""
     pts, mv = _tree()
     medial = pts + mv
     radius = np.sqrt(((mv * mv)[:, 0] + (mv * mv)[:, 1]) + (mv * mv)[:, 2]).astype(np.float32)
     t = lambda a: torch.from_numpy(a).to(backend)
-    keep = outlier_removal(t(medial), t(radius).unsqueeze(1), nb_points=8)
-    ref_keep = so.outlier_removal(medial, radius, 8)
+    keep = outlier_removal(t(medial), t(radius).unsqueeze(1), nb_points=nb)
+    ref_keep = so.outlier_removal(medial, radius, nb)
     np.testing.assert_array_equal(keep.cpu().numpy(), ref_keep)
     medial, radius = medial[ref_keep], np.maximum(radius[ref_keep], np.float32(0.02))
-    g = G.nn_graph(t(medial), t(radius), K=16)
-    ref_e, ref_w = so.nn_graph(medial, radius, 16)
+    g = G.nn_graph(t(medial), t(radius), K=K)
+    ref_e, ref_w = so.nn_graph(medial, radius, K)
     np.testing.assert_array_equal(g.edges.cpu().numpy(), ref_e)
     np.testing.assert_array_equal(g.edge_weights.cpu().numpy(), ref_w)
     assert not (ref_e[:, 1] == 0).any() and (ref_e[:, 0] == ref_e[:, 1]).sum() == len(medial) - 1  # idx > 0 quirk
@@ -192,7 +194,7 @@ def test_components_with_duplicates_and_plateaus(backend):
     _compare_components(backend, pts, mv, block_threads=64)
 
 
-@pytest.mark.parametrize("K,min_conn,min_vertices", [(16, 0.02, 32), (8, 0.02, 32), (16, 0.05, 10)])
+@pytest.mark.parametrize("K,min_conn,min_vertices", [(16, 0.02, 32), (8, 0.02, 32), (16, 0.05, 10), (10, 0.03, 16)])
 def test_skeletonizer_forward_objects(backend, K, min_conn, min_vertices):
     """conf/pipeline.yaml's skeletonizer keywords (K, min_connection_length, minimum_graph_vertices) other than the defaults, too."""
     pts, mv = _tree(n=2000, seed=6)
