@@ -503,7 +503,7 @@ extern "C" int st_knn_radius_seg(const float* src, int64_t n1, const float* dst,
                                  const int32_t* dst_seg_off, int nseg, void* ws, int64_t ws_bytes, void* stream_,
                                  float cell_mean_mult) {
     hipStream_t stream = (hipStream_t)stream_;
-    ST_REQUIRE(K == 1 || K == 8 || K == 16, "knn: K must be 1, 8 or 16 (got %d)", K);
+    ST_REQUIRE(K == 1 || K == 8 || K == 16 || K == 32, "knn: K must be 1, 8, 16 or 32 (got %d)", K);
     ST_REQUIRE(bound_mode == 0 || bound != nullptr, "knn: bound_mode needs a bound array");
     ST_REQUIRE(r >= 0.0f || bound != nullptr, "knn: r < 0 (radius = max(bound)) needs a bound array");
     ST_REQUIRE(cell_hint >= 0.0f || r < 0.0f, "knn: a relative cell size (cell_hint < 0) goes with r < 0");
@@ -530,8 +530,11 @@ extern "C" int st_knn_radius_seg(const float* src, int64_t n1, const float* dst,
     else if (K == 8)
         hipLaunchKernelGGL((k_knn<8>), grid, block, 0, stream, src, n1, (const StGrid*)g, (const uint32_t*)cell_start,
                            (const float4*)recs, r, bound, bound_mode, idx, dist, src_seg_off, nseg, cell_order);
-    else
+    else if (K == 16)
         hipLaunchKernelGGL((k_knn<16>), grid, block, 0, stream, src, n1, (const StGrid*)g, (const uint32_t*)cell_start,
+                           (const float4*)recs, r, bound, bound_mode, idx, dist, src_seg_off, nseg, cell_order);
+    else
+        hipLaunchKernelGGL((k_knn<32>), grid, block, 0, stream, src, n1, (const StGrid*)g, (const uint32_t*)cell_start,
                            (const float4*)recs, r, bound, bound_mode, idx, dist, src_seg_off, nseg, cell_order);
     ST_CHECK_LAUNCH();
     return ST_OK;
