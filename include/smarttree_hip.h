@@ -151,7 +151,9 @@ int st_centre_cloud(const float* xyz, int64_t n, float* out, void* ws, int64_t w
 int st_medial_points(const float* xyz, const float* mv, int64_t n, float* medial, float* radius, void* stream);
 int64_t st_knn_workspace_bytes(int64_t n_dst);
 /* r < 0 (with a bound array): the search radius is max(bound[0..n1)), reduced on the device -- the callers
- * (skeleton/filter.py, skeleton/graph.py) no longer read it back just to pass it in; cell_hint < 0: cell = max(r / -cell_hint, 1e-4) */
+ * (skeleton/filter.py, skeleton/graph.py) no longer read it back just to pass it in; cell_hint < 0: cell = max(r / -cell_hint, 1e-4).
+ * K = 1, 8, 16 or 32 (the rows come out sorted by (distance, index): any other K <= 32 is the first K columns of the next width).
+ * NaN / infinite points are nobody's neighbour and find none; a NaN bound admits nobody, an infinite one every point within r. */
 int st_knn_radius(const float* src, int64_t n1, const float* dst, int64_t n2, int K, float r, const float* bound,
                   int bound_mode, float cell_hint, int64_t* idx, float* dist, void* ws, int64_t ws_bytes, void* stream);
 int64_t st_make_edges_workspace_bytes(int64_t n);
