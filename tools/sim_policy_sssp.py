@@ -144,3 +144,70 @@ for q in quanta:
     print(f"quantum {q:g} m: {its} policy iterations to the fixed point, distances bit-identical to the oracle: {same}")
     print("   per iteration (vertices that switch, vertices whose distance differs from the oracle's, tree depth): "
           + " ".join(f"({a},{b},{c})" for a, b, c in log[:12]) + (" ..." if len(log) > 12 else ""))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Variant: evaluate AND switch in one depth-ordered pass (Gauss-Seidel).  Level L of the current tree takes the best offer of ALL its
+# neighbours -- values of this pass from the levels above, values of the previous pass from the rest (both are path sums, i.e. upper
+# bounds) -- and keeps its predecessor unless another offer is strictly better.  Passes until nobody changes.
+o_dst = np.argsort(dst, kind="stable")
+in_src, in_w = src[o_dst], ww[o_dst]
+in_off = np.searchsorted(dst[o_dst], np.arange(n + 1))
+
+
+def levels_of(pred):
+    children_order = np.argsort(pred, kind="stable")
+    ps = pred[children_order]
+    out, frontier = [], np.array([root])
+    while len(frontier):
+        lo, hi = np.searchsorted(ps, frontier, "left"), np.searchsorted(ps, frontier, "right")
+        cnt = hi - lo
+        if cnt.sum() == 0:
+            break
+        frontier = children_order[np.repeat(lo - np.cumsum(cnt) + cnt, cnt) + np.arange(cnt.sum())]
+        out.append(frontier)
+    return out
+
+
+for q in quanta:
+    approx = d64 if q == 0 else np.floor(d64 / q) * q
+    rank = np.empty(n, np.int64)
+    rank[np.argsort(d64, kind="stable")] = np.arange(n)
+    ok = rank[src] < rank[dst]
+    offer = np.where(ok, approx[src] + ww, np.inf)
+    o = np.lexsort((src, offer, dst))
+    first = np.ones(len(o), bool)
+    first[1:] = dst[o][1:] != dst[o][:-1]
+    pred = np.full(n, -1, np.int64)
+    wpred = np.zeros(n, np.float32)
+    pred[dst[o][first]] = src[o][first]
+    wpred[dst[o][first]] = ww[o][first]
+    pred[root] = -1
+    D, _ = evaluate(pred, wpred)  # pass 0: plain evaluation of the first tree
+    passes, log = 0, []
+    while True:
+        lv = levels_of(pred)
+        assert sum(len(a) for a in lv) == n - 1, "the tree lost a vertex"
+        changed = 0
+        for kids in lv:
+            cnt = in_off[kids + 1] - in_off[kids]
+            idx = np.repeat(in_off[kids] - np.cumsum(cnt) + cnt, cnt) + np.arange(cnt.sum())
+            owner = np.repeat(np.arange(len(kids)), cnt)
+            offers = (D[in_src[idx]] + in_w[idx]).astype(np.float32)
+            cur = (D[pred[kids]] + wpred[kids]).astype(np.float32)  # the tree's own offer under this pass's values
+            oo = np.lexsort((in_src[idx], offers, owner))
+            fst = np.ones(len(oo), bool)
+            fst[1:] = owner[oo][1:] != owner[oo][:-1]
+            best, arg, bw = offers[oo][fst], in_src[idx][oo][fst], in_w[idx][oo][fst]
+            better = best < cur
+            newd = np.where(better, best, cur)
+            changed += int((newd != D[kids]).sum())
+            D[kids] = newd
+            pred[kids[better]] = arg[better]
+            wpred[kids[better]] = bw[better]
+        passes += 1
+        log.append((changed, int((D != dist_ref).sum()), len(lv)))
+        if changed == 0 or passes > 100:
+            break
+    print(f"Gauss-Seidel passes, quantum {q:g} m: {passes} passes (the last one changes nothing), bit-identical: {bool(np.array_equal(D, dist_ref))}")
+    print("   per pass (distances that changed, distances that differ from the oracle's after it, levels): " + " ".join(f"({a},{b},{c})" for a, b, c in log[:14]))
