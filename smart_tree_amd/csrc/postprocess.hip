@@ -7,7 +7,7 @@
 //   TreeSkeleton.prune               tree.py:94-121  (+ BranchSkeleton.length / initial_radius, branch.py:61-67)
 //   TreeSkeleton.repair              tree.py:73-92   (+ pts_to_nearest_tube_gpu, util/queries.py:89-133)
 //   TreeSkeleton.smooth              tree.py:123-134 (zero-padded box filter, only when len > kernel)
-// One workgroup per tree.  Branches are visited in id order (a parent always has a smaller id than its
+// Branches are visited in the order of the branch hierarchy (a parent always has a smaller id than its
 // children, so a child sees its parent already repaired, exactly like the reference's dict walk).
 // Float32 operation order is fixed and mirrored by oracle/pipeline_oracle.py:
 //   dot(a,b) = (ax*bx + ay*by) + az*bz, no contraction; length = sequential sum of segment norms;
@@ -53,29 +53,58 @@ __device__ __forceinline__ float pp_dot(const float* a, const float* b) {
     return s + t;
 }
 
-#define PP_LDS_BRANCHES 8192  // branch tables of this size run their sequential chains out of LDS
-__global__ void __launch_bounds__(PP_BLOCK) k_post_process(PpArgs A) {
-    __shared__ int l_parent[PP_LDS_BRANCHES];
-    __shared__ short l_depth[PP_LDS_BRANCHES];
-    __shared__ uint8_t l_keep[PP_LDS_BRANCHES];
-    const int tree = blockIdx.x, tid = threadIdx.x;
-    const int b0 = A.tree_off[tree], nb = A.tree_off[tree + 1] - b0;
-    const bool in_lds = nb <= PP_LDS_BRANCHES;
-    if (in_lds) for (int b = tid; b < nb; b += PP_BLOCK) l_parent[b] = A.parent[b0 + b];
-    // ---- prune (tree 0 only): length / initial radius per branch in parallel, then the keep chain
-    for (int b = tid; b < nb; b += PP_BLOCK) A.keep[b0 + b] = 1;
-    __syncthreads();
-    bool prune_this = tree == 0;  // tree.py:164-168: only skeleton 0 (of its cloud) is pruned
-    if (A.first_tree) {
-        prune_this = false;
-        for (int k = 0; k < A.n_first; k++) prune_this = prune_this || A.first_tree[k] == tree;  // uniform: n_first <= 64
-    }
-    if (A.do_prune && prune_this && nb > 0) {
-        for (int b = tid >> 6; b < nb; b += PP_WAVES) {  // one wavefront per branch
-            const int s = A.start[b0 + b] + 1, n = A.len[b0 + b], ln = tid & 63;
+// Score of one tube (a, b, radii ra, rb) for the connection point of a branch whose first vertex is pt: |distance to the
+// segment - interpolated radius| (pts_to_nearest_tube_gpu, util/queries.py:107-133), as the ordered bit pattern the argmin
+// works on (NaN counts as minimal).  t comes back for the caller that has to place the projection.
+__device__ __forceinline__ unsigned pp_tube_bits(const float* a, const float* bb, float ra, float rb, const float* pt, float* t_out) {
+    const float ab[3] = {bb[0] - a[0], bb[1] - a[1], bb[2] - a[2]};
+    const float ap[3] = {pt[0] - a[0], pt[1] - a[1], pt[2] - a[2]};
+    float t = pp_dot(ap, ab) / pp_dot(ab, ab);
+    t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
+    const float proj[3] = {a[0] + t * ab[0], a[1] + t * ab[1], a[2] + t * ab[2]};
+    const float r = (1.0f - t) * ra + t * rb;
+    const float d[3] = {proj[0] - pt[0], proj[1] - pt[1], proj[2] - pt[2]};
+    const float score = fabsf(sqrtf(pp_dot(d, d)) - r);
+    *t_out = t;
+    return score != score ? 0u : __float_as_uint(score) + 1u;  // >= 0: bits are ordered
+}
+// (score, tube index) as one key whose MAXIMUM is the minimum score at the smallest index
+__device__ __forceinline__ unsigned long long pp_key(unsigned bits, unsigned i) {
+    return ((unsigned long long)(0xffffffffu - bits) << 32) | (0xffffffffu - i);
+}
+
+// Three launches (round 5; it was one workgroup per tree doing everything, 251 us for one cloud's tree of ~290 branches, every
+// step a chain of dependent loads on ONE compute unit):
+//   k_pp_branch  one wavefront per branch of every tree, the whole chip: the branch's own prune tests (length, initial radius)
+//                and the best tube among its parent's EXTRACTED path -- everything that does not depend on another branch's result
+//   k_pp_tree    one workgroup per tree: the keep chain, the repair levels.  A level's branches are one lane each: only the
+//                parent's first tube (from its connection point, placed one level earlier) is still to be scored against the
+//                key k_pp_branch left
+//   k_pp_smooth  one wavefront per branch: the box filter
+// The key of k_pp_branch travels in the branch's own first two rad_out slots (rad_out is written by k_pp_smooth, last).
+#define PP_WIDE_BLOCK 256
+#define PP_WIDE_GRID 1024
+__global__ void __launch_bounds__(PP_WIDE_BLOCK) k_pp_branch(PpArgs A) {
+    const int B = A.tree_off[A.n_trees], lane = threadIdx.x & 63;
+    const int nw = (int)gridDim.x * (PP_WIDE_BLOCK / 64);
+    for (int g = (int)blockIdx.x * (PP_WIDE_BLOCK / 64) + ((int)threadIdx.x >> 6); g < B; g += nw) {  // wave-uniform
+        int tree = 0, hi = A.n_trees;  // the last tree whose range starts at or before g (empty trees in between are skipped)
+        while (hi - tree > 1) {
+            const int mid = (tree + hi) >> 1;
+            if (A.tree_off[mid] <= g) tree = mid; else hi = mid;
+        }
+        const int b0 = A.tree_off[tree], nb = A.tree_off[tree + 1] - b0;
+        // ---- prune, own tests (skeleton 0 of its cloud only: tree.py:164-168)
+        bool prune_this = tree == 0;
+        if (A.first_tree) {
+            prune_this = false;
+            for (int k = 0; k < A.n_first; k++) prune_this = prune_this || A.first_tree[k] == tree;  // uniform: n_first <= 64
+        }
+        if (A.do_prune && prune_this) {
+            const int s = A.start[g] + 1, n = A.len[g];
             float length = 0.0f;  // lanes evaluate 64 segment norms at a time; they are added in path order (sequential float32 sum)
             for (int i0 = 0; i0 + 1 < n; i0 += 64) {
-                const int i = i0 + ln;
+                const int i = i0 + lane;
                 float seg = 0.0f;
                 if (i + 1 < n) {
                     const float d[3] = {A.xyz[3 * (s + i + 1)] - A.xyz[3 * (s + i)], A.xyz[3 * (s + i + 1) + 1] - A.xyz[3 * (s + i) + 1],
@@ -86,13 +115,60 @@ __global__ void __launch_bounds__(PP_BLOCK) k_post_process(PpArgs A) {
                 for (int j = 0; j < cnt; j++)  // j is wave-uniform: v_readlane, not a cross-lane permute through LDS
                     length = length + __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(seg), j));
             }
-            if (ln == 0) {
+            if (lane == 0) {
                 const float r0 = A.rad_in[s], r1 = A.rad_in[s + n - 1];
                 const float initial = r0 > r1 ? r0 : r1;
-                A.keep[b0 + b] = !(length < A.min_length) && !(initial < A.min_radius);  // own tests (tree.py:113-116)
+                A.keep[g] = !(length < A.min_length) && !(initial < A.min_radius);  // own tests (tree.py:113-116)
+            }
+        } else if (lane == 0) {
+            A.keep[g] = 1;
+        }
+        // ---- repair: the best tube of the parent's extracted path (tube j = path vertices j, j + 1; immutable input)
+        if (A.do_repair) {
+            const int p = A.parent[g];
+            unsigned long long key = 0;
+            if (p >= 0 && p < nb) {
+                const int ps = A.start[b0 + p] + 1, pn = A.len[b0 + p], s = A.start[g];
+                const float pt[3] = {A.xyz[3 * (s + 1)], A.xyz[3 * (s + 1) + 1], A.xyz[3 * (s + 1) + 2]};
+                for (int j = lane; j + 1 < pn; j += 64) {
+                    float a[3], bb[3], t;
+                    for (int k = 0; k < 3; k++) {
+                        a[k] = A.xyz[3 * (ps + j) + k];
+                        bb[k] = A.xyz[3 * (ps + j + 1) + k];
+                    }
+                    const unsigned long long k2 = pp_key(pp_tube_bits(a, bb, A.rad_in[ps + j], A.rad_in[ps + j + 1], pt, &t), (unsigned)j);
+                    key = k2 > key ? k2 : key;
+                }
+                for (int d = 32; d > 0; d >>= 1) {  // wave max of the inverted key = minimum score, smallest index
+                    const unsigned long long o = __shfl_xor(key, d);
+                    key = o > key ? o : key;
+                }
+            }
+            if (lane == 0) {
+                unsigned* slot = (unsigned*)(A.rad_out + A.start[g]);
+                slot[0] = (unsigned)(key >> 32);
+                slot[1] = (unsigned)(key & 0xffffffffu);
             }
         }
-        __syncthreads();
+    }
+}
+
+#define PP_LDS_BRANCHES 8192  // branch tables of this size run their sequential chains out of LDS
+__global__ void __launch_bounds__(PP_BLOCK) k_pp_tree(PpArgs A) {
+    __shared__ int l_parent[PP_LDS_BRANCHES];
+    __shared__ short l_depth[PP_LDS_BRANCHES];
+    __shared__ uint8_t l_keep[PP_LDS_BRANCHES];
+    const int tree = blockIdx.x, tid = threadIdx.x;
+    const int b0 = A.tree_off[tree], nb = A.tree_off[tree + 1] - b0;
+    const bool in_lds = nb <= PP_LDS_BRANCHES;
+    if (in_lds) for (int b = tid; b < nb; b += PP_BLOCK) l_parent[b] = A.parent[b0 + b];
+    // ---- prune (skeleton 0 of its cloud only): the keep chain over the own tests k_pp_branch left in `keep`
+    bool prune_this = tree == 0;  // tree.py:164-168
+    if (A.first_tree) {
+        prune_this = false;
+        for (int k = 0; k < A.n_first; k++) prune_this = prune_this || A.first_tree[k] == tree;  // uniform: n_first <= 64
+    }
+    if (A.do_prune && prune_this && nb > 0) {
         if (in_lds) for (int b = tid; b < nb; b += PP_BLOCK) l_keep[b] = A.keep[b0 + b];
         __syncthreads();
         if (tid == 0) {  // the keep chain is sequential (a child needs its parent's verdict): LDS-resident when it fits
@@ -115,8 +191,7 @@ __global__ void __launch_bounds__(PP_BLOCK) k_post_process(PpArgs A) {
         __syncthreads();
     }
     // ---- repair: nearest point on the (already repaired) parent's tube chain.  A branch only needs its
-    //      parent finished, so branches are processed level by level of the branch hierarchy (one wavefront
-    //      per branch, lanes over the parent's tubes) instead of one after the other.
+    //      parent finished, so branches are processed level by level of the branch hierarchy, a lane per branch.
     __shared__ int s_maxdepth;
     int* depth = A.depth + b0;
     for (int b = tid; b < nb; b += PP_BLOCK) A.repaired[b0 + b] = 0;
@@ -139,70 +214,62 @@ __global__ void __launch_bounds__(PP_BLOCK) k_post_process(PpArgs A) {
     __syncthreads();
     if (in_lds) for (int b = tid; b < nb; b += PP_BLOCK) depth[b] = l_depth[b];
     __syncthreads();
-    const int maxdepth = s_maxdepth, lane = tid & 63, wave = tid >> 6;
+    const int maxdepth = s_maxdepth;
     for (int level = 1; level <= maxdepth; level++) {
-        for (int b = wave; b < nb; b += PP_WAVES) {  // wave-uniform
+        for (int b = tid; b < nb; b += PP_BLOCK) {
             if ((in_lds ? (int)l_depth[b] : depth[b]) != level) continue;
-            const int p = A.parent[b0 + b];
+            const int p = in_lds ? l_parent[b] : A.parent[b0 + b];
             const int prep = __hip_atomic_load(&A.repaired[b0 + p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int ps = A.start[b0 + p] + (prep ? 0 : 1);
-            const int pn = A.len[b0 + p] + (prep ? 1 : 0);
             const int s = A.start[b0 + b];
             const float pt[3] = {A.xyz[3 * (s + 1)], A.xyz[3 * (s + 1) + 1], A.xyz[3 * (s + 1) + 2]};
-            // argmin over the parent's tubes of |dist - radius| (first minimum; NaN counts as minimal)
-            unsigned long long key = 0;
-            for (int i = lane; i + 1 < pn; i += 64) {
+            // argmin over the parent's tubes of |dist - radius| (first minimum; NaN counts as minimal): k_pp_branch's key over the
+            // extracted path (its tube j is tube j + 1 of a repaired parent), and the tube from the parent's connection point
+            const unsigned* slot = (const unsigned*)(A.rad_out + s);
+            unsigned long long key = ((unsigned long long)slot[0] << 32) | slot[1];
+            float t;
+            if (prep) {
+                if (key) key -= 1;  // index j -> j + 1 (the low word holds 0xffffffff - j)
                 float a[3], bb[3];
                 for (int k = 0; k < 3; k++) {
-                    // only the parent's connection point (slot 0, written one level earlier by another wavefront)
-                    // needs the L2-coherent load; the extracted path is immutable input
-                    a[k] = (prep && i == 0) ? pp_ldf(&A.xyz[3 * ps + k]) : A.xyz[3 * (ps + i) + k];
-                    bb[k] = A.xyz[3 * (ps + i + 1) + k];
+                    a[k] = pp_ldf(&A.xyz[3 * ps + k]);  // written one level earlier by another lane: through L2
+                    bb[k] = A.xyz[3 * (ps + 1) + k];
                 }
-                const float ab[3] = {bb[0] - a[0], bb[1] - a[1], bb[2] - a[2]};
-                const float ap[3] = {pt[0] - a[0], pt[1] - a[1], pt[2] - a[2]};
-                float t = pp_dot(ap, ab) / pp_dot(ab, ab);
-                t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
-                const float proj[3] = {a[0] + t * ab[0], a[1] + t * ab[1], a[2] + t * ab[2]};
-                const float r = (1.0f - t) * A.rad_in[ps + i] + t * A.rad_in[ps + i + 1];
-                const float d[3] = {proj[0] - pt[0], proj[1] - pt[1], proj[2] - pt[2]};
-                const float score = fabsf(sqrtf(pp_dot(d, d)) - r);
-                const unsigned bits = score != score ? 0u : __float_as_uint(score) + 1u;  // >= 0: bits are ordered
-                const unsigned long long k = ((unsigned long long)(0xffffffffu - bits) << 32) | (0xffffffffu - (unsigned)i);
-                key = k > key ? k : key;
+                const unsigned long long k0 = pp_key(pp_tube_bits(a, bb, A.rad_in[ps], A.rad_in[ps + 1], pt, &t), 0u);
+                key = k0 > key ? k0 : key;
             }
-            for (int d = 32; d > 0; d >>= 1) {  // wave max of the inverted key = minimum score, smallest index
-                const unsigned long long o = __shfl_xor(key, d);
-                key = o > key ? o : key;
+            const int i = (int)(0xffffffffu - (unsigned)(key & 0xffffffffu));
+            float a[3], bb[3];
+            for (int k = 0; k < 3; k++) {
+                a[k] = (prep && i == 0) ? pp_ldf(&A.xyz[3 * ps + k]) : A.xyz[3 * (ps + i) + k];
+                bb[k] = A.xyz[3 * (ps + i + 1) + k];
             }
-            if (lane == 0) {
-                const int i = (int)(0xffffffffu - (unsigned)(key & 0xffffffffu));
-                float a[3], bb[3];
-                for (int k = 0; k < 3; k++) {
-                    a[k] = (prep && i == 0) ? pp_ldf(&A.xyz[3 * ps + k]) : A.xyz[3 * (ps + i) + k];
-                    bb[k] = A.xyz[3 * (ps + i + 1) + k];
-                }
-                const float ab[3] = {bb[0] - a[0], bb[1] - a[1], bb[2] - a[2]};
-                const float ap[3] = {pt[0] - a[0], pt[1] - a[1], pt[2] - a[2]};
-                float t = pp_dot(ap, ab) / pp_dot(ab, ab);
-                t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
-                for (int k = 0; k < 3; k++) {
-                    const float proj = a[k] + t * ab[k];
-                    A.xyz[3 * s + k] = pt[k] + (proj - pt[k]);  // tree.py:89: tip + vector to the projection
-                }
-                A.repaired[b0 + b] = 1;
+            const float ab[3] = {bb[0] - a[0], bb[1] - a[1], bb[2] - a[2]};
+            const float ap[3] = {pt[0] - a[0], pt[1] - a[1], pt[2] - a[2]};
+            t = pp_dot(ap, ab) / pp_dot(ab, ab);
+            t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
+            for (int k = 0; k < 3; k++) {
+                const float proj = a[k] + t * ab[k];
+                A.xyz[3 * s + k] = pt[k] + (proj - pt[k]);  // tree.py:89: tip + vector to the projection
             }
+            A.repaired[b0 + b] = 1;
         }
+        __threadfence();
         __syncthreads();  // the next level reads this level's connection points (through L2)
     }
-    // ---- radii: box filter over the (possibly prepended) radius array
+}
+
+// ---- radii: box filter over the (possibly prepended) radius array, one wavefront per branch of every tree
+__global__ void __launch_bounds__(PP_WIDE_BLOCK) k_pp_smooth(PpArgs A) {
+    const int B = A.tree_off[A.n_trees], lane = threadIdx.x & 63;
+    const int nw = (int)gridDim.x * (PP_WIDE_BLOCK / 64);
     const float w = A.kernel > 0 ? 1.0f / (float)A.kernel : 0.0f;
     const int half = (A.kernel - 1) / 2;  // F.conv1d(padding="same"): left pad (k-1)/2, the extra sample of an even kernel goes right
-    for (int b = wave; b < nb; b += PP_WAVES) {  // one wavefront per branch
-        const int rep = __hip_atomic_load(&A.repaired[b0 + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int s = A.start[b0 + b] + (rep ? 0 : 1), n = A.len[b0 + b] + rep;
-        const bool sm = A.do_smooth && A.keep[b0 + b] && n > A.kernel;  // tree.py:129
-        if (lane == 0) A.smoothed[b0 + b] = sm;
+    for (int g = (int)blockIdx.x * (PP_WIDE_BLOCK / 64) + ((int)threadIdx.x >> 6); g < B; g += nw) {
+        const int rep = A.repaired[g];
+        const int s = A.start[g] + (rep ? 0 : 1), n = A.len[g] + rep;
+        const bool sm = A.do_smooth && A.keep[g] && n > A.kernel;  // tree.py:129
+        if (lane == 0) A.smoothed[g] = sm;
         for (int i = lane; i < n; i += 64) {
             if (!sm) { A.rad_out[s + i] = A.rad_in[s + i]; continue; }
             float acc = 0.0f;
@@ -234,7 +301,9 @@ extern "C" int st_post_process_seg(int n_trees, const int32_t* tree_off, const i
     A.do_prune = do_prune; A.do_repair = do_repair; A.do_smooth = do_smooth; A.kernel = kernel_size;
     A.min_radius = min_radius; A.min_length = min_length;
     A.first_tree = first_tree; A.n_first = first_tree ? n_first : 0;
-    hipLaunchKernelGGL(k_post_process, dim3((unsigned)n_trees), dim3(PP_BLOCK), 0, (hipStream_t)stream_, A);
+    hipLaunchKernelGGL(k_pp_branch, dim3(PP_WIDE_GRID), dim3(PP_WIDE_BLOCK), 0, (hipStream_t)stream_, A);
+    hipLaunchKernelGGL(k_pp_tree, dim3((unsigned)n_trees), dim3(PP_BLOCK), 0, (hipStream_t)stream_, A);
+    hipLaunchKernelGGL(k_pp_smooth, dim3(PP_WIDE_GRID), dim3(PP_WIDE_BLOCK), 0, (hipStream_t)stream_, A);
     ST_CHECK_LAUNCH();
     return ST_OK;
 }

@@ -15,7 +15,7 @@ class SparseConvTensor:
     def __init__(self, features: torch.Tensor, indices: torch.Tensor, spatial_shape, batch_size: int):
         self.features = features
         self.indices = indices  # [N,4] int32 (batch, z, y, x)
-        self.spatial_shape = spatial_shape
+        self._spatial_shape = spatial_shape  # None = not reduced yet (see the property)
         self.batch_size = batch_size
         self.indice_dict = {}
         self.blk_seg = None  # batched clouds (Cloud.collate): cloud of every batch index coords[:,0] -> per-cloud spatial extents
@@ -24,8 +24,21 @@ class SparseConvTensor:
         # lets the network build its rulebooks from occupancy bricks (csrc/brick.hip) instead of hash tables
         self.brick_hint = None
 
+    @property
+    def spatial_shape(self):
+        """The reference's attribute (sparse.py:15-18: the largest z / y / x, not +1).  No kernel of this package reads it
+        (they take the extent from the indices), so the reduction over the coordinates runs when somebody asks."""
+        if self._spatial_shape is None:
+            c = self.indices
+            self._spatial_shape = torch.max(c, 0)[0][1:] if c.shape[0] else torch.zeros(3, dtype=c.dtype, device=c.device)
+        return self._spatial_shape
+
+    @spatial_shape.setter
+    def spatial_shape(self, value):
+        self._spatial_shape = value
+
     def replace_feature(self, new_features: torch.Tensor) -> "SparseConvTensor":
-        out = SparseConvTensor(new_features, self.indices, self.spatial_shape, self.batch_size)
+        out = SparseConvTensor(new_features, self.indices, self._spatial_shape, self.batch_size)
         out.indice_dict = self.indice_dict
         out.blk_seg, out.n_seg, out.brick_hint = self.blk_seg, self.n_seg, self.brick_hint
         return out
@@ -38,12 +51,7 @@ def sparse_from_batch(features: torch.Tensor, coordinates: torch.Tensor, device,
     batch_size = features.shape[0]
     features = features.to(device)
     coordinates = coordinates.to(device)
-    if coordinates.shape[0]:
-        values, _ = torch.max(coordinates, 0)
-        shape = values[1:]
-    else:
-        shape = torch.zeros(3, dtype=coordinates.dtype, device=device)
-    out = SparseConvTensor(features.contiguous(), coordinates.int().contiguous(), shape, batch_size=batch_size)
+    out = SparseConvTensor(features.contiguous(), coordinates.int().contiguous(), None, batch_size=batch_size)
     if blk_seg is not None and n_seg > 1:
         out.blk_seg, out.n_seg = blk_seg.to(device).int().contiguous(), n_seg
     out.brick_hint = brick_hint

@@ -249,7 +249,7 @@ class DeviceSkeleton(DisjointTreeSkeleton):
     """A DisjointTreeSkeleton whose branches still live on the GPU as flat arrays.
 
     `prune` / `repair` / `smooth` -- called in that order by `Pipeline.post_process` (reference
-    pipeline.py:95-106) -- are recorded and executed by ONE launch of `st_post_process`
+    pipeline.py:95-106) -- are recorded and executed by ONE call of `st_post_process`
     (csrc/postprocess.hip) when `.skeletons` is first read; only then are the geometry and the branch
     table copied to the host (one copy each) and the BranchSkeleton objects built.  Any other call
     order materialises first and falls back to the host implementations of the base class."""

@@ -21,6 +21,18 @@ def _small_batch(n=6000, voxel=0.05, seed=5):
     return vo.voxelize_cloud(xyz, c["rgb"], voxel, block_size=2.0, buffer_size=0.2)
 
 
+def test_sparse_tensor_attributes_of_the_reference():
+    """sparse.py:9-19 of the reference: spatial_shape = the largest z / y / x (not + 1), batch_size = number of voxels.
+    spatial_shape is reduced on first access (no kernel reads it) and travels through replace_feature."""
+    coords = torch.tensor([[0, 3, 9, 1], [1, 7, 2, 4], [0, 0, 0, 11]], dtype=torch.int32)
+    sp = sparse_from_batch(torch.zeros(3, 3), coords, torch.device("cpu"))
+    assert sp.batch_size == 3 and sp._spatial_shape is None
+    assert sp.spatial_shape.tolist() == [7, 9, 11] and sp.spatial_shape.dtype == torch.int32
+    assert sp.replace_feature(torch.ones(3, 8)).spatial_shape.tolist() == [7, 9, 11]
+    empty = sparse_from_batch(torch.zeros(0, 3), torch.zeros((0, 4), dtype=torch.int32), torch.device("cpu"))
+    assert empty.spatial_shape.tolist() == [0, 0, 0]
+
+
 def test_rulebooks_bit_exact(backend):
     vx = _small_batch()
     coords = torch.from_numpy(vx["coords"]).to(backend)
