@@ -145,7 +145,10 @@ int st_pointwise_mlp_heads(const float* x, int64_t n, const float* params, float
  *                            (shortest_path.py:46-55, skeletonize.py:80-85), sample_tree (skeleton/path.py:9-140)
  * st_assemble_branches replaces: the BranchSkeleton / TreeSkeleton construction of skeleton/path.py:128-140 and
  *                   skeletonize.py:86-95 (flat layout consumed by st_post_process)
- * st_post_process   replaces: pipeline.py:95-106 over data_types/tree.py:73-134,164-176 (+ util/queries.py:89-133) */
+ * st_post_process   replaces: pipeline.py:95-106 over data_types/tree.py:73-134,164-176 (+ util/queries.py:89-133).
+ *                   Branch tables as st_assemble_branches lays them out: a parent has a smaller id than its children (the
+ *                   reference's dict walk relies on the same order), every branch owns at least two rad_out slots (they
+ *                   carry a key between the call's launches before the radii are written). */
 /* st_centre_cloud replaces: dataset/augmentations.py:38-41 (CentreCloud over Cloud.bbox, data_types/cloud.py:222-227) */
 int st_centre_cloud(const float* xyz, int64_t n, float* out, void* ws, int64_t ws_bytes, void* stream);
 int st_medial_points(const float* xyz, const float* mv, int64_t n, float* medial, float* radius, void* stream);

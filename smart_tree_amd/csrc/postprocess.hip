@@ -153,68 +153,152 @@ __global__ void __launch_bounds__(PP_WIDE_BLOCK) k_pp_branch(PpArgs A) {
     }
 }
 
-#define PP_LDS_BRANCHES 8192  // branch tables of this size run their sequential chains out of LDS
+#define PP_LDS_BRANCHES 8192  // branch tables of this size run their chains out of LDS
 __global__ void __launch_bounds__(PP_BLOCK) k_pp_tree(PpArgs A) {
     __shared__ int l_parent[PP_LDS_BRANCHES];
     __shared__ short l_depth[PP_LDS_BRANCHES];
     __shared__ uint8_t l_keep[PP_LDS_BRANCHES];
+    __shared__ int s_maxdepth, s_flag;
     const int tree = blockIdx.x, tid = threadIdx.x;
     const int b0 = A.tree_off[tree], nb = A.tree_off[tree + 1] - b0;
     const bool in_lds = nb <= PP_LDS_BRANCHES;
     if (in_lds) for (int b = tid; b < nb; b += PP_BLOCK) l_parent[b] = A.parent[b0 + b];
-    // ---- prune (skeleton 0 of its cloud only): the keep chain over the own tests k_pp_branch left in `keep`
+    // ---- prune (skeleton 0 of its cloud only): the keep chain over the own tests k_pp_branch left in `keep`.
+    //      keep[b] = own[b] and keep[parent[b]] (tree.py:111-112), the root always stays (tree.py:101-103,120).  A parent has a
+    //      smaller id than its children, so the reference's walk in id order computes the one solution of that recurrence; in LDS
+    //      it is reached by passes over all branches at once (as many passes as the hierarchy is deep) instead of one lane's walk.
     bool prune_this = tree == 0;  // tree.py:164-168
     if (A.first_tree) {
         prune_this = false;
         for (int k = 0; k < A.n_first; k++) prune_this = prune_this || A.first_tree[k] == tree;  // uniform: n_first <= 64
     }
     if (A.do_prune && prune_this && nb > 0) {
-        if (in_lds) for (int b = tid; b < nb; b += PP_BLOCK) l_keep[b] = A.keep[b0 + b];
-        __syncthreads();
-        if (tid == 0) {  // the keep chain is sequential (a child needs its parent's verdict): LDS-resident when it fits
-            if (in_lds) {
-                l_keep[0] = 1;  // the root (smallest id) always stays (tree.py:101-103,120)
-                for (int b = 1; b < nb; b++) {
+        if (in_lds) {
+            for (int b = tid; b < nb; b += PP_BLOCK) l_keep[b] = b == 0 ? 1 : A.keep[b0 + b];
+            do {
+                __syncthreads();
+                if (tid == 0) s_flag = 0;
+                __syncthreads();
+                for (int b = tid; b < nb; b += PP_BLOCK) {
+                    if (b == 0 || !l_keep[b]) continue;
                     const int p = l_parent[b];
-                    if (!(p >= 0 && p < nb && l_keep[p])) l_keep[b] = 0;  // tree.py:111-112
+                    if (!(p >= 0 && p < nb && l_keep[p])) { l_keep[b] = 0; s_flag = 1; }
                 }
-            } else {
-                A.keep[b0] = 1;
-                for (int b = 1; b < nb; b++) {
-                    const int p = A.parent[b0 + b];
-                    if (!(p >= 0 && p < nb && A.keep[b0 + p])) A.keep[b0 + b] = 0;
-                }
+                __syncthreads();
+            } while (s_flag);
+            for (int b = tid; b < nb; b += PP_BLOCK) A.keep[b0 + b] = l_keep[b];
+        } else if (tid == 0) {
+            A.keep[b0] = 1;
+            for (int b = 1; b < nb; b++) {
+                const int p = A.parent[b0 + b];
+                if (!(p >= 0 && p < nb && A.keep[b0 + p])) A.keep[b0 + b] = 0;
             }
         }
-        __syncthreads();
-        if (in_lds) for (int b = tid; b < nb; b += PP_BLOCK) A.keep[b0 + b] = l_keep[b];
         __syncthreads();
     }
     // ---- repair: nearest point on the (already repaired) parent's tube chain.  A branch only needs its
     //      parent finished, so branches are processed level by level of the branch hierarchy, a lane per branch.
-    __shared__ int s_maxdepth;
+    //      Level of a branch that is repaired (it and its parent are kept, tree.py:80-82): one more than its parent's, 1 under a
+    //      parent that is not repaired itself; -1 = not repaired.
     int* depth = A.depth + b0;
     for (int b = tid; b < nb; b += PP_BLOCK) A.repaired[b0 + b] = 0;
-    if (in_lds) for (int b = tid; b < nb; b += PP_BLOCK) l_keep[b] = A.keep[b0 + b];
-    __syncthreads();
-    if (tid == 0) {
+    if (in_lds) {
+        for (int b = tid; b < nb; b += PP_BLOCK) l_keep[b] = A.keep[b0 + b];
+        if (tid == 0) s_maxdepth = 0;
+        __syncthreads();
+        for (int b = tid; b < nb; b += PP_BLOCK) {
+            const int p = l_parent[b];
+            l_depth[b] = (A.do_repair && l_keep[b] && p >= 0 && p < nb && l_keep[p]) ? 1 : -1;
+        }
+        do {
+            __syncthreads();
+            if (tid == 0) s_flag = 0;
+            __syncthreads();
+            for (int b = tid; b < nb; b += PP_BLOCK) {
+                const int d = l_depth[b];
+                if (d < 0) continue;
+                const int dp = l_depth[l_parent[b]];
+                int nd = dp < 0 ? 1 : dp + 1;
+                nd = nd > 32767 ? 32767 : nd;
+                if (nd != d) { l_depth[b] = (short)nd; s_flag = 1; }
+            }
+            __syncthreads();
+        } while (s_flag);
+        for (int b = tid; b < nb; b += PP_BLOCK) {
+            depth[b] = l_depth[b];
+            if (l_depth[b] > 0) atomicMax(&s_maxdepth, (int)l_depth[b]);
+        }
+    } else if (tid == 0) {
         int md = 0;
         for (int b = 0; b < nb; b++) {  // parents have smaller ids: one forward pass
-            const int p = in_lds ? l_parent[b] : A.parent[b0 + b];
-            const bool kb = in_lds ? l_keep[b] : A.keep[b0 + b];
-            const bool kp = p >= 0 && p < nb && (in_lds ? l_keep[p] : A.keep[b0 + p]);
-            const bool go = A.do_repair && kb && kp;  // tree.py:80-82
-            const int dp = go ? (in_lds ? (int)l_depth[p] : depth[p]) : -1;
-            const int d = go ? (dp < 0 ? 1 : dp + 1) : -1;  // -1: not repaired; a parent without repair is ready at once
-            if (in_lds) l_depth[b] = (short)(d > 32767 ? 32767 : d); else depth[b] = d;
+            const int p = A.parent[b0 + b];
+            const bool go = A.do_repair && A.keep[b0 + b] && p >= 0 && p < nb && A.keep[b0 + p];
+            const int dp = go ? depth[p] : -1;
+            const int d = go ? (dp < 0 ? 1 : dp + 1) : -1;
+            depth[b] = d;
             if (d > md) md = d;
         }
         s_maxdepth = md > 32767 ? 32767 : md;
     }
     __syncthreads();
-    if (in_lds) for (int b = tid; b < nb; b += PP_BLOCK) depth[b] = l_depth[b];
-    __syncthreads();
     const int maxdepth = s_maxdepth;
+    if (nb <= PP_BLOCK) {
+        // one branch per lane: everything but the parent's connection point (placed one level earlier) is loaded before the
+        // level loop, so a level costs one round trip through L2 instead of a chain of them
+        const int b = tid;
+        const int lev = b < nb ? (int)l_depth[b] : -1;
+        int s = 0, ps = 0, prep = 0;
+        float pt[3] = {0, 0, 0}, b0v[3] = {0, 0, 0}, ai[3] = {0, 0, 0}, bi[3] = {0, 0, 0}, ra0 = 0, rb0 = 0;
+        unsigned long long key_imm = 0;
+        if (lev > 0) {
+            const int p = l_parent[b];
+            prep = l_depth[p] > 0;  // the parent is repaired (at an earlier level) exactly when it has a level
+            ps = A.start[b0 + p] + (prep ? 0 : 1);
+            s = A.start[b0 + b];
+            for (int k = 0; k < 3; k++) pt[k] = A.xyz[3 * (s + 1) + k];
+            const unsigned* slot = (const unsigned*)(A.rad_out + s);
+            key_imm = ((unsigned long long)slot[0] << 32) | slot[1];
+            if (prep) {
+                if (key_imm) key_imm -= 1;  // index j -> j + 1 (the low word holds 0xffffffff - j)
+                for (int k = 0; k < 3; k++) b0v[k] = A.xyz[3 * (ps + 1) + k];
+                ra0 = A.rad_in[ps];
+                rb0 = A.rad_in[ps + 1];
+            }
+            if (key_imm || !prep) {  // the best tube of the extracted path (without one: the slot in front of it, as the chain walk read)
+                const int i = (int)(0xffffffffu - (unsigned)(key_imm & 0xffffffffu));
+                for (int k = 0; k < 3; k++) {
+                    ai[k] = A.xyz[3 * (ps + i) + k];
+                    bi[k] = A.xyz[3 * (ps + i + 1) + k];
+                }
+            }
+        }
+        for (int level = 1; level <= maxdepth; level++) {
+            if (lev == level) {
+                unsigned long long key = key_imm;
+                float a[3] = {ai[0], ai[1], ai[2]}, bb[3] = {bi[0], bi[1], bi[2]}, t;
+                if (prep) {
+                    float a0[3];
+                    for (int k = 0; k < 3; k++) a0[k] = pp_ldf(&A.xyz[3 * ps + k]);  // written one level earlier by another lane: through L2
+                    const unsigned long long k0 = pp_key(pp_tube_bits(a0, b0v, ra0, rb0, pt, &t), 0u);
+                    if (k0 > key) {
+                        for (int k = 0; k < 3; k++) { a[k] = a0[k]; bb[k] = b0v[k]; }
+                    }
+                }
+                const float ab[3] = {bb[0] - a[0], bb[1] - a[1], bb[2] - a[2]};
+                const float ap[3] = {pt[0] - a[0], pt[1] - a[1], pt[2] - a[2]};
+                t = pp_dot(ap, ab) / pp_dot(ab, ab);
+                t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
+                for (int k = 0; k < 3; k++) {
+                    const float proj = a[k] + t * ab[k];
+                    A.xyz[3 * s + k] = pt[k] + (proj - pt[k]);  // tree.py:89: tip + vector to the projection
+                }
+                A.repaired[b0 + b] = 1;
+            }
+            __threadfence();
+            __syncthreads();  // the next level reads this level's connection points (through L2)
+        }
+        return;
+    }
     for (int level = 1; level <= maxdepth; level++) {
         for (int b = tid; b < nb; b += PP_BLOCK) {
             if ((in_lds ? (int)l_depth[b] : depth[b]) != level) continue;
