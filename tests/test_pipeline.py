@@ -61,7 +61,13 @@ def test_process_cloud_stagewise_parity(backend):
     np.testing.assert_array_equal(lc.xyz.cpu().numpy(), ref["xyz"])
     mv = lc.medial_vector.cpu().numpy()
     scale = np.sqrt(np.mean(ref["medial_vector"] ** 2)) + 1e-30
-    assert np.abs(mv - ref["medial_vector"]).max() / scale < 1e-3
+    # north star: 1e-4 relative in float32.  With the shipped checkpoint's BatchNorm statistics (var down to 6.6e-22) two float32
+    # evaluation orders differ by more than that, so the bar is 1e-4 or 4x the distance of the float32 ORACLE from the float64
+    # one on the same input (the construct of tests/test_full_size.py; plain 1e-4 holds with live weights, tests/test_unet.py)
+    ref32 = po.labelled_cloud(c["xyz"], c["rgb"], w, 0.03, dtype=torch.float32)
+    base = np.abs(ref32["medial_vector"].astype(np.float64) - ref["medial_vector"]).max() / scale
+    err = np.abs(mv - ref["medial_vector"]).max() / scale
+    assert err <= max(1e-4, 4 * base), (err, base)
     assert (lc.class_l.cpu().numpy() != ref["class_l"]).mean() < 1e-3
 
     # stage 2: skeleton + post-processing from the SAME labelled cloud must be identical

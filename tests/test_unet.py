@@ -33,6 +33,35 @@ def test_sparse_tensor_attributes_of_the_reference():
     assert empty.spatial_shape.tolist() == [0, 0, 0]
 
 
+def test_sparse_tensor_attributes_equal_the_reference_golden(backend):
+    """tests/golden/sparse_attrs.npz is what the reference's OWN sparse_from_batch (model/sparse.py:9-19) handed to spconv for the
+    collated batch of blocking_50k.npz (tools/make_goldens.py::sparse_attrs_case, a recorder in place of SparseConvTensor):
+    spatial_shape = the largest z / y / x -- one LESS than the true extent --, batch_size = the number of voxels, int32 indices.
+    The mirrored attributes must equal it on both backends; and the rulebooks must NOT take their extent from it (the documented
+    canonical choice): the coarse set of the first strided conv is the one the oracle derives from the
+    true extent max + 1, which differs from what the attribute's extent would give (max-face voxels keep their outputs)."""
+    gold = Path(__file__).parent / "golden"
+    g, a = np.load(gold / "blocking_50k.npz"), np.load(gold / "sparse_attrs.npz")
+    coords = torch.from_numpy(g["collated_coords"])
+    feats = torch.from_numpy(g["collated_xyz"])
+    sp = sparse_from_batch(feats, coords.float(), backend)  # (batch_collate emits float coordinates, dataset.py:216)
+    assert sp.indices.dtype == torch.int32 and str(sp.indices.dtype) == str(a["indices_dtype"])
+    assert sp.indices.device.type == torch.device(backend).type
+    assert sp.batch_size == int(a["batch_size"]) == coords.shape[0]
+    assert sp.spatial_shape.cpu().tolist() == a["spatial_shape"].tolist()
+    assert (a["spatial_shape"] + 1).tolist() == a["true_extent"].tolist()  # the quirk: the attribute is max, not max + 1
+    np.testing.assert_array_equal(sp.indices.cpu().numpy(), g["collated_coords"])
+    # the rulebook builders clip the coarse set at the TRUE extent: equal to the oracle's coarse set, and at least one coarse
+    # voxel exists that an extent of `spatial_shape` (one less) would have cut off
+    pyr = ops.build_pyramid(sp.indices, depth=1)
+    coarse = uo.strided_out_coords(g["collated_coords"])
+    np.testing.assert_array_equal(pyr.coords[1].cpu().numpy(), coarse)
+    ext_attr = (a["spatial_shape"] - 1) // 2 + 1  # spconv's output-size formula (k 3, s 2, p 1) on the attribute's extent
+    ext_true = (a["true_extent"] - 1) // 2 + 1
+    assert (coarse[:, 1:].max(0) + 1 <= ext_true).all()
+    assert (coarse[:, 1:].max(0) + 1 > ext_attr).any(), "this batch has no max-face voxel: the golden no longer exercises the choice"
+
+
 def test_rulebooks_bit_exact(backend):
     vx = _small_batch()
     coords = torch.from_numpy(vx["coords"]).to(backend)

@@ -520,6 +520,31 @@ def loss_case():
     print("loss_vectors", {k: v.tolist() for k, v in out.items() if k.endswith(("focal", "dice"))})
 
 
+def sparse_attrs_case():
+    """The reference's own `sparse_from_batch` (model/sparse.py:9-19) on the collated batch of blocking_50k.npz, with spconv's
+    SparseConvTensor served by a recorder: WHAT the reference hands to spconv -- spatial_shape = the largest z / y / x (NOT + 1),
+    batch_size = the number of voxels, int32 indices.  The attribute is mirrored (smart_tree_amd/model/sparse.py); the rulebooks
+    deliberately do NOT take their extent from it (canonical choices)."""
+    g = np.load(OUT / "blocking_50k.npz")
+    seen = {}
+
+    class SparseConvTensor:
+        def __init__(self, features, indices, spatial_shape, batch_size=None):
+            seen.update(features=features, indices=indices, spatial_shape=spatial_shape, batch_size=batch_size)
+
+    sys.modules["spconv.pytorch"].SparseConvTensor = SparseConvTensor
+    r_sparse = reference("smart_tree.model.sparse")
+    r_sparse.spconv = sys.modules["spconv.pytorch"]
+    feats = torch.from_numpy(np.concatenate([g["collated_xyz"], np.zeros_like(g["collated_xyz"])], 1))
+    coords = torch.from_numpy(g["collated_coords"]).float()  # batch_collate emits float coordinates (dataset.py:216)
+    r_sparse.sparse_from_batch(feats, coords, torch.device("cpu"))
+    out = {"spatial_shape": seen["spatial_shape"].numpy().astype(np.int64), "batch_size": np.int64(seen["batch_size"]),
+           "indices_dtype": np.array(str(seen["indices"].dtype)), "indices_equal_coords": np.bool_(
+               bool(torch.equal(seen["indices"], coords.int()))), "true_extent": g["collated_coords"][:, 1:].max(0).astype(np.int64) + 1}
+    np.savez_compressed(OUT / "sparse_attrs.npz", **out)
+    print("sparse_attrs", {k: (v.tolist() if v.ndim else v.item()) for k, v in out.items()})
+
+
 def tree_dataset_case():
     """The reference's TreeDataset.process_cloud (dataset.py:82-138) on a labelled cloud, no augmentation, with spconv's
     PointToVoxel served by the stand-in (canonical semantics of oracle/voxel_oracle.voxelize_block), then batch_collate of two
@@ -581,6 +606,7 @@ def main():
     skeleton_case("skeleton_small_tree", vx["feats"][m, :3], c["medial_vector"][vx["point"][m]])
     quirks_case()
     blocking_case()
+    sparse_attrs_case()
     nearest_tube_case()
     skeleton_file_case()
     tube_mesh_case()
