@@ -68,6 +68,7 @@ PASSES = 5         # timed passes of K steps; the median is reported
 UPLOAD_PASSES = 3
 SINGLE_CALLS = 7   # process_cloud calls of the single-cloud block
 REP_SET = 20       # clouds of the ground-truth-medial launch set (representative_inputs)
+PROJECTION_CLOUDS = 64  # BASELINE.json configs[2]: a fixed batch of 64 trees (seeds 0..63) over 8 GPUs
 ORDERED = int(os.environ.get("ST_BENCH_ORDERED", "3"))  # 3 (default): voxelise .. network of the batches in flight take turns; 1: voxelise .. adjacency; 0: free-running; 2: only the conv sequences
 SHORT_RUN_STEPS = 128  # below this a run is one or two rounds of batches: nothing to take turns with, the batches run free (unless ST_BENCH_ORDERED is set)
 
@@ -285,9 +286,10 @@ class CloudWorker:
             self.host.append((xyz, zeros))
             self.clouds.append(Cloud(xyz=xyz.to(device), rgb=zeros.to(device)))
         self.last = None
+        self.first = 0  # offset into the resident clouds (strong_scaling_projection times other eighths of the 64)
 
     def batch_clouds(self, first, size):
-        return [self.clouds[(first + k) % len(self.clouds)] for k in range(size)]
+        return [self.clouds[(self.first + first + k) % len(self.clouds)] for k in range(size)]
 
     def upload_batch(self, w, first, size, after=None):
         """Host -> device copies of one batch on worker w's COPY stream (pinned buffers); returns (clouds, event).  `after`: the
@@ -703,6 +705,113 @@ def representative_inputs(device, host_xyz, host_mv, n_set=20, n_points=N_POINTS
     return out
 
 
+def representative_e2e(worker, host_mv, steps, B, points, passes=3):
+    """ONE end-to-end figure on the regime the skeleton stage is written for (round-5 verdict): the same `steps` clouds through
+    the WHOLE path -- upload excluded, CentreCloud, blocks / voxels, the network (it runs and is timed), class filter -- but the
+    skeleton stage consumes the GENERATOR's exact medial vector of every voxel's representative point instead of the network's
+    output (the shipped checkpoints' output on the 10 m benchmark tree carries no information, DESIGN.md section 4: the headline's
+    skeleton stage works on an arbitrary graph that is 2-3x cheaper than this one).  Launch sets as in the timed region
+    (`plan_batches`, one set at a time on one stream); median of `passes` passes; the first cloud's skeleton is compared with the
+    oracle's skeleton of the same labelled points (identical = ids, parents, coordinates, radii of every branch)."""
+    from oracle import pipeline_oracle as po
+    from smart_tree_amd import profiling
+    from smart_tree_amd.data_types.cloud import Cloud, MaskedCloud
+
+    dev, pipe, st = worker.device, worker.pipes[0], worker.streams[0]
+    plan = plan_batches(steps, 1, B)
+    starts = np.concatenate([[0], np.cumsum(plan)]).tolist()
+    n_host = host_mv.shape[0]
+    with torch.cuda.stream(st):
+        gts = [torch.cat([host_mv[(a + k) % n_host].to(dev) for k in range(sz)]) for a, sz in zip(starts, plan)]  # resident, like the inputs
+
+        def one_set(i):
+            clouds = worker.batch_clouds(starts[i], plan[i])
+            batch = Cloud.collate([Cloud(c.xyz, c.rgb) for c in clouds]) if plan[i] > 1 else clouds[0]
+            with profiling.stage("preprocess"):
+                batch = pipe.preprocessing(batch)
+            base, mask = pipe.model_inference.forward(batch).pending()
+            with profiling.stage("class_filter"):
+                lc = Cloud(xyz=base.xyz, rgb=base.rgb, medial_vector=gts[i].index_select(0, pipe.model_inference.last_point_index),
+                           class_l=torch.zeros_like(base.class_l), seg_off=base.seg_off)
+                branch = MaskedCloud(lc, mask).filter_by_class(pipe.branch_classes)
+            sk = pipe.skeletonizer.forward(branch)
+            with profiling.stage("post_process"):
+                pipe.post_process(sk)
+                parts = sk.split()
+            return parts, lc, mask
+
+        def one_pass():
+            first_set = None
+            for i in range(len(plan)):
+                r = one_set(i)
+                first_set = r if i == 0 else first_set
+            st.synchronize()
+            return first_set
+
+        one_pass()
+        ms = []
+        for _ in range(passes):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            first = one_pass()
+            ms.append(1e3 * (time.perf_counter() - t0))
+        profiling.family_mode(True)
+        profiling.enable(True)
+        one_pass()
+        torch.cuda.synchronize()
+        profiling.enable(False)
+        stage = profiling.stage_ms(steps)
+        parts, lc, mask = first
+        a, b = (0, len(lc)) if lc.seg_off is None else [int(v) for v in lc.seg_off[:2].tolist()]
+        keep = mask[a:b].nonzero().view(-1) + a
+        xyz, mv = lc.xyz[keep].cpu().numpy(), lc.medial_vector[keep].cpu().numpy()
+    trees = po.skeleton_from_labelled(xyz, mv, np.zeros((len(xyz), 1), np.float32))
+    po.post_process(trees)
+    med = sorted(ms)[len(ms) // 2]
+    return {"what": "the timed region's %d clouds through the whole path with the skeleton stage fed the generator's exact medial vectors "
+                    "(network still run and timed; inputs resident; launch sets %s, one at a time); median of %d passes" % (steps, plan, passes),
+            "value": steps * points / (med * 1e-3), "unit": "points/s", "ms_per_step": med / steps,
+            "passes_ms_per_step": [round(v / steps, 4) for v in ms], "stage_ms_per_cloud": stage,
+            "graph_vertices_first_cloud": int(len(xyz)), "branches_first_cloud": int(sum(len(t.branches) for t in parts[0].skeletons)),
+            "parity": "identical" if _skeleton_signature(parts[0].skeletons) == _skeleton_signature(trees) else "DIFFERENT"}
+
+
+def strong_scaling_projection(worker, S, B, points, reps=3):
+    """BASELINE.json configs[2] is a FIXED batch of 64 clouds over 8 GPUs (8 per GPU).  No 8-GPU node is the builder's to use, so
+    this is a PROJECTION from one GPU, NOT a scaling measurement: t(n) = one launch set of n of the 64 clouds (seeds 0..63) alone
+    on the GPU, inputs resident, median of `reps`; t64 = all 64 on this one GPU with the timed region's own plan.  With the clouds
+    dealt round-robin, every rank of 8 holds 8 clouds and the job lasts as long as its slowest rank: the 8 sets of 8 are timed
+    one after the other here and the slowest stands for the 8-GPU job (the gather of KBs per cloud is not in it)."""
+    def timed(plan_, streams, first=0):
+        starts_backup = worker.first
+        worker.first = first
+        try:
+            worker.run(plan_, collect=False, streams=streams)
+            ts = []
+            for _ in range(reps):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                worker.run(plan_, collect=False, streams=streams)
+                torch.cuda.synchronize()
+                ts.append(1e3 * (time.perf_counter() - t0))
+        finally:
+            worker.first = starts_backup
+        return sorted(ts)[len(ts) // 2]
+
+    n_all = PROJECTION_CLOUDS
+    sets = {n: round(timed([n], 1), 3) for n in (8, 16, 32, 64)}
+    plan64 = plan_batches(n_all, S, B)
+    t64 = min(timed(plan64, S), sets[64])
+    rank_ms = [round(timed([8], 1, first=8 * r), 3) for r in range(8)]  # rank r of 8: a contiguous eighth stands for its round-robin share
+    slowest = max(rank_ms)
+    return {"note": "PROJECTION from one GPU, NOT a scaling measurement (no 8-GPU node available to the builder): configs[2] = 64 clouds "
+                    "split over 8 ranks = 8 clouds per rank; speed-up = t(64 clouds on this GPU) / t(slowest set of 8)",
+            "ms_one_launch_set": sets, "ms_64_clouds_one_gpu": round(t64, 3), "plan_64_clouds": plan64,
+            "ms_sets_of_8": rank_ms, "projected_speedup_8gpu": round(t64 / slowest, 2),
+            "projected_value_8gpu": n_all * points / (slowest * 1e-3),
+            "target": ">= 6.5x (BASELINE.json north_star)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -715,19 +824,36 @@ def main():
                     "ordering of their chip-filling phases, reported as `free_running` (profiles/r02_free_running.txt)")
     ap.add_argument("--batch", type=int, default=MAX_BATCH, help="clouds per launch set (Pipeline.process_clouds); 1 = one cloud per call")
     ap.add_argument("--streams", type=int, default=STREAMS, help="batches in flight per GPU (one host thread + HIP stream each)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak (default, the driver's contract): every rank runs --steps clouds of its own.  strong (BASELINE.json configs[2]): "
+                         "a FIXED batch of --clouds independent clouds (seeds 0 .. clouds-1) is split round-robin over the ranks, `value` = "
+                         "clouds x points / the slowest rank's time, the skeletons gathered to rank 0 inside the timed region")
+    ap.add_argument("--clouds", type=int, default=0, help="--scaling strong: clouds of the whole job (default: --steps; configs[2]: 64)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    from smart_tree_amd.sharding import shard_indices
+
+    strong = args.scaling == "strong"
+    total_clouds = (args.clouds or args.steps) if strong else world * args.steps
+    # K = the steps THIS rank runs per pass: --steps (weak) or its round-robin share of the fixed batch (strong)
+    my_clouds = shard_indices(total_clouds, rank, world) if strong else None
+    K = len(my_clouds) if strong else args.steps
+    assert K > 0, f"--scaling strong: {total_clouds} clouds cannot feed {world} ranks"
     # the synthetic clouds of this rank, generated by forked processes BEFORE this process has a GPU context: every step of a
     # pass is a different cloud (BASELINE configs[2]: seeds 0..63; rank r draws r * D .. r * D + D - 1, rank 0's first is seed 0)
-    n_distinct = max(1, min(MAX_DISTINCT, args.steps))
+    n_distinct = max(1, min(MAX_DISTINCT, K))
     t_gen = time.perf_counter()
     want_rep = world == 1 and not args.no_extras
-    n_rep = min(REP_SET, n_distinct) if want_rep else 0
-    gen = generate_clouds(args.points, [rank * n_distinct + j for j in range(n_distinct)], max(1, usable_cores() // max(world, 1)), n_mv=n_rep)
+    # one GPU: configs[2]'s 64 seeds are generated whatever --steps says (the timed region uses the first n_distinct of them; the
+    # strong-scaling projection times launch sets of 8 .. 64 clouds), each with the generator's exact medial vectors (representative_e2e)
+    n_gen = max(n_distinct, PROJECTION_CLOUDS) if want_rep and not strong else n_distinct
+    n_rep = n_gen if want_rep else 0
+    seeds = ([my_clouds[j % K] for j in range(n_gen)] if strong else [rank * n_distinct + j for j in range(n_gen)])
+    gen = generate_clouds(args.points, seeds, max(1, usable_cores() // max(world, 1)), n_mv=n_rep)
     host_xyz, host_mv = gen if n_rep > 0 else (gen, None)
     t_gen = time.perf_counter() - t_gen
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
@@ -759,7 +885,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     coll_device = torch.device("cpu") if dryrun else device
     global ORDERED
-    if "ST_BENCH_ORDERED" not in os.environ and args.steps < SHORT_RUN_STEPS:
+    if "ST_BENCH_ORDERED" not in os.environ and K < SHORT_RUN_STEPS:
         ORDERED = 0  # measured at the driver's --steps 20: 1.83 ms per step free-running against 1.96 in turns (profiles/r03_sweep_plan.txt)
 
     from smart_tree_amd import profiling
@@ -774,14 +900,16 @@ def main():
     # and one per rank, or fewer batches in flight (one in flight costs 14 % at 64 clouds per batch: 1.47 instead of 1.29 ms per
     # cloud; a throttled cgroup costs more).  With blocking waits (the default) a worker needs a fifth of a core.
     S = max(1, min(args.streams, max(1, (usable_cores() - world) // ((1 if blocking else 2) * max(world, 1)))))
-    S = max(1, min(S, args.steps // 16), min(S, 3, args.steps // 6))  # see plan_batches
+    S = max(1, min(S, K // 16), min(S, 3, K // 6))  # see plan_batches
     B = max(1, min(args.batch, 64))
     finished = []  # packed skeletons of this rank, gathered to rank 0 once per timed region (no per-step rendezvous:
     #                 clouds differ in cost, a collective per step would make every step as slow as its slowest rank)
     # for the record (one GPU only): the same K steps free-running -- the chip-filling phases of the batches in flight overlap,
     # which fills the bubbles at their host round trips (a few % more throughput) and stretches every kernel's launch bracket
-    S_free = max(1, min(FREE_STREAMS, usable_cores(), max(1, args.steps // 16))) if world == 1 and ORDERED in (1, 3) and args.free_running else 0
-    worker = CloudWorker(device, max(S, S_free), host_xyz, rank)
+    S_free = max(1, min(FREE_STREAMS, usable_cores(), max(1, K // 16))) if world == 1 and ORDERED in (1, 3) and args.free_running else 0
+    # (one GPU: the strong-scaling projection runs 64 clouds with the plan the default command would use -- its worker threads exist)
+    S_proj = max(1, min(args.streams, max(1, (usable_cores() - 1) // (1 if blocking else 2)), PROJECTION_CLOUDS // 16)) if want_rep and not strong else 0
+    worker = CloudWorker(device, max(S, S_free, S_proj), host_xyz, rank)
 
     def run_steps(total, upload=False):
         plan_ = plan_batches(total, S, B)
@@ -809,7 +937,7 @@ def main():
     # has its own allocator pool, and batches differ a little in their voxel / vertex counts: a pool that has seen only one
     # batch still grows during the next few (hipMalloc synchronises the device: measured 2.1 instead of 1.55 ms per cloud
     # when the timed region started after one warm-up batch per stream)
-    plan = plan_batches(args.steps, S, B)
+    plan = plan_batches(K, S, B)
     # SETTLE (untimed, reported as `settle_s` / `settle_steps`; not the warm-up the flag asks for): whole passes over the very batches
     # the timed region will run, until two consecutive passes agree to 5 % AND the process is MIN_UPTIME seconds old.  Why: every
     # stream has its own allocator pool, and batches differ a little in their voxel / vertex counts -- a pool that has seen only
@@ -861,7 +989,7 @@ def main():
             fence()
             cpu0 = os.times()
             t0 = time.perf_counter()
-            run_steps(args.steps)  # returns when every worker has synchronised its streams
+            run_steps(K)  # returns when every worker has synchronised its streams
             gather()  # inside the timed region: the skeletons of all ranks end up on rank 0
             fence()
             dt_pass = time.perf_counter() - t0
@@ -872,24 +1000,24 @@ def main():
     finally:
         gc.enable()
     profiling.enable(False)
-    roof = profiling.roofline(HBM_PEAK_GBS, clouds_per_launch=max(plan_batches(args.steps, S, B)))
-    stage_ms = profiling.stage_ms(args.steps * PASSES)
+    roof = profiling.roofline(HBM_PEAK_GBS, clouds_per_launch=max(plan_batches(K, S, B)))
+    stage_ms = profiling.stage_ms(K * PASSES)
     sk = worker.last
     last = {"trees": len(sk.skeletons), "branches": int(sum(len(t.branches) for t in sk.skeletons))}
     # the same K clouds with the host -> device upload of every cloud inside the pass (pinned host buffers, copy streams)
     up_s = []
-    run_steps(args.steps, upload=True)  # (untimed: the copy streams' allocator pools)
+    run_steps(K, upload=True)  # (untimed: the copy streams' allocator pools)
     gather()
     for _ in range(UPLOAD_PASSES):
         fence()
         t1 = time.perf_counter()
-        run_steps(args.steps, upload=True)
+        run_steps(K, upload=True)
         gather()
         fence()
         up_s.append(time.perf_counter() - t1)
     free = None
     if S_free > 1:
-        plan_free = plan_batches(args.steps, S_free, B)
+        plan_free = plan_batches(K, S_free, B)
         worker.run(plan_free, collect=False, streams=S_free, mode=0)  # untimed: the third stream's allocator pool
         torch.cuda.synchronize()
         profiling.enable(True)
@@ -900,8 +1028,8 @@ def main():
         profiling.enable(False)
         rf = profiling.roofline(HBM_PEAK_GBS, clouds_per_launch=max(plan_free))
         free = {"note": "the same %d steps with %d batches in flight and NO ordering of their chip-filling phases (untimed extra "
-                        "pass): kernels of different batches share the chip, brackets stretch" % (args.steps, S_free),
-                "value": args.steps * args.points / dt_free, "ms_per_step": 1e3 * dt_free / args.steps,
+                        "pass): kernels of different batches share the chip, brackets stretch" % (K, S_free),
+                "value": K * args.points / dt_free, "ms_per_step": 1e3 * dt_free / K,
                 "batches_in_flight": S_free, "roofline_kernel": rf["kernel"], "roofline_frac": rf["frac"],
                 "gather_gemm_hbm_frac": (rf.get("gather_gemm") or {}).get("hbm_frac")}
     # for the record: ONE batch at a time on one stream with the kernel timers on -- solo kernel durations (in the timed region
@@ -910,13 +1038,17 @@ def main():
     if world == 1:
         profiling.family_mode(False)  # every launch bracketed: the per-class table
         profiling.enable(True)
-        worker.run([min(B, max(args.steps, 1))], collect=False, streams=1)
+        worker.run([min(B, max(K, 1))], collect=False, streams=1)
         torch.cuda.synchronize()
         profiling.enable(False)
-        full = profiling.roofline(HBM_PEAK_GBS, clouds_per_launch=min(B, max(args.steps, 1)))  # (PMC traffic scaled to this batch)
-        roof_solo = {"note": "one batch of %d clouds alone on the GPU (untimed extra pass): solo launch durations" % min(B, max(args.steps, 1))}
+        full = profiling.roofline(HBM_PEAK_GBS, clouds_per_launch=min(B, max(K, 1)))  # (PMC traffic scaled to this batch)
+        roof_solo = {"note": "one batch of %d clouds alone on the GPU (untimed extra pass): solo launch durations" % min(B, max(K, 1))}
         roof_solo.update({k: full.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "launches", "avg_us",
                                                   "algorithmic_bytes_per_launch", "branch_selection", "gather_gemm", "all_kernels")})
+    rep_e2e = projection = None
+    if want_rep and not strong and host_mv is not None:
+        rep_e2e = representative_e2e(worker, host_mv, K, B, args.points)
+        projection = strong_scaling_projection(worker, S_proj, B, args.points)
     per_rank = None
     if world > 1:  # every pass: the slowest rank
         mine = torch.tensor([sorted(pass_s)[len(pass_s) // 2], sorted(host_cores)[len(host_cores) // 2]], dtype=torch.float64, device=coll_device)
@@ -930,33 +1062,39 @@ def main():
     dt, dt_up = med(pass_s), med(up_s)
 
     if rank == 0:
-        value = world * args.steps * args.points / dt
-        batches = plan_batches(args.steps, S, B)
+        value = total_clouds * args.points / dt
+        batches = plan_batches(K, S, B)
         gg = (roof or {}).pop("gather_gemm", None)
         out = {
             "metric": "points/sec end-to-end (voxelize->sparse-UNet->skeleton), 1M-pt tree",
-            "value": value, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": warm,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value": value, "unit": "points/s", "n_gpus": world, "steps": total_clouds if strong else K, "warmup": warm,
+            "ms_per_step": 1e3 * dt / (total_clouds if strong else K), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "passes": {"n": PASSES, "statistic": "median", "ms_per_step": [round(1e3 * v / args.steps, 4) for v in pass_s],
-                       "value_min": world * args.steps * args.points / max(pass_s), "value_max": world * args.steps * args.points / min(pass_s)},
-            "value_incl_host_upload": world * args.steps * args.points / dt_up,
-            "incl_host_upload": {"passes": UPLOAD_PASSES, "statistic": "median", "ms_per_step": [round(1e3 * v / args.steps, 4) for v in up_s],
+            "passes": {"n": PASSES, "statistic": "median", "ms_per_step": [round(1e3 * v / (total_clouds if strong else K), 4) for v in pass_s],
+                       "value_min": total_clouds * args.points / max(pass_s), "value_max": total_clouds * args.points / min(pass_s)},
+            "value_incl_host_upload": total_clouds * args.points / dt_up,
+            "incl_host_upload": {"passes": UPLOAD_PASSES, "statistic": "median", "ms_per_step": [round(1e3 * v / (total_clouds if strong else K), 4) for v in up_s],
                                  "note": "every cloud of the pass is copied from pinned host memory inside the pass (24 bytes per point: xyz + rgb); "
                                          "a worker enqueues its NEXT batch's copies on a copy stream before the current batch's kernels"},
             "config": {"workload": f"configs[1]: one {args.points}-point synthetic tree per rank per step, 2 cm voxels, "
                                    "noble-elevator-58 weights, full Pipeline path with prune/repair/smooth; steps run in "
                                    "batches of clouds through ONE launch set (Pipeline.process_clouds)",
-                       "distinct_clouds_per_rank": n_distinct, "seeds": f"{rank * n_distinct}..{rank * n_distinct + n_distinct - 1} (rank r: r * {n_distinct} + j)",
-                       "parallelism": f"cloud-sharded x{world}",
+                       "inputs": "resident in HBM when the timed region starts (the task's bench contract: the PCIe-inclusive rate is never `value`); "
+                                 "SURVEY 8d's reading -- the cloud starts in (pinned) HOST memory -- is `value_incl_host_upload` for the same K steps and "
+                                 "`single_cloud` for one Pipeline.process_cloud call at a time",
+                       "distinct_clouds_per_rank": n_distinct,
+                       "seeds": (f"strong scaling: the job's clouds are seeds 0..{total_clouds - 1}, rank r holds r, r + {world}, ..." if strong else
+                                 f"{rank * n_distinct}..{rank * n_distinct + n_distinct - 1} (rank r: r * {n_distinct} + j)"),
+                       "parallelism": f"cloud-sharded x{world}" + (f" (strong: {total_clouds} clouds in all, {K} on rank 0)" if strong else ""),
+                       "strong_scaling_projection": projection,
                        "clouds_per_launch_set": max(batches), "batches_in_timed_region": len(batches),
                        "batches_in_flight_per_gpu": S, "host_threads_per_gpu": S,
                        "settle_s": round(settle_s, 1), "settle_steps": settle_steps,
                        "settle_note": "untimed passes over the timed region's own batches before the --warmup steps, until two passes agree "
                                       "to 5 % and the process is `warmup_until_process_age_s` old (allocator pools, clock ramp after "
                                       "another GPU process)",
-                       "value_incl_host_upload": world * args.steps * args.points / dt_up,
-                       "ms_per_step_incl_host_upload": 1e3 * dt_up / args.steps,
+                       "value_incl_host_upload": total_clouds * args.points / dt_up,
+                       "ms_per_step_incl_host_upload": 1e3 * dt_up / (total_clouds if strong else K),
                        "single_cloud_ms": None if single is None else single["ms"],
                        "schedule": {1: "the chip-filling phases (voxelise .. adjacency) of the batches in flight take turns; a batch's "
                                        "skeleton stage (one compute unit per tree) overlaps with the other batch's chip-filling phase",
@@ -978,6 +1116,7 @@ def main():
             "roofline": roof,
             "roofline_gather_scatter": gg,
             "single_cloud": single,
+            "representative_e2e": rep_e2e,
             "roofline_solo": roof_solo,
             "free_running": free,
             "stage_ms": stage_ms,
@@ -992,7 +1131,7 @@ def main():
             out["helper_workgroups"] = skeletonize.helper_stats()  # lost > 0: a fall-back of the helper protocol ran (slower, not wrong)
             del worker
             torch.cuda.empty_cache()
-            out["representative_inputs"] = representative_inputs(device, host_xyz, host_mv, n_set=n_rep, n_points=args.points)
+            out["representative_inputs"] = representative_inputs(device, host_xyz, host_mv, n_set=min(REP_SET, n_rep), n_points=args.points)
             out["other_configs"] = extra_configs(device)
         print(json.dumps(out))
     if world > 1:

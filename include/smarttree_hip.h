@@ -26,7 +26,16 @@
 extern "C" {
 #endif
 
+/* 101 (round 6): st_abi_entries added; stats_host of the skeleton calls is 16 x int64 (8 before 100) and their tuning array
+ * 24 x int64 -- a caller built against an older header must check st_abi_entries before passing shorter arrays. */
 int st_version(void);
+/* Array lengths this build of the library reads / writes, so that a caller can check them at run time instead of trusting the
+ * header it was compiled against: what = 0 -> int64 entries of `stats_host` (st_skeleton_components*, st_sssp, st_tree_distance,
+ * st_sample_tree: all ZEROED and written), 1 -> int64 entries of `tuning` (st_skeleton_components_seg: all READ when non-NULL),
+ * 2 -> ST_MAX_SEG (clouds per batched call); anything else -> -1 */
+#define ST_SKELETON_STATS_ENTRIES 16
+#define ST_SKELETON_TUNING_ENTRIES 24
+int st_abi_entries(int what);
 const char* st_last_error(void);
 /* op: 0 scan(n) 1 sort(n) 2 voxelize(n,max_blocks,max_voxels) 3 strided(n) 4 knn(n_dst) 5 make_edges(n)
  *     6 component_layout(n) 7 component_csr(m) 8 skeleton(m,n_comp) */

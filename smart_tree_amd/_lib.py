@@ -25,6 +25,7 @@ I64 = c_int64
 # name -> (restype, argtypes); mirrors include/smarttree_hip.h
 SIGNATURES = {
     "st_version": (c_int, []),
+    "st_abi_entries": (c_int, [c_int]),
     "st_last_error": (ctypes.c_char_p, []),
     "st_scan_workspace_bytes": (I64, [I64]),
     "st_scan_u32": (c_int, [P, P, I64, P, P, I64, P]),
@@ -104,7 +105,7 @@ SIGNATURES = {
 # 5 us launch means queueing behind the other threads -- a convoy that costs more than the launch.  These are bound
 # through PyDLL (GIL kept); everything that waits for the GPU inside the call (a count read back) stays on CDLL.
 ENQUEUE_ONLY = frozenset({
-    "st_version", "st_last_error", "st_scan_workspace_bytes", "st_sort_workspace_bytes", "st_voxelize_workspace_bytes",
+    "st_version", "st_abi_entries", "st_last_error", "st_scan_workspace_bytes", "st_sort_workspace_bytes", "st_voxelize_workspace_bytes",
     "st_hash_capacity", "st_strided_workspace_bytes", "st_head_param_floats", "st_knn_workspace_bytes",
     "st_make_edges_workspace_bytes", "st_connected_components_workspace_bytes", "st_component_layout_workspace_bytes",
     "st_component_csr_workspace_bytes", "st_assemble_workspace_bytes", "st_skeleton_workspace_bytes",

@@ -28,6 +28,7 @@ __global__ void k_grid_init(StGrid* g) {
         for (int a = 0; a < 3; a++) { g->lo_ord[a] = 0xffffffffu; g->hi_ord[a] = 0u; }
         g->rmax_ord = 0u;
         g->bound_sum_fix = 0ull;
+        g->bound_cnt = 0ull;
         g->r = 0.0f;
     }
     if (blockIdx.x == 0 && threadIdx.x < ST_MAX_SEG) { g->seg_rmax_ord[threadIdx.x] = 0u; g->seg_r[threadIdx.x] = 0.0f; }
@@ -42,13 +43,14 @@ __device__ __forceinline__ unsigned grid_wave_max(unsigned v) { for (int d = 32;
 // blockIdx.y = cloud (gridDim.y = 1, seg_off == nullptr: the whole array is one cloud)
 __global__ void __launch_bounds__(KNN_BLOCK) k_bound_max(const float* bound, int64_t n, StGrid* g, const int* seg_off, const uint8_t* valid) {
     __shared__ unsigned m;
-    __shared__ unsigned long long sum;
-    if (threadIdx.x == 0) { m = 0u; sum = 0ull; }
+    __shared__ unsigned long long sum, cnt;
+    if (threadIdx.x == 0) { m = 0u; sum = 0ull; cnt = 0ull; }
     __syncthreads();
     const int seg = blockIdx.y;
     const int64_t i0 = seg_off ? seg_off[seg] : 0, i1 = seg_off ? seg_off[seg + 1] : n;
     unsigned mine = 0u;
     unsigned long long fix = 0ull;  // sum of the bounds in 2^-16 units (a bound is a radius: metres; clamped so 2^40 of them fit)
+    unsigned long long seen = 0ull;  // bounds in that sum
     for (int64_t i = i0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < i1; i += (int64_t)gridDim.x * blockDim.x) {
         if (valid && !valid[i]) continue;  // (a point that is not part of the search: see st_grid_build)
         const float b = bound[i];
@@ -56,18 +58,20 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_bound_max(const float* bound, int
         const unsigned o = st_f2ord(b);
         if (o > mine) mine = o;
         fix += (unsigned long long)(fminf(fmaxf(b, 0.0f), 128.0f) * 65536.0f);  // (NaN -> 0)
+        seen++;
     }
     mine = grid_wave_max(mine);
-    for (int d = 32; d > 0; d >>= 1) fix += __shfl_xor(fix, d);
-    if ((threadIdx.x & 63) == 0) { if (mine) atomicMax(&m, mine); atomicAdd(&sum, fix); }
+    for (int d = 32; d > 0; d >>= 1) { fix += __shfl_xor(fix, d); seen += __shfl_xor(seen, d); }
+    if ((threadIdx.x & 63) == 0) { if (mine) atomicMax(&m, mine); atomicAdd(&sum, fix); atomicAdd(&cnt, seen); }
     __syncthreads();
     if (threadIdx.x == 0) {
         if (m) { atomicMax(&g->rmax_ord, m); atomicMax(&g->seg_rmax_ord[seg], m); }
         if (sum) atomicAdd(&g->bound_sum_fix, sum);
+        if (cnt) atomicAdd(&g->bound_cnt, cnt);
     }
 }
 
-__global__ void __launch_bounds__(KNN_BLOCK) k_grid_bbox(const float* pts, int64_t n, StGrid* g) {
+__global__ void __launch_bounds__(KNN_BLOCK) k_grid_bbox(const float* pts, int64_t n, StGrid* g, const uint8_t* valid) {
     __shared__ unsigned lo[3], hi[3];
     if (threadIdx.x < 3) { lo[threadIdx.x] = 0xffffffffu; hi[threadIdx.x] = 0u; }
     __syncthreads();
@@ -79,6 +83,7 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_grid_bbox(const float* pts, int64
     int a = (int)(e0 % 3);
     for (int64_t e = e0; e < total; e += step, a = (a + step3) % 3) {
         const float pv = pts[e];
+        if (valid && !valid[e / 3]) continue;  // a point outside the searched subset does not size the grid either
         if (!(fabsf(pv) <= 3.0e38f)) continue;  // NaN / infinity: such a point is not part of the search (k_grid_count), it must not size the grid
         const unsigned o = st_f2ord(pv);
 #pragma unroll
@@ -105,8 +110,10 @@ __global__ void k_grid_dims(StGrid* g, float cell, int64_t max_cells, float r, i
     g->r = r;
     if (cell < 0.0f) {
         cell = r / -cell;
-        if (mean_mult > 0.0f && n_bound > 0) {  // ... but no coarser than mean_mult x the mean bound
-            const float mean = (float)((double)g->bound_sum_fix / 65536.0 / (double)n_bound);
+        if (mean_mult > 0.0f && n_bound > 0 && g->bound_cnt > 0ull) {  // ... but no coarser than mean_mult x the mean bound
+            // (the mean over the bounds k_bound_max summed: the valid, non-NaN ones -- dividing by n_bound made the cap shrink with
+            // the valid fraction when the search runs over a subset)
+            const float mean = (float)((double)g->bound_sum_fix / 65536.0 / (double)g->bound_cnt);
             if (mean > 0.0f) cell = fminf(cell, mean_mult * mean);
         }
         cell = fmaxf(cell, 1e-4f);
@@ -190,7 +197,7 @@ int st_grid_build(const float* pts, int64_t n, float cell, int64_t max_cells, St
     unsigned gb = (unsigned)st_min64(st_div_up(n > 0 ? n : 1, KNN_BLOCK), 4096);
     hipLaunchKernelGGL(k_grid_init, dim3(1), dim3(64), 0, stream, g);
     static_assert(ST_MAX_SEG <= 64, "k_grid_init clears the per-cloud radii with one wavefront");
-    hipLaunchKernelGGL(k_grid_bbox, dim3((unsigned)st_min64(st_div_up(3 * (n > 0 ? n : 1), (int64_t)KNN_BLOCK * 8), 512)), dim3(KNN_BLOCK), 0, stream, pts, n, g);
+    hipLaunchKernelGGL(k_grid_bbox, dim3((unsigned)st_min64(st_div_up(3 * (n > 0 ? n : 1), (int64_t)KNN_BLOCK * 8), 512)), dim3(KNN_BLOCK), 0, stream, pts, n, g, valid);
     // No read-back of the cell count (a blocking round trip costs ~1 ms beside other clouds' kernels):
     // the grid is limited to 128 cells per point -- a 2 cm kNN grid over a tree has ~65 -- and histogram, scan and cursor
     // copy run over that bound; cells past the real count stay empty.  A cloud that would need more gets a coarser grid
@@ -503,7 +510,8 @@ extern "C" int st_knn_radius_seg(const float* src, int64_t n1, const float* dst,
                                  const int32_t* dst_seg_off, int nseg, void* ws, int64_t ws_bytes, void* stream_,
                                  float cell_mean_mult) {
     hipStream_t stream = (hipStream_t)stream_;
-    ST_REQUIRE(K == 1 || K == 8 || K == 16 || K == 32, "knn: K must be 1, 8, 16 or 32 (got %d)", K);
+    ST_REQUIRE(K == 1 || K == 8 || K == 16 || K == 32 || K == 64, "knn: K must be 1, 8, 16, 32 or 64 (got %d)", K);
+    static_assert(KNN_CAP >= 128, "a cut keeps K <= 64 keys and the next chunk adds up to 64");
     ST_REQUIRE(bound_mode == 0 || bound != nullptr, "knn: bound_mode needs a bound array");
     ST_REQUIRE(r >= 0.0f || bound != nullptr, "knn: r < 0 (radius = max(bound)) needs a bound array");
     ST_REQUIRE(cell_hint >= 0.0f || r < 0.0f, "knn: a relative cell size (cell_hint < 0) goes with r < 0");
@@ -533,8 +541,11 @@ extern "C" int st_knn_radius_seg(const float* src, int64_t n1, const float* dst,
     else if (K == 16)
         hipLaunchKernelGGL((k_knn<16>), grid, block, 0, stream, src, n1, (const StGrid*)g, (const uint32_t*)cell_start,
                            (const float4*)recs, r, bound, bound_mode, idx, dist, src_seg_off, nseg, cell_order);
-    else
+    else if (K == 32)
         hipLaunchKernelGGL((k_knn<32>), grid, block, 0, stream, src, n1, (const StGrid*)g, (const uint32_t*)cell_start,
+                           (const float4*)recs, r, bound, bound_mode, idx, dist, src_seg_off, nseg, cell_order);
+    else  // 64: the reference's default widths (graph.py:12 knn K = 50, :36 nn_graph K = 40) are columns of this one
+        hipLaunchKernelGGL((k_knn<64>), grid, block, 0, stream, src, n1, (const StGrid*)g, (const uint32_t*)cell_start,
                            (const float4*)recs, r, bound, bound_mode, idx, dist, src_seg_off, nseg, cell_order);
     ST_CHECK_LAUNCH();
     return ST_OK;

@@ -18,7 +18,7 @@ void st_set_error(const char* fmt, ...) {
 extern "C" const char* st_last_error(void) { return g_err; }
 void st_stream_wait(hipStream_t stream) { (void)hipStreamSynchronize(stream); }
 
-extern "C" int st_version(void) { return 100; }
+extern "C" int st_version(void) { return 101; }
 
 // ------------------------------------------------------------------------------------ scan ---
 // 16 items per lane, read as four 16-byte loads where the arrays allow it (the grid builders scan tens of millions of

@@ -27,6 +27,7 @@
 // Semantics and tie-breaks: oracle/skeleton_oracle.c (so_sssp, so_tree_distance, so_sample_tree).
 #include "st_common.h"
 #include "st_grid.h"
+#include "smarttree_hip.h"  // the public declarations of this file's entry points (checked against the definitions by the compiler)
 
 #include <atomic>
 
@@ -1874,6 +1875,12 @@ struct SkHelperLease {  // returned on every way out of the call
     ~SkHelperLease() { if (n > 0) g_helpers_out.fetch_sub(n); }
 };
 
+// lengths of the caller-provided int64 arrays this build reads / writes (include/smarttree_hip.h: st_abi_entries)
+static_assert(ST_TUNE_ENTRIES == ST_SKELETON_TUNING_ENTRIES, "header and library disagree about the tuning array");
+extern "C" int st_abi_entries(int what) {
+    return what == 0 ? ST_SKELETON_STATS_ENTRIES : (what == 1 ? ST_SKELETON_TUNING_ENTRIES : (what == 2 ? ST_MAX_SEG : -1));
+}
+
 extern "C" int64_t st_skeleton_workspace_bytes_seg(int64_t m, int64_t n_comp, int nseg) {
     StArena a(nullptr, 0);
     SkLayout s;
@@ -1921,7 +1928,7 @@ extern "C" int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, c
                                       int64_t ws_bytes, void* stream_, const int64_t* tuning) {
     hipStream_t stream = (hipStream_t)stream_;
     const bool time_select = stats_host && stats_host[7] != 0;
-    if (stats_host) for (int i = 0; i < 16; i++) if (i != 7) stats_host[i] = 0;
+    if (stats_host) for (int i = 0; i < ST_SKELETON_STATS_ENTRIES; i++) if (i != 7) stats_host[i] = 0;
     if (n_comp <= 0 || m <= 0) return ST_OK;
     ST_REQUIRE(!(stages & 2) || tree_dist != nullptr, "skeleton: stage 2 needs a tree_dist buffer");
     if (block_threads <= 0) block_threads = 1024;

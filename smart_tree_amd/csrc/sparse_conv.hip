@@ -936,12 +936,16 @@ extern "C" int st_sparse_conv_fwd(const float* x0, int c0, const float* x1, int 
     ST_REQUIRE(K >= 1 && (nbr != nullptr || K == 1), "conv: a NULL neighbour table means pointwise (K = 1)");
     ST_REQUIRE(c0 > 0 && c0 <= cin && (c0 == cin || x1 != nullptr), "conv: bad concat split");
     ST_REQUIRE((scale == nullptr) == (shift == nullptr), "conv: scale and shift go together");
-    ST_REQUIRE(cin % 4 != 0 || c0 % 4 == 0, "conv: concat split must be a multiple of 4 channels");
-    ST_REQUIRE(cin % 4 == 0 || c0 == cin, "conv: concat needs cin % 4 == 0");
+    ST_REQUIRE(cout >= 1, "conv: cout must be positive");
     if (n_out <= 0) return ST_OK;
+    // the instantiated kernels read the concatenated row in float4 pieces: their split must fall on a multiple of 4 channels
+    // (a concat of a 3-channel input is refused); the generic kernel below takes any split 0 < c0 <= cin
 #define CONV_CASE(CI, CO, COT_)                                                                                  \
-    if (cin == CI && cout == CO)                                                                                 \
-        return conv_launch<CI, COT_>(x0, c0, x1, nbr, K, n_out, nstride, w, cout, scale, shift, residual, relu, y, stream, row_order);
+    if (cin == CI && cout == CO) {                                                                               \
+        ST_REQUIRE(CI % 4 != 0 || c0 % 4 == 0, "conv: concat split must be a multiple of 4 channels");           \
+        ST_REQUIRE(CI % 4 == 0 || c0 == cin, "conv: concat needs cin % 4 == 0");                                  \
+        return conv_launch<CI, COT_>(x0, c0, x1, nbr, K, n_out, nstride, w, cout, scale, shift, residual, relu, y, stream, row_order); \
+    }
     CONV_CASE(3, 8, 8)
     CONV_CASE(8, 8, 8)
     CONV_CASE(8, 16, 16)

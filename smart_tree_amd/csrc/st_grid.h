@@ -20,6 +20,7 @@ struct StGrid {
     unsigned rmax_ord;  // largest per-query bound (order-preserving bits), when the search radius is taken from the device
     float r;            // search radius the kNN kernels use (one cloud) / largest of seg_r (cell sizing)
     unsigned long long bound_sum_fix;  // sum of the per-query bounds in 2^-16 units (integer: the same in every run)
+    unsigned long long bound_cnt;      // how many bounds that sum holds: the VALID, non-NaN ones (a search over a subset counts the subset)
     unsigned seg_rmax_ord[ST_MAX_SEG];
     float seg_r[ST_MAX_SEG];  // per-cloud search radius = max(bound) over THAT cloud, as the one-cloud call computes it
 };

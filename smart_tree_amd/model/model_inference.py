@@ -67,6 +67,10 @@ class ModelInference:
         # optional callable, invoked at the end of every forward() when the network's last kernel has been enqueued (see
         # Skeletonizer.on_wide_phase_done: a caller with several batches in flight can schedule their phases with the two hooks)
         self.on_network_done = None
+        # [M] int64, set by every forward(): the input point each voxel row stands for (index into the cloud / collated batch it
+        # was given) -- lets a caller join any other per-point field to the labelled cloud (bench.py joins the generator's
+        # ground-truth medial vectors for its representative end-to-end figure)
+        self.last_point_index = None
         if self.verbose:
             print("Model Loaded Succesfully")
 
@@ -94,6 +98,7 @@ class ModelInference:
         with profiling.stage("unet"):
             _, _, _, mv, cls = self.model.forward_fused_tail(sparse_input)
         masks = vb.mask
+        self.last_point_index = vb.point_index
         lc = Cloud(xyz=sparse_input.features, rgb=vb.feats[:, 3:6].contiguous(), medial_vector=mv, class_l=cls,
                    seg_off=vb.seg_vox_off)
         if self.on_network_done is not None:

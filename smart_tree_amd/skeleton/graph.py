@@ -30,13 +30,15 @@ def knn(src: torch.Tensor, dest: torch.Tensor, K: int = 50, r: float = 1.0, grid
     src_seg_off / dest_seg_off ([B+1] int32, device): src and dest hold B independent clouds each; a query only sees
     its own cloud (additive keywords, Cloud.collate).
     """
-    if K not in (1, 8, 16, 32):
-        # the kernels hold 1, 8, 16 or 32 neighbours per query; any other K <= 32 is the first K columns of the next width (the rows
-        # are sorted by (distance, index), so the K nearest of 16 are the K nearest).  keep_kernel_width: the table keeps that
-        # width with the columns past K emptied (-1 / NaN) -- what the graph builders, which want a power of two, read
-        if not 1 <= K <= 32:
-            raise ValueError(f"knn: 1 <= K <= 32 (got {K}; the reference's skeletoniser uses 16)")
-        idx, dist, grid = knn(src, dest, 8 if K < 8 else (16 if K < 16 else 32), r, grid, bound, bound_mode, cell, src_seg_off, dest_seg_off)
+    if K not in (1, 8, 16, 32, 64):
+        # the kernels hold 1, 8, 16, 32 or 64 neighbours per query; any other K <= 64 -- the reference's defaults K = 50 (graph.py:12)
+        # and nn_graph's K = 40 (:36) among them -- is the first K columns of the next width (the rows are sorted by (distance,
+        # index), so the K nearest of 64 are the K nearest).  keep_kernel_width: the table keeps that width with the columns
+        # past K emptied (-1 / NaN) -- what the graph builders, which want a power of two, read
+        if not 1 <= K <= 64:
+            raise ValueError(f"knn: 1 <= K <= 64 (got {K}; the reference's skeletoniser uses 16)")
+        idx, dist, grid = knn(src, dest, 8 if K < 8 else (16 if K < 16 else (32 if K < 32 else 64)), r, grid, bound, bound_mode, cell,
+                              src_seg_off, dest_seg_off)
         if keep_kernel_width:
             idx[:, K:] = -1
             dist[:, K:] = float("nan")

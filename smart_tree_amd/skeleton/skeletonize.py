@@ -261,6 +261,7 @@ class DeviceSkeleton(DisjointTreeSkeleton):
         self._host = None  # packed host arrays of the materialised skeleton (valid while nobody has touched the objects)
         self._seg = comp_seg_off  # batched clouds: [n_seg+1] int32 (device) tree range of every cloud
         self._seg_host = None
+        self._parts = None  # split()'s per-cloud views, made ONCE: a view and the batch-level tree are twins (one branch dict)
 
     # -- construction ---------------------------------------------------------------------------
     @staticmethod
@@ -346,6 +347,7 @@ class DeviceSkeleton(DisjointTreeSkeleton):
     def skeletons(self, value):
         self._trees = value
         self._host = None
+        self._parts = None
 
     def _materialise(self) -> List[TreeSkeleton]:
         tree_off, parent, start, length, xyz, rad = self._dev
@@ -394,6 +396,10 @@ class DeviceSkeleton(DisjointTreeSkeleton):
         `Skeletonizer.forward` returns for that cloud alone).  A single cloud gives [self]."""
         if self._seg is None:
             return [self]
+        if getattr(self, "_parts", None) is not None:
+            # the same views on every call: a tree's `_twin` link is one-to-one, a second set of views would take it over and a
+            # host-side edit made through the first set would no longer reach the batch-level tree (advisor, round 5)
+            return self._parts
         trees = self.skeletons
         seg = self._seg_host
         out = []
@@ -406,7 +412,9 @@ class DeviceSkeleton(DisjointTreeSkeleton):
                 part._trees = [TreeSkeleton(local, t.branches) for local, t in enumerate(trees[seg[b]: seg[b + 1]])]
             part._host = self._host
             part._tree_range = (seg[b], seg[b + 1])
+            part._parts = None
             out.append(part)
+        self._parts = out
         return out
 
     def pack(self, cloud_id: int = 0):

@@ -24,7 +24,12 @@ def test_hip_library_exports_every_declared_symbol():
     missing = [n for n in DECLARED if not hasattr(lib, n)]
     assert not missing, missing
     assert set(_lib.SIGNATURES) <= set(DECLARED)
-    assert lib.st_version() >= 100
+    assert lib.st_version() >= 101
+    # the caller-side arrays of the skeleton calls are as long as the library says (advisor, round 5: silent ABI growth)
+    from smart_tree_amd.skeleton import tuning
+    assert lib.st_abi_entries(0) == 16 == int(re.search(r"#define ST_SKELETON_STATS_ENTRIES (\d+)", HEADER).group(1))
+    assert lib.st_abi_entries(1) == int(re.search(r"#define ST_SKELETON_TUNING_ENTRIES (\d+)", HEADER).group(1)) == tuning.ENTRIES
+    assert lib.st_abi_entries(2) == 64 and lib.st_abi_entries(99) == -1
 
 
 def test_product_path_refuses_cpu_tensors():

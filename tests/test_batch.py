@@ -312,3 +312,9 @@ def test_a_cloud_view_and_the_batch_level_tree_share_their_branches(backend):
     if other is not None:
         top = sk.skeletons[seg[other]].branches
         assert parts[other].skeletons[0].branches is top
+    # split() called again hands out the SAME views (a second set would take over the one-to-one twin links and an
+    # edit made through the first set would no longer reach the batch-level tree)
+    again = sk.split()
+    assert all(a is p for a, p in zip(again, parts)) and len(again) == len(parts)
+    first[key].radii = first[key].radii * 0.5
+    assert again[b].skeletons[0].branches[key].radii is first[key].radii is parent.branches[key].radii

@@ -27,7 +27,7 @@ def _tree(n=2500, seed=4, voxel=0.04, exact_medial=False):
     return pts.astype(np.float32), mv.astype(np.float32)
 
 
-@pytest.mark.parametrize("K", [1, 8, 16, 4, 11, 32, 20])
+@pytest.mark.parametrize("K", [1, 8, 16, 4, 11, 32, 20, 64, 50, 40])  # (50 / 40: the defaults of the reference's knn / nn_graph, graph.py:12,36)
 def test_knn_matches_oracle(backend, K):
     rng = np.random.RandomState(K)
     dst = rng.uniform(0, 1, (1500, 3)).astype(np.float32)
@@ -64,7 +64,7 @@ def test_knn_dense_neighbourhoods(backend, K, cell):
     np.testing.assert_array_equal(d.cpu().numpy(), ref_d)
 
 
-@pytest.mark.parametrize("nb,K", [(8, 16), (4, 10), (5, 8), (12, 32), (8, 24)])
+@pytest.mark.parametrize("nb,K", [(8, 16), (4, 10), (5, 8), (12, 32), (8, 24), (8, 40)])  # (40: nn_graph's default in the reference)
 def test_outlier_and_graph_match_oracle(backend, nb, K):
     """nb_points / K other than the pipeline's (filter.py's own default is nb_points = 4): any K <= 16 is served by the next kernel width."""
     pts, mv = _tree()

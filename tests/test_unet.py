@@ -217,7 +217,8 @@ def test_unet_of_the_training_config_depth(backend):
         np.testing.assert_allclose(out[k].cpu().numpy(), ref[k], rtol=1e-4, atol=1e-4 * np.abs(ref[k]).max())
 
 
-@pytest.mark.parametrize("cin,cout,c0", [(6, 8, 6), (5, 7, 5), (24, 40, 12), (16, 48, 16), (128, 64, 64)])
+@pytest.mark.parametrize("cin,cout,c0", [(6, 8, 6), (5, 7, 5), (24, 40, 12), (16, 48, 16), (128, 64, 64),
+                                         (12, 6, 6), (20, 10, 10), (36, 18, 18), (7, 5, 3)])  # (concat splits that are no multiple of 4: planes 6 / 10 / 18)
 def test_conv_of_any_channel_counts(backend, cin, cout, c0):
     """Channel counts no kernel is instantiated for (a model config away from the shipped planes; colour as input channels 4-6):
     the generic kernel behind st_sparse_conv_fwd, with concat, BatchNorm affine, residual, ReLU and a row order, against float64."""
@@ -264,7 +265,8 @@ def _other_architecture(template, planes, hidden, n_classes):
     return random_state_dict({k: np.zeros(sh, np.float32) for k, sh in shapes.items()}, seed=4)
 
 
-@pytest.mark.parametrize("planes,hidden,n_classes", [((12, 24, 40, 72), (10, 6), 3), ((16, 32, 64, 128), (16, 8), 2)])
+@pytest.mark.parametrize("planes,hidden,n_classes", [((12, 24, 40, 72), (10, 6), 3), ((16, 32, 64, 128), (16, 8), 2),
+                                                      ((6, 10, 18, 34), (5, 3), 2)])  # (planes that are no multiples of 4: advisor, round 5)
 def test_unet_of_another_architecture(backend, planes, hidden, n_classes):
     """`unet_planes`, `*_fc_planes` and the number of classes are model-config keywords (conf/training.yaml:123-127): widths no
     kernel is instantiated for run through the generic convolution, heads of other shapes as pointwise convolutions -- every block
