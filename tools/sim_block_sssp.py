@@ -78,7 +78,10 @@ def morton_order(P, bits=20):
 
 
 t0 = time.time()
-order_m = morton_order(P)
+import os
+BITS = int(os.environ.get("MORTON_BITS", "20"))
+order_m = morton_order(P, BITS)
+print("morton bits per axis", BITS)
 print(f"morton order {time.time() - t0:.1f} s")
 
 
@@ -140,6 +143,6 @@ def run(order, B, label):
 
 for B in blocks:
     run(order_m, B, "morton")
-for B in blocks[:1]:
+for B in ([] if os.environ.get("MORTON_ONLY") else blocks[:1]):
     run(np.arange(n), B, "given")
     run(np.argsort(P[:, 1], kind="stable"), B, "y-sorted")
