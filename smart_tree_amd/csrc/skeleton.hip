@@ -496,7 +496,7 @@ __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_sssp_coop(SkArgs A, int ho
 // launch and pulled the final value.  So no edge improves anything at the end: the least fixed point reached from above, the
 // oracle's bits (oracle/skeleton_oracle.c so_sssp), whatever the schedule.
 #define SK_BB 64   // vertices of a block = lanes of the wavefront that relaxes it
-#define SK_BK 32   // in-block adjacency entries per vertex kept in LDS (a row with more re-reads the rest from memory each pass)
+#define SK_BT 32   // row entries per tier: a lane keeps two tiers of its row in registers (a K = 16 graph has rows of ~32, at most ~60)
 struct SkBlocked {
     unsigned* keys;    // [m] sort keys (Morton code, then component)
     unsigned* perm;    // [m] vertex at position p
@@ -620,78 +620,147 @@ __global__ void __launch_bounds__(64) k_sb_roots(SkArgs A, SkBlocked B) {
 }
 
 // Round r: one wavefront per block; a block whose bit is not set in generation r % 3 leaves at once.
+// A run is THREE dependent global round trips -- (dirty word, row bounds, own distance), the row's entries, the outside
+// neighbours' distances -- then passes over registers and 256 bytes of LDS, then stores and mark atomics nobody waits for.
+// (A dependent global access costs 1-2 us on this chip under load; the first version walked the row entry by entry and
+// read the outside distances a second time for the marks: ~10 dependent levels, 17 us for a block alone, 46 us a round.)
+// All data accesses are plain: a value of another block read stale inside a launch is an OLDER, larger one -- the offer
+// made from it is still one a relaxation sequence could make, and a mark decided against it only marks more; launch
+// boundaries make everything visible (the frontier kernels above rely on the same).
+#define SB_TIER(A_, T0_)                                                                                                \
+    _Pragma("unroll") for (int i = 0; i < SK_BT; i++) A_##e[i] = (T0_) + i < e1 ? B.padj[(T0_) + i] : make_uint2(0xffffffffu, 0x7f800000u); \
+    _Pragma("unroll") for (int i = 0; i < SK_BT; i++) {                                                                  \
+        A_##x[i] = A_##e[i].x != 0xffffffffu && (A_##e[i].x >> 6) != b;                                                  \
+        A_##d[i] = B.dpos[A_##x[i] ? A_##e[i].x : (unsigned)p0];                                                         \
+    }                                                                                                                    \
+    _Pragma("unroll") for (int i = 0; i < SK_BT; i++) {                                                                  \
+        const float w_ = __uint_as_float(A_##e[i].y);                                                                    \
+        if (A_##x[i]) { const float o = st_ord2f(A_##d[i]) + w_; curf = o < curf ? o : curf; }                            \
+        A_##q[i] = A_##x[i] || A_##e[i].x == 0xffffffffu ? lane : (A_##e[i].x & 63u);                                    \
+        A_##w[i] = A_##x[i] || A_##e[i].x == 0xffffffffu ? __uint_as_float(0x7f800000u) : w_;                             \
+    }
+#define SB_PULL(A_)                                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < SK_BT; i++) { const float o = s_d[A_##q[i]] + A_##w[i]; nb = o < nb ? o : nb; }
+#define SB_OFFER(A_)                                                                                                    \
+    _Pragma("unroll") for (int i = 0; i < SK_BT; i++)                                                                    \
+        if (A_##x[i] && changed && st_f2ord(curf + __uint_as_float(A_##e[i].y)) < A_##d[i]) {                             \
+            const unsigned qb = A_##e[i].x >> 6;                                                                         \
+            const int rel = (int)qb - (int)b + 32;                                                                       \
+            if (rel >= 0 && rel < 64) near |= 1ull << rel; else sb_mark(B, gout, qb);                                    \
+        }
 __global__ void __launch_bounds__(SK_BB) k_sb_round(SkArgs A, SkBlocked B, int r) {
-    __shared__ float s_w[SK_BK][SK_BB];
-    __shared__ unsigned char s_q[SK_BK][SK_BB];
-    __shared__ unsigned s_d[SK_BB];
+    __shared__ float s_d[SK_BB];
     const unsigned b = blockIdx.x, lane = threadIdx.x;
     const int gin = r % 3, gout = (r + 1) % 3, gclr = (r + 2) % 3;
     // the generation after the next one is cleared here (nobody reads or marks it during this launch)
     if ((b & 31u) == 0u && lane == 0) B.dirty[(int64_t)gclr * B.nw + (b >> 5)] = 0u;
     if (b == 0 && lane == 0) B.flag[gclr] = 0u;
-    if (!((B.dirty[(int64_t)gin * B.nw + (b >> 5)] >> (b & 31u)) & 1u)) return;  // (wave-uniform)
-    const unsigned inf = st_f2ord(__uint_as_float(0x7f800000u));
-    const int64_t p = (int64_t)b * SK_BB + lane;
+    const int64_t p0 = (int64_t)b * SK_BB, p = p0 + lane;
     const bool in = p < A.m;
-    const uint32_t e0 = in ? B.prow[p] : 0u, e1 = in ? B.prow[p + 1] : 0u;
-    const unsigned mine = in ? B.dpos[p] : inf;  // only this block's runs write it, one run per launch
-    unsigned cur = mine;
-    int kin = 0;
-    // pass 1: the row.  In-block entries go to LDS, outside neighbours make their offer now (their distances as this run finds them)
-    for (uint32_t t = e0; t < e1; t++) {
-        const uint2 a = B.padj[t];
-        if ((a.x >> 6) == b) {
-            if (kin < SK_BK) { s_q[kin][lane] = (unsigned char)(a.x & 63u); s_w[kin][lane] = __uint_as_float(a.y); }
-            kin++;
-        } else {
-            const unsigned dq = __hip_atomic_load(&B.dpos[a.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned o = st_f2ord(st_ord2f(dq) + __uint_as_float(a.y));
-            cur = o < cur ? o : cur;
+    const int64_t pc = in ? p : A.m - 1;
+    // first round trip: everything that does not depend on anything else
+    const unsigned dw = B.dirty[(int64_t)gin * B.nw + (b >> 5)];
+    uint32_t e0 = B.prow[pc], e1 = B.prow[pc + 1];
+    const unsigned mine_ = B.dpos[pc];
+    if (!((dw >> (b & 31u)) & 1u)) return;  // (wave-uniform)
+    const long long tk0 = A.ticks ? wall_clock64() : 0;  // developer aid (tuning code 15): phase times of the block runs, entries 16..22
+    const unsigned inf = st_f2ord(__uint_as_float(0x7f800000u));
+    const unsigned mine = in ? mine_ : inf;
+    if (!in) e1 = e0;
+    if ((int64_t)e1 > B.n_adj) e1 = (uint32_t)B.n_adj;  // (cannot happen: n_adj >= row_off[m]; a wrong capacity must not read past the array)
+    // distances are >= 0 and never NaN (weights are finite lengths): float compares order them like their bits
+    float curf = st_ord2f(mine);
+    // second and third round trip: the row in two tiers of SK_BT entries (the second only if some row of the block is that
+    // long) -- entries, then the outside neighbours' distances; both tiers stay in registers (static indices)
+    uint2 ae[SK_BT], ce[SK_BT];
+    unsigned ad[SK_BT], cd[SK_BT], aq[SK_BT], cq[SK_BT];
+    float aw[SK_BT], cw[SK_BT];
+    bool ax[SK_BT], cx[SK_BT];
+    SB_TIER(a, e0)
+    const bool two = __ballot(e1 - e0 > SK_BT) != 0ull;
+    if (two) { SB_TIER(c, e0 + SK_BT) }
+    const bool more = __ballot(e1 - e0 > 2 * SK_BT) != 0ull;  // rows beyond both tiers (not with K = 16): walked from memory
+    if (more)
+        for (uint32_t t = e0 + 2 * SK_BT; t < e1; t++) {
+            const uint2 a = B.padj[t];
+            if ((a.x >> 6) == b) continue;
+            const float o = st_ord2f(B.dpos[a.x]) + __uint_as_float(a.y);
+            curf = o < curf ? o : curf;
         }
-    }
-    const int kst = kin < SK_BK ? kin : SK_BK;
-    s_d[lane] = cur;
-    // relax the block to convergence: every pass pulls over the in-block entries (values of this or the previous pass: both are
-    // offers a relaxation sequence could make)
+    s_d[lane] = curf;
+    const long long tk1 = A.ticks ? wall_clock64() : 0;
+    int passes = 0;
+    // relax the block to convergence: every pass pulls over the in-block entries (values of the previous pass: offers a
+    // relaxation sequence could make); an outside or missing entry offers +inf to the lane itself
     for (;;) {
         __builtin_amdgcn_wave_barrier();
-        unsigned nb = cur;
-        for (int k = 0; k < kst; k++) {
-            const unsigned o = st_f2ord(st_ord2f(s_d[s_q[k][lane]]) + s_w[k][lane]);
-            nb = o < nb ? o : nb;
-        }
-        if (kin > SK_BK) {  // a row with more in-block entries than the LDS list holds: the rest from memory, every pass
-            int seen = 0;
-            for (uint32_t t = e0; t < e1; t++) {
+        passes++;
+        float nb = curf;
+        SB_PULL(a)
+        if (two) { SB_PULL(c) }
+        if (more)
+            for (uint32_t t = e0 + 2 * SK_BT; t < e1; t++) {
                 const uint2 a = B.padj[t];
                 if ((a.x >> 6) != b) continue;
-                if (seen++ < SK_BK) continue;
-                const unsigned o = st_f2ord(st_ord2f(s_d[a.x & 63u]) + __uint_as_float(a.y));
+                const float o = s_d[a.x & 63u] + __uint_as_float(a.y);
                 nb = o < nb ? o : nb;
             }
-        }
-        const bool ch = nb < cur;
+        const bool ch = nb < curf;
         __builtin_amdgcn_wave_barrier();
-        if (ch) { cur = nb; s_d[lane] = cur; }
+        if (ch) { curf = nb; s_d[lane] = curf; }
         if (!__ballot(ch)) break;
     }
+    const unsigned cur = st_f2ord(curf);
     const bool changed = cur < mine;
-    if (changed) __hip_atomic_store(&B.dpos[p], cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (changed) B.dpos[p] = cur;
     if (lane == 0) atomicAdd(&B.flag[3 + gin], 1u);
+    const long long tk2 = A.ticks ? wall_clock64() : 0;
+    if (A.ticks && lane == 0) {
+        atomicAdd((unsigned long long*)&A.ticks[16], 1ull);                           // block runs
+        atomicAdd((unsigned long long*)&A.ticks[17], (unsigned long long)(tk1 - tk0));  // loads (ticks of 10 ns)
+        atomicAdd((unsigned long long*)&A.ticks[18], (unsigned long long)(tk2 - tk1));  // passes
+        atomicAdd((unsigned long long*)&A.ticks[19], (unsigned long long)passes);
+        atomicAdd((unsigned long long*)&A.ticks[20], two ? 1ull : 0ull);
+        atomicAdd((unsigned long long*)&A.ticks[21], more ? 1ull : 0ull);
+    }
     if (!__ballot(changed)) return;
-    // pass 2: who improved offers the new value outside; a neighbour it would improve gets its block marked for the next round.
-    // (The neighbour's distance is read at or above its final value: a stale read only marks more.)
-    if (changed) {
-        const float dc = st_ord2f(cur);
-        for (uint32_t t = e0; t < e1; t++) {
+    // who improved offers the new value outside: a neighbour it would improve -- judged against the distance pass 1 read,
+    // which is at or above the neighbour's final one -- gets its block marked for the next round.  The marks of the wavefront
+    // are collected first (blocks b - 32 .. b + 31 as one 64-bit set: the Morton order keeps neighbours close), then one
+    // atomic per marked WORD; nobody waits for them.
+    unsigned long long near = 0ull;
+    SB_OFFER(a)
+    if (two) { SB_OFFER(c) }
+    if (more && changed)
+        for (uint32_t t = e0 + 2 * SK_BT; t < e1; t++) {
             const uint2 a = B.padj[t];
-            const unsigned qb = a.x >> 6;
-            if (qb == b) continue;
-            const unsigned dq = __hip_atomic_load(&B.dpos[a.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (st_f2ord(dc + __uint_as_float(a.y)) < dq) sb_mark(B, gout, qb);
+            if ((a.x >> 6) != b && st_f2ord(curf + __uint_as_float(a.y)) < B.dpos[a.x]) sb_mark(B, gout, a.x >> 6);
         }
+    for (int d = 32; d > 0; d >>= 1) near |= __shfl_xor(near, d);
+    if (near != 0ull) {
+        // lane l stands for block b - 32 + l; the voters are taken word by word (at most three dirty words cover the window):
+        // the lowest voter of a word ORs all of that word's bits in one atomic
+        const long long blk = (long long)b - 32 + lane;
+        const bool vote = ((near >> lane) & 1ull) && blk >= 0 && blk < B.nblk;
+        const unsigned word = vote ? (unsigned)(blk >> 5) : 0xffffffffu;
+        unsigned long long votes = __ballot(vote);
+        while (votes) {  // (wave-uniform)
+            const int leader = __ffsll((long long)votes) - 1;
+            const unsigned lw = (unsigned)__shfl((int)word, leader);
+            const unsigned long long same = __ballot(vote && word == lw);
+            if ((int)lane == leader) {
+                unsigned bits = 0u;
+                for (unsigned long long m_ = same; m_; m_ &= m_ - 1ull) bits |= 1u << (unsigned)(((long long)b - 32 + (__ffsll((long long)m_) - 1)) & 31);
+                (void)atomicOr(&B.dirty[(int64_t)gout * B.nw + lw], bits);
+            }
+            votes &= ~same;
+        }
+        if (lane == 0) B.flag[gout] = 1u;
     }
 }
+#undef SB_TIER
+#undef SB_PULL
+#undef SB_OFFER
 
 __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sb_finish(SkArgs A, SkBlocked B) {
     SK_VERTEX_LOOP(p) A.dist_ord[B.perm[p]] = B.dpos[p];
