@@ -546,10 +546,7 @@ def _select_phase_table(ticks) -> dict:
     """k_sk_select's in-kernel phase timers (tuning code 15; 100 MHz wall clock, summed over the components of the call)."""
     t = ticks.cpu().numpy()
     us = lambda i: round(float(t[i]) / 100.0, 1)
-    return {"sssp_block_runs": {"runs": int(t[16]), "load_us_per_run": round(float(t[17]) / 100.0 / max(int(t[16]), 1), 2),
-                                "passes_us_per_run": round(float(t[18]) / 100.0 / max(int(t[16]), 1), 2), "passes_per_run": round(float(t[19]) / max(int(t[16]), 1), 2),
-                                "two_tier_runs": int(t[20]), "runs_with_rows_beyond_64": int(t[21])},
-            "rounds": int(t[8]), "speculated_slots": int(t[13]), "commits": int(t[12]), "whole_workgroup_claims": int(t[9]),
+    return {"rounds": int(t[8]), "speculated_slots": int(t[13]), "commits": int(t[12]), "whole_workgroup_claims": int(t[9]),
             "claims_shared_with_helpers": int(t[14]), "candidates": int(t[11]),
             "phase_us": {"head": us(0), "window": us(7), "prune": us(1), "walk_rows": us(2), "claim": us(3), "replay_commit": us(4),
                          "one_mode": us(5), "long_mode": us(6)}}

@@ -300,18 +300,6 @@ int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, const int32_
                                int32_t* path_verts, int32_t* branch_of, int64_t* stats_host, void* ws, int64_t ws_bytes,
                                void* stream, const int64_t* tuning /*NULL = defaults; 24 entries, see csrc/skeleton.hip "Tuning of
                                one call": per-call strategy / sweep knobs (no process-global state)*/);
-/* Round 6: the same call with n_adj = the entries the caller's col / wgt arrays hold (>= row_off[m]) and a workspace of
- * st_skeleton_workspace_bytes_adj bytes: room for the adjacency in block order -- the SSSP then runs by blocks of 64 Morton-ordered
- * vertices relaxed to convergence inside a wavefront (csrc/skeleton.hip k_sb_round) instead of one chip-wide launch per few
- * hop levels; the distances are the same bits.  n_adj = 0 is st_skeleton_components_seg.  Replaces: skeleton/shortest_path.py:12-21. */
-int64_t st_skeleton_workspace_bytes_adj(int64_t m, int64_t n_comp, int nseg, int64_t n_adj);
-int st_skeleton_components_adj(int n_comp, const int32_t* comp_off, const int32_t* comp_seg, const int32_t* vert_seg_off,
-                               int nseg, int64_t m, const float* pts, const float* rad, const float* ysurf,
-                               const uint32_t* row_off, const uint32_t* col, const float* wgt, float grid_cell, int stages,
-                               int block_threads, float* dist, int32_t* pred, int32_t* root_local, float* tree_dist,
-                               int32_t* branch_parent, int32_t* branch_off, int32_t* branch_len, int32_t* n_branches,
-                               int32_t* path_verts, int32_t* branch_of, int64_t* stats_host, void* ws, int64_t ws_bytes,
-                               void* stream, const int64_t* tuning, int64_t n_adj);
 int st_post_process_seg(int n_trees, const int32_t* tree_off, const int32_t* parent, const int32_t* start, const int32_t* len,
                         float* xyz, const float* rad_in, float* rad_out, uint8_t* keep, uint8_t* repaired, uint8_t* smoothed,
                         int32_t* depth_scratch, int do_prune, float min_radius, float min_length, int do_repair,

@@ -94,9 +94,6 @@ SIGNATURES = {
     "st_skeleton_workspace_bytes_seg": (I64, [I64, I64, c_int]),
     "st_skeleton_components_seg": (c_int, [c_int, P, P, P, c_int, I64, P, P, P, P, P, P, c_float, c_int, c_int, P, P, P, P, P, P, P, P,
                                            P, P, ctypes.POINTER(I64), P, I64, P, ctypes.POINTER(I64)]),
-    "st_skeleton_components_adj": (c_int, [c_int, P, P, P, c_int, I64, P, P, P, P, P, P, c_float, c_int, c_int, P, P, P, P, P, P, P, P,
-                                           P, P, ctypes.POINTER(I64), P, I64, P, ctypes.POINTER(I64), I64]),
-    "st_skeleton_workspace_bytes_adj": (I64, [I64, I64, c_int, I64]),
     "st_post_process_seg": (c_int, [c_int, P, P, P, P, P, P, P, P, P, P, P, c_int, c_float, c_float, c_int, c_int, c_int, P, c_int, P]),
     "st_skeleton_components": (c_int, [c_int, P, P, I64, P, P, P, P, P, P, c_float, c_int, c_int, P, P, P, P, P, P, P, P,
                                        P, P, ctypes.POINTER(I64), P, I64, P]),
@@ -116,7 +113,7 @@ ENQUEUE_ONLY = frozenset({
     "st_sparse_conv_mfma_fwd", "st_sparse_conv_b3_fwd", "st_sparse_conv_f16_fwd", "st_pointwise_mlp_heads", "st_medial_points", "st_centre_cloud",
     "st_connected_components", "st_component_csr", "st_post_process", "st_knn_radius", "st_brick_pyramid_workspace_bytes",
     "st_centre_cloud_seg", "st_voxelize_workspace_bytes_seg", "st_build_strided_rulebook_seg", "st_knn_workspace_bytes_seg",
-    "st_knn_radius_seg", "st_skeleton_workspace_bytes_seg", "st_skeleton_workspace_bytes_adj", "st_post_process_seg", "st_radius_count_seg",
+    "st_knn_radius_seg", "st_skeleton_workspace_bytes_seg", "st_post_process_seg", "st_radius_count_seg",
     "st_voxelize_cloud_workspace_bytes", "st_loss_workspace_bytes", "st_spatial_order_workspace_bytes", "st_spatial_order", "st_connected_components_knn", "st_component_csr_knn", "st_component_csr_knn_workspace_bytes", "st_move_rows",
 })
 

@@ -479,293 +479,6 @@ __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_sssp_coop(SkArgs A, int ho
     }
 }
 
-// ---- SSSP by blocks relaxed to convergence (round 6) ------------------------------------------------------------------------
-// The frontier launches above pay one chip-wide dependent step (~5 us: a launch boundary, or a grid barrier, plus a chain of
-// global round trips) per HOP LEVEL of the graph: 360 levels on the graph the shipped checkpoint's output gives, 2400 on
-// medial points that really sit on the branch axes.  Here the vertices of every component are ordered along a Morton curve
-// and cut into blocks of 64 consecutive positions -- a short stretch of one branch --, the adjacency is copied into that order
-// (a block's rows are one contiguous piece of memory, neighbour ids are positions), and a ROUND relaxes every DIRTY block to
-// convergence inside ONE wavefront: the block's distances and its in-block adjacency sit in LDS, the hops inside the block
-// cost LDS round trips, not global ones.  Outside neighbours are read once per run (pull); a vertex that ends a run with a
-// better value than before offers it to its outside neighbours and marks the blocks of those it would improve dirty for the
-// next round.  134 rounds instead of 360 levels, 640 instead of 2400 (tools/sim_block_sssp.py).
-// Exactness: every value ever stored is fl(d[u] + w) of a stored d[u] (an upper bound of the fixed point the oracle's
-// relaxations reach), values only decrease, and the rounds stop when no block is marked: the last run of a block left no
-// in-block edge that improves anything, and the last change of a vertex marked every outside neighbour it could still
-// improve -- against a value of that neighbour that was read at or above its final one --, whose block then ran in a LATER
-// launch and pulled the final value.  So no edge improves anything at the end: the least fixed point reached from above, the
-// oracle's bits (oracle/skeleton_oracle.c so_sssp), whatever the schedule.
-#define SK_BB 64   // vertices of a block = lanes of the wavefront that relaxes it
-#define SK_BT 32   // row entries per tier: a lane keeps two tiers of its row in registers (a K = 16 graph has rows of ~32, at most ~60)
-struct SkBlocked {
-    unsigned* keys;    // [m] sort keys (Morton code, then component)
-    unsigned* perm;    // [m] vertex at position p
-    unsigned* pos;     // [m] position of vertex v
-    unsigned* prow;    // [m + 1] row offsets in position order
-    uint2* padj;       // [n_adj] (position of the neighbour, weight bits), rows in position order
-    unsigned* dpos;    // [m] distance (order-preserving bits) of the vertex at position p
-    unsigned* dirty;   // [3][nw] one bit per block, three generations: read / marked for the next round / being cleared
-    unsigned* flag;    // [8]: [0..2] "generation g has marks", [3..5] block runs of the generation (diagnostic), [6] bounding box ready
-    unsigned* bbox;    // [6] lo / hi of the points as order-preserving bits
-    int64_t nblk, nw, n_adj;
-};
-
-__global__ void k_sb_init(SkBlocked B) {
-    if (threadIdx.x < 8) B.flag[threadIdx.x] = 0u;
-    if (threadIdx.x < 3) { B.bbox[threadIdx.x] = 0xffffffffu; B.bbox[3 + threadIdx.x] = 0u; }
-}
-
-__global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sb_bbox(SkArgs A, SkBlocked B) {
-    __shared__ unsigned lo[3], hi[3];
-    if (threadIdx.x < 3) { lo[threadIdx.x] = 0xffffffffu; hi[threadIdx.x] = 0u; }
-    __syncthreads();
-    unsigned l[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, h[3] = {0u, 0u, 0u};
-    SK_VERTEX_LOOP(v)
-        for (int a = 0; a < 3; a++) {
-            const float pv = A.pts[3 * v + a];
-            if (!(fabsf(pv) <= 3.0e38f)) continue;
-            const unsigned o = st_f2ord(pv);
-            l[a] = o < l[a] ? o : l[a];
-            h[a] = o > h[a] ? o : h[a];
-        }
-    for (int a = 0; a < 3; a++) {
-        for (int d = 32; d > 0; d >>= 1) {
-            const unsigned ol = __shfl_xor(l[a], d), oh = __shfl_xor(h[a], d);
-            l[a] = ol < l[a] ? ol : l[a];
-            h[a] = oh > h[a] ? oh : h[a];
-        }
-        if ((threadIdx.x & 63) == 0) { atomicMin(&lo[a], l[a]); atomicMax(&hi[a], h[a]); }
-    }
-    __syncthreads();
-    if (threadIdx.x < 3 && lo[threadIdx.x] <= hi[threadIdx.x]) { atomicMin(&B.bbox[threadIdx.x], lo[threadIdx.x]); atomicMax(&B.bbox[3 + threadIdx.x], hi[threadIdx.x]); }
-}
-
-__device__ __forceinline__ unsigned sb_spread3(unsigned x) {  // 10 bits -> every third bit
-    x &= 0x3ffu;
-    x = (x | (x << 16)) & 0x030000ffu;
-    x = (x | (x << 8)) & 0x0300f00fu;
-    x = (x | (x << 4)) & 0x030c30c3u;
-    x = (x | (x << 2)) & 0x09249249u;
-    return x;
-}
-
-// pass 0: Morton code of the point on a 1024^3 lattice over the call's bounding box (any order gives the same distances: the
-// order only decides which vertices share a block); pass 1: the component, so that the stable second sort groups the components
-__global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sb_keys(SkArgs A, SkBlocked B, int pass) {
-    float lo[3], inv;
-    if (pass == 0) {
-        float ext = 0.0f;
-        for (int a = 0; a < 3; a++) {
-            lo[a] = B.bbox[a] <= B.bbox[3 + a] ? st_ord2f(B.bbox[a]) : 0.0f;
-            const float e = B.bbox[a] <= B.bbox[3 + a] ? st_ord2f(B.bbox[3 + a]) - lo[a] : 0.0f;
-            ext = e > ext ? e : ext;
-        }
-        inv = ext > 0.0f && ext <= 3.0e38f ? 1023.0f / ext : 0.0f;
-    }
-    SK_VERTEX_LOOP(v) {
-        if (pass == 0) {
-            unsigned q[3];
-            for (int a = 0; a < 3; a++) {
-                const float t = (A.pts[3 * v + a] - lo[a]) * inv;
-                q[a] = t >= 0.0f ? (t < 1023.0f ? (unsigned)t : 1023u) : 0u;  // (NaN -> 0)
-            }
-            B.keys[v] = (sb_spread3(q[0]) << 2) | (sb_spread3(q[1]) << 1) | sb_spread3(q[2]);
-            B.perm[v] = (unsigned)v;
-        } else {
-            B.keys[v] = (unsigned)A.comp_of[B.perm[v]];
-        }
-    }
-}
-
-// position of every vertex; length of every row in position order (prow[p] = degree, scanned afterwards)
-__global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sb_pos(SkArgs A, SkBlocked B) {
-    SK_VERTEX_LOOP(p) {
-        const unsigned v = B.perm[p];
-        B.pos[v] = (unsigned)p;
-        B.prow[p] = A.row_off[v + 1] - A.row_off[v];
-        B.dpos[p] = st_f2ord(__uint_as_float(0x7f800000u));
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) B.prow[A.m] = 0u;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 3 * B.nw; i += (int64_t)gridDim.x * blockDim.x) B.dirty[i] = 0u;
-}
-
-// the adjacency in position order: eight lanes copy a row (coalesced 32-byte pieces, the position gathers in flight together)
-__global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sb_fill(SkArgs A, SkBlocked B) {
-    const int sub = threadIdx.x & 7;
-    const int64_t groups = ((int64_t)gridDim.x * blockDim.x) / 8;
-    for (int64_t p = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / 8; p < A.m; p += groups) {
-        const unsigned v = B.perm[p];
-        const uint32_t s0 = A.row_off[v], n = A.row_off[v + 1] - s0, d0 = B.prow[p];
-        for (uint32_t j = sub; j < n; j += 8)
-            if ((int64_t)d0 + j < B.n_adj) B.padj[d0 + j] = make_uint2(B.pos[A.col[s0 + j]], __float_as_uint(A.wgt[s0 + j]));
-    }
-}
-
-__device__ __forceinline__ void sb_mark(const SkBlocked& B, int gen, unsigned blk) {
-    unsigned* word = &B.dirty[(int64_t)gen * B.nw + (blk >> 5)];
-    const unsigned bit = 1u << (blk & 31u);
-    if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit) return;  // (look first: most marks repeat)
-    (void)atomicOr(word, bit);
-    __hip_atomic_store(&B.flag[gen], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// the roots: distance 0, and -- the root "improved" -- the blocks of its neighbours (and its own) are dirty for round 0
-__global__ void __launch_bounds__(64) k_sb_roots(SkArgs A, SkBlocked B) {
-    const int c = blockIdx.x, base = A.comp_off[c], n = A.comp_off[c + 1] - base;
-    if (n <= 0) return;
-    const unsigned p = B.pos[base + A.root_local[c]];
-    if (threadIdx.x == 0) { B.dpos[p] = st_f2ord(0.0f); sb_mark(B, 0, p >> 6); }
-    for (uint32_t t = B.prow[p] + threadIdx.x, e = B.prow[p + 1]; t < e; t += blockDim.x)
-        if ((int64_t)t < B.n_adj) sb_mark(B, 0, B.padj[t].x >> 6);
-}
-
-// Round r: one wavefront per block; a block whose bit is not set in generation r % 3 leaves at once.
-// A run is THREE dependent global round trips -- (dirty word, row bounds, own distance), the row's entries, the outside
-// neighbours' distances -- then passes over registers and 256 bytes of LDS, then stores and mark atomics nobody waits for.
-// (A dependent global access costs 1-2 us on this chip under load; the first version walked the row entry by entry and
-// read the outside distances a second time for the marks: ~10 dependent levels, 17 us for a block alone, 46 us a round.)
-// All data accesses are plain: a value of another block read stale inside a launch is an OLDER, larger one -- the offer
-// made from it is still one a relaxation sequence could make, and a mark decided against it only marks more; launch
-// boundaries make everything visible (the frontier kernels above rely on the same).
-#define SB_TIER(A_, T0_)                                                                                                \
-    _Pragma("unroll") for (int i = 0; i < SK_BT; i++) A_##e[i] = (T0_) + i < e1 ? B.padj[(T0_) + i] : make_uint2(0xffffffffu, 0x7f800000u); \
-    _Pragma("unroll") for (int i = 0; i < SK_BT; i++) {                                                                  \
-        A_##x[i] = A_##e[i].x != 0xffffffffu && (A_##e[i].x >> 6) != b;                                                  \
-        A_##d[i] = B.dpos[A_##x[i] ? A_##e[i].x : (unsigned)p0];                                                         \
-    }                                                                                                                    \
-    _Pragma("unroll") for (int i = 0; i < SK_BT; i++) {                                                                  \
-        const float w_ = __uint_as_float(A_##e[i].y);                                                                    \
-        if (A_##x[i]) { const float o = st_ord2f(A_##d[i]) + w_; curf = o < curf ? o : curf; }                            \
-        A_##q[i] = A_##x[i] || A_##e[i].x == 0xffffffffu ? lane : (A_##e[i].x & 63u);                                    \
-        A_##w[i] = A_##x[i] || A_##e[i].x == 0xffffffffu ? __uint_as_float(0x7f800000u) : w_;                             \
-    }
-#define SB_PULL(A_)                                                                                                     \
-    _Pragma("unroll") for (int i = 0; i < SK_BT; i++) { const float o = s_d[A_##q[i]] + A_##w[i]; nb = o < nb ? o : nb; }
-#define SB_OFFER(A_)                                                                                                    \
-    _Pragma("unroll") for (int i = 0; i < SK_BT; i++)                                                                    \
-        if (A_##x[i] && changed && st_f2ord(curf + __uint_as_float(A_##e[i].y)) < A_##d[i]) {                             \
-            const unsigned qb = A_##e[i].x >> 6;                                                                         \
-            const int rel = (int)qb - (int)b + 32;                                                                       \
-            if (rel >= 0 && rel < 64) near |= 1ull << rel; else sb_mark(B, gout, qb);                                    \
-        }
-__global__ void __launch_bounds__(SK_BB) k_sb_round(SkArgs A, SkBlocked B, int r) {
-    __shared__ float s_d[SK_BB];
-    const unsigned b = blockIdx.x, lane = threadIdx.x;
-    const int gin = r % 3, gout = (r + 1) % 3, gclr = (r + 2) % 3;
-    // the generation after the next one is cleared here (nobody reads or marks it during this launch)
-    if ((b & 31u) == 0u && lane == 0) B.dirty[(int64_t)gclr * B.nw + (b >> 5)] = 0u;
-    if (b == 0 && lane == 0) B.flag[gclr] = 0u;
-    const int64_t p0 = (int64_t)b * SK_BB, p = p0 + lane;
-    const bool in = p < A.m;
-    const int64_t pc = in ? p : A.m - 1;
-    // first round trip: everything that does not depend on anything else
-    const unsigned dw = B.dirty[(int64_t)gin * B.nw + (b >> 5)];
-    uint32_t e0 = B.prow[pc], e1 = B.prow[pc + 1];
-    const unsigned mine_ = B.dpos[pc];
-    if (!((dw >> (b & 31u)) & 1u)) return;  // (wave-uniform)
-    const long long tk0 = A.ticks ? wall_clock64() : 0;  // developer aid (tuning code 15): phase times of the block runs, entries 16..22
-    const unsigned inf = st_f2ord(__uint_as_float(0x7f800000u));
-    const unsigned mine = in ? mine_ : inf;
-    if (!in) e1 = e0;
-    if ((int64_t)e1 > B.n_adj) e1 = (uint32_t)B.n_adj;  // (cannot happen: n_adj >= row_off[m]; a wrong capacity must not read past the array)
-    // distances are >= 0 and never NaN (weights are finite lengths): float compares order them like their bits
-    float curf = st_ord2f(mine);
-    // second and third round trip: the row in two tiers of SK_BT entries (the second only if some row of the block is that
-    // long) -- entries, then the outside neighbours' distances; both tiers stay in registers (static indices)
-    uint2 ae[SK_BT], ce[SK_BT];
-    unsigned ad[SK_BT], cd[SK_BT], aq[SK_BT], cq[SK_BT];
-    float aw[SK_BT], cw[SK_BT];
-    bool ax[SK_BT], cx[SK_BT];
-    SB_TIER(a, e0)
-    const bool two = __ballot(e1 - e0 > SK_BT) != 0ull;
-    if (two) { SB_TIER(c, e0 + SK_BT) }
-    const bool more = __ballot(e1 - e0 > 2 * SK_BT) != 0ull;  // rows beyond both tiers (not with K = 16): walked from memory
-    if (more)
-        for (uint32_t t = e0 + 2 * SK_BT; t < e1; t++) {
-            const uint2 a = B.padj[t];
-            if ((a.x >> 6) == b) continue;
-            const float o = st_ord2f(B.dpos[a.x]) + __uint_as_float(a.y);
-            curf = o < curf ? o : curf;
-        }
-    s_d[lane] = curf;
-    const long long tk1 = A.ticks ? wall_clock64() : 0;
-    int passes = 0;
-    // relax the block to convergence: every pass pulls over the in-block entries (values of the previous pass: offers a
-    // relaxation sequence could make); an outside or missing entry offers +inf to the lane itself
-    for (;;) {
-        __builtin_amdgcn_wave_barrier();
-        passes++;
-        float nb = curf;
-        SB_PULL(a)
-        if (two) { SB_PULL(c) }
-        if (more)
-            for (uint32_t t = e0 + 2 * SK_BT; t < e1; t++) {
-                const uint2 a = B.padj[t];
-                if ((a.x >> 6) != b) continue;
-                const float o = s_d[a.x & 63u] + __uint_as_float(a.y);
-                nb = o < nb ? o : nb;
-            }
-        const bool ch = nb < curf;
-        __builtin_amdgcn_wave_barrier();
-        if (ch) { curf = nb; s_d[lane] = curf; }
-        if (!__ballot(ch)) break;
-    }
-    const unsigned cur = st_f2ord(curf);
-    const bool changed = cur < mine;
-    if (changed) B.dpos[p] = cur;
-    if (lane == 0) atomicAdd(&B.flag[3 + gin], 1u);
-    const long long tk2 = A.ticks ? wall_clock64() : 0;
-    if (A.ticks && lane == 0) {
-        atomicAdd((unsigned long long*)&A.ticks[16], 1ull);                           // block runs
-        atomicAdd((unsigned long long*)&A.ticks[17], (unsigned long long)(tk1 - tk0));  // loads (ticks of 10 ns)
-        atomicAdd((unsigned long long*)&A.ticks[18], (unsigned long long)(tk2 - tk1));  // passes
-        atomicAdd((unsigned long long*)&A.ticks[19], (unsigned long long)passes);
-        atomicAdd((unsigned long long*)&A.ticks[20], two ? 1ull : 0ull);
-        atomicAdd((unsigned long long*)&A.ticks[21], more ? 1ull : 0ull);
-    }
-    if (!__ballot(changed)) return;
-    // who improved offers the new value outside: a neighbour it would improve -- judged against the distance pass 1 read,
-    // which is at or above the neighbour's final one -- gets its block marked for the next round.  The marks of the wavefront
-    // are collected first (blocks b - 32 .. b + 31 as one 64-bit set: the Morton order keeps neighbours close), then one
-    // atomic per marked WORD; nobody waits for them.
-    unsigned long long near = 0ull;
-    SB_OFFER(a)
-    if (two) { SB_OFFER(c) }
-    if (more && changed)
-        for (uint32_t t = e0 + 2 * SK_BT; t < e1; t++) {
-            const uint2 a = B.padj[t];
-            if ((a.x >> 6) != b && st_f2ord(curf + __uint_as_float(a.y)) < B.dpos[a.x]) sb_mark(B, gout, a.x >> 6);
-        }
-    for (int d = 32; d > 0; d >>= 1) near |= __shfl_xor(near, d);
-    if (near != 0ull) {
-        // lane l stands for block b - 32 + l; the voters are taken word by word (at most three dirty words cover the window):
-        // the lowest voter of a word ORs all of that word's bits in one atomic
-        const long long blk = (long long)b - 32 + lane;
-        const bool vote = ((near >> lane) & 1ull) && blk >= 0 && blk < B.nblk;
-        const unsigned word = vote ? (unsigned)(blk >> 5) : 0xffffffffu;
-        unsigned long long votes = __ballot(vote);
-        while (votes) {  // (wave-uniform)
-            const int leader = __ffsll((long long)votes) - 1;
-            const unsigned lw = (unsigned)__shfl((int)word, leader);
-            const unsigned long long same = __ballot(vote && word == lw);
-            if ((int)lane == leader) {
-                unsigned bits = 0u;
-                for (unsigned long long m_ = same; m_; m_ &= m_ - 1ull) bits |= 1u << (unsigned)(((long long)b - 32 + (__ffsll((long long)m_) - 1)) & 31);
-                (void)atomicOr(&B.dirty[(int64_t)gout * B.nw + lw], bits);
-            }
-            votes &= ~same;
-        }
-        if (lane == 0) B.flag[gout] = 1u;
-    }
-}
-#undef SB_TIER
-#undef SB_PULL
-#undef SB_OFFER
-
-__global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sb_finish(SkArgs A, SkBlocked B) {
-    SK_VERTEX_LOOP(p) A.dist_ord[B.perm[p]] = B.dpos[p];
-}
-
 __global__ void __launch_bounds__(SK_WIDE_BLOCK) k_sk_dist_out(SkArgs A) {
     SK_VERTEX_LOOP(v) A.dist[v] = st_ord2f(A.dist_ord[v]);
 }
@@ -2029,7 +1742,6 @@ struct SkLayout {
     float4* recs;
     char* gws;
     int64_t gws_bytes;
-    SkBlocked blk;  // the blocked SSSP's arrays (n_adj > 0), taken BEHIND everything else: the layout of a call without them is unchanged
 };
 
 static inline int64_t sk_grid_cells(int nseg, int64_t m) {  // (st_grid_build uses at most 128 cells per point: size for that)
@@ -2042,7 +1754,7 @@ static inline int64_t sk_queue_words(int64_t m, int64_t C) { return SK_FS * sk_f
 // termination bits: component c owns the words from (comp_off[c] >> 5) + c, ceil(size / 32) of them
 static inline int64_t sk_term_words(int64_t m, int64_t C) { return m / 32 + C + 2; }
 
-static void sk_layout(StArena& a, int64_t m, int64_t C, SkLayout* s, int nseg = 1, int64_t n_adj = 0) {
+static void sk_layout(StArena& a, int64_t m, int64_t C, SkLayout* s, int nseg = 1) {
     s->dist_ord = a.take<unsigned>(m);
     s->stamp = a.take<unsigned>(m);
     s->q0 = a.take<unsigned>(sk_queue_words(m, C));  // SSSP frontier: SK_FS shard segments + the overflow area (sk_q_reserve)
@@ -2082,22 +1794,6 @@ static void sk_layout(StArena& a, int64_t m, int64_t C, SkLayout* s, int nseg = 
     s->recs = a.take<float4>(m);
     s->gws_bytes = st_grid_ws_bytes(m, sk_grid_cells(nseg, m));
     s->gws = a.take<char>(s->gws_bytes);
-    memset(&s->blk, 0, sizeof(s->blk));
-    if (n_adj > 0) {
-        SkBlocked& b = s->blk;
-        b.n_adj = n_adj;
-        b.nblk = st_div_up(m, SK_BB);
-        b.nw = st_div_up(b.nblk, 32);
-        b.keys = a.take<unsigned>(m);
-        b.perm = a.take<unsigned>(m);
-        b.pos = a.take<unsigned>(m);
-        b.prow = a.take<unsigned>(m + 1);
-        b.dpos = a.take<unsigned>(m);
-        b.dirty = a.take<unsigned>(3 * b.nw);
-        b.flag = a.take<unsigned>(8);
-        b.bbox = a.take<unsigned>(6);
-        b.padj = a.take<uint2>(n_adj);
-    }
 }
 
 // Tuning of one call (st_skeleton_components_seg's `tuning` argument: 16 x int64, entry = ST_TUNE_DEFAULT or NULL array =
@@ -2115,9 +1811,6 @@ static void sk_layout(StArena& a, int64_t m, int64_t C, SkLayout* s, int nseg = 
 //   15 device pointer of 32 int64 phase timers / counters of k_sk_select
 //   16 / 17 / 18 time-outs of the helper protocol in microseconds: a helper's life time, a component's wait for one job's answers,
 //   a helper's wait for its component's workgroup to announce itself (tests/test_helpers.py drives every fall-back with them)
-//   19 SSSP by blocks relaxed to convergence (1) or by frontier launches (0); only st_skeleton_components_adj with n_adj > 0 has
-//   the workspace for the former   20 block rounds per read-back
-#define SK_BLOCKED_DEFAULT 1
 #define ST_TUNE_DEFAULT INT64_MIN
 #define ST_TUNE_ENTRIES 24
 #define SK_MAX_LAUNCH_BATCH 32
@@ -2126,7 +1819,6 @@ struct SkTuning {
     int small_work = SK_SMALL_WORK, iters_per_launch = SK_ITERS_PER_LAUNCH, launch_batch = 24, local_items = 0, wave_work = SK_WAVE_WORK, long_mode = 1;
     int sssp_hops = 4, sssp_batch = 32, sssp_lanes = 32, sssp_first = 2, sssp_blocks = SK_SSSP_BLOCKS, sssp_lcap = SK_LQ;
     int sssp_coop = 0, helpers = -1;  // helpers: -1 = by size, else the number of helper workgroups of a select launch
-    int sssp_blocked = SK_BLOCKED_DEFAULT, sssp_blocked_batch = 32;  // SSSP by blocks relaxed to convergence (needs n_adj > 0); launches per read-back
     long long help_lifetime_us = SK_HELP_LIFETIME_US, help_timeout_us = SK_HELP_TIMEOUT_US, help_announce_us = SK_HELP_ANNOUNCE_US;
     bool small_work_set = false, iters_set = false, long_set = false, launch_set = false;
     long long* ticks = nullptr;
@@ -2152,8 +1844,6 @@ struct SkTuning {
         if (has(16)) help_lifetime_us = t[16] < 0 ? 0 : t[16];
         if (has(17)) help_timeout_us = t[17] < 0 ? 0 : t[17];
         if (has(18)) help_announce_us = t[18] < 0 ? 0 : t[18];
-        if (has(19)) sssp_blocked = t[19] != 0;
-        if (has(20)) sssp_blocked_batch = t[20] < 1 ? 1 : (t[20] > 256 ? 256 : (int)t[20]);
     }
 };
 
@@ -2191,13 +1881,12 @@ extern "C" int st_abi_entries(int what) {
     return what == 0 ? ST_SKELETON_STATS_ENTRIES : (what == 1 ? ST_SKELETON_TUNING_ENTRIES : (what == 2 ? ST_MAX_SEG : -1));
 }
 
-extern "C" int64_t st_skeleton_workspace_bytes_adj(int64_t m, int64_t n_comp, int nseg, int64_t n_adj) {
+extern "C" int64_t st_skeleton_workspace_bytes_seg(int64_t m, int64_t n_comp, int nseg) {
     StArena a(nullptr, 0);
     SkLayout s;
-    sk_layout(a, m > 0 ? m : 1, n_comp > 0 ? n_comp : 1, &s, nseg, n_adj > 0 ? n_adj : 0);
+    sk_layout(a, m > 0 ? m : 1, n_comp > 0 ? n_comp : 1, &s, nseg);
     return a.used;
 }
-extern "C" int64_t st_skeleton_workspace_bytes_seg(int64_t m, int64_t n_comp, int nseg) { return st_skeleton_workspace_bytes_adj(m, n_comp, nseg, 0); }
 extern "C" int64_t st_skeleton_workspace_bytes(int64_t m, int64_t n_comp) { return st_skeleton_workspace_bytes_seg(m, n_comp, 1); }
 
 static inline unsigned sk_vgrid(int64_t m) {
@@ -2229,19 +1918,14 @@ static int sk_read(void* dst, const void* src, size_t bytes, hipStream_t stream)
 // of each component, vert_seg_off [nseg + 1] = the clouds' ranges in the renumbered vertex space (both device arrays,
 // from st_component_layout_seg).  Components never interact, so the only thing the batch shares is the claim grid, where
 // every cloud has its own slab of cells: each component's outputs are those of the one-cloud call.
-//
-// st_skeleton_components_adj (round 6): the same call with `n_adj` = the number of entries the caller's col / wgt arrays hold
-// (>= row_off[m]; the caller knows its capacity, the library would have to read row_off[m] back) and a workspace sized by
-// st_skeleton_workspace_bytes_adj(m, n_comp, nseg, n_adj): room for the adjacency in block order, which the SSSP by blocks
-// relaxed to convergence needs (k_sb_round).  n_adj = 0: the frontier SSSP, exactly st_skeleton_components_seg.
-extern "C" int st_skeleton_components_adj(int n_comp, const int32_t* comp_off, const int32_t* comp_seg,
+extern "C" int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, const int32_t* comp_seg,
                                           const int32_t* vert_seg_off, int nseg, int64_t m,
                                       const float* pts, const float* rad, const float* ysurf, const uint32_t* row_off,
                                       const uint32_t* col, const float* wgt, float grid_cell, int stages, int block_threads,
                                       float* dist, int32_t* pred, int32_t* root_local, float* tree_dist,
                                       int32_t* branch_parent, int32_t* branch_off, int32_t* branch_len, int32_t* n_branches,
                                       int32_t* path_verts, int32_t* branch_of, int64_t* stats_host, void* ws,
-                                      int64_t ws_bytes, void* stream_, const int64_t* tuning, int64_t n_adj) {
+                                      int64_t ws_bytes, void* stream_, const int64_t* tuning) {
     hipStream_t stream = (hipStream_t)stream_;
     const bool time_select = stats_host && stats_host[7] != 0;
     if (stats_host) for (int i = 0; i < ST_SKELETON_STATS_ENTRIES; i++) if (i != 7) stats_host[i] = 0;
@@ -2253,11 +1937,10 @@ extern "C" int st_skeleton_components_adj(int n_comp, const int32_t* comp_off, c
     ST_REQUIRE(nseg >= 1 && nseg <= ST_MAX_SEG, "skeleton: 1 <= clouds per batch <= %d", ST_MAX_SEG);
     ST_REQUIRE(nseg == 1 || (comp_seg && vert_seg_off), "skeleton: a batch needs comp_seg and vert_seg_off");
     if (nseg == 1) { comp_seg = nullptr; vert_seg_off = nullptr; }
-    if (n_adj < 0) n_adj = 0;
     StArena a(ws, ws_bytes);
     SkLayout s;
-    sk_layout(a, m, n_comp, &s, nseg, n_adj);
-    if (!a.ok() || !s.gws || (n_adj > 0 && !s.blk.padj)) {
+    sk_layout(a, m, n_comp, &s, nseg);
+    if (!a.ok() || !s.gws) {
         st_set_error("skeleton: workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)a.used);
         return ST_ERR_WORKSPACE;
     }
@@ -2352,36 +2035,6 @@ extern "C" int st_skeleton_components_adj(int n_comp, const int32_t* comp_off, c
                 hipLaunchKernelGGL(k_sk_init, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A);
                 hipLaunchKernelGGL(k_sk_roots, dim3((unsigned)n_comp), dim3((unsigned)block_threads), 0, stream, A);
             }
-        }
-        if (!coop_done && T.sssp_blocked && n_adj > 0) {
-            // SSSP by blocks relaxed to convergence (k_sb_round): order, adjacency in that order, rounds in batches with one
-            // read-back of the "somebody was marked" flags per batch
-            const SkBlocked& B = s.blk;
-            hipLaunchKernelGGL(k_sb_init, dim3(1), dim3(64), 0, stream, B);
-            hipLaunchKernelGGL(k_sb_bbox, dim3(vg < 512u ? vg : 512u), dim3(SK_WIDE_BLOCK), 0, stream, A, B);
-            hipLaunchKernelGGL(k_sb_keys, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A, B, 0);
-            ST_TRY(st_radix_sort_pairs_u32(B.keys, B.perm, m, 30, s.sort_ws, s.sort_bytes, stream));
-            if (n_comp > 1) {
-                int bits = 1;
-                while ((1ll << bits) < n_comp) bits++;
-                hipLaunchKernelGGL(k_sb_keys, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A, B, 1);
-                ST_TRY(st_radix_sort_pairs_u32(B.keys, B.perm, m, bits, s.sort_ws, s.sort_bytes, stream));
-            }
-            hipLaunchKernelGGL(k_sb_pos, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A, B);
-            ST_TRY(st_exclusive_scan_u32(B.prow, B.prow, m + 1, nullptr, s.sort_ws, s.sort_bytes, stream));
-            hipLaunchKernelGGL(k_sb_fill, dim3((unsigned)st_min64(st_div_up(m * 8, SK_WIDE_BLOCK), 8192)), dim3(SK_WIDE_BLOCK), 0, stream, A, B);
-            hipLaunchKernelGGL(k_sb_roots, dim3((unsigned)n_comp), dim3(64), 0, stream, A, B);
-            unsigned hf[8];
-            for (int r = 0;;) {
-                for (int b = 0; b < T.sssp_blocked_batch; b++, r++)
-                    hipLaunchKernelGGL(k_sb_round, dim3((unsigned)B.nblk), dim3(SK_BB), 0, stream, A, B, r);
-                ST_TRY(sk_read(hf, B.flag, sizeof(hf), stream));
-                sssp_rounds = r;
-                if (hf[r % 3] == 0u) break;  // nobody is marked for the round the next launch would run
-                ST_REQUIRE(r < (1 << 24), "skeleton: blocked SSSP did not converge");
-            }
-            hipLaunchKernelGGL(k_sb_finish, dim3(vg), dim3(SK_WIDE_BLOCK), 0, stream, A, B);
-            coop_done = true;
         }
         for (int r = 0; !coop_done;) {  // frontier rounds in batches, one counter read-back per batch.  The first batch is twice as long:
             // a tree of a million points needs 65-96 launches, an empty round costs ~4 us, a read-back beside other clouds ~1 ms
@@ -2512,19 +2165,6 @@ extern "C" int st_skeleton_components_adj(int n_comp, const int32_t* comp_off, c
     }
     ST_CHECK_LAUNCH();
     return ST_OK;
-}
-
-extern "C" int st_skeleton_components_seg(int n_comp, const int32_t* comp_off, const int32_t* comp_seg,
-                                          const int32_t* vert_seg_off, int nseg, int64_t m,
-                                      const float* pts, const float* rad, const float* ysurf, const uint32_t* row_off,
-                                      const uint32_t* col, const float* wgt, float grid_cell, int stages, int block_threads,
-                                      float* dist, int32_t* pred, int32_t* root_local, float* tree_dist,
-                                      int32_t* branch_parent, int32_t* branch_off, int32_t* branch_len, int32_t* n_branches,
-                                      int32_t* path_verts, int32_t* branch_of, int64_t* stats_host, void* ws,
-                                      int64_t ws_bytes, void* stream_, const int64_t* tuning) {
-    return st_skeleton_components_adj(n_comp, comp_off, comp_seg, vert_seg_off, nseg, m, pts, rad, ysurf, row_off, col, wgt, grid_cell,
-                                      stages, block_threads, dist, pred, root_local, tree_dist, branch_parent, branch_off,
-                                      branch_len, n_branches, path_verts, branch_of, stats_host, ws, ws_bytes, stream_, tuning, 0);
 }
 
 extern "C" int st_skeleton_components(int n_comp, const int32_t* comp_off, const int32_t* comp_size_host, int64_t m,

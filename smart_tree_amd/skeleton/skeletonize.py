@@ -100,19 +100,16 @@ def run_components(comps: ComponentSet, medial_pts: torch.Tensor, radius: torch.
     stats = (ctypes.c_int64 * 16)()
     stats[7] = 1 if profiling.enabled() else 0  # bracket every k_sk_select launch with HIP events
     nseg = comps.n_seg  # batched clouds: every cloud's components use their own slab of the claim grid
-    # the adjacency arrays' capacity (>= row_off[m]): with it the library has room for the adjacency in block order and runs the
-    # SSSP by blocks relaxed to convergence (csrc/skeleton.hip k_sb_round) instead of one launch per few hop levels
-    n_adj = int(min(comps.col.numel(), comps.wgt.numel()))
-    ws = _lib.workspace(L.st_skeleton_workspace_bytes_adj(m, C, nseg, n_adj), dev)
+    ws = _lib.workspace(L.st_skeleton_workspace_bytes_seg(m, C, nseg), dev)
     with profiling.stage("skeleton_kernels"):
-        _lib.check(L.st_skeleton_components_adj(
+        _lib.check(L.st_skeleton_components_seg(
             C, _lib.ptr(comps.comp_off.contiguous()), _lib.ptr(comps.comp_seg.contiguous()) if nseg > 1 else None,
             _lib.ptr(comps.vert_seg_off) if nseg > 1 else None, nseg, m, _lib.ptr(pts), _lib.ptr(rad), _lib.ptr(ys),
             _lib.ptr(comps.row_off), _lib.ptr(comps.col), _lib.ptr(comps.wgt), -float(GRID_DIV), int(stages),
             int(block_threads), _lib.ptr(res.dist), _lib.ptr(res.pred), _lib.ptr(res.root_local), _lib.ptr(res.tree_dist),
             _lib.ptr(res.branch_parent), _lib.ptr(res.branch_off), _lib.ptr(res.branch_len), _lib.ptr(res.n_branches),
             _lib.ptr(res.path_verts), _lib.ptr(res.branch_of), stats, _lib.ptr(ws), ws.numel(), _lib.stream(dev),
-            tuning.skeleton_array(), n_adj))
+            tuning.skeleton_array()))
     res.stats = {"sssp_rounds": stats[0], "plateau_rounds": stats[1], "select_launches": stats[2], "lift_levels": stats[3],
                  "helpers_lost": int(stats[8]), "helpers": int(stats[9])}
     _note_helpers(res.stats)

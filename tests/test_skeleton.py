@@ -161,16 +161,13 @@ def test_components_match_oracle(backend):
     {5: -1, 1: -1, 14: 0, 4: -1},       # ... handed to the chip-wide claim kernel
     {5: 300, 1: 2000, 4: 200},   # a mix: speculative slots, plain and long-path claims
     {5: 300, 1: 2000, 14: 0, 4: 200},   # a mix: slots, plain, local and chip-wide claims
-    {19: 0, 6: 1, 8: 16},        # SSSP by frontier launches: one level per launch, 16 lanes per vertex
-    {19: 0, 6: 7, 7: 2},         # ... seven levels per launch, read-back every second launch
-    {19: 0, 6: 6, 13: 2, 10: 3}, # ... three workgroups, at most two vertices per workgroup and local level (the rest goes back)
-    {19: 0, 12: 1},              # ... every round in ONE persistent launch with grid barriers
-    {19: 0, 12: 1, 6: 7, 10: 3}, # ... seven levels per round, three workgroups
-    {19: 0},                     # ... the frontier launches' defaults
-    {19: 1, 20: 1},              # SSSP by blocks relaxed to convergence (round 6, the default): a read-back after every round
-    {19: 1, 20: 7},              # ... after every seventh
+    {6: 1, 8: 16},               # SSSP: one level per launch, 16 lanes per vertex
+    {6: 7, 7: 2},                # ... seven levels per launch, read-back every second launch
+    {6: 6, 13: 2, 10: 3},        # ... three workgroups, at most two vertices per workgroup and local level (the rest goes back)
+    {12: 1},                     # SSSP: every round in ONE persistent launch with grid barriers
+    {12: 1, 6: 7, 10: 3},        # ... seven levels per round, three workgroups
 ], ids=["noprune", "prune4", "relaunch", "one", "long", "local", "wide", "mixed", "mixed-wide", "sssp-rows",
-        "sssp-hops", "sssp-cap", "sssp-coop", "sssp-coop-hops", "sssp-frontier", "sssp-blocks-1", "sssp-blocks-7"])
+        "sssp-hops", "sssp-cap", "sssp-coop", "sssp-coop-hops"])
 def test_sample_tree_strategies_agree(backend, params):
     """Branch selection has four claim strategies picked by size; each one alone must reproduce the oracle."""
     from smart_tree_amd.skeleton import tuning
