@@ -42,5 +42,5 @@ def outlier_removal(points: torch.Tensor, radii: torch.Tensor, nb_points: int = 
     v8 = None if valid is None else valid.to(torch.uint8).contiguous()
     _lib.check(L.st_radius_count_seg(_lib.ptr(pts), n, _lib.ptr(pts), n, nb_points, -1.0, _lib.ptr(bound), BOUND_LT,
                                      -float(SEARCH_CELL_DIV), _lib.ptr(mask), _lib.ptr(seg_off), _lib.ptr(seg_off), nseg,
-                                     _lib.ptr(ws), ws.numel(), _lib.stream(dev), tuning.knn_cell_mean_mult(), _lib.ptr(v8)))
+                                     _lib.ptr(ws), ws.numel(), _lib.stream(dev), tuning.count_cell_mean_mult(), _lib.ptr(v8)))
     return mask.bool()

@@ -62,3 +62,11 @@ def knn_cell_mean_mult() -> float:
     """The `cell_mean_mult` argument of st_knn_radius_seg / st_radius_count_seg (-1 = library default)."""
     v = current().get(KNN_CELL_MEAN_MULT)
     return -1.0 if v is None else v / 100.0
+
+
+COUNT_CELL_MEAN_MULT = 101  # pseudo code: the same cap for outlier_removal's counting search alone (falls back to KNN_CELL_MEAN_MULT)
+
+
+def count_cell_mean_mult() -> float:
+    v = current().get(COUNT_CELL_MEAN_MULT)
+    return knn_cell_mean_mult() if v is None else v / 100.0
