@@ -147,7 +147,6 @@ class ComponentSet:
     comp_seg: Optional[torch.Tensor] = None  # [C] int32 cloud of each component
     comp_seg_off: Optional[torch.Tensor] = None  # [n_seg+1] int32 component range of each cloud
     vert_seg_off: Optional[torch.Tensor] = None  # [n_seg+1] int32 the clouds' ranges in the renumbered vertex space
-    largest: int = 0  # vertices of the largest component (host; arrives with the layout's count read-back)
 
     def __len__(self):
         return self.n_components
@@ -184,13 +183,13 @@ def connected_components(graph: Graph, minimum_vertices: int = 0) -> ComponentSe
         _lib.check(L.st_connected_components(_lib.ptr(edges), E, n, _lib.ptr(labels), _lib.ptr(ws), ws.numel(), _lib.stream(dev)))
     comp_size, comp_off, vert_order, new_id = i32(n), i32(n + 1), i32(n), i32(n)
     comp_seg, comp_seg_off, vert_seg_off = (i32(n), i32(nseg + 1), i32(nseg + 1)) if nseg > 1 else (None, None, None)
-    nc, nk, biggest = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+    nc, nk = ctypes.c_int64(0), ctypes.c_int64(0)
     ws = _lib.workspace(L.st_component_layout_workspace_bytes(n), dev)
     _lib.check(L.st_component_layout_seg(_lib.ptr(labels), n, int(minimum_vertices), _lib.ptr(seg_off) if nseg > 1 else None, nseg,
                                          _lib.ptr(comp_size), _lib.ptr(comp_off), _lib.ptr(vert_order), _lib.ptr(new_id),
                                          _lib.ptr(comp_seg), _lib.ptr(comp_seg_off), _lib.ptr(vert_seg_off),
                                          ctypes.byref(nc), ctypes.byref(nk), _lib.ptr(ws), ws.numel(), _lib.stream(dev),
-                                         ctypes.byref(biggest)))
+                                         None))  # (max_comp_host: optional, nobody needs the largest component's size on the host)
     C, m = nc.value, nk.value
     row_off, col, wgt = i32(m + 1), i32(2 * E), torch.empty((max(2 * E, 1),), dtype=torch.float32, device=dev)
     if m > 0:
@@ -203,7 +202,7 @@ def connected_components(graph: Graph, minimum_vertices: int = 0) -> ComponentSe
             _lib.check(L.st_component_csr(_lib.ptr(edges), _lib.ptr(w), E, _lib.ptr(new_id), m, _lib.ptr(row_off), _lib.ptr(col),
                                           _lib.ptr(wgt), _lib.ptr(ws), ws.numel(), _lib.stream(dev)))
     return ComponentSet(C, comp_size[:C], comp_off[: C + 1], vert_order[:m], new_id[:n], labels[:n], row_off[: m + 1], col, wgt,
-                        nseg, comp_seg[:C] if comp_seg is not None else None, comp_seg_off, vert_seg_off, int(biggest.value))
+                        nseg, comp_seg[:C] if comp_seg is not None else None, comp_seg_off, vert_seg_off)
 
 
 def remap_edges(edges: torch.Tensor) -> torch.Tensor:
