@@ -1,11 +1,13 @@
 """Headline benchmark: input points/s of the smart-tree inference path on 1M-point synthetic trees.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by torch.distributed.run, one rank per GPU; clouds are sharded, weak scaling)
+    (N > 1: launched by torch.distributed.run, one rank per GPU; clouds are sharded, weak scaling -- every rank runs K clouds of its own;
+     --scaling strong --clouds 64: BASELINE.json configs[2] as written, a FIXED batch split round-robin over the ranks)
 
 A step = one pass of the hot path (CentreCloud -> blocks/voxelise -> UNet -> class filter -> kNN graph -> components
 -> SSSP -> sample_tree -> prune/repair/smooth -> host copy of the skeleton) over ONE 1M-point synthetic tree
-(BASELINE.json configs[1]), inputs resident in HBM when the timed region starts.  Clouds are independent, so a rank
+(BASELINE.json configs[1]), inputs resident in HBM when the timed region starts (the bench contract: the PCIe-inclusive rate is
+reported beside it, never as `value`).  Clouds are independent, so a rank
 runs them in BATCHES of up to `--batch` clouds through one launch set (`Pipeline.process_clouds`: the batch index is
 carried through every kernel; results per cloud are bit-identical to one cloud at a time, tests/test_batch.py) and keeps
 `--streams` batches in flight (one host thread + HIP stream each), so that the single-workgroup skeleton stages of one
@@ -22,6 +24,12 @@ MEDIAN pass (min / max / all passes are in `passes`).  Prints ONE JSON line (ran
                             convolution family's roofline for one cloud at a time
   value_incl_host_upload    the same K steps with every cloud uploaded from pinned host memory inside the pass (copy stream,
                             the next batch's upload overlaps the current batch's kernels); median of 3 passes
+  representative_e2e        (N = 1) the same K clouds through the whole path with the skeleton stage fed the GENERATOR's exact medial
+                            vectors (the network still runs and is timed): one end-to-end figure on the regime the reference runs
+                            the skeleton stage in -- the shipped checkpoint's output on the benchmark tree is arbitrary and gives a
+                            2-3x cheaper graph; the first cloud's skeleton is compared with the oracle's in the run
+  config.strong_scaling_projection  (N = 1) launch sets of 8 / 16 / 32 / 64 of configs[2]'s 64 clouds timed on this one GPU and the
+                            speed-up eight ranks with 8 clouds each would reach: a PROJECTION, not a scaling measurement
   cpu_baseline              (N = 1) the oracle -- a port of the reference algorithm; the reference itself is CUDA-only --
                             timed on this host's cores on one full cloud, whose skeleton is also compared with the GPU's
                             for the same cloud (`parity_in_run`).
