@@ -1819,7 +1819,8 @@ struct SkTuning {
     int small_work = SK_SMALL_WORK, iters_per_launch = SK_ITERS_PER_LAUNCH, launch_batch = 24, local_items = 0, wave_work = SK_WAVE_WORK, long_mode = 1;
     int sssp_hops = 6 /* round 6: 6 levels per launch instead of 4 -- the same on the network's 360-level graph (skeleton kernels 0.548 against 0.537 ms
     per cloud in a set of twenty, 657-660 against 655-662 M points/s; 8 levels: 0.562 ms, 645-655 M), 8 % less on the 2400-level graph of exact medial
-    vectors (a set of twenty 36.2 -> 33.3 ms, one cloud 16.5 -> 15.5; 8 levels: 32.9 / 15.4): profiles/r06_ab_hops2.txt, r06_sweep_gt_sssp.txt */, sssp_batch = 32, sssp_lanes = 32, sssp_first = 2, sssp_blocks = SK_SSSP_BLOCKS, sssp_lcap = SK_LQ;
+    vectors (a set of twenty 36.2 -> 33.3 ms, one cloud 16.5 -> 15.5; 8 levels: 32.9 / 15.4): profiles/r06_ab_hops2.txt, r06_sweep_gt_sssp.txt */, sssp_batch = 36 /* launches per read-back; the first batch is sssp_first x this = 72 launches = 432 levels: the 1M-point trees' graphs are
+    260-384 levels deep, so one batch ends them (with 32 a set of twenty needed a second batch of 32 mostly empty launches) */, sssp_lanes = 32, sssp_first = 2, sssp_blocks = SK_SSSP_BLOCKS, sssp_lcap = SK_LQ;
     int sssp_coop = 0, helpers = -1;  // helpers: -1 = by size, else the number of helper workgroups of a select launch
     long long help_lifetime_us = SK_HELP_LIFETIME_US, help_timeout_us = SK_HELP_TIMEOUT_US, help_announce_us = SK_HELP_ANNOUNCE_US;
     bool small_work_set = false, iters_set = false, long_set = false, launch_set = false;
