@@ -8,4 +8,4 @@ for w in $(seq 1 30); do python $R/tools/trace_one_batch.py /tmp/prof_tb20 $w > 
 # the last launch set of 20 clouds that ran with the timers off (wall 25-32 ms)
 for w in $(seq 1 30); do if grep -q "wall \(2[5-9]\|3[0-2]\)\." /tmp/tb20_$w.txt; then cp /tmp/tb20_$w.txt $R/gpurun_out/trace_set20.txt; break; fi; done
 # ... and one single-cloud call (process_cloud from pinned host memory: ~410 kernels)
-for w in $(seq 1 30); do if grep -q "launch set: 4[0-3][0-9] kernels, wall \(9\|10\|11\)\." /tmp/tb20_$w.txt; then cp /tmp/tb20_$w.txt $R/gpurun_out/trace_single_cloud.txt; break; fi; done
+for w in $(seq 1 30); do if grep -q "launch set: \(3[5-9]\|4[0-3]\)[0-9] kernels, wall \(9\|10\|11\)\." /tmp/tb20_$w.txt; then cp /tmp/tb20_$w.txt $R/gpurun_out/trace_single_cloud.txt; break; fi; done
