@@ -17,6 +17,21 @@ import torch.nn.functional as F
 
 _PER_POINT = ("xyz", "rgb", "medial_vector", "branch_direction", "branch_ids", "class_l")
 
+_CLASS_LISTS: dict = {}
+
+
+def _class_tensor(classes, device) -> torch.Tensor:
+    """`classes` as a device tensor, made once per (list, device): `torch.as_tensor(list, device=gpu)` is a pageable host-to-device
+    copy the HOST waits for -- behind everything already enqueued on the stream, i.e. in `filter_by_class` behind the whole network --
+    so the kernels of the next stage were only enqueued once the GPU had run dry (a ~35 us hole per call in the kernel trace)."""
+    if torch.is_tensor(classes):
+        return classes.to(device)
+    key = (tuple(int(c) for c in classes), str(device))
+    t = _CLASS_LISTS.get(key)
+    if t is None:
+        t = _CLASS_LISTS[key] = torch.as_tensor(list(key[0]), device=device)
+    return t
+
 
 @dataclass
 class Cloud:
@@ -98,7 +113,7 @@ class Cloud:
         return out
 
     def filter_by_class(self, classes) -> "Cloud":
-        wanted = torch.as_tensor(classes, device=self.class_l.device)
+        wanted = _class_tensor(classes, self.class_l.device)
         return self.filter(torch.isin(self.class_l, wanted).view(-1))
 
     def to_device(self, device) -> "Cloud":
@@ -217,7 +232,7 @@ class MaskedCloud(Cloud):
         base, mask = self.__dict__["_base"], self.__dict__["_mask"]
         if self.__dict__["_real"] is not None or base.class_l is None:
             return self._cloud().filter_by_class(classes)
-        wanted = torch.as_tensor(classes, device=base.class_l.device)
+        wanted = _class_tensor(classes, base.class_l.device)
         return MaskedCloud(base, mask & torch.isin(base.class_l, wanted).view(-1))
 
     def pending(self):
